@@ -1,0 +1,125 @@
+"""ctypes binding of libb4r_hip.so (include/b4r.h).  There is NO CPU fallback: if the HIP library is missing or a
+call fails, an exception is raised.  This is the stub a maintainer of the reference would add to bind the library
+(INTEGRATION.md)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libb4r_hip.so")
+
+
+class B4RError(RuntimeError):
+    pass
+
+
+class ModelConfig(C.Structure):
+    _fields_ = [("vocab_size", C.c_int32), ("hidden_size", C.c_int32), ("num_layers", C.c_int32),
+                ("num_heads", C.c_int32), ("inner_dim", C.c_int32), ("max_seq_len", C.c_int32),
+                ("output_dropout", C.c_float), ("attention_dropout", C.c_float), ("ln_eps", C.c_float)]
+
+
+class Batch(C.Structure):
+    _fields_ = [("input_word_ids", C.c_void_p), ("input_mask", C.c_void_p), ("masked_lm_positions", C.c_void_p),
+                ("masked_lm_ids", C.c_void_p), ("B", C.c_int32), ("L", C.c_int32), ("P", C.c_int32)]
+
+
+class AdamWConfig(C.Structure):
+    _fields_ = [("init_lr", C.c_float), ("end_lr", C.c_float), ("num_train_steps", C.c_int32),
+                ("num_warmup_steps", C.c_int32), ("weight_decay_rate", C.c_float), ("beta_1", C.c_float),
+                ("beta_2", C.c_float), ("epsilon", C.c_float), ("clip_norm", C.c_float)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int32), ("B", C.c_void_p), ("ldb", C.c_int32), ("C", C.c_void_p),
+                ("ldc", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("b_is_nk", C.c_int32),
+                ("epilogue", C.c_int32), ("bias", C.c_void_p), ("C2", C.c_void_p), ("ldc2", C.c_int32),
+                ("R", C.c_void_p), ("ldr", C.c_int32), ("qscale", C.c_float), ("qcols", C.c_int32),
+                ("rng", C.c_void_p), ("drop_stream", C.c_uint32), ("drop_rate", C.c_float), ("a_dropout", C.c_int32)]
+
+
+class GemmTnDesc(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int32), ("B", C.c_void_p), ("ldb", C.c_int32), ("out", C.c_void_p),
+                ("ldo", C.c_int32), ("R", C.c_int32), ("Mo", C.c_int32), ("No", C.c_int32), ("colsum", C.c_void_p),
+                ("colsum_a", C.c_void_p), ("rng", C.c_void_p), ("drop_stream", C.c_uint32), ("drop_rate", C.c_float),
+                ("b_dropout", C.c_int32), ("accumulate", C.c_int32)]
+
+
+# b4r_train_state: 16 x 32-bit words; word indices of the float fields
+STATE_WORDS = 16
+ST_SEED, ST_STEP_LO, ST_STEP = 0, 1, 2  # step is int64 at words 2..3
+ST_LOSS_SUM, ST_VALID, ST_CORRECT_MASKED, ST_CORRECT_ALL, ST_SLOTS_ALL, ST_SQNORM, ST_GRAD_NORM, ST_LR = range(4, 12)
+
+EPI_NONE, EPI_BIAS, EPI_BIAS_QSCALE, EPI_BIAS_GELU, EPI_BIAS_DROP_RES, EPI_GELU_BWD, EPI_ADD_RES, EPI_BIAS_TANH = range(8)
+FLAG_TRAINING, FLAG_POOLER = 1, 2
+
+_P, _I32, _I64, _F, _U32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint32
+
+# name -> (restype, argtypes).  Every symbol declared in include/b4r.h appears here (tests check the two lists agree).
+PROTOTYPES = {
+    "b4r_version": (C.c_int, []),
+    "b4r_last_error": (C.c_size_t, [C.c_char_p, C.c_size_t]),
+    "b4r_param_total_floats": (_I64, [C.POINTER(ModelConfig)]),
+    "b4r_param_decay_floats": (_I64, [C.POINTER(ModelConfig)]),
+    "b4r_param_count": (_I32, [C.POINTER(ModelConfig)]),
+    "b4r_param_info": (C.c_int, [C.POINTER(ModelConfig), _I32, C.c_char_p, C.c_size_t, C.POINTER(_I64),
+                                 C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32)]),
+    "b4r_pooler_floats": (_I64, [C.POINTER(ModelConfig)]),
+    "b4r_workspace_bytes": (_I64, [C.POINTER(ModelConfig), _I32, _I32, _I32]),
+    "b4r_workspace_region": (C.c_int, [C.POINTER(ModelConfig), _I32, _I32, _I32, C.c_char_p, C.POINTER(_I64),
+                                       C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32)]),
+    "b4r_forward": (C.c_int, [C.POINTER(ModelConfig), C.POINTER(Batch), _P, _P, _P, _I64, _P, _I32, _P]),
+    "b4r_loss": (C.c_int, [C.POINTER(ModelConfig), C.POINTER(Batch), _P, _I64, _P, _I32, _P]),
+    "b4r_backward": (C.c_int, [C.POINTER(ModelConfig), C.POINTER(Batch), _P, _P, _P, _I64, _P, _I32, _P]),
+    "b4r_optimizer_step": (C.c_int, [C.POINTER(ModelConfig), C.POINTER(AdamWConfig), _P, _P, _P, _P, _P, _I64, _P, _P]),
+    "b4r_state_begin_step": (C.c_int, [_P, _P]),
+    "b4r_train_step": (C.c_int, [C.POINTER(ModelConfig), C.POINTER(AdamWConfig), C.POINTER(Batch), _P, _P, _P, _P, _P,
+                                 _I64, _P, _P]),
+    "b4r_rank_candidates": (C.c_int, [_P, _I32, _P, _P, _P, _I32, _P, _I32, _I32, _P, _P, _P, _P, _P]),
+    "b4r_embed_ln_fwd": (C.c_int, [_P, _I32, _I32, _P, _I32, _P, _P, _P, _I32, _F, _P, _P, _P, _P, _F, _P]),
+    "b4r_ln_fwd": (C.c_int, [_P, _I32, _I32, _P, _P, _F, _P, _P, _P, _P]),
+    "b4r_ln_bwd_scratch_floats": (_I64, [_I32, _I32]),
+    "b4r_ln_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P]),
+    "b4r_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _P]),
+    "b4r_gemm_tn_scratch_floats": (_I64, [_I32, _I32, _I32]),
+    "b4r_gemm_tn_f32": (C.c_int, [C.POINTER(GemmTnDesc), _P, _P]),
+    "b4r_attn_fwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P, _P, _U32, _F, _P]),
+    "b4r_attn_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _F, _P, _P, _U32, _F, _P]),
+    "b4r_gather_rows": (C.c_int, [_P, _I32, _P, _I64, _I32, _I32, _I32, _P, _P]),
+    "b4r_scatter_add_rows": (C.c_int, [_P, _P, _I64, _I32, _I32, _I32, _P, _I32, _P, _P]),
+    "b4r_softmax_ce": (C.c_int, [_P, _I32, _I32, _I32, _P, _P, _P, _I32, _P]),
+    "b4r_global_sqnorm": (C.c_int, [_P, _I64, _P, _P, _P]),
+    "b4r_adamw_step": (C.c_int, [C.POINTER(AdamWConfig), _P, _P, _P, _P, _I64, _I64, _P, _P]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library.  Fails loudly: the product has no other compute path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise B4RError(f"{LIB_PATH} is missing: build it first (python -c 'import __graft_entry__ as g; g.build()' "
+                       f"or bert4rec_amd/build.py). bert4rec_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(512)
+    load().b4r_last_error(buf, 512)
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        raise B4RError(f"{what or 'b4r call'} failed with code {rc}: {last_error()}")

@@ -1,0 +1,116 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) BERT4Rec kernels.  wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/b4r.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define B4R_WAVE 64
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing (host)
+// ---------------------------------------------------------------------------------------------
+void b4r_set_error(const char* fmt, ...);
+#define B4R_CHECK_ARG(cond, code, ...)            \
+  do {                                            \
+    if (!(cond)) {                                \
+      b4r_set_error(__VA_ARGS__);                 \
+      return (code);                              \
+    }                                             \
+  } while (0)
+#define B4R_CHECK_LAUNCH(what)                                                   \
+  do {                                                                           \
+    hipError_t e__ = hipGetLastError();                                          \
+    if (e__ != hipSuccess) {                                                     \
+      b4r_set_error("%s: launch failed: %s", (what), hipGetErrorString(e__));    \
+      return B4R_E_HIP;                                                          \
+    }                                                                            \
+  } while (0)
+
+static inline int b4r_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline bool b4r_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// dropout sites (stream ids of the counter-hash RNG); restated in oracle/bert4rec_oracle.py
+#define B4R_STREAM_EMB 0u
+#define B4R_STREAM_ATTN_PROBS(layer) (1u + 4u * (uint32_t)(layer))
+#define B4R_STREAM_ATTN_OUT(layer) (2u + 4u * (uint32_t)(layer))
+#define B4R_STREAM_FFN_OUT(layer) (3u + 4u * (uint32_t)(layer))
+
+// ---------------------------------------------------------------------------------------------
+// counter-hash dropout.  keep(idx) is a pure function of (seed, step, stream, idx) so forward and backward
+// regenerate the same mask without storing it.  Restated in oracle/bert4rec_oracle.py::dropout_keep_mask.
+// ---------------------------------------------------------------------------------------------
+struct DropArgs {
+  const uint32_t* rng;  // device: rng[0] = seed, rng[1] = step (low 32 bits); nullptr => dropout disabled
+  uint32_t stream;      // dropout site id (B4R_STREAM_*)
+  uint32_t thr;         // drop if hash < thr;  thr = (uint32)(rate * 2^32)
+  float scale;          // 1 / (1 - rate)
+};
+
+static inline DropArgs b4r_make_drop(const uint32_t* rng, uint32_t stream, float rate, int training) {
+  DropArgs d;
+  d.rng = nullptr; d.stream = stream; d.thr = 0; d.scale = 1.0f;
+  if (training && rate > 0.0f && rng != nullptr) {
+    d.rng = rng;
+    d.thr = (uint32_t)((double)rate * 4294967296.0);
+    d.scale = 1.0f / (1.0f - rate);
+  }
+  return d;
+}
+
+__device__ __forceinline__ uint32_t b4r_hash32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+  return x;
+}
+
+struct DropCtx {
+  uint32_t seed, key, thr;
+  float scale;
+  bool on;
+};
+
+__device__ __forceinline__ DropCtx b4r_drop_ctx(const DropArgs& a) {
+  DropCtx c;
+  c.on = (a.rng != nullptr) && (a.thr != 0);
+  c.thr = a.thr; c.scale = a.scale; c.seed = 0; c.key = 0;
+  if (c.on) {
+    c.seed = a.rng[0];
+    c.key = b4r_hash32(a.stream * 0x9E3779B9u + a.rng[1]);
+  }
+  return c;
+}
+
+__device__ __forceinline__ bool b4r_keep(const DropCtx& c, uint64_t idx) {
+  uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+  uint32_t h = b4r_hash32(lo ^ c.seed);
+  h = b4r_hash32((h ^ (hi * 0x85EBCA6Bu)) + c.key);
+  return h >= c.thr;
+}
+
+// x -> dropout(x)
+__device__ __forceinline__ float b4r_drop(const DropCtx& c, float x, uint64_t idx) {
+  if (!c.on) return x;
+  return b4r_keep(c, idx) ? x * c.scale : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// math
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float b4r_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// d/dx [0.5 x (1+erf(x/sqrt2))] = 0.5 (1+erf(x/sqrt2)) + x * exp(-x^2/2) / sqrt(2 pi)
+__device__ __forceinline__ float b4r_gelu_grad(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
+
+__device__ __forceinline__ float b4r_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float b4r_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

@@ -1,0 +1,449 @@
+// Dense layers on the exact-fp32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32: bitwise a k-ordered fmaf chain).
+//
+//   gemm_kernel     C[M,N] = A[M,K] . B      B as [K,N] (forward: Keras kernels are [in,out]) or as [N,K]
+//                   (C = A.B^T: input gradients, and the tied vocabulary projection T.E^T of tfm MaskedLM)
+//                   128x64 output tile per 256-thread workgroup, K staged 32 at a time through LDS, fused epilogues.
+//   gemm_tn_kernel  out[Mo,No] = A[R,Mo]^T . B[R,No]   weight gradients: rows R split over workgroups, partial
+//                   slabs + ordered reduce (bitwise reproducible, no float atomics), bias column sums fused.
+//
+// MFMA 32x32x2 f32 operand map (guide §3): lane l holds A[i=l&31][k=l>>5], B[k=l>>5][j=l&31];
+// C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+// The k index fed to the two lane halves is permuted (half h takes k = 8t+4h+r) so that one ds_read_b128 serves four
+// MFMA steps; A and B use the same permutation, so the sum over k is unchanged.
+#include "b4r_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 64, BK = 32;
+constexpr int LDS_A = BK + 4;   // 36 floats: conflict-free ds_read_b128 down a column of 16 rows
+constexpr int LDS_BN = BN;      // B as [k][n]: ds_read_b32 across n, conflict-free
+constexpr int LDS_BK = BK + 4;  // B as [n][k]
+
+struct GemmP {
+  const float* A; const float* B; float* C; const float* bias; float* C2; const float* R;
+  int lda, ldb, ldc, ldc2, ldr;
+  int M, N, K;
+  int tiles_n;
+  int a_vec, b_vec;
+  float qscale; int qcols;
+  DropArgs drop;
+};
+
+__device__ __forceinline__ f32x4 load4_guard(const float* base, int64_t off, int n_valid, bool vec) {
+  // n_valid: how many of the 4 consecutive elements are in range (<=0: none)
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (n_valid >= 4 && vec) {
+    v = *reinterpret_cast<const f32x4*>(base + off);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (e < n_valid) v[e] = base[off + e];
+  }
+  return v;
+}
+
+template <bool B_NK, int EPI, bool A_DROP>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
+  __shared__ __attribute__((aligned(16))) float sA[BM * LDS_A];
+  __shared__ __attribute__((aligned(16))) float sB[B_NK ? BN * LDS_BK : BK * LDS_BN];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile_m = blockIdx.x / p.tiles_n, tile_n = blockIdx.x % p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int h = lane >> 5, l31 = lane & 31;
+
+  DropCtx dctx = b4r_drop_ctx(p.drop);
+
+  f32x16 acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+
+  f32x4 ra[4], rb[2];
+
+  auto load_tiles = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = tid + 256 * i;
+      const int row = f >> 3, c4 = (f & 7) * 4;
+      const int gr = m0 + row, gk = k0 + c4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (gr < p.M) v = load4_guard(p.A, (int64_t)gr * p.lda + gk, p.K - gk, p.a_vec != 0);
+      if (A_DROP) {
+        if (dctx.on) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = b4r_drop(dctx, v[e], (uint64_t)gr * (uint64_t)p.K + (uint64_t)(gk + e));
+        }
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int f = tid + 256 * i;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (B_NK) {
+        const int nr = f >> 3, c4 = (f & 7) * 4;
+        const int gn = n0 + nr, gk = k0 + c4;
+        if (gn < p.N) v = load4_guard(p.B, (int64_t)gn * p.ldb + gk, p.K - gk, p.b_vec != 0);
+      } else {
+        const int kr = f >> 4, c4 = (f & 15) * 4;
+        const int gk = k0 + kr, gn = n0 + c4;
+        if (gk < p.K) v = load4_guard(p.B, (int64_t)gk * p.ldb + gn, p.N - gn, p.b_vec != 0);
+      }
+      rb[i] = v;
+    }
+  };
+
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int f = tid + 256 * i;
+      const int row = f >> 3, c4 = (f & 7) * 4;
+      *reinterpret_cast<f32x4*>(&sA[row * LDS_A + c4]) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int f = tid + 256 * i;
+      if (B_NK) {
+        const int nr = f >> 3, c4 = (f & 7) * 4;
+        *reinterpret_cast<f32x4*>(&sB[nr * LDS_BK + c4]) = rb[i];
+      } else {
+        const int kr = f >> 4, c4 = (f & 15) * 4;
+        *reinterpret_cast<f32x4*>(&sB[kr * LDS_BN + c4]) = rb[i];
+      }
+    }
+  };
+
+  const int nk = (p.K + BK - 1) / BK;
+  load_tiles(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    store_tiles();
+    __syncthreads();
+    if (kt + 1 < nk) load_tiles((kt + 1) * BK);
+    const int arow = wave * 32 + l31;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(&sA[arow * LDS_A + 8 * t + 4 * h]);
+      if (B_NK) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(&sB[l31 * LDS_BK + 8 * t + 4 * h]);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(&sB[(32 + l31) * LDS_BK + 8 * t + 4 * h]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b0[r], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b1[r], acc1, 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kk = 8 * t + 4 * h + r;
+          const float b0 = sB[kk * LDS_BN + l31];
+          const float b1 = sB[kk * LDS_BN + 32 + l31];
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b0, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[r], b1, acc1, 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue -------------------------------------------------------------------------------------------
+#pragma unroll
+  for (int jt = 0; jt < 2; ++jt) {
+    const int col = n0 + jt * 32 + l31;
+    if (col >= p.N) continue;
+    float bv = 0.f;
+    if (EPI == B4R_EPI_BIAS || EPI == B4R_EPI_BIAS_QSCALE || EPI == B4R_EPI_BIAS_GELU || EPI == B4R_EPI_BIAS_DROP_RES ||
+        EPI == B4R_EPI_BIAS_TANH)
+      bv = p.bias[col];
+    const float qs = (EPI == B4R_EPI_BIAS_QSCALE && col < p.qcols) ? p.qscale : 1.0f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = m0 + wave * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      if (row >= p.M) continue;
+      float v = (jt == 0 ? acc0[reg] : acc1[reg]);
+      const int64_t co = (int64_t)row * p.ldc + col;
+      if (EPI == B4R_EPI_NONE) {
+        p.C[co] = v;
+      } else if (EPI == B4R_EPI_BIAS) {
+        p.C[co] = v + bv;
+      } else if (EPI == B4R_EPI_BIAS_QSCALE) {
+        p.C[co] = (v + bv) * qs;
+      } else if (EPI == B4R_EPI_BIAS_GELU) {
+        const float pre = v + bv;
+        p.C2[(int64_t)row * p.ldc2 + col] = pre;
+        p.C[co] = b4r_gelu(pre);
+      } else if (EPI == B4R_EPI_BIAS_DROP_RES) {
+        float y = v + bv;
+        y = b4r_drop(dctx, y, (uint64_t)row * (uint64_t)p.N + (uint64_t)col);
+        p.C[co] = p.R[(int64_t)row * p.ldr + col] + y;
+      } else if (EPI == B4R_EPI_GELU_BWD) {
+        p.C[co] = v * b4r_gelu_grad(p.R[(int64_t)row * p.ldr + col]);
+      } else if (EPI == B4R_EPI_ADD_RES) {
+        p.C[co] = v + p.R[(int64_t)row * p.ldr + col];
+      } else if (EPI == B4R_EPI_BIAS_TANH) {
+        p.C[co] = tanhf(v + bv);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// TN: out[Mo,No] = sum_r A[r,Mo]^T B[r,No]
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int TB = 64;   // output tile 64 x 64
+constexpr int TK = 32;   // rows per stage
+
+struct TnP {
+  const float* A; const float* B; float* slab; float* colsum_slab; float* colsum_a_slab;
+  int lda, ldb;
+  int R, Mo, No;
+  int chunk;  // rows per z-slice (multiple of TK)
+  int a_vec, b_vec;
+  DropArgs drop;
+};
+
+template <bool B_DROP>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(TnP p) {
+  __shared__ __attribute__((aligned(16))) float sA[TK * TB];
+  __shared__ __attribute__((aligned(16))) float sB[TK * TB];
+  __shared__ float sRed[4 * TB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i0 = blockIdx.x * TB, j0 = blockIdx.y * TB, z = blockIdx.z;
+  const int r_begin = z * p.chunk;
+  const int r_end = min(p.R, r_begin + p.chunk);
+  const int h = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  const bool do_colsum = (p.colsum_slab != nullptr) && (blockIdx.x == 0);
+  const bool do_colsum_a = (p.colsum_a_slab != nullptr) && (blockIdx.y == 0);
+
+  DropCtx dctx = b4r_drop_ctx(p.drop);
+
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  float cs = 0.f, csa = 0.f;
+
+  f32x4 ra[2], rb[2];
+  auto load_tiles = [&](int r0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int f = tid + 256 * i;
+      const int rr = f >> 4, c4 = (f & 15) * 4;
+      const int gr = r0 + rr;
+      f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+      if (gr < r_end) {
+        va = load4_guard(p.A, (int64_t)gr * p.lda + i0 + c4, p.Mo - (i0 + c4), p.a_vec != 0);
+        vb = load4_guard(p.B, (int64_t)gr * p.ldb + j0 + c4, p.No - (j0 + c4), p.b_vec != 0);
+        if (B_DROP) {
+          if (dctx.on) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              vb[e] = b4r_drop(dctx, vb[e], (uint64_t)gr * (uint64_t)p.No + (uint64_t)(j0 + c4 + e));
+          }
+        }
+      }
+      ra[i] = va; rb[i] = vb;
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int f = tid + 256 * i;
+      const int rr = f >> 4, c4 = (f & 15) * 4;
+      *reinterpret_cast<f32x4*>(&sA[rr * TB + c4]) = ra[i];
+      *reinterpret_cast<f32x4*>(&sB[rr * TB + c4]) = rb[i];
+    }
+  };
+
+  if (r_begin < r_end) load_tiles(r_begin);
+  for (int r0 = r_begin; r0 < r_end; r0 += TK) {
+    __syncthreads();
+    store_tiles();
+    __syncthreads();
+    if (r0 + TK < r_end) load_tiles(r0 + TK);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const float a = sA[(2 * s + h) * TB + 32 * wm + l31];
+      const float b = sB[(2 * s + h) * TB + 32 * wn + l31];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    if (do_colsum) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) cs += sB[(wave * 8 + r) * TB + lane];
+    }
+    if (do_colsum_a) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) csa += sA[(wave * 8 + r) * TB + lane];
+    }
+  }
+
+  const int col = j0 + 32 * wn + l31;
+  if (col < p.No) {
+    float* slab = p.slab + (int64_t)z * p.Mo * p.No;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = i0 + 32 * wm + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      if (row < p.Mo) slab[(int64_t)row * p.No + col] = acc[reg];
+    }
+  }
+  if (do_colsum) {
+    sRed[wave * TB + lane] = cs;
+    __syncthreads();
+    if (tid < TB && j0 + tid < p.No)
+      p.colsum_slab[(int64_t)z * p.No + j0 + tid] = (sRed[tid] + sRed[TB + tid]) + (sRed[2 * TB + tid] + sRed[3 * TB + tid]);
+  }
+  if (do_colsum_a) {
+    __syncthreads();
+    sRed[wave * TB + lane] = csa;
+    __syncthreads();
+    if (tid < TB && i0 + tid < p.Mo)
+      p.colsum_a_slab[(int64_t)z * p.Mo + i0 + tid] = (sRed[tid] + sRed[TB + tid]) + (sRed[2 * TB + tid] + sRed[3 * TB + tid]);
+  }
+}
+
+// out[row*ldo+col] (+)= sum_z slab[z][row][col]   (z ascending: fixed order)
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* slab, int S, int Mo, int No, float* out, int ldo,
+                                                          int accumulate, const float* cslab, float* colsum,
+                                                          const float* caslab, float* colsum_a) {
+  const int64_t total = (int64_t)Mo * No;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int z = 0; z < S; ++z) s += slab[(int64_t)z * total + e];
+    const int row = (int)(e / No), col = (int)(e % No);
+    float* o = out + (int64_t)row * ldo + col;
+    *o = accumulate ? (*o + s) : s;
+  }
+  if (colsum != nullptr && blockIdx.x == 0) {
+    for (int c = threadIdx.x; c < No; c += 256) {
+      float s = 0.f;
+      for (int z = 0; z < S; ++z) s += cslab[(int64_t)z * No + c];
+      colsum[c] = s;
+    }
+  }
+  if (colsum_a != nullptr && blockIdx.x == 0) {
+    for (int c = threadIdx.x; c < Mo; c += 256) {
+      float s = 0.f;
+      for (int z = 0; z < S; ++z) s += caslab[(int64_t)z * Mo + c];
+      colsum_a[c] = s;
+    }
+  }
+}
+
+int tn_split(int R, int Mo, int No) {
+  const int tiles = b4r_cdiv(Mo, TB) * b4r_cdiv(No, TB);
+  int S = b4r_cdiv(768, tiles);
+  const int max_s = b4r_cdiv(R, 4 * TK);  // at least 128 rows per slice
+  if (S > max_s) S = max_s;
+  if (S < 1) S = 1;
+  if (S > 512) S = 512;
+  return S;
+}
+
+template <bool B_NK, int EPI>
+void launch_gemm(const GemmP& p, int a_drop, dim3 grid, hipStream_t s) {
+  if (a_drop)
+    hipLaunchKernelGGL((gemm_kernel<B_NK, EPI, true>), grid, dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL((gemm_kernel<B_NK, EPI, false>), grid, dim3(256), 0, s, p);
+}
+
+template <bool B_NK>
+int dispatch_epi(const GemmP& p, int epi, int a_drop, dim3 grid, hipStream_t s) {
+  switch (epi) {
+    case B4R_EPI_NONE: launch_gemm<B_NK, B4R_EPI_NONE>(p, a_drop, grid, s); break;
+    case B4R_EPI_BIAS: launch_gemm<B_NK, B4R_EPI_BIAS>(p, a_drop, grid, s); break;
+    case B4R_EPI_BIAS_QSCALE: launch_gemm<B_NK, B4R_EPI_BIAS_QSCALE>(p, a_drop, grid, s); break;
+    case B4R_EPI_BIAS_GELU: launch_gemm<B_NK, B4R_EPI_BIAS_GELU>(p, a_drop, grid, s); break;
+    case B4R_EPI_BIAS_DROP_RES: launch_gemm<B_NK, B4R_EPI_BIAS_DROP_RES>(p, a_drop, grid, s); break;
+    case B4R_EPI_GELU_BWD: launch_gemm<B_NK, B4R_EPI_GELU_BWD>(p, a_drop, grid, s); break;
+    case B4R_EPI_ADD_RES: launch_gemm<B_NK, B4R_EPI_ADD_RES>(p, a_drop, grid, s); break;
+    case B4R_EPI_BIAS_TANH: launch_gemm<B_NK, B4R_EPI_BIAS_TANH>(p, a_drop, grid, s); break;
+    default: b4r_set_error("b4r_gemm_f32: unknown epilogue %d", epi); return B4R_E_BADARG;
+  }
+  return B4R_OK;
+}
+
+}  // namespace
+
+int b4r_launch_slab_reduce(const float* slab, int S, int Mo, int No, float* out, int ldo, int accumulate,
+                           hipStream_t stream) {
+  const int64_t total = (int64_t)Mo * No;
+  int rgrid = (int)((total + 255) / 256);
+  if (rgrid > 2048) rgrid = 2048;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(rgrid), dim3(256), 0, stream, slab, S, Mo, No, out, ldo, accumulate,
+                     (const float*)nullptr, (float*)nullptr, (const float*)nullptr, (float*)nullptr);
+  B4R_CHECK_LAUNCH("slab_reduce");
+  return B4R_OK;
+}
+
+extern "C" int b4r_gemm_f32(const b4r_gemm_desc* d, b4r_stream_t stream) {
+  B4R_CHECK_ARG(d != nullptr, B4R_E_BADARG, "b4r_gemm_f32: null descriptor");
+  B4R_CHECK_ARG(d->A && d->B && d->C, B4R_E_BADARG, "b4r_gemm_f32: null operand");
+  B4R_CHECK_ARG(d->M > 0 && d->N > 0 && d->K > 0, B4R_E_SHAPE, "b4r_gemm_f32: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
+  B4R_CHECK_ARG(d->lda >= d->K && d->ldc >= d->N && d->ldb >= (d->b_is_nk ? d->K : d->N), B4R_E_SHAPE,
+                "b4r_gemm_f32: leading dimension smaller than the row length");
+  const int epi = d->epilogue;
+  const bool needs_bias = epi == B4R_EPI_BIAS || epi == B4R_EPI_BIAS_QSCALE || epi == B4R_EPI_BIAS_GELU ||
+                          epi == B4R_EPI_BIAS_DROP_RES || epi == B4R_EPI_BIAS_TANH;
+  B4R_CHECK_ARG(!needs_bias || d->bias, B4R_E_BADARG, "b4r_gemm_f32: epilogue %d needs a bias", epi);
+  const bool needs_r = epi == B4R_EPI_BIAS_DROP_RES || epi == B4R_EPI_GELU_BWD || epi == B4R_EPI_ADD_RES;
+  B4R_CHECK_ARG(!needs_r || (d->R && d->ldr >= d->N), B4R_E_BADARG, "b4r_gemm_f32: epilogue %d needs R", epi);
+  B4R_CHECK_ARG(epi != B4R_EPI_BIAS_GELU || (d->C2 && d->ldc2 >= d->N), B4R_E_BADARG, "b4r_gemm_f32: BIAS_GELU needs C2");
+
+  GemmP p;
+  p.A = d->A; p.B = d->B; p.C = d->C; p.bias = d->bias; p.C2 = d->C2; p.R = d->R;
+  p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldc2 = d->ldc2; p.ldr = d->ldr;
+  p.M = d->M; p.N = d->N; p.K = d->K;
+  p.tiles_n = b4r_cdiv(d->N, BN);
+  p.a_vec = (b4r_aligned16(d->A) && (d->lda % 4 == 0)) ? 1 : 0;
+  p.b_vec = (b4r_aligned16(d->B) && (d->ldb % 4 == 0)) ? 1 : 0;
+  p.qscale = d->qscale; p.qcols = d->qcols;
+  p.drop = b4r_make_drop(d->rng, d->drop_stream, d->drop_rate, 1);
+  const int a_drop = (d->a_dropout && p.drop.rng != nullptr) ? 1 : 0;
+  const int64_t tiles = (int64_t)b4r_cdiv(d->M, BM) * p.tiles_n;
+  B4R_CHECK_ARG(tiles < 2147483647LL, B4R_E_SHAPE, "b4r_gemm_f32: too many tiles");
+  dim3 grid((unsigned)tiles);
+  int rc = d->b_is_nk ? dispatch_epi<true>(p, epi, a_drop, grid, (hipStream_t)stream)
+                      : dispatch_epi<false>(p, epi, a_drop, grid, (hipStream_t)stream);
+  if (rc != B4R_OK) return rc;
+  B4R_CHECK_LAUNCH("b4r_gemm_f32");
+  return B4R_OK;
+}
+
+extern "C" int64_t b4r_gemm_tn_scratch_floats(int32_t R, int32_t Mo, int32_t No) {
+  if (R <= 0 || Mo <= 0 || No <= 0) return 0;
+  const int S = tn_split(R, Mo, No);
+  return (int64_t)S * Mo * No + (int64_t)S * No + (int64_t)S * Mo;
+}
+
+extern "C" int b4r_gemm_tn_f32(const b4r_gemm_tn_desc* d, float* scratch, b4r_stream_t stream) {
+  B4R_CHECK_ARG(d != nullptr && scratch != nullptr, B4R_E_BADARG, "b4r_gemm_tn_f32: null argument");
+  B4R_CHECK_ARG(d->A && d->B && d->out, B4R_E_BADARG, "b4r_gemm_tn_f32: null operand");
+  B4R_CHECK_ARG(d->R > 0 && d->Mo > 0 && d->No > 0, B4R_E_SHAPE, "b4r_gemm_tn_f32: bad shape");
+  B4R_CHECK_ARG(d->lda >= d->Mo && d->ldb >= d->No && d->ldo >= d->No, B4R_E_SHAPE, "b4r_gemm_tn_f32: bad leading dimension");
+  const int S = tn_split(d->R, d->Mo, d->No);
+  TnP p;
+  p.A = d->A; p.B = d->B; p.lda = d->lda; p.ldb = d->ldb;
+  p.R = d->R; p.Mo = d->Mo; p.No = d->No;
+  p.chunk = b4r_cdiv(b4r_cdiv(d->R, S), TK) * TK;
+  p.slab = scratch;
+  p.colsum_slab = d->colsum ? scratch + (int64_t)S * d->Mo * d->No : nullptr;
+  p.colsum_a_slab = d->colsum_a ? scratch + (int64_t)S * d->Mo * d->No + (int64_t)S * d->No : nullptr;
+  p.a_vec = (b4r_aligned16(d->A) && (d->lda % 4 == 0)) ? 1 : 0;
+  p.b_vec = (b4r_aligned16(d->B) && (d->ldb % 4 == 0)) ? 1 : 0;
+  p.drop = b4r_make_drop(d->rng, d->drop_stream, d->drop_rate, 1);
+  const bool b_drop = d->b_dropout && p.drop.rng != nullptr;
+  dim3 grid(b4r_cdiv(d->Mo, TB), b4r_cdiv(d->No, TB), S);
+  if (b_drop)
+    hipLaunchKernelGGL((gemm_tn_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL((gemm_tn_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  B4R_CHECK_LAUNCH("b4r_gemm_tn_f32");
+  const int64_t total = (int64_t)d->Mo * d->No;
+  int rgrid = (int)((total + 255) / 256);
+  if (rgrid > 2048) rgrid = 2048;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(rgrid), dim3(256), 0, (hipStream_t)stream, p.slab, S, d->Mo, d->No,
+                     d->out, d->ldo, d->accumulate, p.colsum_slab, d->colsum, p.colsum_a_slab, d->colsum_a);
+  B4R_CHECK_LAUNCH("b4r_gemm_tn_f32 reduce");
+  return B4R_OK;
+}

@@ -1,0 +1,465 @@
+// Model-level entry points: parameter / workspace layout and the launch sequences of one forward, loss, backward and
+// optimizer step.  Host code only: every function just enqueues kernels on the caller's stream (hipGraph-capturable).
+//
+// Follows  BERT4RecModel.call        bert4rec/models/bert4rec_model.py:110-149
+//          Bert4RecEncoder.call      bert4rec/models/components/networks/bert4rec_encoder.py:186-231
+//          (tfm TransformerEncoderBlock post-LN, Keras MultiHeadAttention, tfm MaskedLM: SURVEY.md §8 a4-a8)
+//          train_step                bert4rec_model.py:151-173
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "b4r_common.h"
+
+// ---- internal launchers defined in the other translation units --------------------------------------------------
+int b4r_ln_bwd_launch(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
+                      int rows, int H, float* dz, float* dgamma, float* dbeta, float* scratch, const int64_t* ids,
+                      const float* table, const float* pos_table, int L, int V, DropArgs drop, hipStream_t stream);
+int b4r_scatter_add_rows_impl(const float* src, const int64_t* idx, int64_t idx_add_per, int per, int n, int H,
+                              float* dst, int dst_ld, const int64_t* skip_if_zero, int64_t dst_rows, hipStream_t stream);
+int b4r_batch_colsum(const float* x, int B, int L, int H, float* dpos, float* scratch, hipStream_t stream);
+int b4r_mul_gelu_grad(float* du, const float* pre, int64_t n, hipStream_t stream);
+
+// ---- error message (thread local) ---------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void b4r_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" size_t b4r_last_error(char* buf, size_t cap) {
+  const size_t n = strlen(g_err);
+  if (buf && cap) {
+    const size_t c = n < cap - 1 ? n : cap - 1;
+    memcpy(buf, g_err, c);
+    buf[c] = 0;
+  }
+  return n;
+}
+extern "C" int b4r_version(void) { return B4R_VERSION; }
+
+namespace {
+
+inline int64_t up4(int64_t x) { return (x + 3) & ~(int64_t)3; }
+inline int64_t up32(int64_t x) { return (x + 31) & ~(int64_t)31; }
+
+int check_cfg(const b4r_model_config* c) {
+  B4R_CHECK_ARG(c != nullptr, B4R_E_BADARG, "null model config");
+  B4R_CHECK_ARG(c->vocab_size > 0 && c->num_layers > 0 && c->num_layers <= B4R_MAX_LAYERS && c->num_heads > 0 &&
+                    c->inner_dim > 0 && c->max_seq_len > 0,
+                B4R_E_SHAPE, "bad model config");
+  B4R_CHECK_ARG(c->hidden_size == 32 * c->num_heads, B4R_E_SHAPE,
+                "hidden_size %d / num_heads %d: head_dim must be 32", c->hidden_size, c->num_heads);
+  const int H = c->hidden_size;
+  B4R_CHECK_ARG(H == 32 || H == 64 || H == 128 || H == 256 || H == 512 || H == 1024, B4R_E_SHAPE,
+                "hidden_size %d not supported (32,64,128,256,512,1024)", H);
+  B4R_CHECK_ARG(c->inner_dim % 4 == 0, B4R_E_SHAPE, "inner_dim must be a multiple of 4");
+  B4R_CHECK_ARG(c->output_dropout >= 0.f && c->output_dropout < 1.f && c->attention_dropout >= 0.f && c->attention_dropout < 1.f,
+                B4R_E_BADARG, "dropout rates must be in [0,1)");
+  return B4R_OK;
+}
+
+struct ParamEntry {
+  std::string name;
+  int64_t offset;
+  int rows, cols, ld, decay;
+};
+
+struct ParamLayout {
+  int64_t total = 0, n_decay = 0;
+  int64_t word_emb = 0, pos_emb = 0, emb_ln_g = 0, emb_ln_b = 0;
+  int64_t wqkv[B4R_MAX_LAYERS], wo[B4R_MAX_LAYERS], w1[B4R_MAX_LAYERS], w2[B4R_MAX_LAYERS];
+  int64_t bqkv[B4R_MAX_LAYERS], bo[B4R_MAX_LAYERS], ln1_g[B4R_MAX_LAYERS], ln1_b[B4R_MAX_LAYERS], b1[B4R_MAX_LAYERS],
+      b2[B4R_MAX_LAYERS], ln2_g[B4R_MAX_LAYERS], ln2_b[B4R_MAX_LAYERS];
+  int64_t wd = 0, bd = 0, lnm_g = 0, lnm_b = 0, out_bias = 0;
+  std::vector<ParamEntry> entries;
+};
+
+ParamLayout make_param_layout(const b4r_model_config& c) {
+  ParamLayout p;
+  const int64_t H = c.hidden_size, I = c.inner_dim, V = c.vocab_size, Lm = c.max_seq_len;
+  int64_t off = 0;
+  auto take = [&](int64_t n) { int64_t o = off; off += up4(n); return o; };
+  auto add = [&](const std::string& name, int64_t o, int rows, int cols, int ld, int decay) {
+    p.entries.push_back(ParamEntry{name, o, rows, cols, ld, decay});
+  };
+  // ---- weight-decayed region: kernels and the two embedding tables
+  p.word_emb = take(V * H); add("word_embeddings/embeddings", p.word_emb, (int)V, (int)H, (int)H, 1);
+  p.pos_emb = take(Lm * H); add("position_embedding/embeddings", p.pos_emb, (int)Lm, (int)H, (int)H, 1);
+  for (int i = 0; i < c.num_layers; ++i) {
+    const std::string pre = "transformer/layer_" + std::to_string(i);
+    p.wqkv[i] = take(H * 3 * H);
+    add(pre + "/self_attention/query/kernel", p.wqkv[i], (int)H, (int)H, (int)(3 * H), 1);
+    add(pre + "/self_attention/key/kernel", p.wqkv[i] + H, (int)H, (int)H, (int)(3 * H), 1);
+    add(pre + "/self_attention/value/kernel", p.wqkv[i] + 2 * H, (int)H, (int)H, (int)(3 * H), 1);
+    p.wo[i] = take(H * H); add(pre + "/self_attention/attention_output/kernel", p.wo[i], (int)H, (int)H, (int)H, 1);
+    p.w1[i] = take(H * I); add(pre + "/intermediate/kernel", p.w1[i], (int)H, (int)I, (int)I, 1);
+    p.w2[i] = take(I * H); add(pre + "/output/kernel", p.w2[i], (int)I, (int)H, (int)H, 1);
+  }
+  p.wd = take(H * H); add("cls/predictions/transform/dense/kernel", p.wd, (int)H, (int)H, (int)H, 1);
+  p.n_decay = off;
+  // ---- not decayed: every bias and LayerNorm gamma/beta
+  p.emb_ln_g = take(H); add("embeddings/layer_norm/gamma", p.emb_ln_g, 1, (int)H, (int)H, 0);
+  p.emb_ln_b = take(H); add("embeddings/layer_norm/beta", p.emb_ln_b, 1, (int)H, (int)H, 0);
+  for (int i = 0; i < c.num_layers; ++i) {
+    const std::string pre = "transformer/layer_" + std::to_string(i);
+    p.bqkv[i] = take(3 * H);
+    add(pre + "/self_attention/query/bias", p.bqkv[i], 1, (int)H, (int)H, 0);
+    add(pre + "/self_attention/key/bias", p.bqkv[i] + H, 1, (int)H, (int)H, 0);
+    add(pre + "/self_attention/value/bias", p.bqkv[i] + 2 * H, 1, (int)H, (int)H, 0);
+    p.bo[i] = take(H); add(pre + "/self_attention/attention_output/bias", p.bo[i], 1, (int)H, (int)H, 0);
+    p.ln1_g[i] = take(H); add(pre + "/self_attention_layer_norm/gamma", p.ln1_g[i], 1, (int)H, (int)H, 0);
+    p.ln1_b[i] = take(H); add(pre + "/self_attention_layer_norm/beta", p.ln1_b[i], 1, (int)H, (int)H, 0);
+    p.b1[i] = take(I); add(pre + "/intermediate/bias", p.b1[i], 1, (int)I, (int)I, 0);
+    p.b2[i] = take(H); add(pre + "/output/bias", p.b2[i], 1, (int)H, (int)H, 0);
+    p.ln2_g[i] = take(H); add(pre + "/output_layer_norm/gamma", p.ln2_g[i], 1, (int)H, (int)H, 0);
+    p.ln2_b[i] = take(H); add(pre + "/output_layer_norm/beta", p.ln2_b[i], 1, (int)H, (int)H, 0);
+  }
+  p.bd = take(H); add("cls/predictions/transform/dense/bias", p.bd, 1, (int)H, (int)H, 0);
+  p.lnm_g = take(H); add("cls/predictions/transform/LayerNorm/gamma", p.lnm_g, 1, (int)H, (int)H, 0);
+  p.lnm_b = take(H); add("cls/predictions/transform/LayerNorm/beta", p.lnm_b, 1, (int)H, (int)H, 0);
+  p.out_bias = take(V); add("cls/predictions/output_bias/bias", p.out_bias, 1, (int)V, (int)V, 0);
+  p.total = off;
+  return p;
+}
+
+struct WsLayout {
+  int64_t total = 0;  // floats
+  int64_t N = 0, M = 0, Vp = 0;
+  int64_t x0, mean0, rstd0;
+  int64_t qkv[B4R_MAX_LAYERS], lse[B4R_MAX_LAYERS], ctx[B4R_MAX_LAYERS], z1[B4R_MAX_LAYERS], mean1[B4R_MAX_LAYERS],
+      rstd1[B4R_MAX_LAYERS], x1[B4R_MAX_LAYERS], fpre[B4R_MAX_LAYERS], f[B4R_MAX_LAYERS], z2[B4R_MAX_LAYERS],
+      mean2[B4R_MAX_LAYERS], rstd2[B4R_MAX_LAYERS], x2[B4R_MAX_LAYERS];
+  int64_t gath, upre, u, meanm, rstdm, t, logits, rowsc, pooled;
+  int64_t dx, da, db, dctx, dqkv, df, dt, dg;
+  int64_t scratch, scratch_floats;
+};
+
+WsLayout make_ws_layout(const b4r_model_config& c, int B, int L, int P) {
+  WsLayout w;
+  const int64_t H = c.hidden_size, I = c.inner_dim, V = c.vocab_size;
+  const int64_t N = (int64_t)B * L, M = (int64_t)B * (P > 0 ? P : 0);
+  w.N = N; w.M = M; w.Vp = up32(V);
+  int64_t off = 0;
+  auto take = [&](int64_t n) { int64_t o = off; off += up4(n); return o; };
+  w.x0 = take(N * H); w.mean0 = take(N); w.rstd0 = take(N);
+  for (int i = 0; i < c.num_layers; ++i) {
+    w.qkv[i] = take(N * 3 * H); w.lse[i] = take((int64_t)B * c.num_heads * L); w.ctx[i] = take(N * H);
+    w.z1[i] = take(N * H); w.mean1[i] = take(N); w.rstd1[i] = take(N); w.x1[i] = take(N * H);
+    w.fpre[i] = take(N * I); w.f[i] = take(N * I);
+    w.z2[i] = take(N * H); w.mean2[i] = take(N); w.rstd2[i] = take(N); w.x2[i] = take(N * H);
+  }
+  w.gath = take(M * H); w.upre = take(M * H); w.u = take(M * H); w.meanm = take(M); w.rstdm = take(M);
+  w.t = take(M * H); w.logits = take(M * w.Vp); w.rowsc = take(4 * M); w.pooled = take((int64_t)B * H);
+  w.dx = take(N * H); w.da = take(N * H); w.db = take(N * H); w.dctx = take(N * H);
+  w.dqkv = take(N * 3 * H); w.df = take(N * I); w.dt = take(M * H); w.dg = take(M * H);
+  // scratch: the largest of every two-stage reduction that uses it (they run one after another on the stream)
+  int64_t s = 4096;
+  auto mx = [&](int64_t v) { if (v > s) s = v; };
+  mx(b4r_ln_bwd_scratch_floats((int)N, (int)H));
+  if (M > 0) mx(b4r_ln_bwd_scratch_floats((int)M, (int)H));
+  mx(b4r_gemm_tn_scratch_floats((int)N, (int)H, (int)(3 * H)));
+  mx(b4r_gemm_tn_scratch_floats((int)N, (int)H, (int)H));
+  mx(b4r_gemm_tn_scratch_floats((int)N, (int)H, (int)I));
+  mx(b4r_gemm_tn_scratch_floats((int)N, (int)I, (int)H));
+  if (M > 0) {
+    mx(b4r_gemm_tn_scratch_floats((int)M, (int)V, (int)H));
+    mx(b4r_gemm_tn_scratch_floats((int)M, (int)H, (int)H));
+  }
+  mx((int64_t)b4r_cdiv(B, 16) * L * H);  // position-table gradient partials
+  w.scratch = take(s); w.scratch_floats = s;
+  w.total = off;
+  return w;
+}
+
+int check_batch(const b4r_batch* b, const b4r_model_config* c, bool need_mlm) {
+  B4R_CHECK_ARG(b != nullptr, B4R_E_BADARG, "null batch");
+  B4R_CHECK_ARG(b->input_word_ids && b->input_mask, B4R_E_BADARG, "batch needs input_word_ids and input_mask");
+  B4R_CHECK_ARG(b->B > 0 && b->L > 0 && b->P >= 0, B4R_E_SHAPE, "bad batch shape B=%d L=%d P=%d", b->B, b->L, b->P);
+  B4R_CHECK_ARG(b->L <= c->max_seq_len, B4R_E_SHAPE, "sequence length %d exceeds max_sequence_length %d", b->L, c->max_seq_len);
+  B4R_CHECK_ARG(b->L <= 256, B4R_E_SHAPE, "sequence length %d > 256 not supported", b->L);
+  B4R_CHECK_ARG(!need_mlm || (b->masked_lm_positions && b->P > 0), B4R_E_BADARG, "batch needs masked_lm_positions");
+  return B4R_OK;
+}
+
+#define RC(x)                 \
+  do {                        \
+    int rc__ = (x);           \
+    if (rc__ != B4R_OK) return rc__; \
+  } while (0)
+
+int gemm(const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, int M, int N, int K, int b_is_nk, int epi,
+         const float* bias, float* C2, int ldc2, const float* R, int ldr, float qscale, int qcols, const uint32_t* rng,
+         uint32_t stream_id, float rate, int a_dropout, hipStream_t s) {
+  b4r_gemm_desc d{};
+  d.A = A; d.lda = lda; d.B = Bm; d.ldb = ldb; d.C = C; d.ldc = ldc; d.M = M; d.N = N; d.K = K;
+  d.b_is_nk = b_is_nk; d.epilogue = epi; d.bias = bias; d.C2 = C2; d.ldc2 = ldc2; d.R = R; d.ldr = ldr;
+  d.qscale = qscale; d.qcols = qcols; d.rng = rng; d.drop_stream = stream_id; d.drop_rate = rate; d.a_dropout = a_dropout;
+  return b4r_gemm_f32(&d, (b4r_stream_t)s);
+}
+
+int gemm_tn(const float* A, int lda, const float* Bm, int ldb, float* out, int ldo, int R, int Mo, int No, float* colsum,
+            float* colsum_a, const uint32_t* rng, uint32_t stream_id, float rate, int b_dropout, float* scratch,
+            hipStream_t s) {
+  b4r_gemm_tn_desc d{};
+  d.A = A; d.lda = lda; d.B = Bm; d.ldb = ldb; d.out = out; d.ldo = ldo; d.R = R; d.Mo = Mo; d.No = No;
+  d.colsum = colsum; d.colsum_a = colsum_a; d.rng = rng; d.drop_stream = stream_id; d.drop_rate = rate;
+  d.b_dropout = b_dropout; d.accumulate = 0;
+  return b4r_gemm_tn_f32(&d, scratch, (b4r_stream_t)s);
+}
+
+}  // namespace
+
+// ===============================================================================================================
+extern "C" int64_t b4r_param_total_floats(const b4r_model_config* cfg) {
+  if (check_cfg(cfg)) return -1;
+  return make_param_layout(*cfg).total;
+}
+extern "C" int64_t b4r_param_decay_floats(const b4r_model_config* cfg) {
+  if (check_cfg(cfg)) return -1;
+  return make_param_layout(*cfg).n_decay;
+}
+extern "C" int32_t b4r_param_count(const b4r_model_config* cfg) {
+  if (check_cfg(cfg)) return -1;
+  return (int32_t)make_param_layout(*cfg).entries.size();
+}
+extern "C" int b4r_param_info(const b4r_model_config* cfg, int32_t index, char* name, size_t name_cap, int64_t* offset,
+                              int32_t* rows, int32_t* cols, int32_t* ld, int32_t* decay) {
+  RC(check_cfg(cfg));
+  const ParamLayout p = make_param_layout(*cfg);
+  B4R_CHECK_ARG(index >= 0 && index < (int)p.entries.size(), B4R_E_BADARG, "b4r_param_info: index %d out of range", index);
+  const ParamEntry& e = p.entries[index];
+  if (name && name_cap) snprintf(name, name_cap, "%s", e.name.c_str());
+  if (offset) *offset = e.offset;
+  if (rows) *rows = e.rows;
+  if (cols) *cols = e.cols;
+  if (ld) *ld = e.ld;
+  if (decay) *decay = e.decay;
+  return B4R_OK;
+}
+extern "C" int64_t b4r_pooler_floats(const b4r_model_config* cfg) {
+  if (check_cfg(cfg)) return -1;
+  return (int64_t)cfg->hidden_size * cfg->hidden_size + cfg->hidden_size;
+}
+extern "C" int64_t b4r_workspace_bytes(const b4r_model_config* cfg, int32_t B, int32_t L, int32_t P) {
+  if (check_cfg(cfg) || B <= 0 || L <= 0 || P < 0) return -1;
+  return make_ws_layout(*cfg, B, L, P).total * (int64_t)sizeof(float);
+}
+extern "C" int b4r_workspace_region(const b4r_model_config* cfg, int32_t B, int32_t L, int32_t P, const char* name,
+                                    int64_t* offset_floats, int32_t* rows, int32_t* cols, int32_t* ld) {
+  RC(check_cfg(cfg));
+  B4R_CHECK_ARG(name && B > 0 && L > 0 && P >= 0, B4R_E_BADARG, "b4r_workspace_region: bad argument");
+  const WsLayout w = make_ws_layout(*cfg, B, L, P);
+  const int H = cfg->hidden_size, nl = cfg->num_layers;
+  int64_t off = -1; int r = 0, c = 0, l = 0;
+  const std::string n(name);
+  if (n == "sequence_output") { off = w.x2[nl - 1]; r = (int)w.N; c = H; l = H; }
+  else if (n == "embeddings") { off = w.x0; r = (int)w.N; c = H; l = H; }
+  else if (n == "mlm_logits") { off = w.logits; r = (int)w.M; c = cfg->vocab_size; l = (int)w.Vp; }
+  else if (n == "mlm_hidden") { off = w.t; r = (int)w.M; c = H; l = H; }
+  else if (n == "pooled_output") { off = w.pooled; r = B; c = H; l = H; }
+  else if (n == "grad_sequence_output") { off = w.dx; r = (int)w.N; c = H; l = H; }
+  else if (n.rfind("encoder_output_", 0) == 0) {
+    const int i = atoi(n.c_str() + 15);
+    B4R_CHECK_ARG(i >= 0 && i < nl, B4R_E_BADARG, "b4r_workspace_region: no layer %d", i);
+    off = w.x2[i]; r = (int)w.N; c = H; l = H;
+  } else if (n.rfind("attention_context_", 0) == 0) {
+    const int i = atoi(n.c_str() + 18);
+    B4R_CHECK_ARG(i >= 0 && i < nl, B4R_E_BADARG, "b4r_workspace_region: no layer %d", i);
+    off = w.ctx[i]; r = (int)w.N; c = H; l = H;
+  }
+  B4R_CHECK_ARG(off >= 0, B4R_E_BADARG, "b4r_workspace_region: unknown region '%s'", name);
+  if (offset_floats) *offset_floats = off;
+  if (rows) *rows = r;
+  if (cols) *cols = c;
+  if (ld) *ld = l;
+  return B4R_OK;
+}
+
+// ===============================================================================================================
+extern "C" int b4r_forward(const b4r_model_config* cfg, const b4r_batch* batch, const float* params, const float* pooler,
+                           void* workspace, int64_t workspace_bytes, b4r_train_state* state, int32_t flags,
+                           b4r_stream_t stream) {
+  RC(check_cfg(cfg));
+  RC(check_batch(batch, cfg, false));
+  B4R_CHECK_ARG(params && workspace, B4R_E_BADARG, "b4r_forward: null params/workspace");
+  B4R_CHECK_ARG(b4r_aligned16(params) && b4r_aligned16(workspace), B4R_E_ALIGN, "b4r_forward: buffers must be 16-byte aligned");
+  const int B = batch->B, L = batch->L, P = batch->masked_lm_positions ? batch->P : 0;
+  const ParamLayout pl = make_param_layout(*cfg);
+  const WsLayout w = make_ws_layout(*cfg, B, L, batch->P);
+  B4R_CHECK_ARG(workspace_bytes >= w.total * (int64_t)sizeof(float), B4R_E_NOMEM, "b4r_forward: workspace too small (%lld < %lld)",
+                (long long)workspace_bytes, (long long)(w.total * sizeof(float)));
+  const int training = (flags & B4R_FLAG_TRAINING) ? 1 : 0;
+  B4R_CHECK_ARG(!training || state || (cfg->output_dropout == 0.f && cfg->attention_dropout == 0.f), B4R_E_BADARG,
+                "b4r_forward: training with dropout needs a state (rng)");
+  const uint32_t* rng = training ? reinterpret_cast<const uint32_t*>(state) : nullptr;
+  const float od = training ? cfg->output_dropout : 0.f, adp = training ? cfg->attention_dropout : 0.f;
+  float* ws = static_cast<float*>(workspace);
+  hipStream_t s = (hipStream_t)stream;
+  const int H = cfg->hidden_size, I = cfg->inner_dim, V = cfg->vocab_size, N = B * L, M = B * P;
+  const float qscale = 1.0f / sqrtf(32.0f);
+
+  RC(b4r_embed_ln_fwd(batch->input_word_ids, B, L, params + pl.word_emb, V, params + pl.pos_emb, params + pl.emb_ln_g,
+                      params + pl.emb_ln_b, H, cfg->ln_eps, ws + w.x0, ws + w.mean0, ws + w.rstd0, rng, od, stream));
+  const float* x = ws + w.x0;
+  for (int i = 0; i < cfg->num_layers; ++i) {
+    RC(gemm(x, H, params + pl.wqkv[i], 3 * H, ws + w.qkv[i], 3 * H, N, 3 * H, H, 0, B4R_EPI_BIAS_QSCALE, params + pl.bqkv[i],
+            nullptr, 0, nullptr, 0, qscale, H, nullptr, 0, 0.f, 0, s));
+    RC(b4r_attn_fwd(ws + w.qkv[i], batch->input_mask, B, L, cfg->num_heads, ws + w.ctx[i], ws + w.lse[i], rng,
+                    B4R_STREAM_ATTN_PROBS(i), adp, stream));
+    RC(gemm(ws + w.ctx[i], H, params + pl.wo[i], H, ws + w.z1[i], H, N, H, H, 0, B4R_EPI_BIAS_DROP_RES, params + pl.bo[i],
+            nullptr, 0, x, H, 1.f, 0, rng, B4R_STREAM_ATTN_OUT(i), od, 0, s));
+    RC(b4r_ln_fwd(ws + w.z1[i], N, H, params + pl.ln1_g[i], params + pl.ln1_b[i], cfg->ln_eps, ws + w.x1[i], ws + w.mean1[i],
+                  ws + w.rstd1[i], stream));
+    RC(gemm(ws + w.x1[i], H, params + pl.w1[i], I, ws + w.f[i], I, N, I, H, 0, B4R_EPI_BIAS_GELU, params + pl.b1[i],
+            ws + w.fpre[i], I, nullptr, 0, 1.f, 0, nullptr, 0, 0.f, 0, s));
+    RC(gemm(ws + w.f[i], I, params + pl.w2[i], H, ws + w.z2[i], H, N, H, I, 0, B4R_EPI_BIAS_DROP_RES, params + pl.b2[i],
+            nullptr, 0, ws + w.x1[i], H, 1.f, 0, rng, B4R_STREAM_FFN_OUT(i), od, 0, s));
+    RC(b4r_ln_fwd(ws + w.z2[i], N, H, params + pl.ln2_g[i], params + pl.ln2_b[i], cfg->ln_eps, ws + w.x2[i], ws + w.mean2[i],
+                  ws + w.rstd2[i], stream));
+    x = ws + w.x2[i];
+  }
+  if ((flags & B4R_FLAG_POOLER) && pooler) {
+    // tanh(x[:,0,:] . Wp + bp): rows b of A are L*H apart
+    RC(gemm(x, L * H, pooler, H, ws + w.pooled, H, B, H, H, 0, B4R_EPI_BIAS_TANH, pooler + (int64_t)H * H, nullptr, 0, nullptr,
+            0, 1.f, 0, nullptr, 0, 0.f, 0, s));
+  }
+  if (P > 0) {
+    // tfm MaskedLM: gather -> dense(gelu) -> LayerNorm -> . E^T + bias
+    RC(b4r_gather_rows(x, H, batch->masked_lm_positions, L, P, M, H, ws + w.gath, stream));
+    RC(gemm(ws + w.gath, H, params + pl.wd, H, ws + w.u, H, M, H, H, 0, B4R_EPI_BIAS_GELU, params + pl.bd, ws + w.upre, H,
+            nullptr, 0, 1.f, 0, nullptr, 0, 0.f, 0, s));
+    RC(b4r_ln_fwd(ws + w.u, M, H, params + pl.lnm_g, params + pl.lnm_b, cfg->ln_eps, ws + w.t, ws + w.meanm, ws + w.rstdm, stream));
+    RC(gemm(ws + w.t, H, params + pl.word_emb, H, ws + w.logits, (int)w.Vp, M, V, H, 1, B4R_EPI_BIAS, params + pl.out_bias,
+            nullptr, 0, nullptr, 0, 1.f, 0, nullptr, 0, 0.f, 0, s));
+  }
+  return B4R_OK;
+}
+
+extern "C" int b4r_loss(const b4r_model_config* cfg, const b4r_batch* batch, void* workspace, int64_t workspace_bytes,
+                        b4r_train_state* state, int32_t want_grad, b4r_stream_t stream) {
+  RC(check_cfg(cfg));
+  RC(check_batch(batch, cfg, true));
+  B4R_CHECK_ARG(batch->masked_lm_ids && workspace && state, B4R_E_BADARG, "b4r_loss: needs masked_lm_ids, workspace, state");
+  const WsLayout w = make_ws_layout(*cfg, batch->B, batch->L, batch->P);
+  B4R_CHECK_ARG(workspace_bytes >= w.total * (int64_t)sizeof(float), B4R_E_NOMEM, "b4r_loss: workspace too small");
+  float* ws = static_cast<float*>(workspace);
+  return b4r_softmax_ce(ws + w.logits, (int)w.M, cfg->vocab_size, (int)w.Vp, batch->masked_lm_ids, ws + w.rowsc, state,
+                        want_grad, stream);
+}
+
+extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch, const float* params, float* grads,
+                            void* workspace, int64_t workspace_bytes, b4r_train_state* state, int32_t flags,
+                            b4r_stream_t stream) {
+  RC(check_cfg(cfg));
+  RC(check_batch(batch, cfg, true));
+  B4R_CHECK_ARG(params && grads && workspace && batch->masked_lm_ids, B4R_E_BADARG, "b4r_backward: null argument");
+  B4R_CHECK_ARG(b4r_aligned16(params) && b4r_aligned16(grads) && b4r_aligned16(workspace), B4R_E_ALIGN,
+                "b4r_backward: buffers must be 16-byte aligned");
+  const int B = batch->B, L = batch->L, P = batch->P;
+  const ParamLayout pl = make_param_layout(*cfg);
+  const WsLayout w = make_ws_layout(*cfg, B, L, P);
+  B4R_CHECK_ARG(workspace_bytes >= w.total * (int64_t)sizeof(float), B4R_E_NOMEM, "b4r_backward: workspace too small");
+  const int training = (flags & B4R_FLAG_TRAINING) ? 1 : 0;
+  const uint32_t* rng = training ? reinterpret_cast<const uint32_t*>(state) : nullptr;
+  const float od = training ? cfg->output_dropout : 0.f, adp = training ? cfg->attention_dropout : 0.f;
+  float* ws = static_cast<float*>(workspace);
+  hipStream_t s = (hipStream_t)stream;
+  const int H = cfg->hidden_size, I = cfg->inner_dim, V = cfg->vocab_size, N = B * L, M = B * P, Vp = (int)w.Vp;
+  const float qscale = 1.0f / sqrtf(32.0f);
+  float* scratch = ws + w.scratch;
+  const DropArgs nodrop = b4r_make_drop(nullptr, 0, 0.f, 0);
+
+  if (hipMemsetAsync(grads, 0, (size_t)pl.total * sizeof(float), s) != hipSuccess ||
+      hipMemsetAsync(ws + w.dx, 0, (size_t)N * H * sizeof(float), s) != hipSuccess) {
+    b4r_set_error("b4r_backward: hipMemsetAsync failed");
+    return B4R_E_HIP;
+  }
+
+  // ---- masked-LM head (logits buffer holds d loss_sum / d logits, pad columns zero) --------------------------------
+  float* dlog = ws + w.logits;
+  // dT = dlogits . E
+  RC(gemm(dlog, Vp, params + pl.word_emb, H, ws + w.dt, H, M, H, V, 0, B4R_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 1.f, 0,
+          nullptr, 0, 0.f, 0, s));
+  // dE = dlogits^T . T ; d output_bias = column sums of dlogits
+  RC(gemm_tn(dlog, Vp, ws + w.t, H, grads + pl.word_emb, H, M, V, H, nullptr, grads + pl.out_bias, nullptr, 0, 0.f, 0, scratch, s));
+  // LayerNorm of the transform
+  RC(b4r_ln_bwd_launch(ws + w.dt, ws + w.u, ws + w.meanm, ws + w.rstdm, params + pl.lnm_g, M, H, ws + w.dt, grads + pl.lnm_g,
+                       grads + pl.lnm_b, scratch, nullptr, nullptr, nullptr, 1, 1, nodrop, s));
+  RC(b4r_mul_gelu_grad(ws + w.dt, ws + w.upre, (int64_t)M * H, s));
+  RC(gemm_tn(ws + w.gath, H, ws + w.dt, H, grads + pl.wd, H, M, H, H, grads + pl.bd, nullptr, nullptr, 0, 0.f, 0, scratch, s));
+  RC(gemm(ws + w.dt, H, params + pl.wd, H, ws + w.dg, H, M, H, H, 1, B4R_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 1.f, 0,
+          nullptr, 0, 0.f, 0, s));
+  // scatter into d sequence_output (slots with y_true == 0 carry exactly zero gradient and are skipped)
+  RC(b4r_scatter_add_rows_impl(ws + w.dg, batch->masked_lm_positions, L, P, M, H, ws + w.dx, H, batch->masked_lm_ids, N, s));
+
+  // ---- encoder layers, last to first ---------------------------------------------------------------------------------
+  for (int i = cfg->num_layers - 1; i >= 0; --i) {
+    const float* x_in = (i == 0) ? ws + w.x0 : ws + w.x2[i - 1];
+    // output LayerNorm
+    RC(b4r_ln_bwd_launch(ws + w.dx, ws + w.z2[i], ws + w.mean2[i], ws + w.rstd2[i], params + pl.ln2_g[i], N, H, ws + w.da,
+                         grads + pl.ln2_g[i], grads + pl.ln2_b[i], scratch, nullptr, nullptr, nullptr, 1, 1, nodrop, s));
+    // FFN: dFpre = (dropmask(dz2) . W2^T) * gelu'(fpre)
+    RC(gemm(ws + w.da, H, params + pl.w2[i], H, ws + w.df, I, N, I, H, 1, B4R_EPI_GELU_BWD, nullptr, nullptr, 0, ws + w.fpre[i],
+            I, 1.f, 0, rng, B4R_STREAM_FFN_OUT(i), od, 1, s));
+    RC(gemm_tn(ws + w.f[i], I, ws + w.da, H, grads + pl.w2[i], H, N, I, H, grads + pl.b2[i], nullptr, rng, B4R_STREAM_FFN_OUT(i),
+               od, 1, scratch, s));
+    // dX1 = dFpre . W1^T + dz2
+    RC(gemm(ws + w.df, I, params + pl.w1[i], I, ws + w.db, H, N, H, I, 1, B4R_EPI_ADD_RES, nullptr, nullptr, 0, ws + w.da, H, 1.f,
+            0, nullptr, 0, 0.f, 0, s));
+    RC(gemm_tn(ws + w.x1[i], H, ws + w.df, I, grads + pl.w1[i], I, N, H, I, grads + pl.b1[i], nullptr, nullptr, 0, 0.f, 0, scratch, s));
+    // attention LayerNorm
+    RC(b4r_ln_bwd_launch(ws + w.db, ws + w.z1[i], ws + w.mean1[i], ws + w.rstd1[i], params + pl.ln1_g[i], N, H, ws + w.db,
+                         grads + pl.ln1_g[i], grads + pl.ln1_b[i], scratch, nullptr, nullptr, nullptr, 1, 1, nodrop, s));
+    // attention output projection
+    RC(gemm(ws + w.db, H, params + pl.wo[i], H, ws + w.dctx, H, N, H, H, 1, B4R_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 1.f, 0,
+            rng, B4R_STREAM_ATTN_OUT(i), od, 1, s));
+    RC(gemm_tn(ws + w.ctx[i], H, ws + w.db, H, grads + pl.wo[i], H, N, H, H, grads + pl.bo[i], nullptr, rng,
+               B4R_STREAM_ATTN_OUT(i), od, 1, scratch, s));
+    // attention core
+    RC(b4r_attn_bwd(ws + w.qkv[i], batch->input_mask, ws + w.ctx[i], ws + w.lse[i], ws + w.dctx, B, L, cfg->num_heads, qscale,
+                    ws + w.dqkv, rng, B4R_STREAM_ATTN_PROBS(i), adp, stream));
+    // QKV projection: dX_in = dqkv . Wqkv^T + dz1
+    RC(gemm(ws + w.dqkv, 3 * H, params + pl.wqkv[i], 3 * H, ws + w.dx, H, N, H, 3 * H, 1, B4R_EPI_ADD_RES, nullptr, nullptr, 0,
+            ws + w.db, H, 1.f, 0, nullptr, 0, 0.f, 0, s));
+    RC(gemm_tn(x_in, H, ws + w.dqkv, 3 * H, grads + pl.wqkv[i], 3 * H, N, H, 3 * H, grads + pl.bqkv[i], nullptr, nullptr, 0, 0.f,
+               0, scratch, s));
+  }
+  // ---- embedding stage: dropout -> LayerNorm -> (word table scatter-add, position table batch sum) ---------------------
+  RC(b4r_ln_bwd_launch(ws + w.dx, nullptr, ws + w.mean0, ws + w.rstd0, params + pl.emb_ln_g, N, H, ws + w.da, grads + pl.emb_ln_g,
+                       grads + pl.emb_ln_b, scratch, batch->input_word_ids, params + pl.word_emb, params + pl.pos_emb, L, V,
+                       b4r_make_drop(rng, B4R_STREAM_EMB, od, 1), s));
+  RC(b4r_scatter_add_rows_impl(ws + w.da, batch->input_word_ids, 0, 1, N, H, grads + pl.word_emb, H, nullptr, V, s));
+  RC(b4r_batch_colsum(ws + w.da, B, L, H, grads + pl.pos_emb, scratch, s));
+  return B4R_OK;
+}
+
+extern "C" int b4r_optimizer_step(const b4r_model_config* cfg, const b4r_adamw_config* hp, float* params, const float* grads,
+                                  float* adam_m, float* adam_v, void* workspace, int64_t workspace_bytes,
+                                  b4r_train_state* state, b4r_stream_t stream) {
+  RC(check_cfg(cfg));
+  B4R_CHECK_ARG(hp && params && grads && adam_m && adam_v && workspace && state, B4R_E_BADARG, "b4r_optimizer_step: null argument");
+  B4R_CHECK_ARG(workspace_bytes >= 4096 * (int64_t)sizeof(float), B4R_E_NOMEM, "b4r_optimizer_step: workspace too small");
+  const ParamLayout pl = make_param_layout(*cfg);
+  // the scratch region sits at the END of the workspace; any 4096-float area works, use the start of the buffer the
+  // backward no longer needs: the first floats of the workspace hold x0 which is dead after backward.
+  float* scratch = static_cast<float*>(workspace);
+  RC(b4r_global_sqnorm(grads, pl.total, scratch, state, stream));
+  RC(b4r_adamw_step(hp, params, grads, adam_m, adam_v, pl.total, pl.n_decay, state, stream));
+  return B4R_OK;
+}
+
+extern "C" int b4r_train_step(const b4r_model_config* cfg, const b4r_adamw_config* hp, const b4r_batch* batch, float* params,
+                              float* grads, float* adam_m, float* adam_v, void* workspace, int64_t workspace_bytes,
+                              b4r_train_state* state, b4r_stream_t stream) {
+  RC(b4r_state_begin_step(state, stream));
+  RC(b4r_forward(cfg, batch, params, nullptr, workspace, workspace_bytes, state, B4R_FLAG_TRAINING, stream));
+  RC(b4r_loss(cfg, batch, workspace, workspace_bytes, state, 1, stream));
+  RC(b4r_backward(cfg, batch, params, grads, workspace, workspace_bytes, state, B4R_FLAG_TRAINING, stream));
+  RC(b4r_optimizer_step(cfg, hp, params, grads, adam_m, adam_v, workspace, workspace_bytes, state, stream));
+  return B4R_OK;
+}

@@ -1,0 +1,738 @@
+// HBM-bound row kernels: embedding gather + positional add + LayerNorm, LayerNorm fwd/bwd, row gather / scatter-add,
+// softmax cross-entropy with fused argmax metrics, global-norm + AdamW over the flat parameter buffer.
+//
+// Row layout: a row of width H = 4*LPR*NV floats is owned by LPR lanes, each holding NV float4 (16 B per lane per
+// access: coalesced 16-B vector loads, guide G13); a 64-lane wave therefore owns 64/LPR rows, and row statistics are
+// xor-shuffle reductions inside the LPR-lane group.
+#include "b4r_common.h"
+
+int b4r_launch_slab_reduce(const float* slab, int S, int Mo, int No, float* out, int ldo, int accumulate,
+                           hipStream_t stream);
+
+namespace {
+
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// -----------------------------------------------------------------------------------------------------------
+// LayerNorm forward (optionally fed by the embedding gather)
+//   Keras non-fused LayerNormalization: mean, biased var, inv = rsqrt(var+eps)*gamma, y = x*inv + (beta - mean*inv)
+// -----------------------------------------------------------------------------------------------------------
+struct LnFwdP {
+  const float* z;            // [rows,H]   (EMBED: unused)
+  const int64_t* ids;        // EMBED: [rows] token ids
+  const float* table;        // EMBED: [V,H]
+  const float* pos_table;    // EMBED: [Lmax,H]
+  int L, V;
+  const float* gamma; const float* beta;
+  float* y; float* mean; float* rstd;
+  int rows, H;
+  float eps;
+  DropArgs drop;
+};
+
+template <int LPR, int NV, bool EMBED>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdP p) {
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % LPR, slot = lane / LPR;
+  const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * RPW + slot;
+  if (row >= p.rows) return;  // whole LPR-group exits together; shuffles below stay inside the group
+  DropCtx dctx = b4r_drop_ctx(p.drop);
+
+  f32x4 x[NV];
+  float s = 0.f;
+  if (EMBED) {
+    int64_t id = p.ids[row];
+    if (id < 0 || id >= p.V) id = 0;  // out-of-range ids read the PAD row instead of faulting
+    const int l = (int)(row % p.L);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int c = (v * LPR + sub) * 4;
+      const f32x4 e = *reinterpret_cast<const f32x4*>(p.table + id * p.H + c);
+      const f32x4 q = *reinterpret_cast<const f32x4*>(p.pos_table + (int64_t)l * p.H + c);
+      x[v] = e + q;
+    }
+  } else {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int c = (v * LPR + sub) * 4;
+      x[v] = *reinterpret_cast<const f32x4*>(p.z + row * p.H + c);
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < NV; ++v) s += (x[v][0] + x[v][1]) + (x[v][2] + x[v][3]);
+  const float mean = group_sum<LPR>(s) / (float)p.H;
+  float q = 0.f;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float d = x[v][e] - mean; q += d * d; }
+  }
+  const float var = group_sum<LPR>(q) / (float)p.H;
+  const float rstd = rsqrtf(var + p.eps);
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int c = (v * LPR + sub) * 4;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + c);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(p.beta + c);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float inv = rstd * g[e];
+      float yv = x[v][e] * inv + (b[e] - mean * inv);
+      yv = b4r_drop(dctx, yv, (uint64_t)row * (uint64_t)p.H + (uint64_t)(c + e));
+      o[e] = yv;
+    }
+    *reinterpret_cast<f32x4*>(p.y + row * p.H + c) = o;
+  }
+  if (sub == 0) {
+    if (p.mean) p.mean[row] = mean;
+    if (p.rstd) p.rstd[row] = rstd;
+  }
+}
+
+// -----------------------------------------------------------------------------------------------------------
+// LayerNorm backward.  dz = rstd*(g - mean(g) - xhat*mean(g*xhat)), g = dy*gamma; column partials of dgamma/dbeta.
+// EMBED: z is recomputed as E[id]+P[pos] and dy first goes back through the embedding dropout.
+// -----------------------------------------------------------------------------------------------------------
+struct LnBwdP {
+  const float* dy; const float* z; const float* mean; const float* rstd; const float* gamma;
+  const int64_t* ids; const float* table; const float* pos_table; int L, V;
+  float* dz; float* partial;  // partial[gridDim.x][2][H]
+  int rows, H;
+  DropArgs drop;
+};
+
+template <int LPR, int NV, bool EMBED>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdP p) {
+  constexpr int RPW = 64 / LPR;
+  extern __shared__ float sred[];  // [4*RPW][2*H]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % LPR, slot = lane / LPR;
+  DropCtx dctx = b4r_drop_ctx(p.drop);
+
+  f32x4 g4[NV], dg[NV], db[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    g4[v] = *reinterpret_cast<const f32x4*>(p.gamma + (v * LPR + sub) * 4);
+    dg[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    db[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const int64_t rows_per_block = 4 * RPW;
+  for (int64_t base = (int64_t)blockIdx.x * rows_per_block; base < p.rows; base += (int64_t)gridDim.x * rows_per_block) {
+    const int64_t row = base + wave * RPW + slot;
+    const bool live = row < p.rows;
+    const int64_t rr = live ? row : 0;
+    const float mean = p.mean[rr], rstd = p.rstd[rr];
+    f32x4 xh[NV], gg[NV];
+    float s1 = 0.f, s2 = 0.f;
+    int64_t id = 0; int l = 0;
+    if (EMBED) {
+      id = p.ids[rr];
+      if (id < 0 || id >= p.V) id = 0;
+      l = (int)(rr % p.L);
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int c = (v * LPR + sub) * 4;
+      f32x4 d = *reinterpret_cast<const f32x4*>(p.dy + rr * p.H + c);
+      f32x4 zz;
+      if (EMBED) {
+        zz = *reinterpret_cast<const f32x4*>(p.table + id * p.H + c) +
+             *reinterpret_cast<const f32x4*>(p.pos_table + (int64_t)l * p.H + c);
+      } else {
+        zz = *reinterpret_cast<const f32x4*>(p.z + rr * p.H + c);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float de = d[e];
+        if (EMBED) de = b4r_drop(dctx, de, (uint64_t)rr * (uint64_t)p.H + (uint64_t)(c + e));
+        if (!live) de = 0.f;
+        const float xhat = (zz[e] - mean) * rstd;
+        const float g = de * g4[v][e];
+        xh[v][e] = xhat; gg[v][e] = g;
+        s1 += g; s2 += g * xhat;
+        dg[v][e] += de * xhat;
+        db[v][e] += de;
+      }
+    }
+    const float c1 = group_sum<LPR>(s1) / (float)p.H;
+    const float c2 = group_sum<LPR>(s2) / (float)p.H;
+    if (live) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const int c = (v * LPR + sub) * 4;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rstd * (gg[v][e] - c1 - xh[v][e] * c2);
+        *reinterpret_cast<f32x4*>(p.dz + row * p.H + c) = o;
+      }
+    }
+  }
+  // block-level column reduction of dgamma / dbeta in a fixed order
+  const int srow = wave * RPW + slot;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int c = (v * LPR + sub) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      sred[srow * 2 * p.H + c + e] = dg[v][e];
+      sred[srow * 2 * p.H + p.H + c + e] = db[v][e];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * p.H; c += 256) {
+    float s = 0.f;
+    for (int r = 0; r < 4 * RPW; ++r) s += sred[r * 2 * p.H + c];
+    p.partial[(int64_t)blockIdx.x * 2 * p.H + c] = s;
+  }
+}
+
+int ln_bwd_grid(int rows, int H) {
+  int lpr = H / 4; if (lpr > 64) lpr = 64;
+  const int rpb = 4 * (64 / lpr);
+  int g = b4r_cdiv(rows, rpb);
+  if (g > 512) g = 512;
+  if (g < 1) g = 1;
+  return g;
+}
+
+template <bool EMBED>
+int launch_ln_fwd(const LnFwdP& p, hipStream_t s) {
+  const int H = p.H;
+#define LN_FWD_CASE(LPR_, NV_)                                                                              \
+  {                                                                                                         \
+    const int rpb = 4 * (64 / LPR_);                                                                        \
+    hipLaunchKernelGGL((ln_fwd_kernel<LPR_, NV_, EMBED>), dim3(b4r_cdiv(p.rows, rpb)), dim3(256), 0, s, p); \
+  }
+  switch (H) {
+    case 32: LN_FWD_CASE(8, 1) break;
+    case 64: LN_FWD_CASE(16, 1) break;
+    case 128: LN_FWD_CASE(32, 1) break;
+    case 256: LN_FWD_CASE(64, 1) break;
+    case 512: LN_FWD_CASE(64, 2) break;
+    case 1024: LN_FWD_CASE(64, 4) break;
+    default: b4r_set_error("layer norm: hidden size %d not supported (32,64,128,256,512,1024)", H); return B4R_E_SHAPE;
+  }
+#undef LN_FWD_CASE
+  return B4R_OK;
+}
+
+template <bool EMBED>
+int launch_ln_bwd(const LnBwdP& p, int grid, hipStream_t s) {
+  const int H = p.H;
+#define LN_BWD_CASE(LPR_, NV_)                                                                           \
+  {                                                                                                      \
+    const size_t sh = (size_t)4 * (64 / LPR_) * 2 * H * sizeof(float);                                   \
+    hipLaunchKernelGGL((ln_bwd_kernel<LPR_, NV_, EMBED>), dim3(grid), dim3(256), sh, s, p);              \
+  }
+  switch (H) {
+    case 32: LN_BWD_CASE(8, 1) break;
+    case 64: LN_BWD_CASE(16, 1) break;
+    case 128: LN_BWD_CASE(32, 1) break;
+    case 256: LN_BWD_CASE(64, 1) break;
+    case 512: LN_BWD_CASE(64, 2) break;
+    case 1024: LN_BWD_CASE(64, 4) break;
+    default: b4r_set_error("layer norm: hidden size %d not supported", H); return B4R_E_SHAPE;
+  }
+#undef LN_BWD_CASE
+  return B4R_OK;
+}
+
+// -----------------------------------------------------------------------------------------------------------
+// gather / scatter-add of rows, and the batch column-sum that yields the position-table gradient
+// -----------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* src, int src_ld, const int64_t* idx,
+                                                          int64_t idx_add_per, int per, int n, int H, float* dst) {
+  const int h4 = H / 4;
+  const int64_t total = (int64_t)n * h4;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int i = (int)(t / h4), c = (int)(t % h4) * 4;
+    int64_t pos = idx[i];
+    if (idx_add_per > 0) pos = pos < 0 ? 0 : (pos >= idx_add_per ? idx_add_per - 1 : pos);  // clamp into the group
+    const int64_t r = pos + (int64_t)(i / per) * idx_add_per;
+    *reinterpret_cast<f32x4*>(dst + (int64_t)i * H + c) = *reinterpret_cast<const f32x4*>(src + r * src_ld + c);
+  }
+}
+
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* src, const int64_t* idx, int64_t idx_add_per,
+                                                               int per, int n, int H, float* dst, int dst_ld,
+                                                               const int64_t* skip_if_zero, int64_t dst_rows) {
+  const int h4 = H / 4;
+  const int64_t total = (int64_t)n * h4;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int i = (int)(t / h4), c = (int)(t % h4) * 4;
+    if (skip_if_zero != nullptr && skip_if_zero[i] == 0) continue;
+    int64_t pos = idx[i];
+    if (idx_add_per > 0) pos = pos < 0 ? 0 : (pos >= idx_add_per ? idx_add_per - 1 : pos);
+    const int64_t r = pos + (int64_t)(i / per) * idx_add_per;
+    if (r < 0 || r >= dst_rows) continue;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + (int64_t)i * H + c);
+    float* d = dst + r * dst_ld + c;
+    atomicAdd(d + 0, v[0]); atomicAdd(d + 1, v[1]); atomicAdd(d + 2, v[2]); atomicAdd(d + 3, v[3]);
+  }
+}
+
+// du[i] *= gelu'(pre[i])   (MLM transform backward)
+__global__ __launch_bounds__(256) void mul_gelu_grad_kernel(float* du, const float* pre, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 d = *reinterpret_cast<f32x4*>(du + 4 * i);
+    const f32x4 x = *reinterpret_cast<const f32x4*>(pre + 4 * i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d[e] *= b4r_gelu_grad(x[e]);
+    *reinterpret_cast<f32x4*>(du + 4 * i) = d;
+  }
+}
+
+// partial[s][l][c] = sum over b in slice s of x[(b*L + l)*H + c]
+__global__ __launch_bounds__(256) void batch_colsum_kernel(const float* x, int B, int L, int H, int bchunk, float* partial) {
+  const int h4 = H / 4;
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (int64_t)L * h4) return;
+  const int l = (int)(t / h4), c = (int)(t % h4) * 4;
+  const int b0 = blockIdx.y * bchunk, b1 = min(B, b0 + bchunk);
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int b = b0; b < b1; ++b) s += *reinterpret_cast<const f32x4*>(x + ((int64_t)b * L + l) * H + c);
+  *reinterpret_cast<f32x4*>(partial + ((int64_t)blockIdx.y * L + l) * H + c) = s;
+}
+
+// -----------------------------------------------------------------------------------------------------------
+// softmax cross entropy + argmax metrics, one workgroup per row
+// -----------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_ce_kernel(float* logits, int V, int ld, const int64_t* y_true,
+                                                         float* row_out, int want_grad) {
+  __shared__ float s_val[4];
+  __shared__ int s_idx[4];
+  __shared__ float s_sum[4];
+  const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* row = logits + (int64_t)m * ld;
+  const int nv = ld / 4;
+  int64_t y = y_true[m];
+  const bool y_ok = (y >= 0 && y < V);
+  const float y_logit = y_ok ? row[y] : 0.f;
+
+  float best = -INFINITY; int bidx = 0x7fffffff;
+  for (int v = tid; v < nv; v += 256) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(row + 4 * v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = 4 * v + e;
+      if (c < V && (x[e] > best || (x[e] == best && c < bidx))) { best = x[e]; bidx = c; }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bidx, o, 64);
+    if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+  }
+  if (lane == 0) { s_val[wave] = best; s_idx[wave] = bidx; }
+  __syncthreads();
+  best = s_val[0]; bidx = s_idx[0];
+#pragma unroll
+  for (int w = 1; w < 4; ++w)
+    if (s_val[w] > best || (s_val[w] == best && s_idx[w] < bidx)) { best = s_val[w]; bidx = s_idx[w]; }
+
+  float sum = 0.f;
+  for (int v = tid; v < nv; v += 256) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(row + 4 * v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (4 * v + e < V) sum += __expf(x[e] - best);
+  }
+  sum = b4r_wave_sum(sum);
+  if (lane == 0) s_sum[wave] = sum;
+  __syncthreads();
+  sum = (s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3]);
+  const float lse = best + __logf(sum);
+  const bool valid = (y != 0);
+  if (tid == 0) {
+    row_out[4 * (int64_t)m + 0] = (valid && y_ok) ? (lse - y_logit) : 0.f;
+    row_out[4 * (int64_t)m + 1] = valid ? 1.f : 0.f;
+    row_out[4 * (int64_t)m + 2] = (valid && (int64_t)bidx == y) ? 1.f : 0.f;
+    row_out[4 * (int64_t)m + 3] = ((int64_t)bidx == y) ? 1.f : 0.f;
+  }
+  if (want_grad) {
+    __syncthreads();  // every thread has finished reading the row
+    for (int v = tid; v < nv; v += 256) {
+      f32x4 x = *reinterpret_cast<const f32x4*>(row + 4 * v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = 4 * v + e;
+        float g = 0.f;
+        if (valid && c < V) g = __expf(x[e] - lse) - ((int64_t)c == y ? 1.f : 0.f);
+        x[e] = g;
+      }
+      *reinterpret_cast<f32x4*>(row + 4 * v) = x;
+    }
+  }
+}
+
+// ordered reduction of the per-row scalars into the state (single workgroup => fixed summation order)
+__global__ __launch_bounds__(1024) void ce_finalize_kernel(const float* row_out, int M, b4r_train_state* st) {
+  __shared__ float s[4][1024];
+  const int tid = threadIdx.x;
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int m = tid; m < M; m += 1024) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) a[q] += row_out[4 * (int64_t)m + q];
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) s[q][tid] = a[q];
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (tid < o) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s[q][tid] += s[q][tid + o];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    st->loss_sum += s[0][0];
+    st->valid_count += s[1][0];
+    st->correct_masked += s[2][0];
+    st->correct_all += s[3][0];
+    st->slots_all += (float)M;
+  }
+}
+
+__global__ void state_begin_kernel(b4r_train_state* st) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    st->loss_sum = 0.f; st->valid_count = 0.f; st->correct_masked = 0.f; st->correct_all = 0.f; st->slots_all = 0.f;
+    st->grad_sqnorm = 0.f; st->grad_norm = 0.f;
+  }
+}
+
+// -----------------------------------------------------------------------------------------------------------
+// global norm + AdamW
+// -----------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* g, int64_t n, float* partial) {
+  __shared__ float s[4];
+  const int64_t n4 = n / 4;
+  const int64_t per = (n4 + gridDim.x - 1) / gridDim.x;
+  const int64_t b = (int64_t)blockIdx.x * per, e = min(n4, b + per);
+  float acc = 0.f;
+  for (int64_t i = b + threadIdx.x; i < e; i += 256) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(g + 4 * i);
+    acc += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+  }
+  if (blockIdx.x == gridDim.x - 1) {
+    for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += 256) acc += g[i] * g[i];
+  }
+  acc = b4r_wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+
+__global__ __launch_bounds__(256) void sqnorm_final_kernel(const float* partial, int np, b4r_train_state* st) {
+  __shared__ float s[256];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < np; i += 256) a += partial[i];
+  s[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) st->grad_sqnorm = s[0];
+}
+
+struct AdamP {
+  float* p; const float* g; float* m; float* v;
+  int64_t n, n_decay;
+  b4r_adamw_config hp;
+  b4r_train_state* st;
+};
+
+// WarmUp over PolynomialDecay(power 1), float32 like TF: adam_w_optimizer.py:22-36
+__device__ __forceinline__ float lr_schedule(const b4r_adamw_config& hp, int64_t step) {
+  const float s = (float)step;
+  if (hp.num_warmup_steps > 0 && s < (float)hp.num_warmup_steps) return hp.init_lr * (s / (float)hp.num_warmup_steps);
+  const float T = (float)hp.num_train_steps;
+  const float gs = fminf(s, T);
+  const float pr = gs / T;
+  return (hp.init_lr - hp.end_lr) * (1.0f - pr) + hp.end_lr;
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(AdamP a) {
+  const int64_t step = a.st->step;
+  const float cnt = a.st->valid_count;
+  const float inv_cnt = cnt > 0.f ? 1.0f / cnt : 1.0f;
+  const float gnorm = sqrtf(a.st->grad_sqnorm) * inv_cnt;
+  const float clip_scale = a.hp.clip_norm > 0.f ? a.hp.clip_norm / fmaxf(gnorm, a.hp.clip_norm) : 1.0f;
+  const float lr_t = lr_schedule(a.hp, step);
+  const float t = (float)(step + 1);
+  const float b1p = powf(a.hp.beta_1, t), b2p = powf(a.hp.beta_2, t);
+  const float alpha = lr_t * sqrtf(1.0f - b2p) / (1.0f - b1p);
+  const float omb1 = 1.0f - a.hp.beta_1, omb2 = 1.0f - a.hp.beta_2;
+  const float wd = a.hp.weight_decay_rate, eps = a.hp.epsilon;
+  const int64_t n4 = a.n / 4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 p = *reinterpret_cast<f32x4*>(a.p + 4 * i);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(a.g + 4 * i);
+    f32x4 m = *reinterpret_cast<f32x4*>(a.m + 4 * i);
+    f32x4 v = *reinterpret_cast<f32x4*>(a.v + 4 * i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float ge = (g[e] * inv_cnt) * clip_scale;
+      float pe = p[e];
+      if (wd != 0.f && 4 * i + e < a.n_decay) pe -= lr_t * pe * wd;   // _decay_weights_op, before Adam
+      m[e] += (ge - m[e]) * omb1;
+      v[e] += (ge * ge - v[e]) * omb2;
+      pe -= (m[e] * alpha) / (sqrtf(v[e]) + eps);
+      p[e] = pe;
+    }
+    *reinterpret_cast<f32x4*>(a.p + 4 * i) = p;
+    *reinterpret_cast<f32x4*>(a.m + 4 * i) = m;
+    *reinterpret_cast<f32x4*>(a.v + 4 * i) = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { a.st->grad_norm = gnorm; a.st->lr = lr_t; }
+}
+
+__global__ void state_advance_kernel(b4r_train_state* st) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) { st->step += 1; st->step_lo = (uint32_t)st->step; }
+}
+
+// -----------------------------------------------------------------------------------------------------------
+// candidate ranking: one workgroup per ranked slot
+// -----------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(128) void rank_kernel(const float* hidden, int hidden_ld, const int64_t* hidden_row,
+                                                   const float* table, const float* bias, int H, const int64_t* cand,
+                                                   int C, const int64_t* gt, int64_t* ranking, int32_t* gt_rank,
+                                                   float* scores_out) {
+  extern __shared__ float sm[];  // [H] hidden row, then [C] scores
+  __shared__ int s_best;
+  float* sh = sm; float* sc = sm + H;
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const int64_t hr = hidden_row ? hidden_row[r] : (int64_t)r;
+  for (int k = tid; k < H; k += 128) sh[k] = hidden[hr * hidden_ld + k];
+  if (tid == 0) s_best = 0x7fffffff;
+  __syncthreads();
+  const int64_t* cr = cand + (int64_t)r * C;
+  for (int j = tid; j < C; j += 128) {
+    const int64_t c = cr[j];
+    const float* e = table + c * H;
+    float acc = 0.f;
+    for (int k = 0; k < H; ++k) acc = __builtin_fmaf(sh[k], e[k], acc);  // k-ordered fp32 fma chain (spec)
+    const float s = acc + bias[c];
+    sc[j] = s;
+    if (scores_out) scores_out[(int64_t)r * C + j] = s;
+  }
+  __syncthreads();
+  const int64_t g = gt ? gt[r] : -1;
+  for (int j = tid; j < C; j += 128) {
+    const float sj = sc[j];
+    int pos = 0;
+    for (int i = 0; i < C; ++i) {
+      const float si = sc[i];
+      pos += (si > sj || (si == sj && i < j)) ? 1 : 0;
+    }
+    if (ranking) ranking[(int64_t)r * C + pos] = cr[j];
+    if (gt && cr[j] == g) atomicMin(&s_best, pos);
+  }
+  __syncthreads();
+  if (tid == 0 && gt_rank) gt_rank[r] = (s_best == 0x7fffffff) ? 0 : s_best + 1;
+}
+
+}  // namespace
+
+// ===============================================================================================================
+// C ABI
+// ===============================================================================================================
+extern "C" int b4r_embed_ln_fwd(const int64_t* ids, int32_t B, int32_t L, const float* table, int32_t V,
+                                const float* pos_table, const float* gamma, const float* beta, int32_t H, float eps,
+                                float* out, float* mean, float* rstd, const uint32_t* rng, float dropout,
+                                b4r_stream_t stream) {
+  B4R_CHECK_ARG(ids && table && pos_table && gamma && beta && out, B4R_E_BADARG, "b4r_embed_ln_fwd: null argument");
+  B4R_CHECK_ARG(B > 0 && L > 0 && V > 0, B4R_E_SHAPE, "b4r_embed_ln_fwd: bad shape");
+  LnFwdP p{};
+  p.ids = ids; p.table = table; p.pos_table = pos_table; p.L = L; p.V = V;
+  p.gamma = gamma; p.beta = beta; p.y = out; p.mean = mean; p.rstd = rstd;
+  p.rows = B * L; p.H = H; p.eps = eps;
+  p.drop = b4r_make_drop(rng, B4R_STREAM_EMB, dropout, 1);
+  int rc = launch_ln_fwd<true>(p, (hipStream_t)stream);
+  if (rc) return rc;
+  B4R_CHECK_LAUNCH("b4r_embed_ln_fwd");
+  return B4R_OK;
+}
+
+extern "C" int b4r_ln_fwd(const float* z, int32_t rows, int32_t H, const float* gamma, const float* beta, float eps,
+                          float* y, float* mean, float* rstd, b4r_stream_t stream) {
+  B4R_CHECK_ARG(z && gamma && beta && y, B4R_E_BADARG, "b4r_ln_fwd: null argument");
+  B4R_CHECK_ARG(rows > 0, B4R_E_SHAPE, "b4r_ln_fwd: bad shape");
+  LnFwdP p{};
+  p.z = z; p.gamma = gamma; p.beta = beta; p.y = y; p.mean = mean; p.rstd = rstd;
+  p.rows = rows; p.H = H; p.eps = eps; p.L = 1; p.V = 1;
+  p.drop = b4r_make_drop(nullptr, 0, 0.f, 0);
+  int rc = launch_ln_fwd<false>(p, (hipStream_t)stream);
+  if (rc) return rc;
+  B4R_CHECK_LAUNCH("b4r_ln_fwd");
+  return B4R_OK;
+}
+
+extern "C" int64_t b4r_ln_bwd_scratch_floats(int32_t rows, int32_t H) {
+  if (rows <= 0 || H < 32) return 0;
+  return (int64_t)ln_bwd_grid(rows, H) * 2 * H;
+}
+
+namespace {
+// out_a[c] = sum_s partial[s][c], out_b[c] = sum_s partial[s][H + c]
+__global__ __launch_bounds__(256) void ln_partial_reduce_kernel(const float* partial, int S, int H, float* dgamma, float* dbeta) {
+  for (int c = blockIdx.x * 256 + threadIdx.x; c < 2 * H; c += gridDim.x * 256) {
+    float s = 0.f;
+    for (int z = 0; z < S; ++z) s += partial[(int64_t)z * 2 * H + c];
+    if (c < H) dgamma[c] = s; else dbeta[c - H] = s;
+  }
+}
+}  // namespace
+
+int b4r_ln_bwd_launch(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
+                      int rows, int H, float* dz, float* dgamma, float* dbeta, float* scratch, const int64_t* ids,
+                      const float* table, const float* pos_table, int L, int V, DropArgs drop, hipStream_t stream) {
+  LnBwdP p{};
+  p.dy = dy; p.z = z; p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.dz = dz; p.partial = scratch;
+  p.ids = ids; p.table = table; p.pos_table = pos_table; p.L = L; p.V = V;
+  p.rows = rows; p.H = H; p.drop = drop;
+  const int grid = ln_bwd_grid(rows, H);
+  int rc = ids ? launch_ln_bwd<true>(p, grid, stream) : launch_ln_bwd<false>(p, grid, stream);
+  if (rc) return rc;
+  B4R_CHECK_LAUNCH("ln_bwd");
+  hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3(b4r_cdiv(2 * H, 256)), dim3(256), 0, stream, scratch, grid, H,
+                     dgamma, dbeta);
+  B4R_CHECK_LAUNCH("ln_bwd reduce");
+  return B4R_OK;
+}
+
+extern "C" int b4r_ln_bwd(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
+                          int32_t rows, int32_t H, float* dz, float* dgamma, float* dbeta, float* scratch,
+                          b4r_stream_t stream) {
+  B4R_CHECK_ARG(dy && z && mean && rstd && gamma && dz && dgamma && dbeta && scratch, B4R_E_BADARG,
+                "b4r_ln_bwd: null argument");
+  B4R_CHECK_ARG(rows > 0, B4R_E_SHAPE, "b4r_ln_bwd: bad shape");
+  return b4r_ln_bwd_launch(dy, z, mean, rstd, gamma, rows, H, dz, dgamma, dbeta, scratch, nullptr, nullptr, nullptr, 1,
+                           1, b4r_make_drop(nullptr, 0, 0.f, 0), (hipStream_t)stream);
+}
+
+extern "C" int b4r_gather_rows(const float* src, int32_t src_ld, const int64_t* idx, int64_t idx_add_per, int32_t per,
+                               int32_t n, int32_t H, float* dst, b4r_stream_t stream) {
+  B4R_CHECK_ARG(src && idx && dst, B4R_E_BADARG, "b4r_gather_rows: null argument");
+  B4R_CHECK_ARG(n > 0 && H > 0 && H % 4 == 0 && per > 0 && src_ld % 4 == 0, B4R_E_SHAPE, "b4r_gather_rows: bad shape");
+  int grid = b4r_cdiv((int64_t)n * (H / 4), 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, src_ld, idx, idx_add_per,
+                     per, n, H, dst);
+  B4R_CHECK_LAUNCH("b4r_gather_rows");
+  return B4R_OK;
+}
+
+int b4r_scatter_add_rows_impl(const float* src, const int64_t* idx, int64_t idx_add_per, int per, int n, int H,
+                              float* dst, int dst_ld, const int64_t* skip_if_zero, int64_t dst_rows, hipStream_t stream) {
+  int grid = b4r_cdiv((int64_t)n * (H / 4), 256);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid), dim3(256), 0, stream, src, idx, idx_add_per, per, n, H, dst,
+                     dst_ld, skip_if_zero, dst_rows);
+  B4R_CHECK_LAUNCH("b4r_scatter_add_rows");
+  return B4R_OK;
+}
+
+extern "C" int b4r_scatter_add_rows(const float* src, const int64_t* idx, int64_t idx_add_per, int32_t per, int32_t n,
+                                    int32_t H, float* dst, int32_t dst_ld, const int64_t* skip_if_zero,
+                                    b4r_stream_t stream) {
+  B4R_CHECK_ARG(src && idx && dst, B4R_E_BADARG, "b4r_scatter_add_rows: null argument");
+  B4R_CHECK_ARG(n > 0 && H > 0 && H % 4 == 0 && per > 0 && dst_ld % 4 == 0, B4R_E_SHAPE, "b4r_scatter_add_rows: bad shape");
+  return b4r_scatter_add_rows_impl(src, idx, idx_add_per, per, n, H, dst, dst_ld, skip_if_zero, (int64_t)1 << 62,
+                                   (hipStream_t)stream);
+}
+
+int b4r_mul_gelu_grad(float* du, const float* pre, int64_t n, hipStream_t stream) {
+  int grid = (int)((n / 4 + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(mul_gelu_grad_kernel, dim3(grid), dim3(256), 0, stream, du, pre, n / 4);
+  B4R_CHECK_LAUNCH("mul_gelu_grad");
+  return B4R_OK;
+}
+
+// dpos[l][c] = sum_b x[(b*L+l)*H + c]; scratch >= ceil(B/16)*L*H floats
+int b4r_batch_colsum(const float* x, int B, int L, int H, float* dpos, float* scratch, hipStream_t stream) {
+  const int bchunk = 16;
+  const int S = b4r_cdiv(B, bchunk);
+  dim3 grid(b4r_cdiv((int64_t)L * (H / 4), 256), S);
+  hipLaunchKernelGGL(batch_colsum_kernel, grid, dim3(256), 0, stream, x, B, L, H, bchunk, scratch);
+  B4R_CHECK_LAUNCH("batch_colsum");
+  return b4r_launch_slab_reduce(scratch, S, L, H, dpos, H, 0, stream);
+}
+
+extern "C" int b4r_softmax_ce(float* logits, int32_t M, int32_t V, int32_t ld, const int64_t* y_true,
+                              float* row_scratch, b4r_train_state* state, int32_t want_grad, b4r_stream_t stream) {
+  B4R_CHECK_ARG(logits && y_true && row_scratch && state, B4R_E_BADARG, "b4r_softmax_ce: null argument");
+  B4R_CHECK_ARG(M > 0 && V > 0 && ld >= V, B4R_E_SHAPE, "b4r_softmax_ce: bad shape");
+  B4R_CHECK_ARG(ld % 4 == 0 && b4r_aligned16(logits), B4R_E_ALIGN, "b4r_softmax_ce: logits need ld %% 4 == 0 and 16-byte alignment");
+  hipLaunchKernelGGL(softmax_ce_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, logits, V, ld, y_true, row_scratch,
+                     want_grad);
+  B4R_CHECK_LAUNCH("b4r_softmax_ce");
+  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, row_scratch, M, state);
+  B4R_CHECK_LAUNCH("b4r_softmax_ce finalize");
+  return B4R_OK;
+}
+
+extern "C" int b4r_state_begin_step(b4r_train_state* state, b4r_stream_t stream) {
+  B4R_CHECK_ARG(state, B4R_E_BADARG, "b4r_state_begin_step: null state");
+  hipLaunchKernelGGL(state_begin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state);
+  B4R_CHECK_LAUNCH("b4r_state_begin_step");
+  return B4R_OK;
+}
+
+extern "C" int b4r_global_sqnorm(const float* g, int64_t n, float* scratch, b4r_train_state* state, b4r_stream_t stream) {
+  B4R_CHECK_ARG(g && scratch && state, B4R_E_BADARG, "b4r_global_sqnorm: null argument");
+  B4R_CHECK_ARG(n > 0, B4R_E_SHAPE, "b4r_global_sqnorm: bad size");
+  B4R_CHECK_ARG(b4r_aligned16(g), B4R_E_ALIGN, "b4r_global_sqnorm: buffer must be 16-byte aligned");
+  int np = (int)((n / 4 + 1023) / 1024);
+  if (np > 1024) np = 1024;
+  if (np < 1) np = 1;
+  hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(np), dim3(256), 0, (hipStream_t)stream, g, n, scratch);
+  B4R_CHECK_LAUNCH("b4r_global_sqnorm");
+  hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, np, state);
+  B4R_CHECK_LAUNCH("b4r_global_sqnorm final");
+  return B4R_OK;
+}
+
+extern "C" int b4r_adamw_step(const b4r_adamw_config* hp, float* params, const float* grads, float* adam_m,
+                              float* adam_v, int64_t n, int64_t n_decay, b4r_train_state* state, b4r_stream_t stream) {
+  B4R_CHECK_ARG(hp && params && grads && adam_m && adam_v && state, B4R_E_BADARG, "b4r_adamw_step: null argument");
+  B4R_CHECK_ARG(n > 0 && n % 4 == 0 && n_decay >= 0 && n_decay <= n, B4R_E_SHAPE, "b4r_adamw_step: n must be a positive multiple of 4");
+  B4R_CHECK_ARG(b4r_aligned16(params) && b4r_aligned16(grads) && b4r_aligned16(adam_m) && b4r_aligned16(adam_v),
+                B4R_E_ALIGN, "b4r_adamw_step: buffers must be 16-byte aligned");
+  AdamP a;
+  a.p = params; a.g = grads; a.m = adam_m; a.v = adam_v; a.n = n; a.n_decay = n_decay; a.hp = *hp; a.st = state;
+  int grid = (int)((n / 4 + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  B4R_CHECK_LAUNCH("b4r_adamw_step");
+  hipLaunchKernelGGL(state_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state);
+  B4R_CHECK_LAUNCH("b4r_adamw_step advance");
+  return B4R_OK;
+}
+
+extern "C" int b4r_rank_candidates(const float* hidden, int32_t hidden_ld, const int64_t* hidden_row, const float* table,
+                                   const float* bias, int32_t H, const int64_t* cand, int32_t R, int32_t C,
+                                   const int64_t* gt, int64_t* ranking, int32_t* gt_rank, float* scores,
+                                   b4r_stream_t stream) {
+  B4R_CHECK_ARG(hidden && table && bias && cand, B4R_E_BADARG, "b4r_rank_candidates: null argument");
+  B4R_CHECK_ARG(R > 0 && C > 0 && H > 0 && hidden_ld >= H, B4R_E_SHAPE, "b4r_rank_candidates: bad shape");
+  const size_t sh = (size_t)(H + C) * sizeof(float);
+  B4R_CHECK_ARG(sh <= 160 * 1024 - 64, B4R_E_SHAPE, "b4r_rank_candidates: %d candidates do not fit in LDS", C);
+  if (sh > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    if (e != hipSuccess) { b4r_set_error("b4r_rank_candidates: cannot raise LDS limit: %s", hipGetErrorString(e)); return B4R_E_HIP; }
+  }
+  hipLaunchKernelGGL(rank_kernel, dim3(R), dim3(128), sh, (hipStream_t)stream, hidden, hidden_ld, hidden_row, table, bias,
+                     H, cand, C, gt, ranking, gt_rank, scores);
+  B4R_CHECK_LAUNCH("b4r_rank_candidates");
+  return B4R_OK;
+}

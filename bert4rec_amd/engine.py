@@ -1,0 +1,295 @@
+"""Host-side driver of the HIP hot path: owns the flat parameter / gradient / Adam buffers, the workspace and the
+device-resident train state, and calls the C ABI (include/b4r.h) on the current torch stream.
+
+PyTorch is used here only as the owner of device memory and streams.  No compute happens in torch and nothing falls back
+to CPU: without the HIP library and a GPU every compute method raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Iterable, List, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import AdamWConfig, B4RError, Batch, ModelConfig
+
+BATCH_KEYS = ("input_word_ids", "input_mask", "masked_lm_positions", "masked_lm_ids")
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream(device: torch.device) -> int:
+    if device.type != "cuda":
+        raise B4RError("bert4rec_amd computes only on an AMD GPU (device 'cuda' under ROCm); got device '%s'" % device)
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def make_model_config(vocab_size: int, hidden_size: int, num_layers: int, num_attention_heads: int,
+                      max_sequence_length: int, inner_dim: int, output_dropout: float = 0.1,
+                      attention_dropout: float = 0.1, ln_eps: float = 1e-12) -> ModelConfig:
+    return ModelConfig(int(vocab_size), int(hidden_size), int(num_layers), int(num_attention_heads), int(inner_dim),
+                       int(max_sequence_length), float(output_dropout), float(attention_dropout), float(ln_eps))
+
+
+def make_adamw_config(init_lr: float = 1e-4, num_train_steps: int = 400000, num_warmup_steps: int = 100,
+                      end_lr: float = 0.0, weight_decay_rate: float = 0.01, beta_1: float = 0.9, beta_2: float = 0.999,
+                      epsilon: float = 1e-6, gradient_clip_norm: float = 5.0) -> AdamWConfig:
+    """Defaults of create_adam_w_optimizer, bert4rec/trainers/optimizers/__init__.py:7-15, and of
+    AdamWeightDecay.gradient_clip_norm, adam_w_optimizer.py:67."""
+    return AdamWConfig(float(init_lr), float(end_lr), int(num_train_steps), int(num_warmup_steps or 0),
+                       float(weight_decay_rate), float(beta_1), float(beta_2), float(epsilon), float(gradient_clip_norm))
+
+
+class ParamInfo:
+    __slots__ = ("name", "offset", "rows", "cols", "ld", "decay")
+
+    def __init__(self, name, offset, rows, cols, ld, decay):
+        self.name, self.offset, self.rows, self.cols, self.ld, self.decay = name, offset, rows, cols, ld, decay
+
+
+def param_table(cfg: ModelConfig) -> List[ParamInfo]:
+    """Named layout of the flat parameter buffer (names = the reference's Keras variable names)."""
+    lib = _lib.load()
+    n = lib.b4r_param_count(C.byref(cfg))
+    if n < 0:
+        raise B4RError("invalid model config: " + _lib.last_error())
+    out = []
+    name = C.create_string_buffer(256)
+    off, rows, cols, ld, dec = C.c_int64(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+    for i in range(n):
+        _lib.check(lib.b4r_param_info(C.byref(cfg), i, name, 256, C.byref(off), C.byref(rows), C.byref(cols),
+                                      C.byref(ld), C.byref(dec)), "b4r_param_info")
+        out.append(ParamInfo(name.value.decode(), off.value, rows.value, cols.value, ld.value, dec.value))
+    return out
+
+
+def keras_shape(name: str, info: ParamInfo, cfg: ModelConfig) -> Tuple[int, ...]:
+    """Shape the reference's Keras variable of that name has (MHA kernels are [H,h,d] / [h,d,H])."""
+    h, d = cfg.num_heads, cfg.hidden_size // cfg.num_heads
+    if name.endswith(("self_attention/query/kernel", "self_attention/key/kernel", "self_attention/value/kernel")):
+        return (info.rows, h, d)
+    if name.endswith(("self_attention/query/bias", "self_attention/key/bias", "self_attention/value/bias")):
+        return (h, d)
+    if name.endswith("self_attention/attention_output/kernel"):
+        return (h, d, info.cols)
+    if info.rows == 1:
+        return (info.cols,)
+    return (info.rows, info.cols)
+
+
+class Engine:
+    """One replica of the model on one GPU."""
+
+    def __init__(self, cfg: ModelConfig, device="cuda", seed: int = 0):
+        self.lib = _lib.load()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        total = self.lib.b4r_param_total_floats(C.byref(cfg))
+        if total < 0:
+            raise ValueError("invalid encoder configuration: " + _lib.last_error())
+        self.n_params = int(total)
+        self.n_decay = int(self.lib.b4r_param_decay_floats(C.byref(cfg)))
+        self.table = param_table(cfg)
+        self.params = torch.zeros(self.n_params, dtype=torch.float32, device=self.device)
+        self.pooler = torch.zeros(int(self.lib.b4r_pooler_floats(C.byref(cfg))), dtype=torch.float32, device=self.device)
+        self.grads: Optional[torch.Tensor] = None
+        self.adam_m: Optional[torch.Tensor] = None
+        self.adam_v: Optional[torch.Tensor] = None
+        # b4r_train_state: 16 words (seed, step_lo, step(int64), 8 floats, 4 reserved)
+        self.state = torch.zeros(_lib.STATE_WORDS, dtype=torch.int32, device=self.device)
+        self._ws: Dict[Tuple[int, int, int], torch.Tensor] = {}
+        self.set_seed(seed)
+
+    # ---- parameters -----------------------------------------------------------------------------------------------
+    def view(self, name: str, buf: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Strided view of one named variable inside a flat buffer (params by default)."""
+        buf = self.params if buf is None else buf
+        for e in self.table:
+            if e.name == name:
+                return torch.as_strided(buf, (e.rows, e.cols), (e.ld, 1), e.offset)
+        if name == "pooler_transform/kernel":
+            H = self.cfg.hidden_size
+            return self.pooler[: H * H].view(H, H)
+        if name == "pooler_transform/bias":
+            H = self.cfg.hidden_size
+            return self.pooler[H * H:]
+        raise KeyError(name)
+
+    def named_parameters(self, buf: Optional[torch.Tensor] = None) -> Iterable[Tuple[str, torch.Tensor]]:
+        for e in self.table:
+            yield e.name, self.view(e.name, buf)
+
+    def variable_names(self) -> List[str]:
+        return [e.name for e in self.table] + ["pooler_transform/kernel", "pooler_transform/bias"]
+
+    def init_parameters(self, seed: int = 3, mlm_initializer: str = "glorot_uniform") -> None:
+        """TruncatedNormal(0.02) everywhere (bert4rec_encoder.py:73-74), glorot_uniform for the MLM dense
+        (bert4rec_model.py:42,76-81), LayerNorm gamma 1 / beta 0, biases 0."""
+        g = torch.Generator().manual_seed(seed)
+        host = torch.zeros(self.n_params, dtype=torch.float32)
+        for e in self.table:
+            v = torch.as_strided(host, (e.rows, e.cols), (e.ld, 1), e.offset)
+            if e.name.endswith("gamma"):
+                v.fill_(1.0)
+            elif e.name.endswith(("beta", "bias")):
+                v.zero_()
+            elif e.name == "cls/predictions/transform/dense/kernel" and mlm_initializer == "glorot_uniform":
+                lim = math.sqrt(6.0 / (e.rows + e.cols))
+                v.copy_((torch.rand((e.rows, e.cols), generator=g) * 2 - 1) * lim)
+            else:
+                t = torch.empty((e.rows, e.cols))
+                torch.nn.init.trunc_normal_(t, mean=0.0, std=0.02, a=-0.04, b=0.04, generator=g)
+                v.copy_(t)
+        self.params.copy_(host)
+        H = self.cfg.hidden_size
+        pk = torch.empty((H, H))
+        torch.nn.init.trunc_normal_(pk, mean=0.0, std=0.02, a=-0.04, b=0.04, generator=g)
+        self.pooler.zero_()
+        self.pooler[: H * H].copy_(pk.reshape(-1))
+
+    def load_named(self, tensors: Dict[str, torch.Tensor]) -> None:
+        """Copy variables given under the reference's names/shapes into the flat buffer."""
+        for name, t in tensors.items():
+            v = self.view(name)
+            v.copy_(t.detach().to(torch.float32).reshape(v.shape).to(self.device))
+
+    def export_named(self, buf: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        out = {}
+        for e in self.table:
+            out[e.name] = self.view(e.name, buf).detach().cpu().clone().reshape(keras_shape(e.name, e, self.cfg))
+        if buf is None:
+            out["pooler_transform/kernel"] = self.view("pooler_transform/kernel").detach().cpu().clone()
+            out["pooler_transform/bias"] = self.view("pooler_transform/bias").detach().cpu().clone()
+        return out
+
+    # ---- state ----------------------------------------------------------------------------------------------------
+    def set_seed(self, seed: int) -> None:
+        s = int(seed) & 0xFFFFFFFF
+        self.state[_lib.ST_SEED] = s - (1 << 32) if s >= (1 << 31) else s
+
+    def set_step(self, step: int) -> None:
+        lo = int(step) & 0xFFFFFFFF
+        self.state[_lib.ST_STEP_LO] = lo - (1 << 32) if lo >= (1 << 31) else lo
+        self.state[_lib.ST_STEP:_lib.ST_STEP + 2].view(torch.int64)[0] = int(step)
+
+    def read_state(self) -> Dict[str, float]:
+        """Synchronising read of the device state (metrics of the last step)."""
+        host = self.state.cpu()
+        f = host.view(torch.float32)
+        step = int(host[_lib.ST_STEP:_lib.ST_STEP + 2].view(torch.int64)[0])
+        return dict(step=step, loss_sum=float(f[_lib.ST_LOSS_SUM]), valid_count=float(f[_lib.ST_VALID]),
+                    correct_masked=float(f[_lib.ST_CORRECT_MASKED]), correct_all=float(f[_lib.ST_CORRECT_ALL]),
+                    slots_all=float(f[_lib.ST_SLOTS_ALL]), grad_sqnorm=float(f[_lib.ST_SQNORM]),
+                    grad_norm=float(f[_lib.ST_GRAD_NORM]), lr=float(f[_lib.ST_LR]))
+
+    def ensure_training_buffers(self) -> None:
+        if self.grads is None:
+            self.grads = torch.zeros_like(self.params)
+            self.adam_m = torch.zeros_like(self.params)
+            self.adam_v = torch.zeros_like(self.params)
+
+    # ---- workspace ------------------------------------------------------------------------------------------------
+    def workspace(self, B: int, L: int, P: int) -> torch.Tensor:
+        key = (B, L, P)
+        ws = self._ws.get(key)
+        if ws is None:
+            nbytes = self.lib.b4r_workspace_bytes(C.byref(self.cfg), B, L, P)
+            if nbytes < 0:
+                raise B4RError("b4r_workspace_bytes: " + _lib.last_error())
+            if len(self._ws) > 4:
+                self._ws.clear()
+            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
+            self._ws[key] = ws
+        return ws
+
+    def region(self, name: str, B: int, L: int, P: int) -> torch.Tensor:
+        off, rows, cols, ld = C.c_int64(), C.c_int32(), C.c_int32(), C.c_int32()
+        _lib.check(self.lib.b4r_workspace_region(C.byref(self.cfg), B, L, P, name.encode(), C.byref(off), C.byref(rows),
+                                                 C.byref(cols), C.byref(ld)), "b4r_workspace_region")
+        return torch.as_strided(self.workspace(B, L, P), (rows.value, cols.value), (ld.value, 1), off.value)
+
+    # ---- batches --------------------------------------------------------------------------------------------------
+    def prepare_batch(self, batch: Dict[str, torch.Tensor]) -> Tuple[Batch, Dict[str, torch.Tensor]]:
+        """Move the int64 batch dict (bert4rec_model.py:15-22) to the device; returns the C struct and the tensors that
+        must stay alive while the kernels run."""
+        keep: Dict[str, torch.Tensor] = {}
+        for k in BATCH_KEYS:
+            if k in batch and batch[k] is not None:
+                t = torch.as_tensor(batch[k])
+                if t.dim() != 2:
+                    raise ValueError(f"batch['{k}'] must be rank 2 [batch, length], got shape {tuple(t.shape)}")
+                keep[k] = t.to(device=self.device, dtype=torch.int64).contiguous()
+        if "input_word_ids" not in keep or "input_mask" not in keep:
+            raise ValueError("batch needs 'input_word_ids' and 'input_mask'")
+        B, L = keep["input_word_ids"].shape
+        if keep["input_mask"].shape != (B, L):
+            raise ValueError("input_mask shape differs from input_word_ids")
+        P = 0
+        if "masked_lm_positions" in keep:
+            if keep["masked_lm_positions"].shape[0] != B:
+                raise ValueError("masked_lm_positions batch size differs")
+            P = keep["masked_lm_positions"].shape[1]
+            if "masked_lm_ids" in keep and keep["masked_lm_ids"].shape != (B, P):
+                raise ValueError("masked_lm_ids shape differs from masked_lm_positions")
+        cb = Batch(_ptr(keep["input_word_ids"]), _ptr(keep["input_mask"]), _ptr(keep.get("masked_lm_positions")),
+                   _ptr(keep.get("masked_lm_ids")), B, L, P)
+        return cb, keep
+
+    # ---- compute --------------------------------------------------------------------------------------------------
+    def forward(self, cb: Batch, training: bool = False, pooler: bool = True) -> None:
+        ws = self.workspace(cb.B, cb.L, cb.P)
+        flags = (_lib.FLAG_TRAINING if training else 0) | (_lib.FLAG_POOLER if pooler else 0)
+        _lib.check(self.lib.b4r_forward(C.byref(self.cfg), C.byref(cb), _ptr(self.params), _ptr(self.pooler), _ptr(ws),
+                                        ws.numel() * 4, _ptr(self.state), flags, _stream(self.device)), "b4r_forward")
+
+    def begin_step(self) -> None:
+        _lib.check(self.lib.b4r_state_begin_step(_ptr(self.state), _stream(self.device)), "b4r_state_begin_step")
+
+    def loss(self, cb: Batch, want_grad: bool) -> None:
+        ws = self.workspace(cb.B, cb.L, cb.P)
+        _lib.check(self.lib.b4r_loss(C.byref(self.cfg), C.byref(cb), _ptr(ws), ws.numel() * 4, _ptr(self.state),
+                                     1 if want_grad else 0, _stream(self.device)), "b4r_loss")
+
+    def backward(self, cb: Batch, training: bool = True) -> None:
+        self.ensure_training_buffers()
+        ws = self.workspace(cb.B, cb.L, cb.P)
+        _lib.check(self.lib.b4r_backward(C.byref(self.cfg), C.byref(cb), _ptr(self.params), _ptr(self.grads), _ptr(ws),
+                                         ws.numel() * 4, _ptr(self.state), _lib.FLAG_TRAINING if training else 0,
+                                         _stream(self.device)), "b4r_backward")
+
+    def optimizer_step(self, hp: AdamWConfig, cb: Batch) -> None:
+        self.ensure_training_buffers()
+        ws = self.workspace(cb.B, cb.L, cb.P)
+        _lib.check(self.lib.b4r_optimizer_step(C.byref(self.cfg), C.byref(hp), _ptr(self.params), _ptr(self.grads),
+                                               _ptr(self.adam_m), _ptr(self.adam_v), _ptr(ws), ws.numel() * 4,
+                                               _ptr(self.state), _stream(self.device)), "b4r_optimizer_step")
+
+    def train_step(self, hp: AdamWConfig, cb: Batch) -> None:
+        """BERT4RecModel.train_step (bert4rec_model.py:151-173) as one enqueue; metrics stay on the device."""
+        self.ensure_training_buffers()
+        ws = self.workspace(cb.B, cb.L, cb.P)
+        _lib.check(self.lib.b4r_train_step(C.byref(self.cfg), C.byref(hp), C.byref(cb), _ptr(self.params), _ptr(self.grads),
+                                           _ptr(self.adam_m), _ptr(self.adam_v), _ptr(ws), ws.numel() * 4, _ptr(self.state),
+                                           _stream(self.device)), "b4r_train_step")
+
+    def rank_candidates(self, hidden: torch.Tensor, hidden_rows: Optional[torch.Tensor], cand: torch.Tensor,
+                        gt: Optional[torch.Tensor], want_ranking: bool = True, want_scores: bool = False):
+        """b4r_rank_candidates on `hidden` [*,H] (ld = stride(0)); cand [R,C] int64; gt [R] int64 or None."""
+        R, Cn = cand.shape
+        cand = cand.to(device=self.device, dtype=torch.int64).contiguous()
+        gt_d = None if gt is None else gt.to(device=self.device, dtype=torch.int64).contiguous()
+        rows_d = None if hidden_rows is None else hidden_rows.to(device=self.device, dtype=torch.int64).contiguous()
+        ranking = torch.empty((R, Cn), dtype=torch.int64, device=self.device) if want_ranking else None
+        gt_rank = torch.empty((R,), dtype=torch.int32, device=self.device) if gt is not None else None
+        scores = torch.empty((R, Cn), dtype=torch.float32, device=self.device) if want_scores else None
+        H = self.cfg.hidden_size
+        _lib.check(self.lib.b4r_rank_candidates(_ptr(hidden), hidden.stride(0), _ptr(rows_d),
+                                                _ptr(self.view("word_embeddings/embeddings")),
+                                                _ptr(self.view("cls/predictions/output_bias/bias")), H, _ptr(cand), R, Cn,
+                                                _ptr(gt_d), _ptr(ranking), _ptr(gt_rank), _ptr(scores),
+                                                _stream(self.device)), "b4r_rank_candidates")
+        return ranking, gt_rank, scores

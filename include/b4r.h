@@ -1,0 +1,248 @@
+/* b4r.h  --  C ABI of libb4r_hip.so: the MI355X (gfx950) BERT4Rec hot path.
+ *
+ * The reference (maneymarkus/BERT4Rec, Python on TensorFlow 2.10) has no FFI boundary of its own: its hot path sits
+ * behind Keras object interfaces.  Each entry point below replaces the TensorFlow kernels reached
+ * from one of those call sites; the reference file:line it replaces is cited on every declaration.  A maintainer of
+ * the reference would bind this library with ctypes exactly as bert4rec_amd/_lib.py does.
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, negative = B4R_E_*; nothing throws; b4r_last_error() returns the
+ *     message of the last failure on the calling thread.
+ *   - tensor arguments are CALLER-OWNED DEVICE pointers (contiguous row-major unless a leading dimension is given),
+ *     float32 values and int64 ids exactly as the reference's batch dict holds them (bert4rec_model.py:15-22).
+ *   - the library allocates nothing persistent; scratch comes from a caller workspace whose size is queried first.
+ *   - every op only ENQUEUES on the given hipStream_t: no host synchronisation, no internal threads; safe to
+ *     capture in a hipGraph.  All step-varying scalars (step counter, dropout seed, loss sums, gradient norm)
+ *     live in the device-resident b4r_train_state, never in by-value arguments.
+ */
+#ifndef B4R_H_
+#define B4R_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* b4r_stream_t; /* == hipStream_t */
+
+#define B4R_VERSION 100
+#define B4R_MAX_LAYERS 32
+
+enum { B4R_OK = 0, B4R_E_BADARG = -1, B4R_E_SHAPE = -2, B4R_E_ALIGN = -3, B4R_E_HIP = -4, B4R_E_NOMEM = -5 };
+
+/* Encoder hyper-parameters: Bert4RecEncoder.__init__ kwargs, bert4rec_encoder.py:62-80, as set by
+ * bert4rec/config/bert4rec_train_configs/ *.json.  head_dim = hidden_size / num_heads must be 32 (true for every
+ * shipped config). */
+typedef struct b4r_model_config {
+  int32_t vocab_size;
+  int32_t hidden_size;
+  int32_t num_layers;
+  int32_t num_heads;
+  int32_t inner_dim;
+  int32_t max_seq_len; /* max_sequence_length: rows of the position table */
+  float output_dropout;
+  float attention_dropout;
+  float ln_eps; /* 1e-12: bert4rec_encoder.py:117, tfm TransformerEncoderBlock norm_epsilon, tfm MaskedLM */
+} b4r_model_config;
+
+/* One batch, the dict of bert4rec_model.py:15-22 / bert4rec_preprocessor.py:48-116.  All int64 [B, .] row-major. */
+typedef struct b4r_batch {
+  const int64_t* input_word_ids;      /* [B,L] */
+  const int64_t* input_mask;          /* [B,L] 1 = real token (incl. masked), 0 = pad */
+  const int64_t* masked_lm_positions; /* [B,P] or NULL (then no MLM head) */
+  const int64_t* masked_lm_ids;       /* [B,P] y_true; 0 = ignored slot (trainer_utils.py:13) ; NULL for inference */
+  int32_t B, L, P;
+} b4r_batch;
+
+/* AdamWeightDecay + WarmUp/PolynomialDecay: optimizers/__init__.py:7-56, adam_w_optimizer.py:53-76 */
+typedef struct b4r_adamw_config {
+  float init_lr;            /* 1e-4 */
+  float end_lr;             /* 0 */
+  int32_t num_train_steps;  /* 400000 */
+  int32_t num_warmup_steps; /* 100 */
+  float weight_decay_rate;  /* 0.01 */
+  float beta_1, beta_2;     /* 0.9, 0.999 */
+  float epsilon;            /* 1e-6 */
+  float clip_norm;          /* 5.0 (gradient_clip_norm, adam_w_optimizer.py:67); <= 0 disables */
+} b4r_adamw_config;
+
+/* Device-resident state, 64 bytes, owned by the caller (one torch tensor).  Kernels read and write it; the host reads
+ * it back only when it wants the metrics.  Layout is part of the ABI. */
+typedef struct b4r_train_state {
+  uint32_t seed;        /* [0]  dropout seed                                                         */
+  uint32_t step_lo;     /* [1]  low 32 bits of the optimizer iteration (0-based), also the dropout step */
+  int64_t step;         /* [2,3] optimizer.iterations                                                */
+  float loss_sum;       /* [4]  sum over valid slots of the per-slot CE  (trainer_utils.py:19-22 numerator)   */
+  float valid_count;    /* [5]  number of slots with masked_lm_ids != 0  (denominator)                */
+  float correct_masked; /* [6]  argmax == y_true over valid slots        (trainer_utils.py:49-60)     */
+  float correct_all;    /* [7]  argmax == y_true over all B*P slots      (SparseCategoricalAccuracy)  */
+  float slots_all;      /* [8]  B*P of the batch                                                      */
+  float grad_sqnorm;    /* [9]  sum g^2 of the (summed, un-normalised) gradient buffer                */
+  float grad_norm;      /* [10] global norm of the mean gradient as clip_by_global_norm sees it      */
+  float lr;             /* [11] lr_t used by the last optimizer step                                  */
+  float reserved[4];
+} b4r_train_state;
+
+/* ------------------------------------------------------------------------------------------------------------ */
+int b4r_version(void);
+/* copies the calling thread's last error message (NUL-terminated) and returns its length */
+size_t b4r_last_error(char* buf, size_t cap);
+
+/* ---- parameter layout ---------------------------------------------------------------------------------------
+ * All trainable variables live in ONE flat fp32 buffer (so that clip / AdamW / the DP all-reduce are one pass).
+ * The first b4r_param_decay_floats() floats are the weight-decayed variables (kernels + the two embedding tables),
+ * the rest are the biases and LayerNorm gamma/beta (adam_w_optimizer.py:154-168 with optimizers/__init__.py:35-36).
+ * Entries are named after the reference's Keras variables ("transformer/layer_0/self_attention/query/kernel", ...).
+ * query/key/value kernels are column blocks of one [H,3H] matrix (ld = 3H) so that QKV is a single GEMM.
+ * The pooler (bert4rec_encoder.py:149-153) is not on the loss path (gradient None): it lives in a separate buffer. */
+int64_t b4r_param_total_floats(const b4r_model_config* cfg);  /* size of the flat buffer (padded to 4) */
+int64_t b4r_param_decay_floats(const b4r_model_config* cfg);
+int32_t b4r_param_count(const b4r_model_config* cfg);
+int b4r_param_info(const b4r_model_config* cfg, int32_t index, char* name, size_t name_cap, int64_t* offset,
+                   int32_t* rows, int32_t* cols, int32_t* ld, int32_t* decay);
+int64_t b4r_pooler_floats(const b4r_model_config* cfg); /* [H,H] kernel then [H] bias */
+
+/* ---- workspace ----------------------------------------------------------------------------------------------
+ * One caller buffer holds every activation saved for backward plus scratch.  Named regions (outputs of
+ * BERT4RecModel.call, bert4rec_model.py:110-149) are located with b4r_workspace_region:
+ *   "sequence_output" [B*L,H], "encoder_output_<i>" [B*L,H], "mlm_logits" [B*P, ld>=V], "mlm_hidden" [B*P,H],
+ *   "pooled_output" [B,H], "embeddings" [B*L,H]. */
+int64_t b4r_workspace_bytes(const b4r_model_config* cfg, int32_t B, int32_t L, int32_t P);
+int b4r_workspace_region(const b4r_model_config* cfg, int32_t B, int32_t L, int32_t P, const char* name,
+                         int64_t* offset_floats, int32_t* rows, int32_t* cols, int32_t* ld);
+
+/* ---- model level --------------------------------------------------------------------------------------------
+ * b4r_forward          replaces BERT4RecModel.call            bert4rec_model.py:110-149  (encoder + MaskedLM)
+ *                      = Bert4RecEncoder.call                  bert4rec_encoder.py:186-231
+ * b4r_loss             replaces MaskedSparseCategoricalCrossentropy.call trainer_utils.py:12-23 and the two metrics
+ *                      trainer_utils.py:49-60 / bert4rec_trainer.py:28-33; writes sums into b4r_train_state and
+ *                      (with want_grad) overwrites the logits with d(loss_sum)/d(logits)
+ * b4r_backward         replaces tape.gradient                  bert4rec_model.py:166-167 (gradient of loss_SUM; the
+ *                      1/valid_count factor is applied inside b4r_optimizer_step, so a data-parallel caller can
+ *                      all-reduce grads and state sums in between: SURVEY.md §8e)
+ * b4r_optimizer_step   replaces AdamWeightDecay.apply_gradients adam_w_optimizer.py:100-137 (+ schedule :22-36)
+ * flags: bit0 = training (dropout on), bit1 = also compute pooled_output. */
+#define B4R_FLAG_TRAINING 1
+#define B4R_FLAG_POOLER 2
+int b4r_forward(const b4r_model_config* cfg, const b4r_batch* batch, const float* params, const float* pooler,
+                void* workspace, int64_t workspace_bytes, b4r_train_state* state, int32_t flags, b4r_stream_t stream);
+int b4r_loss(const b4r_model_config* cfg, const b4r_batch* batch, void* workspace, int64_t workspace_bytes,
+             b4r_train_state* state, int32_t want_grad, b4r_stream_t stream);
+int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch, const float* params, float* grads,
+                 void* workspace, int64_t workspace_bytes, b4r_train_state* state, int32_t flags,
+                 b4r_stream_t stream);
+int b4r_optimizer_step(const b4r_model_config* cfg, const b4r_adamw_config* hp, float* params, const float* grads,
+                       float* adam_m, float* adam_v, void* workspace, int64_t workspace_bytes,
+                       b4r_train_state* state, b4r_stream_t stream);
+/* zero the per-step sums of the state (loss_sum .. grad_norm); call before b4r_loss */
+int b4r_state_begin_step(b4r_train_state* state, b4r_stream_t stream);
+/* BERT4RecModel.train_step, bert4rec_model.py:151-173 = begin_step + forward + loss + backward + optimizer_step */
+int b4r_train_step(const b4r_model_config* cfg, const b4r_adamw_config* hp, const b4r_batch* batch, float* params,
+                   float* grads, float* adam_m, float* adam_v, void* workspace, int64_t workspace_bytes,
+                   b4r_train_state* state, b4r_stream_t stream);
+
+/* ---- ranking ------------------------------------------------------------------------------------------------
+ * replaces BERT4RecModel.rank_items bert4rec_model.py:224-239 (gather candidate logits, tf.argsort DESCENDING,
+ * gather candidates) and the rank lookup of bert4rec_evaluator.py:113-117.
+ * score(r,j) = fma-chain_k(hidden[hidden_row[r]][k] * table[cand[r][j]][k]) + bias[cand[r][j]]  (k ascending, fp32)
+ * ranking[r][pos] = cand[r][j] with pos = #{i: s_i > s_j} + #{i<j: s_i == s_j}   (stable descending)
+ * gt_rank[r] = 1 + min{pos_j : cand[r][j] == gt[r]}  (0 if gt[r] is not a candidate).  Any output may be NULL. */
+int b4r_rank_candidates(const float* hidden, int32_t hidden_ld, const int64_t* hidden_row, const float* table,
+                        const float* bias, int32_t H, const int64_t* cand, int32_t R, int32_t C, const int64_t* gt,
+                        int64_t* ranking, int32_t* gt_rank, float* scores, b4r_stream_t stream);
+
+/* ---- op level (each is also a stage of the model-level calls; exposed for parity tests and reuse) ------------ */
+
+/* x = dropout(LN(E[ids] + P[pos]))   bert4rec_encoder.py:198-211 */
+int b4r_embed_ln_fwd(const int64_t* ids, int32_t B, int32_t L, const float* table, int32_t V, const float* pos_table,
+                     const float* gamma, const float* beta, int32_t H, float eps, float* out, float* mean,
+                     float* rstd, const uint32_t* rng, float dropout, b4r_stream_t stream);
+
+/* y = LN(z) rows of width H; saves mean / rstd */
+int b4r_ln_fwd(const float* z, int32_t rows, int32_t H, const float* gamma, const float* beta, float eps, float* y,
+               float* mean, float* rstd, b4r_stream_t stream);
+/* dz from dy; dgamma/dbeta [H] (deterministic two-stage column sums; scratch >= b4r_ln_bwd_scratch_floats) */
+int64_t b4r_ln_bwd_scratch_floats(int32_t rows, int32_t H);
+int b4r_ln_bwd(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
+               int32_t rows, int32_t H, float* dz, float* dgamma, float* dbeta, float* scratch,
+               b4r_stream_t stream);
+
+/* epilogues of b4r_gemm_f32 */
+enum {
+  B4R_EPI_NONE = 0,          /* C = acc                                                   */
+  B4R_EPI_BIAS = 1,          /* C = acc + bias                                            */
+  B4R_EPI_BIAS_QSCALE = 2,   /* C = (acc + bias) * (col < qcols ? qscale : 1)   (Keras MHA query scaling)     */
+  B4R_EPI_BIAS_GELU = 3,     /* C2 = acc + bias ; C = gelu_erf(C2)                        */
+  B4R_EPI_BIAS_DROP_RES = 4, /* C = R + dropout(acc + bias)                               */
+  B4R_EPI_GELU_BWD = 5,      /* C = acc * gelu'(R)                                        */
+  B4R_EPI_ADD_RES = 6,       /* C = acc + R                                               */
+  B4R_EPI_BIAS_TANH = 7      /* C = tanh(acc + bias)                     (pooler, bert4rec_encoder.py:149-153) */
+};
+typedef struct b4r_gemm_desc {
+  const float* A; int32_t lda;   /* [M,K] row-major                                       */
+  const float* B; int32_t ldb;   /* b_is_nk == 0: [K,N] ; b_is_nk == 1: [N,K]  (C = A.B^T) */
+  float* C; int32_t ldc;         /* [M,N]                                                 */
+  int32_t M, N, K;
+  int32_t b_is_nk;
+  int32_t epilogue;
+  const float* bias;             /* [N]                                                   */
+  float* C2; int32_t ldc2;
+  const float* R; int32_t ldr;
+  float qscale; int32_t qcols;
+  /* dropout: on the epilogue (B4R_EPI_BIAS_DROP_RES, element index row*N+col) or, with a_dropout=1, on the A operand
+   * as it is loaded (element index row*K+col): dY = dz * mask / keep without materialising dY */
+  const uint32_t* rng; uint32_t drop_stream; float drop_rate; int32_t a_dropout;
+} b4r_gemm_desc;
+/* dense layers of the encoder / MLM head (Keras Dense / EinsumDense / MultiHeadAttention projections) on the exact
+ * fp32 matrix cores (v_mfma_f32_32x32x2_f32) */
+int b4r_gemm_f32(const b4r_gemm_desc* d, b4r_stream_t stream);
+
+/* out[Mo,No] = A[R,Mo]^T . B[R,No]  (weight gradients), optional colsum[No] = sum_r B[r,:] (bias gradients).
+ * Deterministic split over R: partial slabs in `scratch` then an ordered reduce.  b_dropout as above (index r*No+c). */
+typedef struct b4r_gemm_tn_desc {
+  const float* A; int32_t lda;
+  const float* B; int32_t ldb;
+  float* out; int32_t ldo;
+  int32_t R, Mo, No;
+  float* colsum;   /* [No] = sum_r B[r,:] (after the optional dropout) or NULL */
+  float* colsum_a; /* [Mo] = sum_r A[r,:] or NULL                              */
+  const uint32_t* rng; uint32_t drop_stream; float drop_rate; int32_t b_dropout;
+  int32_t accumulate; /* 1: out += result (out must hold defined values) */
+} b4r_gemm_tn_desc;
+int64_t b4r_gemm_tn_scratch_floats(int32_t R, int32_t Mo, int32_t No);
+int b4r_gemm_tn_f32(const b4r_gemm_tn_desc* d, float* scratch, b4r_stream_t stream);
+
+/* Keras MultiHeadAttention core for one layer, head_dim 32: ctx = dropout(softmax(q k^T + (1-mask)*-1e9)) v
+ * qkv [B*L, 3H] (q pre-scaled by 1/sqrt(d)), ctx [B*L, H], lse [B, heads, L]; input_mask int64 [B,L]. */
+int b4r_attn_fwd(const float* qkv, const int64_t* input_mask, int32_t B, int32_t L, int32_t heads, float* ctx,
+                 float* lse, const uint32_t* rng, uint32_t drop_stream, float drop_rate, b4r_stream_t stream);
+/* dqkv [B*L,3H] from dctx; dq is returned multiplied by qscale (gradient wrt the un-scaled query projection) */
+int b4r_attn_bwd(const float* qkv, const int64_t* input_mask, const float* ctx, const float* lse, const float* dctx,
+                 int32_t B, int32_t L, int32_t heads, float qscale, float* dqkv, const uint32_t* rng,
+                 uint32_t drop_stream, float drop_rate, b4r_stream_t stream);
+
+/* rows gather / scatter-add:  dst[i,:] = src[idx[i],:]   /   dst[idx[i],:] += src[i,:] (fp32 atomics) */
+int b4r_gather_rows(const float* src, int32_t src_ld, const int64_t* idx, int64_t idx_add_per, int32_t per,
+                    int32_t n, int32_t H, float* dst, b4r_stream_t stream);
+int b4r_scatter_add_rows(const float* src, const int64_t* idx, int64_t idx_add_per, int32_t per, int32_t n, int32_t H,
+                         float* dst, int32_t dst_ld, const int64_t* skip_if_zero, b4r_stream_t stream);
+
+/* per-row softmax cross entropy over logits [M, ld] (V valid columns) + argmax metrics; row scalars then an ordered
+ * single-workgroup reduction into the state.  want_grad: logits <- softmax - onehot for valid rows, 0 otherwise
+ * (pad columns V..ld-1 are zeroed).   trainer_utils.py:12-23,49-60 */
+int b4r_softmax_ce(float* logits, int32_t M, int32_t V, int32_t ld, const int64_t* y_true, float* row_scratch,
+                   b4r_train_state* state, int32_t want_grad, b4r_stream_t stream);
+
+/* sum of squares of a flat buffer into state->grad_sqnorm (deterministic), scratch >= 1024 floats */
+int b4r_global_sqnorm(const float* g, int64_t n, float* scratch, b4r_train_state* state, b4r_stream_t stream);
+/* fused clip + decoupled decay + Adam over the flat buffers; first n_decay floats are decayed.  Uses
+ * state->{step, valid_count, grad_sqnorm}; writes state->{grad_norm, lr} and advances state->step. */
+int b4r_adamw_step(const b4r_adamw_config* hp, float* params, const float* grads, float* adam_m, float* adam_v,
+                   int64_t n, int64_t n_decay, b4r_train_state* state, b4r_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* B4R_H_ */

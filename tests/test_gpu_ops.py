@@ -1,0 +1,334 @@
+"""GPU parity tests, op level: every HIP kernel is called through the C ABI and compared with a plain torch-CPU fp32/fp64
+restatement of the same op (tolerances stated per test).  Dropout masks are compared exactly through the oracle's
+restatement of the counter hash."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from bert4rec_amd import _lib
+from oracle import bert4rec_oracle as orc
+from tests import b4r_testlib as T
+from tests.b4r_testlib import P, stream
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+TOL = 2e-5  # fp32 matrix-core sums of <= 4k terms of O(1) magnitude vs fp64
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.float32)
+
+
+def gelu(x):
+    return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def gelu_grad(x):
+    return 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 70, 64), (128, 64, 32), (257, 192, 100), (64, 256, 256), (5, 3, 7)])
+def test_gemm_nn_epilogues(M, N, K):
+    A, B, bias, R = rnd(M, K, seed=1), rnd(K, N, seed=2, scale=0.3), rnd(N, seed=3), rnd(M, N, seed=4)
+    ref = A.double() @ B.double()
+    Ad, Bd, bd, Rd = A.to(DEV), B.to(DEV), bias.to(DEV), R.to(DEV)
+    scale = max(1.0, float(ref.abs().max()))
+    c, _ = T.gemm(Ad, Bd, M, N, K)
+    assert T.maxdiff(c, ref) < TOL * scale
+    c, _ = T.gemm(Ad, Bd, M, N, K, epi=_lib.EPI_BIAS, bias=bd)
+    assert T.maxdiff(c, ref + bias.double()) < TOL * scale
+    qc = N // 3
+    c, _ = T.gemm(Ad, Bd, M, N, K, epi=_lib.EPI_BIAS_QSCALE, bias=bd, qscale=0.25, qcols=qc)
+    want = ref + bias.double()
+    want[:, :qc] *= 0.25
+    assert T.maxdiff(c, want) < TOL * scale
+    c, c2 = T.gemm(Ad, Bd, M, N, K, epi=_lib.EPI_BIAS_GELU, bias=bd, want_c2=True)
+    assert T.maxdiff(c2, ref + bias.double()) < TOL * scale
+    assert T.maxdiff(c, gelu(ref + bias.double())) < TOL * scale
+    c, _ = T.gemm(Ad, Bd, M, N, K, epi=_lib.EPI_BIAS_DROP_RES, bias=bd, R=Rd)
+    assert T.maxdiff(c, ref + bias.double() + R.double()) < TOL * scale
+    c, _ = T.gemm(Ad, Bd, M, N, K, epi=_lib.EPI_GELU_BWD, R=Rd)
+    assert T.maxdiff(c, ref * gelu_grad(R.double())) < TOL * scale
+    c, _ = T.gemm(Ad, Bd, M, N, K, epi=_lib.EPI_ADD_RES, R=Rd)
+    assert T.maxdiff(c, ref + R.double()) < TOL * scale
+    c, _ = T.gemm(Ad, Bd, M, N, K, epi=_lib.EPI_BIAS_TANH, bias=bd)
+    assert T.maxdiff(c, torch.tanh(ref + bias.double())) < TOL * scale
+
+
+def test_gemm_dropout_epilogue_and_a_operand():
+    M, N, K, rate, seed, step, sid = 200, 64, 96, 0.2, 99, 7, 5
+    A, B, bias, R = rnd(M, K, seed=1), rnd(K, N, seed=2, scale=0.3), rnd(N, seed=3), rnd(M, N, seed=4)
+    st = T.new_state(seed, step)
+    keep = orc.dropout_keep_mask((M, N), rate, seed, step, sid).double()
+    ref = (A.double() @ B.double() + bias.double()) * keep / (1 - rate) + R.double()
+    c, _ = T.gemm(A.to(DEV), B.to(DEV), M, N, K, epi=_lib.EPI_BIAS_DROP_RES, bias=bias.to(DEV), R=R.to(DEV), rng=st,
+                  drop_stream=sid, drop_rate=rate)
+    assert T.maxdiff(c, ref) < 1e-4
+    assert abs(float(keep.mean()) - 0.8) < 0.02
+    # dropout applied to the A operand while it is loaded (backward of a dropped projection)
+    keep_a = orc.dropout_keep_mask((M, K), rate, seed, step, sid).double()
+    ref = (A.double() * keep_a / (1 - rate)) @ B.double()
+    c, _ = T.gemm(A.to(DEV), B.to(DEV), M, N, K, rng=st, drop_stream=sid, drop_rate=rate, a_dropout=1)
+    assert T.maxdiff(c, ref) < 1e-4
+
+
+@pytest.mark.parametrize("M,N,K,ldc", [(256, 3709, 64, 3712), (130, 37, 16, 64), (96, 64, 192, 64)])
+def test_gemm_nt_vocab_projection(M, N, K, ldc):
+    """C = A.B^T with B [N,K]: the tied projection T.E^T + b (tfm MaskedLM) incl. the padded leading dimension."""
+    A, B, bias = rnd(M, K, seed=5), rnd(N, K, seed=6, scale=0.05), rnd(N, seed=7, scale=0.1)
+    ref = A.double() @ B.double().t() + bias.double()
+    c, _ = T.gemm(A.to(DEV), B.to(DEV), M, N, K, b_is_nk=1, epi=_lib.EPI_BIAS, bias=bias.to(DEV), ldc=ldc)
+    assert T.maxdiff(c, ref) < TOL
+
+
+def test_gemm_k_tail_padded_rows():
+    """dT = dlogits[M, V (ld Vp)] . E[V,H]: K = 3709 is neither a multiple of the K tile nor of 4."""
+    M, V, Vp, H = 96, 3709, 3712, 64
+    dl = torch.zeros(M, Vp)
+    dl[:, :V] = rnd(M, V, seed=8, scale=0.02)
+    dl[:, V:] = 1e30  # must never be read into the sum
+    E = rnd(V, H, seed=9, scale=0.05)
+    ref = dl[:, :V].double() @ E.double()
+    c, _ = T.gemm(dl.to(DEV), E.to(DEV), M, H, V)
+    assert T.maxdiff(c, ref) < TOL
+
+
+@pytest.mark.parametrize("R,Mo,No", [(1000, 64, 192), (517, 300, 64), (4096, 64, 64), (33, 5, 9)])
+def test_gemm_tn_weight_gradient(R, Mo, No):
+    A, B = rnd(R, Mo, seed=10), rnd(R, No, seed=11)
+    ref = A.double().t() @ B.double()
+    out, cs, csa = T.gemm_tn(A.to(DEV), B.to(DEV), R, Mo, No, want_colsum=True, want_colsum_a=True)
+    s = max(1.0, float(ref.abs().max()))
+    assert T.maxdiff(out, ref) < 5e-5 * s
+    assert T.maxdiff(cs, B.double().sum(0)) < 5e-5 * s
+    assert T.maxdiff(csa, A.double().sum(0)) < 5e-5 * s
+    # bitwise reproducible (ordered slab reduction, no atomics)
+    out2, cs2, _ = T.gemm_tn(A.to(DEV), B.to(DEV), R, Mo, No, want_colsum=True)
+    assert torch.equal(out, out2) and torch.equal(cs, cs2)
+
+
+def test_gemm_tn_dropout_on_b():
+    R, Mo, No, rate, seed, step, sid = 700, 64, 64, 0.3, 5, 11, 2
+    A, B = rnd(R, Mo, seed=12), rnd(R, No, seed=13)
+    st = T.new_state(seed, step)
+    keep = orc.dropout_keep_mask((R, No), rate, seed, step, sid).double()
+    Bd = B.double() * keep / (1 - rate)
+    out, cs, _ = T.gemm_tn(A.to(DEV), B.to(DEV), R, Mo, No, want_colsum=True, rng=st, drop_stream=sid, drop_rate=rate,
+                           b_dropout=1)
+    assert T.maxdiff(out, A.double().t() @ Bd) < 2e-4
+    assert T.maxdiff(cs, Bd.sum(0)) < 2e-4
+
+
+@pytest.mark.parametrize("H", [32, 64, 128, 256, 512])
+def test_layer_norm_fwd_bwd(H):
+    rows = 333
+    lib = _lib.load()
+    z = rnd(rows, H, seed=14, scale=2.0) + 0.5
+    gamma, beta, dy = rnd(H, seed=15) + 1.0, rnd(H, seed=16), rnd(rows, H, seed=17)
+    zr = z.clone().double().requires_grad_(True)
+    gr, br = gamma.clone().double().requires_grad_(True), beta.clone().double().requires_grad_(True)
+    yr = orc.layer_norm(zr, gr, br, 1e-12)
+    yr.backward(dy.double())
+    zd, gd, bd = z.to(DEV), gamma.to(DEV), beta.to(DEV)
+    y = torch.empty_like(zd)
+    mean = torch.empty(rows, device=DEV)
+    rstd = torch.empty(rows, device=DEV)
+    _lib.check(lib.b4r_ln_fwd(P(zd), rows, H, P(gd), P(bd), 1e-12, P(y), P(mean), P(rstd), stream()))
+    assert T.maxdiff(y, yr) < 2e-5
+    dz = torch.empty_like(zd)
+    dg, db = torch.empty(H, device=DEV), torch.empty(H, device=DEV)
+    scratch = torch.empty(lib.b4r_ln_bwd_scratch_floats(rows, H), device=DEV)
+    _lib.check(lib.b4r_ln_bwd(P(dy.to(DEV)), P(zd), P(mean), P(rstd), P(gd), rows, H, P(dz), P(dg), P(db), P(scratch), stream()))
+    assert T.maxdiff(dz, zr.grad) < 5e-5
+    assert T.maxdiff(dg, gr.grad) < 2e-4
+    assert T.maxdiff(db, br.grad) < 2e-4
+
+
+@pytest.mark.parametrize("rate", [0.0, 0.2])
+def test_embedding_stage(rate):
+    """x = dropout(LN(E[ids] + P[:L]))  bert4rec_encoder.py:198-211"""
+    lib = _lib.load()
+    B, L, V, H, Lmax, seed, step = 7, 23, 101, 64, 40, 77, 3
+    ids = torch.randint(0, V, (B, L), generator=torch.Generator().manual_seed(1))
+    E, Pos = rnd(V, H, seed=18, scale=0.02), rnd(Lmax, H, seed=19, scale=0.02)
+    gamma, beta = rnd(H, seed=20) + 1, rnd(H, seed=21)
+    ref = orc.layer_norm((E[ids] + Pos[:L][None]).double(), gamma.double(), beta.double(), 1e-12)
+    if rate > 0:
+        ref = ref * orc.dropout_keep_mask((B, L, H), rate, seed, step, orc.STREAM_EMB).double() / (1 - rate)
+    st = T.new_state(seed, step)
+    out = torch.empty(B * L, H, device=DEV)
+    mean, rstd = torch.empty(B * L, device=DEV), torch.empty(B * L, device=DEV)
+    _lib.check(lib.b4r_embed_ln_fwd(P(ids.to(DEV)), B, L, P(E.to(DEV)), V, P(Pos.to(DEV)), P(gamma.to(DEV)), P(beta.to(DEV)),
+                                    H, 1e-12, P(out), P(mean), P(rstd), P(st), rate, stream()))
+    assert T.maxdiff(out.view(B, L, H), ref) < 3e-4  # LN of ~0.03-magnitude rows: rstd ~ 35 amplifies fp32 rounding
+
+
+def attention_reference(q, k, v, mask, rate=0.0, keep=None):
+    """q,k,v [B,L,h,d] (q already scaled); mask [B,L] -> ctx [B,L,h,d], fp64"""
+    s = torch.einsum("bqhd,bkhd->bhqk", q, k) + (1.0 - mask.double())[:, None, None, :] * -1e9
+    a = torch.softmax(s, dim=-1)
+    if keep is not None:
+        a = a * keep.double() / (1 - rate)
+    return torch.einsum("bhqk,bkhd->bqhd", a, v)
+
+
+@pytest.mark.parametrize("B,L,heads,rate", [(3, 50, 2, 0.0), (2, 200, 2, 0.0), (2, 200, 2, 0.2), (2, 64, 4, 0.1),
+                                             (3, 17, 1, 0.0), (1, 130, 8, 0.0), (1, 256, 2, 0.0)])
+def test_attention_fwd_bwd(B, L, heads, rate):
+    lib = _lib.load()
+    H, d, seed, step, sid = heads * 32, 32, 21, 4, 9
+    qkv = rnd(B * L, 3 * H, seed=22, scale=1.0)
+    g = torch.Generator().manual_seed(3)
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    lens[0] = L
+    mask = (torch.arange(L)[None, :] < lens[:, None]).to(torch.int64)
+    if B > 1:
+        mask[1, 0] = 0  # an interior hole: the mask is per key, not a length
+    dctx = rnd(B * L, H, seed=23)
+    x = qkv.double().view(B, L, 3, heads, d).clone().requires_grad_(True)
+    keep = orc.dropout_keep_mask((B, heads, L, L), rate, seed, step, sid) if rate > 0 else None
+    ctx_ref = attention_reference(x[:, :, 0], x[:, :, 1], x[:, :, 2], mask, rate, keep)
+    ctx_ref.backward(dctx.double().view(B, L, heads, d))
+    st = T.new_state(seed, step)
+    qd, md = qkv.to(DEV), mask.to(DEV)
+    ctx = torch.full((B * L, H), float("nan"), device=DEV)
+    lse = torch.empty(B * heads * L, device=DEV)
+    _lib.check(lib.b4r_attn_fwd(P(qd), P(md), B, L, heads, P(ctx), P(lse), P(st), sid, rate, stream()))
+    assert T.maxdiff(ctx.view(B, L, heads, d), ctx_ref) < 5e-5
+    dqkv = torch.full((B * L, 3 * H), float("nan"), device=DEV)
+    qscale = 0.5
+    _lib.check(lib.b4r_attn_bwd(P(qd), P(md), P(ctx), P(lse), P(dctx.to(DEV)), B, L, heads, qscale, P(dqkv), P(st), sid,
+                                rate, stream()))
+    gref = x.grad.view(B * L, 3, H).clone()
+    gref[:, 0] *= qscale
+    assert T.maxdiff(dqkv.view(B * L, 3, H), gref) < 2e-4
+
+
+def test_attention_fully_masked_row_is_uniform():
+    """Keras adds -1e9 (not -inf): a row whose keys are all masked attends uniformly."""
+    lib = _lib.load()
+    B, L, heads = 1, 20, 1
+    qkv = rnd(B * L, 96, seed=30)
+    mask = torch.zeros(B, L, dtype=torch.int64)
+    ctx = torch.empty(B * L, 32, device=DEV)
+    lse = torch.empty(L, device=DEV)
+    _lib.check(lib.b4r_attn_fwd(P(qkv.to(DEV)), P(mask.to(DEV)), B, L, heads, P(ctx), P(lse), None, 0, 0.0, stream()))
+    want = qkv[:, 64:96].double().mean(0, keepdim=True).expand(L, 32)
+    assert T.maxdiff(ctx, want) < 1e-5
+
+
+def test_softmax_cross_entropy_and_metrics():
+    """trainer_utils.py:12-23 (loss) and :49-60 / SparseCategoricalAccuracy (metrics)"""
+    lib = _lib.load()
+    M, V, ld = 123, 3709, 3712
+    logits = rnd(M, V, seed=31, scale=2.0)
+    y = torch.randint(0, V, (M,), generator=torch.Generator().manual_seed(5))
+    y[::4] = 0  # ignored slots
+    y[1] = int(logits[1].argmax())
+    y[2] = int(logits[2].argmax())
+    buf = torch.full((M, ld), 7.0)
+    buf[:, :V] = logits
+    bd = buf.to(DEV)
+    st = T.new_state()
+    rows = torch.empty(4 * M, device=DEV)
+    _lib.check(lib.b4r_state_begin_step(P(st), stream()))
+    _lib.check(lib.b4r_softmax_ce(P(bd), M, V, ld, P(y.to(DEV)), P(rows), P(st), 1, stream()))
+    f = T.state_floats(st)
+    lr = logits.double().requires_grad_(True)
+    valid = (y != 0)
+    per = torch.logsumexp(lr, -1) - lr[torch.arange(M), y]
+    loss_sum = (per * valid).sum()
+    loss_sum.backward()
+    assert abs(float(f[_lib.ST_LOSS_SUM]) - float(loss_sum)) < 1e-3 * max(1.0, float(loss_sum)) * 1e-2 + 1e-3
+    assert float(f[_lib.ST_VALID]) == float(valid.sum())
+    pred = logits.argmax(-1)
+    assert float(f[_lib.ST_CORRECT_MASKED]) == float(((pred == y) & valid).sum())
+    assert float(f[_lib.ST_CORRECT_ALL]) == float((pred == y).sum())
+    assert float(f[_lib.ST_SLOTS_ALL]) == M
+    out = bd.cpu()
+    assert T.maxdiff(out[:, :V], lr.grad) < 2e-6
+    assert float(out[:, V:].abs().max()) == 0.0
+
+
+def test_adamw_matches_reference_update():
+    """adam_w_optimizer.py:100-137: clip by global norm -> decoupled decay -> Keras Adam; schedule :22-36"""
+    lib = _lib.load()
+    n, n_decay = 4096 + 8, 3000
+    hp_o = orc.AdamWConfig()
+    hp = _lib.AdamWConfig(hp_o.init_lr, hp_o.end_lr, hp_o.num_train_steps, hp_o.num_warmup_steps, hp_o.weight_decay_rate,
+                          hp_o.beta_1, hp_o.beta_2, hp_o.epsilon, hp_o.gradient_clip_norm)
+    for step, gscale, count in [(0, 1.0, 1.0), (5, 40.0, 7.0), (150, 0.01, 3.0), (100, 1.0, 10.0)]:
+        p0, g, m0, v0 = rnd(n, seed=40), rnd(n, seed=41, scale=gscale), rnd(n, seed=42, scale=0.01), rnd(n, seed=43, scale=0.01).abs()
+        # reference: names chosen so that the first tensor decays and the second does not
+        params = {"w/kernel": p0[:n_decay].clone(), "b/bias": p0[n_decay:].clone()}
+        grads = {"w/kernel": g[:n_decay] / count, "b/bias": g[n_decay:] / count}
+        m = {"w/kernel": m0[:n_decay].clone(), "b/bias": m0[n_decay:].clone()}
+        v = {"w/kernel": v0[:n_decay].clone(), "b/bias": v0[n_decay:].clone()}
+        gnorm = orc.adamw_apply(params, grads, m, v, step, hp_o)
+        st = T.new_state(step=step)
+        st.view(torch.float32)[_lib.ST_VALID] = count
+        pd, gd, md, vd = p0.to(DEV), g.to(DEV), m0.to(DEV), v0.to(DEV)
+        scratch = torch.empty(4096, device=DEV)
+        _lib.check(lib.b4r_global_sqnorm(P(gd), n, P(scratch), P(st), stream()))
+        _lib.check(lib.b4r_adamw_step(C.byref(hp), P(pd), P(gd), P(md), P(vd), n, n_decay, P(st), stream()))
+        f = T.state_floats(st)
+        assert abs(float(f[_lib.ST_GRAD_NORM]) - gnorm) < 1e-5 * max(1.0, gnorm)
+        assert abs(float(f[_lib.ST_LR]) - float(orc.learning_rate(step, hp_o))) < 1e-12
+        want_p = torch.cat([params["w/kernel"], params["b/bias"]])
+        want_m = torch.cat([m["w/kernel"], m["b/bias"]])
+        want_v = torch.cat([v["w/kernel"], v["b/bias"]])
+        assert T.maxdiff(pd, want_p) < 2e-7 + 1e-6 * float(orc.learning_rate(step, hp_o)) / 1e-4
+        assert T.maxdiff(md, want_m) < 1e-6 * max(1.0, gscale)
+        assert T.maxdiff(vd, want_v) < 1e-6 * max(1.0, gscale * gscale)
+        assert int(st.cpu()[_lib.ST_STEP:_lib.ST_STEP + 2].view(torch.int64)[0]) == step + 1
+
+
+def _c_rank_oracle():
+    import os
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    so = os.path.join(here, "librank_oracle.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", here])
+    return C.CDLL(so)
+
+
+@pytest.mark.parametrize("R,Cn,H,V", [(64, 101, 64, 3709), (5, 300, 256, 1000), (3, 3709, 64, 3709)])
+def test_rank_candidates_bit_exact_against_c_oracle(R, Cn, H, V):
+    """bert4rec_model.py:224-239 + bert4rec_evaluator.py:113-117; scores and ranked ids must be BIT-exact."""
+    lib = _lib.load()
+    co = _c_rank_oracle()
+    g = torch.Generator().manual_seed(7)
+    hidden, table, bias = rnd(R, H, seed=50), rnd(V, H, seed=51, scale=0.05), rnd(V, seed=52, scale=0.01)
+    cand = torch.stack([torch.randperm(V, generator=g)[:Cn] for _ in range(R)]).to(torch.int64)
+    # engineered ties: duplicate table rows so that equal scores occur; stable order must keep the lower index first
+    table[cand[0, 5]] = table[cand[0, 9]]
+    bias[cand[0, 5]] = bias[cand[0, 9]]
+    gt = cand[:, -1].clone()
+    hn, tn, bn, cn = hidden.numpy(), table.numpy(), bias.numpy(), cand.numpy()
+    sc = np.zeros((R, Cn), np.float32)
+    f32p, i64p, i32p = C.POINTER(C.c_float), C.POINTER(C.c_int64), C.POINTER(C.c_int32)
+    co.rank_oracle_scores(hn.ctypes.data_as(f32p), tn.ctypes.data_as(f32p), bn.ctypes.data_as(f32p),
+                          cn.ctypes.data_as(i64p), C.c_int64(R), C.c_int64(Cn), C.c_int64(H), sc.ctypes.data_as(f32p))
+    rk = np.zeros((R, Cn), np.int64)
+    pos = np.zeros((R, Cn), np.int32)
+    co.rank_oracle_rank(sc.ctypes.data_as(f32p), cn.ctypes.data_as(i64p), C.c_int64(R), C.c_int64(Cn),
+                        rk.ctypes.data_as(i64p), pos.ctypes.data_as(i32p))
+    ranking = torch.empty(R, Cn, dtype=torch.int64, device=DEV)
+    gt_rank = torch.empty(R, dtype=torch.int32, device=DEV)
+    scores = torch.empty(R, Cn, device=DEV)
+    _lib.check(lib.b4r_rank_candidates(P(hidden.to(DEV)), H, None, P(table.to(DEV)), P(bias.to(DEV)), H, P(cand.to(DEV)),
+                                       R, Cn, P(gt.to(DEV)), P(ranking), P(gt_rank), P(scores), stream()))
+    assert np.array_equal(scores.cpu().numpy().view(np.uint32), sc.view(np.uint32)), "scores not bit-identical"
+    assert np.array_equal(ranking.cpu().numpy(), rk)
+    want_rank = orc.rank_of_ground_truth(rk, gt.numpy())
+    assert np.array_equal(gt_rank.cpu().numpy().astype(np.int64), want_rank)
+    # the numpy oracle agrees with the C oracle as well
+    r2, _ = orc.rank_candidates(sc, cn)
+    assert np.array_equal(r2, rk)
+    assert sc[0, 5] == sc[0, 9] and pos[0, 5] + 1 == pos[0, 9]

@@ -143,7 +143,8 @@ def test_layer_norm_fwd_bwd(H):
     dz = torch.empty_like(zd)
     dg, db = torch.empty(H, device=DEV), torch.empty(H, device=DEV)
     scratch = torch.empty(lib.b4r_ln_bwd_scratch_floats(rows, H), device=DEV)
-    _lib.check(lib.b4r_ln_bwd(P(dy.to(DEV)), P(zd), P(mean), P(rstd), P(gd), rows, H, P(dz), P(dg), P(db), P(scratch), stream()))
+    dyd = dy.to(DEV)
+    _lib.check(lib.b4r_ln_bwd(P(dyd), P(zd), P(mean), P(rstd), P(gd), rows, H, P(dz), P(dg), P(db), P(scratch), stream()))
     assert T.maxdiff(dz, zr.grad) < 5e-5
     assert T.maxdiff(dg, gr.grad) < 2e-4
     assert T.maxdiff(db, br.grad) < 2e-4
@@ -163,8 +164,9 @@ def test_embedding_stage(rate):
     st = T.new_state(seed, step)
     out = torch.empty(B * L, H, device=DEV)
     mean, rstd = torch.empty(B * L, device=DEV), torch.empty(B * L, device=DEV)
-    _lib.check(lib.b4r_embed_ln_fwd(P(ids.to(DEV)), B, L, P(E.to(DEV)), V, P(Pos.to(DEV)), P(gamma.to(DEV)), P(beta.to(DEV)),
-                                    H, 1e-12, P(out), P(mean), P(rstd), P(st), rate, stream()))
+    idd, Ed, Pd, gd, bd = ids.to(DEV), E.to(DEV), Pos.to(DEV), gamma.to(DEV), beta.to(DEV)  # keep alive: no temporaries
+    _lib.check(lib.b4r_embed_ln_fwd(P(idd), B, L, P(Ed), V, P(Pd), P(gd), P(bd), H, 1e-12, P(out), P(mean), P(rstd), P(st),
+                                    rate, stream()))
     assert T.maxdiff(out.view(B, L, H), ref) < 3e-4  # LN of ~0.03-magnitude rows: rstd ~ 35 amplifies fp32 rounding
 
 
@@ -202,8 +204,8 @@ def test_attention_fwd_bwd(B, L, heads, rate):
     assert T.maxdiff(ctx.view(B, L, heads, d), ctx_ref) < 5e-5
     dqkv = torch.full((B * L, 3 * H), float("nan"), device=DEV)
     qscale = 0.5
-    _lib.check(lib.b4r_attn_bwd(P(qd), P(md), P(ctx), P(lse), P(dctx.to(DEV)), B, L, heads, qscale, P(dqkv), P(st), sid,
-                                rate, stream()))
+    dcd = dctx.to(DEV)
+    _lib.check(lib.b4r_attn_bwd(P(qd), P(md), P(ctx), P(lse), P(dcd), B, L, heads, qscale, P(dqkv), P(st), sid, rate, stream()))
     gref = x.grad.view(B * L, 3, H).clone()
     gref[:, 0] *= qscale
     assert T.maxdiff(dqkv.view(B * L, 3, H), gref) < 2e-4
@@ -217,7 +219,8 @@ def test_attention_fully_masked_row_is_uniform():
     mask = torch.zeros(B, L, dtype=torch.int64)
     ctx = torch.empty(B * L, 32, device=DEV)
     lse = torch.empty(L, device=DEV)
-    _lib.check(lib.b4r_attn_fwd(P(qkv.to(DEV)), P(mask.to(DEV)), B, L, heads, P(ctx), P(lse), None, 0, 0.0, stream()))
+    qd, md = qkv.to(DEV), mask.to(DEV)
+    _lib.check(lib.b4r_attn_fwd(P(qd), P(md), B, L, heads, P(ctx), P(lse), None, 0, 0.0, stream()))
     want = qkv[:, 64:96].double().mean(0, keepdim=True).expand(L, 32)
     assert T.maxdiff(ctx, want) < 1e-5
 
@@ -237,7 +240,8 @@ def test_softmax_cross_entropy_and_metrics():
     st = T.new_state()
     rows = torch.empty(4 * M, device=DEV)
     _lib.check(lib.b4r_state_begin_step(P(st), stream()))
-    _lib.check(lib.b4r_softmax_ce(P(bd), M, V, ld, P(y.to(DEV)), P(rows), P(st), 1, stream()))
+    yd = y.to(DEV)
+    _lib.check(lib.b4r_softmax_ce(P(bd), M, V, ld, P(yd), P(rows), P(st), 1, stream()))
     f = T.state_floats(st)
     lr = logits.double().requires_grad_(True)
     valid = (y != 0)
@@ -322,8 +326,9 @@ def test_rank_candidates_bit_exact_against_c_oracle(R, Cn, H, V):
     ranking = torch.empty(R, Cn, dtype=torch.int64, device=DEV)
     gt_rank = torch.empty(R, dtype=torch.int32, device=DEV)
     scores = torch.empty(R, Cn, device=DEV)
-    _lib.check(lib.b4r_rank_candidates(P(hidden.to(DEV)), H, None, P(table.to(DEV)), P(bias.to(DEV)), H, P(cand.to(DEV)),
-                                       R, Cn, P(gt.to(DEV)), P(ranking), P(gt_rank), P(scores), stream()))
+    hd, td, bd, cd, gd = hidden.to(DEV), table.to(DEV), bias.to(DEV), cand.to(DEV), gt.to(DEV)  # keep alive
+    _lib.check(lib.b4r_rank_candidates(P(hd), H, None, P(td), P(bd), H, P(cd), R, Cn, P(gd), P(ranking), P(gt_rank),
+                                       P(scores), stream()))
     assert np.array_equal(scores.cpu().numpy().view(np.uint32), sc.view(np.uint32)), "scores not bit-identical"
     assert np.array_equal(ranking.cpu().numpy(), rk)
     want_rank = orc.rank_of_ground_truth(rk, gt.numpy())

@@ -24,6 +24,8 @@ struct GemmP {
   int lda, ldb, ldc, ldc2, ldr;
   int M, N, K;
   int tiles_n;
+  int k_chunk;            // K range per blockIdx.y (multiple of BK); == K rounded up when not split
+  int64_t split_stride;   // floats between the C slabs of consecutive K splits
   int a_vec, b_vec;
   float qscale; int qcols;
   DropArgs drop;
@@ -113,13 +115,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
     }
   };
 
-  const int nk = (p.K + BK - 1) / BK;
-  load_tiles(0);
+  const int k_begin = blockIdx.y * p.k_chunk;
+  const int k_end = min(p.K, k_begin + p.k_chunk);
+  const int nk = (k_end - k_begin + BK - 1) / BK;
+  if (blockIdx.y > 0) p.C += (int64_t)blockIdx.y * p.split_stride;
+  if (nk > 0) load_tiles(k_begin);
   for (int kt = 0; kt < nk; ++kt) {
     __syncthreads();
     store_tiles();
     __syncthreads();
-    if (kt + 1 < nk) load_tiles((kt + 1) * BK);
+    if (kt + 1 < nk) load_tiles(k_begin + (kt + 1) * BK);
     const int arow = wave * 32 + l31;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -301,41 +306,55 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnP p) {
   }
 }
 
-// out[row*ldo+col] (+)= sum_z slab[z][row][col]   (z ascending: fixed order)
+// out[row*ldo+col] (+)= sum_z slab[z][row][col].  A workgroup owns 64 consecutive elements; its 4 waves each sum every
+// 4th slab (independent loads in flight), then the 4 partial sums are combined in a fixed order: bitwise reproducible.
+// The two optional column-sum strips ride along as extra "elements" behind the matrix.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* slab, int S, int Mo, int No, float* out, int ldo,
                                                           int accumulate, const float* cslab, float* colsum,
                                                           const float* caslab, float* colsum_a) {
+  __shared__ float sp[4][64];
   const int64_t total = (int64_t)Mo * No;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    float s = 0.f;
-    for (int z = 0; z < S; ++z) s += slab[(int64_t)z * total + e];
-    const int row = (int)(e / No), col = (int)(e % No);
-    float* o = out + (int64_t)row * ldo + col;
-    *o = accumulate ? (*o + s) : s;
+  const int64_t n_cs = colsum ? No : 0, n_csa = colsum_a ? Mo : 0;
+  const int64_t e = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int zl = threadIdx.x >> 6;
+  const float* src = nullptr;
+  int64_t stride = 0, idx = 0;
+  if (e < total) { src = slab; stride = total; idx = e; }
+  else if (e < total + n_cs) { src = cslab; stride = No; idx = e - total; }
+  else if (e < total + n_cs + n_csa) { src = caslab; stride = Mo; idx = e - total - n_cs; }
+  float s = 0.f;
+  if (src) {
+    for (int z = zl; z < S; z += 4) s += src[(int64_t)z * stride + idx];
   }
-  if (colsum != nullptr && blockIdx.x == 0) {
-    for (int c = threadIdx.x; c < No; c += 256) {
-      float s = 0.f;
-      for (int z = 0; z < S; ++z) s += cslab[(int64_t)z * No + c];
-      colsum[c] = s;
-    }
-  }
-  if (colsum_a != nullptr && blockIdx.x == 0) {
-    for (int c = threadIdx.x; c < Mo; c += 256) {
-      float s = 0.f;
-      for (int z = 0; z < S; ++z) s += caslab[(int64_t)z * Mo + c];
-      colsum_a[c] = s;
+  sp[zl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (zl == 0 && src) {
+    const int l = threadIdx.x;
+    s = (sp[0][l] + sp[1][l]) + (sp[2][l] + sp[3][l]);
+    if (e < total) {
+      const int row = (int)(e / No), col = (int)(e % No);
+      float* o = out + (int64_t)row * ldo + col;
+      *o = accumulate ? (*o + s) : s;
+    } else if (e < total + n_cs) {
+      colsum[idx] = s;
+    } else {
+      colsum_a[idx] = s;
     }
   }
 }
 
+int slab_reduce_grid(int Mo, int No, bool cs, bool csa) {
+  return b4r_cdiv((int64_t)Mo * No + (cs ? No : 0) + (csa ? Mo : 0), 64);
+}
+
 int tn_split(int R, int Mo, int No) {
+  // about one workgroup per CU in total; at most 64 slabs so that the ordered reduction stays short
   const int tiles = b4r_cdiv(Mo, TB) * b4r_cdiv(No, TB);
-  int S = b4r_cdiv(768, tiles);
+  int S = b4r_cdiv(320, tiles);
   const int max_s = b4r_cdiv(R, 4 * TK);  // at least 128 rows per slice
   if (S > max_s) S = max_s;
+  if (S > 64) S = 64;
   if (S < 1) S = 1;
-  if (S > 512) S = 512;
   return S;
 }
 
@@ -367,10 +386,8 @@ int dispatch_epi(const GemmP& p, int epi, int a_drop, dim3 grid, hipStream_t s) 
 
 int b4r_launch_slab_reduce(const float* slab, int S, int Mo, int No, float* out, int ldo, int accumulate,
                            hipStream_t stream) {
-  const int64_t total = (int64_t)Mo * No;
-  int rgrid = (int)((total + 255) / 256);
-  if (rgrid > 2048) rgrid = 2048;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(rgrid), dim3(256), 0, stream, slab, S, Mo, No, out, ldo, accumulate,
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(slab_reduce_grid(Mo, No, false, false)), dim3(256), 0, stream, slab, S, Mo,
+                     No, out, ldo, accumulate,
                      (const float*)nullptr, (float*)nullptr, (const float*)nullptr, (float*)nullptr);
   B4R_CHECK_LAUNCH("slab_reduce");
   return B4R_OK;
@@ -395,6 +412,8 @@ extern "C" int b4r_gemm_f32(const b4r_gemm_desc* d, b4r_stream_t stream) {
   p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldc2 = d->ldc2; p.ldr = d->ldr;
   p.M = d->M; p.N = d->N; p.K = d->K;
   p.tiles_n = b4r_cdiv(d->N, BN);
+  p.k_chunk = b4r_cdiv(d->K, BK) * BK;
+  p.split_stride = 0;
   p.a_vec = (b4r_aligned16(d->A) && (d->lda % 4 == 0)) ? 1 : 0;
   p.b_vec = (b4r_aligned16(d->B) && (d->ldb % 4 == 0)) ? 1 : 0;
   p.qscale = d->qscale; p.qcols = d->qcols;
@@ -408,6 +427,32 @@ extern "C" int b4r_gemm_f32(const b4r_gemm_desc* d, b4r_stream_t stream) {
   if (rc != B4R_OK) return rc;
   B4R_CHECK_LAUNCH("b4r_gemm_f32");
   return B4R_OK;
+}
+
+// C[M,N] = A.B with the K range split over `splits` workgroups per tile: partial products go to slabs in `scratch`
+// (>= splits*M*N floats) and are summed in a fixed order.  Used where M*N is small and K is long (dT = dlogits.E, K = V).
+int b4r_gemm_f32_splitk(const b4r_gemm_desc* d, int splits, float* scratch, hipStream_t stream) {
+  B4R_CHECK_ARG(d && scratch && d->epilogue == B4R_EPI_NONE && !d->a_dropout, B4R_E_BADARG, "gemm_splitk: plain product only");
+  if (splits <= 1) return b4r_gemm_f32(d, (b4r_stream_t)stream);
+  GemmP p;
+  p.A = d->A; p.B = d->B; p.C = scratch; p.bias = nullptr; p.C2 = nullptr; p.R = nullptr;
+  p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->N; p.ldc2 = 0; p.ldr = 0;
+  p.M = d->M; p.N = d->N; p.K = d->K;
+  p.tiles_n = b4r_cdiv(d->N, BN);
+  p.k_chunk = b4r_cdiv(b4r_cdiv(d->K, splits), BK) * BK;
+  p.split_stride = (int64_t)d->M * d->N;
+  p.a_vec = (b4r_aligned16(d->A) && (d->lda % 4 == 0)) ? 1 : 0;
+  p.b_vec = (b4r_aligned16(d->B) && (d->ldb % 4 == 0)) ? 1 : 0;
+  p.qscale = 1.f; p.qcols = 0;
+  p.drop = b4r_make_drop(nullptr, 0, 0.f, 0);
+  const int64_t tiles = (int64_t)b4r_cdiv(d->M, BM) * p.tiles_n;
+  dim3 grid((unsigned)tiles, (unsigned)splits);
+  if (d->b_is_nk)
+    hipLaunchKernelGGL((gemm_kernel<true, B4R_EPI_NONE, false>), grid, dim3(256), 0, stream, p);
+  else
+    hipLaunchKernelGGL((gemm_kernel<false, B4R_EPI_NONE, false>), grid, dim3(256), 0, stream, p);
+  B4R_CHECK_LAUNCH("gemm_splitk");
+  return b4r_launch_slab_reduce(scratch, splits, d->M, d->N, d->C, d->ldc, 0, stream);
 }
 
 extern "C" int64_t b4r_gemm_tn_scratch_floats(int32_t R, int32_t Mo, int32_t No) {
@@ -439,10 +484,8 @@ extern "C" int b4r_gemm_tn_f32(const b4r_gemm_tn_desc* d, float* scratch, b4r_st
   else
     hipLaunchKernelGGL((gemm_tn_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, p);
   B4R_CHECK_LAUNCH("b4r_gemm_tn_f32");
-  const int64_t total = (int64_t)d->Mo * d->No;
-  int rgrid = (int)((total + 255) / 256);
-  if (rgrid > 2048) rgrid = 2048;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(rgrid), dim3(256), 0, (hipStream_t)stream, p.slab, S, d->Mo, d->No,
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(slab_reduce_grid(d->Mo, d->No, d->colsum != nullptr, d->colsum_a != nullptr)),
+                     dim3(256), 0, (hipStream_t)stream, p.slab, S, d->Mo, d->No,
                      d->out, d->ldo, d->accumulate, p.colsum_slab, d->colsum, p.colsum_a_slab, d->colsum_a);
   B4R_CHECK_LAUNCH("b4r_gemm_tn_f32 reduce");
   return B4R_OK;

@@ -22,6 +22,7 @@ int b4r_scatter_add_rows_impl(const float* src, const int64_t* idx, int64_t idx_
                               float* dst, int dst_ld, const int64_t* skip_if_zero, int64_t dst_rows, hipStream_t stream);
 int b4r_batch_colsum(const float* x, int B, int L, int H, float* dpos, float* scratch, hipStream_t stream);
 int b4r_mul_gelu_grad(float* du, const float* pre, int64_t n, hipStream_t stream);
+int b4r_gemm_f32_splitk(const b4r_gemm_desc* d, int splits, float* scratch, hipStream_t stream);
 
 // ---- error message (thread local) ---------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -127,6 +128,17 @@ ParamLayout make_param_layout(const b4r_model_config& c) {
   return p;
 }
 
+// K splits of dT = dlogits.E: enough workgroups to cover the chip (tiles of 128 rows x 64 columns)
+int mlm_dt_splits(int64_t M, int64_t H, int64_t V) {
+  const int64_t tiles = ((M + 127) / 128) * ((H + 63) / 64);
+  int64_t s = (512 + tiles - 1) / tiles;
+  const int64_t max_s = (V + 255) / 256;
+  if (s > max_s) s = max_s;
+  if (s > 16) s = 16;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
 struct WsLayout {
   int64_t total = 0;  // floats
   int64_t N = 0, M = 0, Vp = 0;
@@ -169,6 +181,7 @@ WsLayout make_ws_layout(const b4r_model_config& c, int B, int L, int P) {
   if (M > 0) {
     mx(b4r_gemm_tn_scratch_floats((int)M, (int)V, (int)H));
     mx(b4r_gemm_tn_scratch_floats((int)M, (int)H, (int)H));
+    mx((int64_t)mlm_dt_splits(M, H, V) * M * H);
   }
   mx((int64_t)b4r_cdiv(B, 16) * L * H);  // position-table gradient partials
   w.scratch = take(s); w.scratch_floats = s;
@@ -382,9 +395,13 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
 
   // ---- masked-LM head (logits buffer holds d loss_sum / d logits, pad columns zero) --------------------------------
   float* dlog = ws + w.logits;
-  // dT = dlogits . E
-  RC(gemm(dlog, Vp, params + pl.word_emb, H, ws + w.dt, H, M, H, V, 0, B4R_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 1.f, 0,
-          nullptr, 0, 0.f, 0, s));
+  // dT = dlogits . E   (K = V is long and the output small: split K so that the whole chip streams dlogits)
+  {
+    b4r_gemm_desc d{};
+    d.A = dlog; d.lda = Vp; d.B = params + pl.word_emb; d.ldb = H; d.C = ws + w.dt; d.ldc = H;
+    d.M = M; d.N = H; d.K = V; d.b_is_nk = 0; d.epilogue = B4R_EPI_NONE;
+    RC(b4r_gemm_f32_splitk(&d, mlm_dt_splits(M, H, V), scratch, s));
+  }
   // dE = dlogits^T . T ; d output_bias = column sums of dlogits
   RC(gemm_tn(dlog, Vp, ws + w.t, H, grads + pl.word_emb, H, M, V, H, nullptr, grads + pl.out_bias, nullptr, 0, 0.f, 0, scratch, s));
   // LayerNorm of the transform

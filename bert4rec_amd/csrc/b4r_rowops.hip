@@ -197,7 +197,7 @@ int ln_bwd_grid(int rows, int H) {
   int lpr = H / 4; if (lpr > 64) lpr = 64;
   const int rpb = 4 * (64 / lpr);
   int g = b4r_cdiv(rows, rpb);
-  if (g > 512) g = 512;
+  if (g > 256) g = 256;
   if (g < 1) g = 1;
   return g;
 }
@@ -260,21 +260,20 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* src, int 
   }
 }
 
+// one lane per float: a wave-instruction adds 64 consecutive dwords (256 contiguous bytes of one or a few rows), the
+// shape at which global float atomics run at full rate (MI355X_MICROARCH.md 'Global float atomics')
 __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* src, const int64_t* idx, int64_t idx_add_per,
                                                                int per, int n, int H, float* dst, int dst_ld,
                                                                const int64_t* skip_if_zero, int64_t dst_rows) {
-  const int h4 = H / 4;
-  const int64_t total = (int64_t)n * h4;
+  const int64_t total = (int64_t)n * H;
   for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
-    const int i = (int)(t / h4), c = (int)(t % h4) * 4;
+    const int i = (int)(t / H), c = (int)(t % H);
     if (skip_if_zero != nullptr && skip_if_zero[i] == 0) continue;
     int64_t pos = idx[i];
     if (idx_add_per > 0) pos = pos < 0 ? 0 : (pos >= idx_add_per ? idx_add_per - 1 : pos);
     const int64_t r = pos + (int64_t)(i / per) * idx_add_per;
     if (r < 0 || r >= dst_rows) continue;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(src + (int64_t)i * H + c);
-    float* d = dst + r * dst_ld + c;
-    atomicAdd(d + 0, v[0]); atomicAdd(d + 1, v[1]); atomicAdd(d + 2, v[2]); atomicAdd(d + 3, v[3]);
+    atomicAdd(dst + r * dst_ld + c, src[(int64_t)i * H + c]);
   }
 }
 
@@ -582,12 +581,23 @@ extern "C" int64_t b4r_ln_bwd_scratch_floats(int32_t rows, int32_t H) {
 }
 
 namespace {
-// out_a[c] = sum_s partial[s][c], out_b[c] = sum_s partial[s][H + c]
+// dgamma[c] = sum_s partial[s][c], dbeta[c] = sum_s partial[s][H + c]; 16 columns x 16 slab lanes per workgroup,
+// combined in a fixed order
 __global__ __launch_bounds__(256) void ln_partial_reduce_kernel(const float* partial, int S, int H, float* dgamma, float* dbeta) {
-  for (int c = blockIdx.x * 256 + threadIdx.x; c < 2 * H; c += gridDim.x * 256) {
-    float s = 0.f;
-    for (int z = 0; z < S; ++z) s += partial[(int64_t)z * 2 * H + c];
-    if (c < H) dgamma[c] = s; else dbeta[c - H] = s;
+  __shared__ float sp[16][16];
+  const int cl = threadIdx.x & 15, zl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  float s = 0.f;
+  if (c < 2 * H) {
+    for (int z = zl; z < S; z += 16) s += partial[(int64_t)z * 2 * H + c];
+  }
+  sp[zl][cl] = s;
+  __syncthreads();
+  if (zl == 0 && c < 2 * H) {
+    float t = 0.f;
+#pragma unroll
+    for (int z = 0; z < 16; ++z) t += sp[z][cl];
+    if (c < H) dgamma[c] = t; else dbeta[c - H] = t;
   }
 }
 }  // namespace
@@ -603,7 +613,7 @@ int b4r_ln_bwd_launch(const float* dy, const float* z, const float* mean, const 
   int rc = ids ? launch_ln_bwd<true>(p, grid, stream) : launch_ln_bwd<false>(p, grid, stream);
   if (rc) return rc;
   B4R_CHECK_LAUNCH("ln_bwd");
-  hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3(b4r_cdiv(2 * H, 256)), dim3(256), 0, stream, scratch, grid, H,
+  hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3(b4r_cdiv(2 * H, 16)), dim3(256), 0, stream, scratch, grid, H,
                      dgamma, dbeta);
   B4R_CHECK_LAUNCH("ln_bwd reduce");
   return B4R_OK;
@@ -633,8 +643,8 @@ extern "C" int b4r_gather_rows(const float* src, int32_t src_ld, const int64_t* 
 
 int b4r_scatter_add_rows_impl(const float* src, const int64_t* idx, int64_t idx_add_per, int per, int n, int H,
                               float* dst, int dst_ld, const int64_t* skip_if_zero, int64_t dst_rows, hipStream_t stream) {
-  int grid = b4r_cdiv((int64_t)n * (H / 4), 256);
-  if (grid > 4096) grid = 4096;
+  int grid = b4r_cdiv((int64_t)n * H, 256);
+  if (grid > 8192) grid = 8192;
   hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid), dim3(256), 0, stream, src, idx, idx_add_per, per, n, H, dst,
                      dst_ld, skip_if_zero, dst_rows);
   B4R_CHECK_LAUNCH("b4r_scatter_add_rows");

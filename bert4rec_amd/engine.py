@@ -188,7 +188,10 @@ class Engine:
 
     def ensure_training_buffers(self) -> None:
         if self.grads is None:
-            self.grads = torch.zeros_like(self.params)
+            from .distributed import alloc_grad_buffer
+            # gradients + a small tail that carries the per-step sums through the data-parallel all-reduce
+            self.grad_ext = alloc_grad_buffer(self.n_params, self.device)
+            self.grads = self.grad_ext[: self.n_params]
             self.adam_m = torch.zeros_like(self.params)
             self.adam_v = torch.zeros_like(self.params)
 
@@ -275,6 +278,18 @@ class Engine:
         _lib.check(self.lib.b4r_train_step(C.byref(self.cfg), C.byref(hp), C.byref(cb), _ptr(self.params), _ptr(self.grads),
                                            _ptr(self.adam_m), _ptr(self.adam_v), _ptr(ws), ws.numel() * 4, _ptr(self.state),
                                            _stream(self.device)), "b4r_train_step")
+
+    def dp_train_step(self, hp: AdamWConfig, cb: Batch, group=None) -> None:
+        """Data-parallel train step: local forward/backward of the loss SUM, one all-reduce (RCCL over xGMI) of
+        [grads | loss sums], then the clip + AdamW step on the reduced buffer (identical on every rank)."""
+        from .distributed import allreduce_step
+        self.ensure_training_buffers()
+        self.begin_step()
+        self.forward(cb, training=True, pooler=False)
+        self.loss(cb, want_grad=True)
+        self.backward(cb, training=True)
+        allreduce_step(self.grad_ext, self.state, self.n_params, group)
+        self.optimizer_step(hp, cb)
 
     def rank_candidates(self, hidden: torch.Tensor, hidden_rows: Optional[torch.Tensor], cand: torch.Tensor,
                         gt: Optional[torch.Tensor], want_ranking: bool = True, want_scores: bool = False):

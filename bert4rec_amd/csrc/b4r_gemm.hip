@@ -306,13 +306,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnP p) {
   }
 }
 
-// out[row*ldo+col] (+)= sum_z slab[z][row][col].  A workgroup owns 64 consecutive elements; its 4 waves each sum every
-// 4th slab (independent loads in flight), then the 4 partial sums are combined in a fixed order: bitwise reproducible.
+// out[row*ldo+col] (+)= sum_z slab[z][row][col].  A workgroup owns 64 consecutive elements; its 16 waves each sum every
+// 16th slab (independent loads in flight), then the 16 partial sums are combined in a fixed order: bitwise reproducible.
 // The two optional column-sum strips ride along as extra "elements" behind the matrix.
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* slab, int S, int Mo, int No, float* out, int ldo,
+constexpr int RZ = 16;
+__global__ __launch_bounds__(64 * RZ) void slab_reduce_kernel(const float* slab, int S, int Mo, int No, float* out, int ldo,
                                                           int accumulate, const float* cslab, float* colsum,
                                                           const float* caslab, float* colsum_a) {
-  __shared__ float sp[4][64];
+  __shared__ float sp[RZ][64];
   const int64_t total = (int64_t)Mo * No;
   const int64_t n_cs = colsum ? No : 0, n_csa = colsum_a ? Mo : 0;
   const int64_t e = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
@@ -324,13 +325,15 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* slab, int
   else if (e < total + n_cs + n_csa) { src = caslab; stride = Mo; idx = e - total - n_cs; }
   float s = 0.f;
   if (src) {
-    for (int z = zl; z < S; z += 4) s += src[(int64_t)z * stride + idx];
+    for (int z = zl; z < S; z += RZ) s += src[(int64_t)z * stride + idx];
   }
   sp[zl][threadIdx.x & 63] = s;
   __syncthreads();
   if (zl == 0 && src) {
     const int l = threadIdx.x;
-    s = (sp[0][l] + sp[1][l]) + (sp[2][l] + sp[3][l]);
+    s = 0.f;
+#pragma unroll
+    for (int z = 0; z < RZ; ++z) s += sp[z][l];
     if (e < total) {
       const int row = (int)(e / No), col = (int)(e % No);
       float* o = out + (int64_t)row * ldo + col;
@@ -348,12 +351,13 @@ int slab_reduce_grid(int Mo, int No, bool cs, bool csa) {
 }
 
 int tn_split(int R, int Mo, int No) {
-  // about one workgroup per CU in total; at most 64 slabs so that the ordered reduction stays short
+  // about four workgroups per CU in total (each keeps only one 16 KB stage in flight, so residency hides the HBM
+  // latency); at most 256 slabs so that the ordered reduction stays short
   const int tiles = b4r_cdiv(Mo, TB) * b4r_cdiv(No, TB);
-  int S = b4r_cdiv(320, tiles);
+  int S = b4r_cdiv(1024, tiles);
   const int max_s = b4r_cdiv(R, 4 * TK);  // at least 128 rows per slice
   if (S > max_s) S = max_s;
-  if (S > 64) S = 64;
+  if (S > 256) S = 256;
   if (S < 1) S = 1;
   return S;
 }
@@ -386,7 +390,7 @@ int dispatch_epi(const GemmP& p, int epi, int a_drop, dim3 grid, hipStream_t s) 
 
 int b4r_launch_slab_reduce(const float* slab, int S, int Mo, int No, float* out, int ldo, int accumulate,
                            hipStream_t stream) {
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(slab_reduce_grid(Mo, No, false, false)), dim3(256), 0, stream, slab, S, Mo,
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(slab_reduce_grid(Mo, No, false, false)), dim3(64 * RZ), 0, stream, slab, S, Mo,
                      No, out, ldo, accumulate,
                      (const float*)nullptr, (float*)nullptr, (const float*)nullptr, (float*)nullptr);
   B4R_CHECK_LAUNCH("slab_reduce");
@@ -485,7 +489,7 @@ extern "C" int b4r_gemm_tn_f32(const b4r_gemm_tn_desc* d, float* scratch, b4r_st
     hipLaunchKernelGGL((gemm_tn_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, p);
   B4R_CHECK_LAUNCH("b4r_gemm_tn_f32");
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(slab_reduce_grid(d->Mo, d->No, d->colsum != nullptr, d->colsum_a != nullptr)),
-                     dim3(256), 0, (hipStream_t)stream, p.slab, S, d->Mo, d->No,
+                     dim3(64 * RZ), 0, (hipStream_t)stream, p.slab, S, d->Mo, d->No,
                      d->out, d->ldo, d->accumulate, p.colsum_slab, d->colsum, p.colsum_a_slab, d->colsum_a);
   B4R_CHECK_LAUNCH("b4r_gemm_tn_f32 reduce");
   return B4R_OK;

@@ -19,7 +19,8 @@ int b4r_ln_bwd_launch(const float* dy, const float* z, const float* mean, const 
                       int rows, int H, float* dz, float* dgamma, float* dbeta, float* scratch, const int64_t* ids,
                       const float* table, const float* pos_table, int L, int V, DropArgs drop, hipStream_t stream);
 int b4r_scatter_add_rows_impl(const float* src, const int64_t* idx, int64_t idx_add_per, int per, int n, int H,
-                              float* dst, int dst_ld, const int64_t* skip_if_zero, int64_t dst_rows, hipStream_t stream);
+                              float* dst, int dst_ld, const int64_t* skip_if_zero, int64_t dst_rows, int hot_rows,
+                              hipStream_t stream);
 int b4r_batch_colsum(const float* x, int B, int L, int H, float* dpos, float* scratch, hipStream_t stream);
 int b4r_mul_gelu_grad(float* du, const float* pre, int64_t n, hipStream_t stream);
 int b4r_gemm_f32_splitk(const b4r_gemm_desc* d, int splits, float* scratch, hipStream_t stream);
@@ -412,7 +413,7 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
   RC(gemm(ws + w.dt, H, params + pl.wd, H, ws + w.dg, H, M, H, H, 1, B4R_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 1.f, 0,
           nullptr, 0, 0.f, 0, s));
   // scatter into d sequence_output (slots with y_true == 0 carry exactly zero gradient and are skipped)
-  RC(b4r_scatter_add_rows_impl(ws + w.dg, batch->masked_lm_positions, L, P, M, H, ws + w.dx, H, batch->masked_lm_ids, N, s));
+  RC(b4r_scatter_add_rows_impl(ws + w.dg, batch->masked_lm_positions, L, P, M, H, ws + w.dx, H, batch->masked_lm_ids, N, 0, s));
 
   // ---- encoder layers, last to first ---------------------------------------------------------------------------------
   for (int i = cfg->num_layers - 1; i >= 0; --i) {
@@ -450,7 +451,7 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
   RC(b4r_ln_bwd_launch(ws + w.dx, nullptr, ws + w.mean0, ws + w.rstd0, params + pl.emb_ln_g, N, H, ws + w.da, grads + pl.emb_ln_g,
                        grads + pl.emb_ln_b, scratch, batch->input_word_ids, params + pl.word_emb, params + pl.pos_emb, L, V,
                        b4r_make_drop(rng, B4R_STREAM_EMB, od, 1), s));
-  RC(b4r_scatter_add_rows_impl(ws + w.da, batch->input_word_ids, 0, 1, N, H, grads + pl.word_emb, H, nullptr, V, s));
+  RC(b4r_scatter_add_rows_impl(ws + w.da, batch->input_word_ids, 0, 1, N, H, grads + pl.word_emb, H, nullptr, V, 3, s));
   RC(b4r_batch_colsum(ws + w.da, B, L, H, grads + pl.pos_emb, scratch, s));
   return B4R_OK;
 }

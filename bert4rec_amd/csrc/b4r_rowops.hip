@@ -264,7 +264,14 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* src, int 
 // shape at which global float atomics run at full rate (MI355X_MICROARCH.md 'Global float atomics')
 __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* src, const int64_t* idx, int64_t idx_add_per,
                                                                int per, int n, int H, float* dst, int dst_ld,
-                                                               const int64_t* skip_if_zero, int64_t dst_rows) {
+                                                               const int64_t* skip_if_zero, int64_t dst_rows,
+                                                               int hot_rows) {
+  // hot_rows > 0: destination rows [0, hot_rows) (the special tokens PAD/MASK/UNK of the item table: [MASK] alone is
+  // ~20 % of all tokens) are first summed in LDS and flushed once per workgroup, instead of thousands of global
+  // atomics queueing on the same 256 bytes.
+  extern __shared__ float s_hot[];
+  for (int k = threadIdx.x; k < hot_rows * H; k += 256) s_hot[k] = 0.f;
+  if (hot_rows > 0) __syncthreads();
   const int64_t total = (int64_t)n * H;
   for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
     const int i = (int)(t / H), c = (int)(t % H);
@@ -273,7 +280,16 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* src,
     if (idx_add_per > 0) pos = pos < 0 ? 0 : (pos >= idx_add_per ? idx_add_per - 1 : pos);
     const int64_t r = pos + (int64_t)(i / per) * idx_add_per;
     if (r < 0 || r >= dst_rows) continue;
-    atomicAdd(dst + r * dst_ld + c, src[(int64_t)i * H + c]);
+    const float v = src[(int64_t)i * H + c];
+    if (r < hot_rows) atomicAdd(&s_hot[(int)r * H + c], v);
+    else atomicAdd(dst + r * dst_ld + c, v);
+  }
+  if (hot_rows > 0) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < hot_rows * H; k += 256) {
+      const float v = s_hot[k];
+      if (v != 0.f) atomicAdd(dst + (int64_t)(k / H) * dst_ld + (k % H), v);
+    }
   }
 }
 
@@ -642,11 +658,13 @@ extern "C" int b4r_gather_rows(const float* src, int32_t src_ld, const int64_t* 
 }
 
 int b4r_scatter_add_rows_impl(const float* src, const int64_t* idx, int64_t idx_add_per, int per, int n, int H,
-                              float* dst, int dst_ld, const int64_t* skip_if_zero, int64_t dst_rows, hipStream_t stream) {
+                              float* dst, int dst_ld, const int64_t* skip_if_zero, int64_t dst_rows, int hot_rows,
+                              hipStream_t stream) {
   int grid = b4r_cdiv((int64_t)n * H, 256);
-  if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid), dim3(256), 0, stream, src, idx, idx_add_per, per, n, H, dst,
-                     dst_ld, skip_if_zero, dst_rows);
+  const int cap = hot_rows > 0 ? 1024 : 8192;
+  if (grid > cap) grid = cap;
+  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid), dim3(256), (size_t)hot_rows * H * sizeof(float), stream, src, idx,
+                     idx_add_per, per, n, H, dst, dst_ld, skip_if_zero, dst_rows, hot_rows);
   B4R_CHECK_LAUNCH("b4r_scatter_add_rows");
   return B4R_OK;
 }
@@ -656,7 +674,7 @@ extern "C" int b4r_scatter_add_rows(const float* src, const int64_t* idx, int64_
                                     b4r_stream_t stream) {
   B4R_CHECK_ARG(src && idx && dst, B4R_E_BADARG, "b4r_scatter_add_rows: null argument");
   B4R_CHECK_ARG(n > 0 && H > 0 && H % 4 == 0 && per > 0 && dst_ld % 4 == 0, B4R_E_SHAPE, "b4r_scatter_add_rows: bad shape");
-  return b4r_scatter_add_rows_impl(src, idx, idx_add_per, per, n, H, dst, dst_ld, skip_if_zero, (int64_t)1 << 62,
+  return b4r_scatter_add_rows_impl(src, idx, idx_add_per, per, n, H, dst, dst_ld, skip_if_zero, (int64_t)1 << 62, 0,
                                    (hipStream_t)stream);
 }
 

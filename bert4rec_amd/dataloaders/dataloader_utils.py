@@ -1,0 +1,252 @@
+"""Batch construction utilities (mirror bert4rec/dataloaders/dataloader_utils.py).  Integer work on the host; the
+outputs are the int64 batch dict the HIP path consumes.
+
+Containers replace tf.data.Dataset: `SequenceDataset` (ragged python sequences per user), `ExampleDataset`
+(per-example dict of fixed-length int64 arrays) and `BatchedDataset` (list of batch dicts of torch int64 tensors; like
+the reference's `.cache()` after shuffle+batch, the batches -- masks and order -- are fixed once built)."""
+from __future__ import annotations
+
+import collections
+import random
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import pandas as pd
+import torch
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# containers
+# ---------------------------------------------------------------------------------------------------------------------
+class SequenceDataset:
+    """One python list (the user's item sequence) per element."""
+
+    def __init__(self, sequences: Sequence[Sequence]):
+        self.sequences = [list(s) for s in sequences]
+
+    def __len__(self):
+        return len(self.sequences)
+
+    def __iter__(self):
+        return iter(self.sequences)
+
+    def cardinality(self) -> int:
+        return len(self.sequences)
+
+    def repeat(self, n: int) -> "SequenceDataset":
+        return SequenceDataset(self.sequences * n)
+
+    def take(self, n: int) -> "SequenceDataset":
+        return SequenceDataset(self.sequences[:n])
+
+    def skip(self, n: int) -> "SequenceDataset":
+        return SequenceDataset(self.sequences[n:])
+
+    def shuffle(self, seed=None) -> "SequenceDataset":
+        idx = np.random.RandomState(seed).permutation(len(self.sequences))
+        return SequenceDataset([self.sequences[i] for i in idx])
+
+    def concatenate(self, other: "SequenceDataset") -> "SequenceDataset":
+        return SequenceDataset(self.sequences + other.sequences)
+
+
+class ExampleDataset:
+    """Processed examples: a list of dicts of 1-D int64 numpy arrays (the 6 keys of the batch contract)."""
+
+    def __init__(self, examples: List[Dict[str, np.ndarray]]):
+        self.examples = examples
+
+    def __len__(self):
+        return len(self.examples)
+
+    def __iter__(self):
+        return iter(self.examples)
+
+    def cardinality(self) -> int:
+        return len(self.examples)
+
+    def concatenate(self, other: "ExampleDataset") -> "ExampleDataset":
+        return ExampleDataset(self.examples + other.examples)
+
+    def take(self, n: int) -> "ExampleDataset":
+        return ExampleDataset(self.examples[:n])
+
+    def skip(self, n: int) -> "ExampleDataset":
+        return ExampleDataset(self.examples[n:])
+
+    def shuffle(self, seed=None) -> "ExampleDataset":
+        idx = np.random.RandomState(seed).permutation(len(self.examples))
+        return ExampleDataset([self.examples[i] for i in idx])
+
+
+class BatchedDataset:
+    """List of batch dicts (torch int64 [B, .]).  Iterating yields the same batches every epoch (== tf .cache())."""
+
+    def __init__(self, batches: List[Dict[str, torch.Tensor]]):
+        self.batches = batches
+        self._device_batches = None
+        self._device = None
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __iter__(self):
+        return iter(self._device_batches if self._device_batches is not None else self.batches)
+
+    def cardinality(self) -> int:
+        return len(self.batches)
+
+    def cache_on_device(self, device) -> "BatchedDataset":
+        """Keep a copy of every batch in HBM (a whole ML-1M epoch is ~200 MB): no per-step host->device traffic."""
+        device = torch.device(device)
+        if device.type != "cuda":
+            return self
+        if self._device_batches is None or self._device != device:
+            self._device_batches = [{k: v.to(device, non_blocking=True) for k, v in b.items()} for b in self.batches]
+            self._device = device
+        return self
+
+    def host_batches(self):
+        return self.batches
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# reference utilities
+# ---------------------------------------------------------------------------------------------------------------------
+def rank_items_by_popularity(items: list) -> list:
+    """dataloader_utils.py:14-18: most frequent first, ties keep first-occurrence order, duplicates removed."""
+    sorted_item_list = sorted(items, key=collections.Counter(items).get, reverse=True)
+    return list(dict.fromkeys(sorted_item_list))
+
+
+def duplicate_dataset(ds: SequenceDataset, duplication_factor: int) -> SequenceDataset:
+    """dataloader_utils.py:177-183"""
+    if duplication_factor < 1:
+        raise ValueError(f"A duplication factor of less than 1 (given: {duplication_factor}) is not allowed!")
+    return ds.repeat(duplication_factor) if duplication_factor > 1 else ds
+
+
+def make_sequence_df(df: pd.DataFrame, group_column_name: str, extract_sequences: list,
+                     min_sequence_length: int = 0) -> pd.DataFrame:
+    rows = []
+    for _, g in df.groupby(group_column_name):
+        row = {}
+        ok = True
+        for col in extract_sequences:
+            seq = g[col].to_list()
+            if len(seq) < min_sequence_length:
+                ok = False
+                break
+            row[col] = seq
+        if ok:
+            rows.append(row)
+    return pd.DataFrame(rows)
+
+
+def split_sequence_df(df: pd.DataFrame, group_by_column: str, extract_columns: list,
+                      min_sequence_length: int = 5) -> Tuple[pd.DataFrame, pd.DataFrame, pd.DataFrame]:
+    """dataloader_utils.py:113-174: per user, train = first n-2, val = first n-1, test = all n items, only when
+    n >= min_sequence_length; shorter sequences go to train only (whole)."""
+    if group_by_column not in df.columns:
+        raise ValueError(f"Group column key {group_by_column} is not present in columns in dataframe: {df.columns}")
+    if len(extract_columns) - 1 > len(df.columns):
+        raise ValueError("More columns to extract have been given than there are actual columns in the dataframe: "
+                         f"{len(df.columns)}")
+    for col in extract_columns:
+        if col not in df.columns:
+            raise ValueError(f"Column key {col} of the extract_columns argument is not present in columns in "
+                             f"dataframe: {df.columns}")
+    train, val, test = {}, {}, {}
+    for i, (_, g) in enumerate(df.groupby(group_by_column)):
+        train[i], val[i], test[i] = {}, {}, {}
+        for col in extract_columns:
+            seq = g[col].to_list()
+            train[i][col] = seq
+            if len(seq) >= min_sequence_length:
+                train[i][col] = seq[:-2]
+                val[i][col] = seq[:-1]
+                test[i][col] = seq
+    to_df = lambda d: pd.DataFrame.from_dict(d, orient="index")
+    return to_df(train), to_df(val), to_df(test)
+
+
+def convert_df_to_ds(df: pd.DataFrame, datatypes: list = None) -> SequenceDataset:
+    """Single sequence column -> SequenceDataset (rows that are NaN -- users too short for val/test -- are dropped)."""
+    if datatypes is not None and len(datatypes) != len(df.columns):
+        raise ValueError(f"The given datatypes list ({datatypes}, len: {len(datatypes)}) has to have as many elements "
+                         f"as columns in the given df ({len(df.columns)}).")
+    if len(df.columns) == 0:
+        return SequenceDataset([])
+    col = df[df.columns[0]]
+    return SequenceDataset([s for s in col.to_list() if isinstance(s, (list, tuple, np.ndarray))])
+
+
+def apply_dynamic_masking_task(sequence: np.ndarray, max_selections_per_seq: int, mask_token_id: int,
+                               special_token_ids: List[int], vocab_size: int, selection_rate: float = 0.2,
+                               mask_token_rate: float = 0.8, random_token_rate: float = 0.1,
+                               seed: int = None) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """dataloader_utils.py:186-261.  Uses python's `random` in the same call order as the reference, so equal seeds give
+    equal outputs (pinned by tests/golden/reference_goldens.json)."""
+    dtype = sequence.dtype
+    random.seed(seed)
+    n_plain = int((~np.isin(sequence, special_token_ids)).sum())
+    num_to_predict = min(max_selections_per_seq, max(1, int(n_plain * selection_rate)))
+    selectable_vocab = None
+    pos_indexes = list(range(n_plain))
+    random.shuffle(pos_indexes)
+    pos_indexes = sorted(pos_indexes[:num_to_predict])
+    masked_token_ids = sequence.copy()
+    ids, positions = [], []
+    for index in pos_indexes:
+        if len(ids) >= num_to_predict:
+            break
+        replaced_token = sequence[index]
+        rn = random.random()
+        if rn < mask_token_rate + random_token_rate:
+            if selectable_vocab is None:
+                selectable_vocab = [i for i in range(vocab_size) if i not in special_token_ids]
+            replaced_token = random.choice(selectable_vocab)
+        if rn < mask_token_rate:
+            replaced_token = mask_token_id
+        masked_token_ids[index] = replaced_token
+        ids.append(sequence[index])
+        positions.append(index)
+    return masked_token_ids, np.array(positions, dtype=dtype), np.array(ids, dtype=dtype)
+
+
+def mask_last_token_only(sequence: np.ndarray, mask_token_id: int):
+    """dataloader_utils.py:264-269"""
+    seq = np.array(sequence, dtype=np.int64)
+    masked_lm_ids = np.array([seq[-1]], dtype=np.int64)
+    seq[-1] = mask_token_id
+    return seq, np.array([len(seq) - 1], dtype=np.int64), masked_lm_ids
+
+
+def split_dataset(ds, ds_size: int = None, train_split: float = 0.8, val_split: float = 0.1, test_split: float = 0.1,
+                  shuffle: bool = True, shuffle_size: int = 10000, seed: int = 12):
+    """dataloader_utils.py:272-303 (the shuffle is a seeded permutation; tf's stream cannot be reproduced)."""
+    if (train_split + test_split + val_split) != 1:
+        raise ValueError("The dataset can only be split in parts that sum up to 1 or a 100%.")
+    if ds_size is None:
+        ds_size = len(ds)
+    if shuffle:
+        ds = ds.shuffle(seed=seed)
+    train_size = int(train_split * ds_size)
+    val_size = int(val_split * ds_size)
+    return ds.take(train_size), ds.skip(train_size).take(val_size), ds.skip(train_size).skip(val_size)
+
+
+def make_batches(dataset: ExampleDataset, buffer_size: int = None, batch_size: int = 64, squeeze_tensors: bool = False,
+                 reshuffle_each_iteration: bool = False, seed: int = None) -> BatchedDataset:
+    """dataloader_utils.py:306-346: shuffle(all) -> batch (last batch may be partial) -> cache.  Because the reference
+    caches AFTER shuffle+batch, batch composition and masks are frozen after the first epoch; so are they here."""
+    if reshuffle_each_iteration:
+        raise NotImplementedError("reshuffle_each_iteration has no effect behind the reference's .cache(); not offered")
+    n = len(dataset)
+    order = np.random.RandomState(seed).permutation(n)
+    batches = []
+    for s in range(0, n, batch_size):
+        idx = order[s:s + batch_size]
+        keys = dataset.examples[idx[0]].keys()
+        batches.append({k: torch.from_numpy(np.stack([dataset.examples[i][k] for i in idx]).astype(np.int64)) for k in keys})
+    return BatchedDataset(batches)

@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/reference_goldens.json by RUNNING the numpy/python parts of the reference
+(/root/reference, read-only) in the build container.  Only data (inputs and expected outputs) is written; no reference
+source travels.  The GPU box never runs this script (it has no /root/reference).
+
+What can be executed here: TensorFlow, tensorflow_models and absl are not installed, so the float path cannot run.
+The integer/numpy functions below never touch TensorFlow; to import their modules the script registers inert
+placeholder modules for the missing imports (they are never called by the captured functions).
+
+    python tests/golden/make_reference_goldens.py
+"""
+import importlib
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import pandas as pd
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_goldens.json")
+
+
+class _Inert(types.ModuleType):
+    """Module placeholder: any attribute is another placeholder; calling it returns a placeholder."""
+
+    def __getattr__(self, name):
+        if name.startswith("__") and name.endswith("__"):
+            raise AttributeError(name)
+        child = _Inert(self.__name__ + "." + name)
+        setattr(self, name, child)
+        return child
+
+    def __call__(self, *a, **k):
+        return _Inert(self.__name__ + "()")
+
+    def __mro_entries__(self, bases):
+        return (object,)
+
+    def __or__(self, other):
+        return self
+
+    def __getitem__(self, item):
+        return self
+
+
+def install_placeholders():
+    for name in ("absl", "absl.logging", "tensorflow", "tensorflow.python", "tensorflow.python.framework",
+                 "tensorflow.python.framework.ops", "tensorflow_models", "wget", "zstandard"):
+        if name not in sys.modules:
+            sys.modules[name] = _Inert(name)
+    sys.modules["absl"].logging = sys.modules["absl.logging"]
+
+
+def load_by_path(name, rel):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def main():
+    os.environ.setdefault("VIRTUAL_ENV", "/tmp")
+    install_placeholders()
+    sys.path.insert(0, REF)
+    out = {"generated_from": "maneymarkus/BERT4Rec @ /root/reference (numpy/python parts only)"}
+
+    # ---- 1. evaluation metrics (no placeholders involved) -----------------------------------------------------------
+    em = load_by_path("ref_evaluation_metrics", "bert4rec/evaluation/evaluation_metrics.py")
+    rank_lists = {"ranks_1": [1, 2, 3, 4, 5], "ranks_2": [1, 5, 10, 15, 20], "ranks_3": [2, 8, 4, 13, 20, 6, 3, 11, 2, 5],
+                  "ranks_4": [1], "ranks_5": [101, 57, 1, 10, 11, 5, 6, 2]}
+    metrics_out = {}
+    for key, ranks in rank_lists.items():
+        ms = [em.Counter(name="Valid Ranks"), em.NDCG(1), em.NDCG(5), em.NDCG(10), em.HR(1), em.HR(5), em.HR(10), em.MAP()]
+        for r in ranks:
+            for m in ms:
+                m.update(r)
+        metrics_out[key] = {"ranks": ranks, "results": {m.name: float(m.result()) for m in ms}}
+    out["evaluation_metrics"] = metrics_out
+
+    # ---- 2. masking / popularity / split utilities --------------------------------------------------------------------
+    du = load_by_path("ref_dataloader_utils", "bert4rec/dataloaders/dataloader_utils.py")
+    cases = []
+    for seed, n, max_sel, rate, mtr, rtr, vocab in [(7, 20, 40, 0.2, 1.0, 0.0, 3709), (1, 200, 40, 0.2, 1.0, 0.0, 3709),
+                                                    (2, 50, 20, 0.4, 1.0, 0.0, 13047), (3, 7, 40, 0.2, 1.0, 0.0, 100),
+                                                    (4, 3, 40, 0.2, 1.0, 0.0, 100), (5, 60, 5, 0.6, 1.0, 0.0, 500),
+                                                    (6, 30, 40, 0.5, 0.8, 0.1, 50), (8, 30, 40, 0.5, 0.5, 0.5, 50)]:
+        rng = np.random.default_rng(seed)
+        seq = rng.integers(3, vocab, size=n).astype(np.int64)
+        toks, pos, ids = du.apply_dynamic_masking_task(seq.copy(), max_sel, 1, [2, 0], vocab, rate, mtr, rtr, seed=seed)
+        cases.append({"seed": seed, "sequence": seq.tolist(), "max_selections_per_seq": max_sel, "mask_token_id": 1,
+                      "special_token_ids": [2, 0], "vocab_size": vocab, "selection_rate": rate, "mask_token_rate": mtr,
+                      "random_token_rate": rtr, "masked_token_ids": np.asarray(toks).tolist(),
+                      "masked_lm_positions": np.asarray(pos).tolist(), "masked_lm_ids": np.asarray(ids).tolist()})
+    out["apply_dynamic_masking_task"] = cases
+    pop_in = ["a", "b", "a", "c", "b", "a", "d", "d", "e", "d", "d"]
+    out["rank_items_by_popularity"] = {"items": pop_in, "ranked": du.rank_items_by_popularity(list(pop_in))}
+    rows = []
+    for uid, n in [(1, 6), (2, 2), (3, 3), (4, 9), (5, 1)]:
+        for j in range(n):
+            rows.append({"uid": uid, "item": f"i{uid}_{j}", "timestamp": 100 * uid + j})
+    df = pd.DataFrame(rows)
+    tr, va, te = du.split_sequence_df(df, "uid", ["item"], 3)
+    clean = lambda d: [x if isinstance(x, list) else None for x in d["item"].to_list()] if len(d.columns) else []
+    out["split_sequence_df"] = {"rows": rows, "min_sequence_length": 3, "train": clean(tr), "val": clean(va), "test": clean(te)}
+
+    # ---- 3. samplers (seeded) --------------------------------------------------------------------------------------------
+    smp = importlib.import_module("bert4rec.dataloaders.samplers")
+    rng = np.random.default_rng(0)
+    vocab = list(range(0, 60))
+    source = rng.choice(np.arange(3, 60), size=800, p=(lambda p: p / p.sum())(1.0 / np.arange(1, 58))).tolist()
+    without = [3, 4, 5, 9, 0]
+    s_out = {"vocab": vocab, "source": source, "without": without, "cases": []}
+    for ident, kw in [("pop_random", dict(sample_size=10, seed=11)), ("pop_random", dict(sample_size=25, seed=12)),
+                      ("random", dict(sample_size=10, seed=13)), ("popular", dict(sample_size=10))]:
+        s = smp.get(ident, source=list(source), vocab=list(vocab), **kw)
+        s_out["cases"].append({"sampler": ident, "kwargs": kw, "sample": s.sample(),
+                               "sample_without": s.sample(without=list(without))})
+    out["samplers"] = s_out
+
+    with open(OUT, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", OUT, os.path.getsize(OUT), "bytes")
+
+
+if __name__ == "__main__":
+    main()

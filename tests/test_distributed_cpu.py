@@ -1,0 +1,87 @@
+"""Data-parallel exchange on CPU: world_size 2, gloo.  Each rank back-propagates the loss SUM of its half
+of the batch (oracle autograd stands in for the HIP backward, which needs a GPU), the product's one flat all-reduce
+combines gradients and loss sums, and the result must equal the single-process step on the whole batch."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from bert4rec_amd import _lib
+from bert4rec_amd.distributed import allreduce_step, shard_rows
+from bert4rec_amd.engine import Engine, make_model_config
+from oracle import bert4rec_oracle as orc
+
+CFG = orc.OracleConfig(vocab_size=41, hidden_size=64, num_layers=1, num_attention_heads=2, max_sequence_length=12, inner_dim=64)
+B, L, P = 6, 12, 4
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _sum_loss_grads(params, batch):
+    leaf = {n: p.detach().clone().requires_grad_(orc.is_trainable(n)) for n, p in params.items()}
+    out = orc.model_forward(leaf, batch, CFG, training=False)
+    y = batch["masked_lm_ids"]
+    lse = torch.logsumexp(out["mlm_logits"], -1)
+    picked = torch.gather(out["mlm_logits"], -1, y.unsqueeze(-1)).squeeze(-1)
+    mask = (y != 0).float()
+    loss_sum = ((lse - picked) * mask).sum()
+    names = [n for n in leaf if orc.is_trainable(n)]
+    gs = torch.autograd.grad(loss_sum, [leaf[n] for n in names])
+    return float(loss_sum), float(mask.sum()), dict(zip(names, gs))
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    params = orc.init_params(CFG, 3)
+    full = orc.synthetic_batch(B, L, P, CFG.vocab_size, seed=4, ragged=True)
+    sl = shard_rows(B, rank, world)
+    local = {k: v[sl] for k, v in full.items()}
+    loss_sum, count, grads = _sum_loss_grads(params, local)
+    eng = Engine(make_model_config(CFG.vocab_size, 64, 1, 2, 12, 64, 0.0, 0.0), "cpu")
+    eng.ensure_training_buffers()
+    for n, g in grads.items():
+        v = eng.view(n, eng.grads)
+        v.copy_(g.reshape(v.shape))
+    f = eng.state.view(torch.float32)
+    f[_lib.ST_LOSS_SUM], f[_lib.ST_VALID] = loss_sum, count
+    f[_lib.ST_CORRECT_MASKED], f[_lib.ST_CORRECT_ALL], f[_lib.ST_SLOTS_ALL] = 1.0 + rank, 2.0, float(local["masked_lm_ids"].numel())
+    allreduce_step(eng.grad_ext, eng.state, eng.n_params)
+    if rank == 0:
+        ret["state"] = eng.state.view(torch.float32).clone()
+        ret["grads"] = {n: eng.view(n, eng.grads).clone() for n in grads}
+        ret["pad"] = float(eng.grad_ext[eng.n_params + 5:].abs().sum())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_allreduce_equals_single_process_step():
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+        state, grads, pad = ret["state"], ret["grads"], ret["pad"]
+    params = orc.init_params(CFG, 3)
+    full = orc.synthetic_batch(B, L, P, CFG.vocab_size, seed=4, ragged=True)
+    loss_ref, grads_ref, _ = orc.loss_and_grads(params, full, CFG, training=False)
+    count = float((full["masked_lm_ids"] != 0).sum())
+    assert float(state[_lib.ST_VALID]) == count and float(state[_lib.ST_SLOTS_ALL]) == B * P
+    assert float(state[_lib.ST_CORRECT_MASKED]) == 3.0 and float(state[_lib.ST_CORRECT_ALL]) == 4.0 and pad == 0.0
+    assert abs(float(state[_lib.ST_LOSS_SUM]) / count - float(loss_ref)) < 1e-5
+    for n, g in grads_ref.items():
+        got = grads[n] / count          # the optimizer kernel applies 1/valid_count after the reduction
+        assert float((got - g.reshape(got.shape)).abs().max()) < 1e-6 + 1e-4 * float(g.abs().max()), n
+
+
+def test_shard_rows_partitions_without_overlap():
+    for n, w in [(256, 8), (10, 4), (3, 8)]:
+        rows = [i for r in range(w) for i in range(*shard_rows(n, r, w).indices(n))]
+        assert rows == list(range(n))

@@ -140,6 +140,7 @@ def main():
         d.C, d.ldc = logits.data_ptr(), logits.stride(0)
         d.M, d.N, d.K, d.b_is_nk, d.epilogue = M, V, H, 1, _lib.EPI_BIAS
         d.bias = eng.view("cls/predictions/output_bias/bias").data_ptr()
+        d.c_pad_scratch = 1  # exactly as b4r_forward launches it: the pad columns V..Vp-1 of the logits rows are scratch
         stream = torch.cuda.current_stream().cuda_stream
         for _ in range(5):
             _lib.check(lib.b4r_gemm_f32(C.byref(d), stream))

@@ -37,7 +37,8 @@ class GemmDesc(C.Structure):
                 ("ldc", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("b_is_nk", C.c_int32),
                 ("epilogue", C.c_int32), ("bias", C.c_void_p), ("C2", C.c_void_p), ("ldc2", C.c_int32),
                 ("R", C.c_void_p), ("ldr", C.c_int32), ("qscale", C.c_float), ("qcols", C.c_int32),
-                ("rng", C.c_void_p), ("drop_stream", C.c_uint32), ("drop_rate", C.c_float), ("a_dropout", C.c_int32)]
+                ("rng", C.c_void_p), ("drop_stream", C.c_uint32), ("drop_rate", C.c_float), ("a_dropout", C.c_int32),
+                ("c_pad_scratch", C.c_int32)]
 
 
 class GemmTnDesc(C.Structure):
@@ -54,6 +55,7 @@ ST_LOSS_SUM, ST_VALID, ST_CORRECT_MASKED, ST_CORRECT_ALL, ST_SLOTS_ALL, ST_SQNOR
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_QSCALE, EPI_BIAS_GELU, EPI_BIAS_DROP_RES, EPI_GELU_BWD, EPI_ADD_RES, EPI_BIAS_TANH = range(8)
 FLAG_TRAINING, FLAG_POOLER = 1, 2
+GEMM_F32, GEMM_BF16X3 = 0, 1
 
 _P, _I32, _I64, _F, _U32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint32
 
@@ -82,6 +84,8 @@ PROTOTYPES = {
     "b4r_ln_fwd": (C.c_int, [_P, _I32, _I32, _P, _P, _F, _P, _P, _P, _P]),
     "b4r_ln_bwd_scratch_floats": (_I64, [_I32, _I32]),
     "b4r_ln_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _P, _P, _P, _P, _P]),
+    "b4r_set_gemm_mode": (C.c_int, [C.c_int]),
+    "b4r_get_gemm_mode": (C.c_int, []),
     "b4r_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _P]),
     "b4r_gemm_tn_scratch_floats": (_I64, [_I32, _I32, _I32]),
     "b4r_gemm_tn_f32": (C.c_int, [C.POINTER(GemmTnDesc), _P, _P]),

@@ -397,6 +397,25 @@ int b4r_launch_slab_reduce(const float* slab, int S, int Mo, int No, float* out,
   return B4R_OK;
 }
 
+int b4r_launch_slab_reduce_full(const float* slab, int S, int Mo, int No, float* out, int ldo, int accumulate,
+                                const float* cslab, float* colsum, const float* caslab, float* colsum_a, hipStream_t stream) {
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(slab_reduce_grid(Mo, No, colsum != nullptr, colsum_a != nullptr)), dim3(64 * RZ),
+                     0, stream, slab, S, Mo, No, out, ldo, accumulate, cslab, colsum, caslab, colsum_a);
+  B4R_CHECK_LAUNCH("slab_reduce");
+  return B4R_OK;
+}
+
+// ---- arithmetic mode of the dense layers ------------------------------------------------------------------------------
+int b4r_gemm_rx_launch(const b4r_gemm_desc* d, hipStream_t stream);
+bool b4r_gemm_rx_supported(const b4r_gemm_desc* d);
+static int g_gemm_mode = B4R_GEMM_BF16X3;
+extern "C" int b4r_set_gemm_mode(int mode) {
+  B4R_CHECK_ARG(mode == B4R_GEMM_F32 || mode == B4R_GEMM_BF16X3, B4R_E_BADARG, "b4r_set_gemm_mode: unknown mode %d", mode);
+  g_gemm_mode = mode;
+  return B4R_OK;
+}
+extern "C" int b4r_get_gemm_mode(void) { return g_gemm_mode; }
+
 extern "C" int b4r_gemm_f32(const b4r_gemm_desc* d, b4r_stream_t stream) {
   B4R_CHECK_ARG(d != nullptr, B4R_E_BADARG, "b4r_gemm_f32: null descriptor");
   B4R_CHECK_ARG(d->A && d->B && d->C, B4R_E_BADARG, "b4r_gemm_f32: null operand");
@@ -410,6 +429,8 @@ extern "C" int b4r_gemm_f32(const b4r_gemm_desc* d, b4r_stream_t stream) {
   const bool needs_r = epi == B4R_EPI_BIAS_DROP_RES || epi == B4R_EPI_GELU_BWD || epi == B4R_EPI_ADD_RES;
   B4R_CHECK_ARG(!needs_r || (d->R && d->ldr >= d->N), B4R_E_BADARG, "b4r_gemm_f32: epilogue %d needs R", epi);
   B4R_CHECK_ARG(epi != B4R_EPI_BIAS_GELU || (d->C2 && d->ldc2 >= d->N), B4R_E_BADARG, "b4r_gemm_f32: BIAS_GELU needs C2");
+  B4R_CHECK_ARG(epi >= B4R_EPI_NONE && epi <= B4R_EPI_BIAS_TANH, B4R_E_BADARG, "b4r_gemm_f32: unknown epilogue %d", epi);
+  if (g_gemm_mode == B4R_GEMM_BF16X3 && b4r_gemm_rx_supported(d)) return b4r_gemm_rx_launch(d, (hipStream_t)stream);
 
   GemmP p;
   p.A = d->A; p.B = d->B; p.C = d->C; p.bias = d->bias; p.C2 = d->C2; p.R = d->R;

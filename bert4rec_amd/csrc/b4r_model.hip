@@ -213,6 +213,7 @@ int gemm(const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, i
   d.A = A; d.lda = lda; d.B = Bm; d.ldb = ldb; d.C = C; d.ldc = ldc; d.M = M; d.N = N; d.K = K;
   d.b_is_nk = b_is_nk; d.epilogue = epi; d.bias = bias; d.C2 = C2; d.ldc2 = ldc2; d.R = R; d.ldr = ldr;
   d.qscale = qscale; d.qcols = qcols; d.rng = rng; d.drop_stream = stream_id; d.drop_rate = rate; d.a_dropout = a_dropout;
+  d.c_pad_scratch = 1;  // every C of the model path is a workspace region whose pad columns are scratch
   return b4r_gemm_f32(&d, (b4r_stream_t)s);
 }
 

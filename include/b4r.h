@@ -194,7 +194,18 @@ typedef struct b4r_gemm_desc {
   /* dropout: on the epilogue (B4R_EPI_BIAS_DROP_RES, element index row*N+col) or, with a_dropout=1, on the A operand
    * as it is loaded (element index row*K+col): dY = dz * mask / keep without materialising dY */
   const uint32_t* rng; uint32_t drop_stream; float drop_rate; int32_t a_dropout;
+  /* 1: columns [N, roundup(N,4)) of C / C2 (inside ldc) are scratch the kernel may overwrite, and of R may be read */
+  int32_t c_pad_scratch;
 } b4r_gemm_desc;
+/* Arithmetic of the dense layers (process-wide switch; default B4R_GEMM_BF16X3):
+ *   B4R_GEMM_F32     exact fp32 matrix cores (v_mfma_f32_32x32x2_f32), LDS-tiled
+ *   B4R_GEMM_BF16X3  products with K <= 64 run on the bf16 matrix cores with a 3-term hi/lo split of both fp32 operands and
+ *                    fp32 accumulation (~1e-5 of the fp32 result at 5.3x the matrix-core throughput, operands loaded
+ *                    straight into registers); K > 64 and the weight-gradient products stay on the exact path */
+enum { B4R_GEMM_F32 = 0, B4R_GEMM_BF16X3 = 1 };
+int b4r_set_gemm_mode(int mode);
+int b4r_get_gemm_mode(void);
+
 /* dense layers of the encoder / MLM head (Keras Dense / EinsumDense / MultiHeadAttention projections) on the exact
  * fp32 matrix cores (v_mfma_f32_32x32x2_f32) */
 int b4r_gemm_f32(const b4r_gemm_desc* d, b4r_stream_t stream);

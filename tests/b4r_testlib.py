@@ -28,7 +28,7 @@ def state_floats(st):
 
 
 def gemm(A, B, M, N, K, b_is_nk=0, epi=_lib.EPI_NONE, bias=None, R=None, want_c2=False, qscale=1.0, qcols=0,
-         rng=None, drop_stream=0, drop_rate=0.0, a_dropout=0, ldc=None, lda=None, ldb=None):
+         rng=None, drop_stream=0, drop_rate=0.0, a_dropout=0, ldc=None, lda=None, ldb=None, c_pad_scratch=0):
     lib = _lib.load()
     ldc = ldc or N
     Cm = torch.full((M, ldc), float("nan"), dtype=torch.float32, device=A.device)
@@ -44,6 +44,7 @@ def gemm(A, B, M, N, K, b_is_nk=0, epi=_lib.EPI_NONE, bias=None, R=None, want_c2
     d.R, d.ldr = P(R), (R.stride(0) if R is not None else 0)
     d.qscale, d.qcols = qscale, qcols
     d.rng, d.drop_stream, d.drop_rate, d.a_dropout = P(rng), drop_stream, drop_rate, a_dropout
+    d.c_pad_scratch = c_pad_scratch
     _lib.check(lib.b4r_gemm_f32(C.byref(d), stream()), "b4r_gemm_f32")
     return Cm[:, :N], C2
 

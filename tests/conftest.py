@@ -24,3 +24,14 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(params=["f32", "bf16x3"])
+def gemm_mode(request):
+    """Run a GPU test under both arithmetic modes of the dense layers (include/b4r.h b4r_set_gemm_mode)."""
+    from bert4rec_amd import _lib
+    lib = _lib.load()
+    prev = lib.b4r_get_gemm_mode()
+    _lib.check(lib.b4r_set_gemm_mode(_lib.GEMM_F32 if request.param == "f32" else _lib.GEMM_BF16X3))
+    yield request.param
+    lib.b4r_set_gemm_mode(prev)

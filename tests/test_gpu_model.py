@@ -11,7 +11,7 @@ from bert4rec_amd import _lib
 from bert4rec_amd.engine import Engine, make_adamw_config, make_model_config
 from oracle import bert4rec_oracle as orc
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("gemm_mode")]
 
 LOGIT_TOL = 1e-3
 

@@ -13,7 +13,7 @@ from oracle import bert4rec_oracle as orc
 from tests import b4r_testlib as T
 from tests.b4r_testlib import P, stream
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("gemm_mode")]
 
 DEV = "cuda"
 TOL = 2e-5  # fp32 matrix-core sums of <= 4k terms of O(1) magnitude vs fp64
@@ -32,7 +32,8 @@ def gelu_grad(x):
     return 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 70, 64), (128, 64, 32), (257, 192, 100), (64, 256, 256), (5, 3, 7)])
+@pytest.mark.parametrize("M,N,K", [(300, 70, 64), (128, 64, 32), (257, 192, 100), (64, 256, 256), (5, 3, 7), (512, 192, 64),
+                                   (96, 256, 64), (1024, 64, 64)])
 def test_gemm_nn_epilogues(M, N, K):
     A, B, bias, R = rnd(M, K, seed=1), rnd(K, N, seed=2, scale=0.3), rnd(N, seed=3), rnd(M, N, seed=4)
     ref = A.double() @ B.double()
@@ -84,6 +85,9 @@ def test_gemm_nt_vocab_projection(M, N, K, ldc):
     ref = A.double() @ B.double().t() + bias.double()
     c, _ = T.gemm(A.to(DEV), B.to(DEV), M, N, K, b_is_nk=1, epi=_lib.EPI_BIAS, bias=bias.to(DEV), ldc=ldc)
     assert T.maxdiff(c, ref) < TOL
+    # with the pad columns of C declared scratch the register-operand bf16x3 kernel may take the shape (N % 4 != 0)
+    c, _ = T.gemm(A.to(DEV), B.to(DEV), M, N, K, b_is_nk=1, epi=_lib.EPI_BIAS, bias=bias.to(DEV), ldc=ldc, c_pad_scratch=1)
+    assert T.maxdiff(c, ref) < TOL
 
 
 def test_gemm_k_tail_padded_rows():
@@ -120,7 +124,8 @@ def test_gemm_tn_dropout_on_b():
     Bd = B.double() * keep / (1 - rate)
     out, cs, _ = T.gemm_tn(A.to(DEV), B.to(DEV), R, Mo, No, want_colsum=True, rng=st, drop_stream=sid, drop_rate=rate,
                            b_dropout=1)
-    assert T.maxdiff(out, A.double().t() @ Bd) < 2e-4
+    ref = A.double().t() @ Bd
+    assert T.maxdiff(out, ref) < 1e-5 * float(ref.abs().max())
     assert T.maxdiff(cs, Bd.sum(0)) < 2e-4
 
 

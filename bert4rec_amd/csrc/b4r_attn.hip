@@ -12,16 +12,23 @@
 // the accumulator's ROW index), so nothing is transposed through LDS.  The dK/dV kernel uses the other orientation
 // (S = Q.K^T, a wave owns 16 keys and sweeps the queries) for the same reason: dV^T = dO^T.A and dK^T = Q^T.dS sum over
 // queries = its accumulator rows.  No cross-workgroup sums, so the backward is bitwise reproducible.
+//
+// LDS tiles are [rows][32 floats] with an XOR swizzle of the column (tile_idx) that makes BOTH operand access patterns
+// conflict-free for ds_read_b32: (1) 16 rows x 2 adjacent columns (A operand of q.k^T-like products) and (2) 16 adjacent
+// columns x rows 4g+s (A operand of the products that consume an accumulator tile).  A workgroup is 8 waves = 128 queries
+// (or keys): K and V (52 KB at L = 200) are staged once per 128 rows and two workgroups fit a CU (16 waves).
 #include "b4r_common.h"
 
 namespace {
 
-constexpr int LDH = 36;  // LDS row stride (floats) of the [rows][32] operand tiles: 16-B aligned rows, <=2-way conflicts
+constexpr int WAVES = 8;         // waves per workgroup
+constexpr int ROWS_WG = 16 * WAVES;
 
 struct AttnP {
   const float* qkv; const int64_t* mask; const float* ctx; const float* lse_in; const float* dctx;
   float* ctx_out; float* lse_out; float* dqkv;
   int B, L, heads, H, Lp;
+  int reg_rows;  // rows per LDS region of the dQ kernel: max(Lp, 128)
   float qscale;
   DropArgs drop;
 };
@@ -30,19 +37,26 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// rows [0,nrows) of a [*,32] head slice -> LDS tile with stride LDH; rows beyond `valid` are zero
+// swizzled position of (row, col) in a [rows][32] tile; bit 0 of the column is untouched (8-byte pairs stay adjacent)
+__device__ __forceinline__ int tile_idx(int row, int col) {
+  return row * 32 + (col ^ ((2 * (row & 15)) ^ (16 * ((row >> 2) & 1))));
+}
+
+// rows [0,nrows) of a [*,32] head slice -> swizzled LDS tile; rows beyond `valid` are zero
 __device__ __forceinline__ void load_head_rows(float* dst, const float* src, int64_t row0, int ld, int nrows, int valid) {
-  for (int f = threadIdx.x; f < nrows * 8; f += 256) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  for (int f = threadIdx.x; f < nrows * 8; f += 64 * WAVES) {
     const int r = f >> 3, c = (f & 7) * 4;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (r < valid) v = *reinterpret_cast<const f32x4*>(src + (row0 + r) * ld + c);
-    *reinterpret_cast<f32x4*>(dst + r * LDH + c) = v;
+    *reinterpret_cast<f32x2*>(dst + tile_idx(r, c)) = (f32x2){v[0], v[1]};
+    *reinterpret_cast<f32x2*>(dst + tile_idx(r, c + 2)) = (f32x2){v[2], v[3]};
   }
 }
 
 // D[r] = sum_c dO[r][c] * O[r][c] over the 32 columns of this head, for rows [0,nrows); rows beyond valid -> 0
 __device__ __forceinline__ void rowdot_head(float* sD, const float* dO, const float* O, int64_t row0, int ld, int nrows, int valid) {
-  for (int base = 0; base < nrows; base += 64) {
+  for (int base = 0; base < nrows; base += 16 * WAVES) {
     const int r = base + (threadIdx.x >> 2), part = threadIdx.x & 3;
     float s = 0.f;
     if (r < valid) {
@@ -60,40 +74,42 @@ __device__ __forceinline__ void rowdot_head(float* sD, const float* dO, const fl
 }
 
 // -----------------------------------------------------------------------------------------------------------
-// forward: workgroup = 64 queries of one (batch, head); wave = 16 queries x all keys
+// forward: workgroup = 128 queries of one (batch, head); wave = 16 queries x all keys
+// LDS: [K tile | V tile | sAdd]; the query tile borrows the K region first (its fragments live in registers afterwards)
 // -----------------------------------------------------------------------------------------------------------
 template <int KT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
+__global__ __launch_bounds__(64 * WAVES) void attn_fwd_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int Lp = KT * 16;
   float* sK = smem;
-  float* sV = sK + Lp * LDH;
-  float* sQ = sV + Lp * LDH;
-  float* sAdd = sQ + 64 * LDH;
+  float* sV = sK + Lp * 32;
+  float* sAdd = sV + Lp * 32;
 
-  const int b = blockIdx.z, hd = blockIdx.y, q0 = blockIdx.x * 64;
+  const int b = blockIdx.z, hd = blockIdx.y, q0 = blockIdx.x * ROWS_WG;
   const int L = p.L, H = p.H, ld3 = 3 * H;
   const int64_t row0 = (int64_t)b * L;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
 
-  load_head_rows(sK, p.qkv + H + hd * 32, row0, ld3, Lp, L);
-  load_head_rows(sV, p.qkv + 2 * H + hd * 32, row0, ld3, Lp, L);
-  load_head_rows(sQ, p.qkv + hd * 32, row0 + q0, ld3, 64, L - q0);
-  for (int k = threadIdx.x; k < Lp; k += 256)
-    sAdd[k] = (k < L) ? (1.0f - (float)p.mask[row0 + k]) * -1e9f : -INFINITY;
+  load_head_rows(sK, p.qkv + hd * 32, row0 + q0, ld3, ROWS_WG, L - q0);   // Q tile in the K region
   __syncthreads();
-
-  const int q = q0 + 16 * wave + i;
   float qf[8];
 #pragma unroll
-  for (int s = 0; s < 8; ++s) qf[s] = sQ[(16 * wave + i) * LDH + 4 * s + g];
+  for (int s = 0; s < 8; ++s) qf[s] = sK[tile_idx(16 * wave + i, 4 * s + g)];
+  __syncthreads();
+  load_head_rows(sK, p.qkv + H + hd * 32, row0, ld3, Lp, L);
+  load_head_rows(sV, p.qkv + 2 * H + hd * 32, row0, ld3, Lp, L);
+  for (int k = threadIdx.x; k < Lp; k += 64 * WAVES)
+    sAdd[k] = (k < L) ? (1.0f - (float)p.mask[row0 + k]) * -1e9f : -INFINITY;
+  __syncthreads();
+  if (q0 + 16 * wave >= L) return;  // wave-uniform; no barrier below
 
+  const int q = q0 + 16 * wave + i;
   f32x4 acc[KT];
 #pragma unroll
   for (int t = 0; t < KT; ++t) {
     f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < 8; ++s) c = mfma16(sK[(16 * t + i) * LDH + 4 * s + g], qf[s], c);
+    for (int s = 0; s < 8; ++s) c = mfma16(sK[tile_idx(16 * t + i, 4 * s + g)], qf[s], c);
     acc[t] = c;
   }
   float m = -INFINITY;
@@ -126,8 +142,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
       const int key = 16 * t + 4 * g + s;
       float pv = acc[t][s] * inv;
       if (dctx.on) pv = b4r_keep(dctx, dbase + (uint64_t)key) ? pv * dctx.scale : 0.f;
-      o0 = mfma16(sV[key * LDH + i], pv, o0);
-      o1 = mfma16(sV[key * LDH + 16 + i], pv, o1);
+      o0 = mfma16(sV[tile_idx(key, i)], pv, o0);
+      o1 = mfma16(sV[tile_idx(key, 16 + i)], pv, o1);
     }
   }
   if (q < L) {
@@ -139,41 +155,43 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnP p) {
 
 // -----------------------------------------------------------------------------------------------------------
 // backward, dQ: same decomposition as the forward; probabilities recomputed from the saved log-sum-exp
+// LDS: [K tile | V tile | sAdd | sD]; Q and dO tiles borrow the K / V regions first
 // -----------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
+__global__ __launch_bounds__(64 * WAVES) void attn_bwd_dq_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int Lp = p.Lp, KT = Lp / 16;
   float* sK = smem;
-  float* sV = sK + Lp * LDH;
-  float* sQ = sV + Lp * LDH;
-  float* sdO = sQ + 64 * LDH;
-  float* sAdd = sdO + 64 * LDH;
-  float* sD = sAdd + Lp;
+  float* sV = sK + p.reg_rows * 32;
+  float* sAdd = sV + p.reg_rows * 32;
+  float* sD = sAdd + p.reg_rows;
 
-  const int b = blockIdx.z, hd = blockIdx.y, q0 = blockIdx.x * 64;
+  const int b = blockIdx.z, hd = blockIdx.y, q0 = blockIdx.x * ROWS_WG;
   const int L = p.L, H = p.H, ld3 = 3 * H;
   const int64_t row0 = (int64_t)b * L;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
 
+  load_head_rows(sK, p.qkv + hd * 32, row0 + q0, ld3, ROWS_WG, L - q0);   // Q tile
+  load_head_rows(sV, p.dctx + hd * 32, row0 + q0, H, ROWS_WG, L - q0);    // dO tile
+  rowdot_head(sD, p.dctx + hd * 32, p.ctx + hd * 32, row0 + q0, H, ROWS_WG, L - q0);
+  __syncthreads();
+  float qf[8], dof[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    qf[s] = sK[tile_idx(16 * wave + i, 4 * s + g)];
+    dof[s] = sV[tile_idx(16 * wave + i, 4 * s + g)];
+  }
+  const float Dq = sD[16 * wave + i];
+  __syncthreads();
   load_head_rows(sK, p.qkv + H + hd * 32, row0, ld3, Lp, L);
   load_head_rows(sV, p.qkv + 2 * H + hd * 32, row0, ld3, Lp, L);
-  load_head_rows(sQ, p.qkv + hd * 32, row0 + q0, ld3, 64, L - q0);
-  load_head_rows(sdO, p.dctx + hd * 32, row0 + q0, H, 64, L - q0);
-  rowdot_head(sD, p.dctx + hd * 32, p.ctx + hd * 32, row0 + q0, H, 64, L - q0);
-  for (int k = threadIdx.x; k < Lp; k += 256)
+  for (int k = threadIdx.x; k < Lp; k += 64 * WAVES)
     sAdd[k] = (k < L) ? (1.0f - (float)p.mask[row0 + k]) * -1e9f : -INFINITY;
   __syncthreads();
+  if (q0 + 16 * wave >= L) return;
 
   const int q = q0 + 16 * wave + i;
   const bool qlive = q < L;
   const float lse = qlive ? p.lse_in[((int64_t)b * p.heads + hd) * L + q] : 0.f;
-  const float Dq = sD[16 * wave + i];
-  float qf[8], dof[8];
-#pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    qf[s] = sQ[(16 * wave + i) * LDH + 4 * s + g];
-    dof[s] = sdO[(16 * wave + i) * LDH + 4 * s + g];
-  }
   DropCtx dctx = b4r_drop_ctx(p.drop);
   const uint64_t dbase = (((uint64_t)b * p.heads + hd) * L + (uint64_t)(qlive ? q : 0)) * (uint64_t)L;
 
@@ -182,8 +200,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
     f32x4 sc = {0.f, 0.f, 0.f, 0.f}, da = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      sc = mfma16(sK[(16 * t + i) * LDH + 4 * s + g], qf[s], sc);
-      da = mfma16(sV[(16 * t + i) * LDH + 4 * s + g], dof[s], da);
+      sc = mfma16(sK[tile_idx(16 * t + i, 4 * s + g)], qf[s], sc);
+      da = mfma16(sV[tile_idx(16 * t + i, 4 * s + g)], dof[s], da);
     }
     const f32x4 ad = *reinterpret_cast<const f32x4*>(&sAdd[16 * t + 4 * g]);
 #pragma unroll
@@ -193,8 +211,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
       float dA = da[s];
       if (dctx.on) dA = b4r_keep(dctx, dbase + (uint64_t)key) ? dA * dctx.scale : 0.f;
       const float ds = pr * (dA - Dq);
-      dq0 = mfma16(sK[key * LDH + i], ds, dq0);
-      dq1 = mfma16(sK[key * LDH + 16 + i], ds, dq1);
+      dq0 = mfma16(sK[tile_idx(key, i)], ds, dq0);
+      dq1 = mfma16(sK[tile_idx(key, 16 + i)], ds, dq1);
     }
   }
   if (qlive) {
@@ -205,14 +223,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnP p) {
 }
 
 // -----------------------------------------------------------------------------------------------------------
-// backward, dK / dV: workgroup = 64 keys of one (batch, head); wave = 16 keys x all queries
+// backward, dK / dV: workgroup = 128 keys of one (batch, head); wave = 16 keys x all queries
+// LDS: [Q tile | dO tile | sLse | sD]
 // -----------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p) {
+__global__ __launch_bounds__(64 * WAVES) void attn_bwd_dkv_kernel(AttnP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int Lp = p.Lp, KT = Lp / 16;
   float* sQ = smem;
-  float* sdO = sQ + Lp * LDH;
-  float* sLse = sdO + Lp * LDH;
+  float* sdO = sQ + Lp * 32;
+  float* sLse = sdO + Lp * 32;
   float* sD = sLse + Lp;
 
   const int b = blockIdx.z, hd = blockIdx.y;
@@ -223,11 +242,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p) {
   load_head_rows(sQ, p.qkv + hd * 32, row0, ld3, Lp, L);
   load_head_rows(sdO, p.dctx + hd * 32, row0, H, Lp, L);
   rowdot_head(sD, p.dctx + hd * 32, p.ctx + hd * 32, row0, H, Lp, L);
-  for (int k = threadIdx.x; k < Lp; k += 256)
+  for (int k = threadIdx.x; k < Lp; k += 64 * WAVES)
     sLse[k] = (k < L) ? p.lse_in[((int64_t)b * p.heads + hd) * L + k] : INFINITY;  // +inf => probability 0 for pad queries
   __syncthreads();
 
-  const int k0 = (blockIdx.x * 4 + wave) * 16;
+  const int k0 = (blockIdx.x * WAVES + wave) * 16;
   if (k0 >= L) return;  // no barrier below
   const int key = k0 + i;
   const bool klive = key < L;
@@ -246,8 +265,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p) {
     f32x4 sc = {0.f, 0.f, 0.f, 0.f}, da = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      sc = mfma16(sQ[(16 * t + i) * LDH + 4 * s + g], kf[s], sc);
-      da = mfma16(sdO[(16 * t + i) * LDH + 4 * s + g], vf[s], da);
+      sc = mfma16(sQ[tile_idx(16 * t + i, 4 * s + g)], kf[s], sc);
+      da = mfma16(sdO[tile_idx(16 * t + i, 4 * s + g)], vf[s], da);
     }
     const f32x4 ls = *reinterpret_cast<const f32x4*>(&sLse[16 * t + 4 * g]);
     const f32x4 dd = *reinterpret_cast<const f32x4*>(&sD[16 * t + 4 * g]);
@@ -262,10 +281,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnP p) {
         dA = keep ? dA * dctx.scale : 0.f;
       }
       const float ds = pr * (dA - dd[s]);
-      dv0 = mfma16(sdO[qq * LDH + i], ad, dv0);
-      dv1 = mfma16(sdO[qq * LDH + 16 + i], ad, dv1);
-      dk0 = mfma16(sQ[qq * LDH + i], ds, dk0);
-      dk1 = mfma16(sQ[qq * LDH + 16 + i], ds, dk1);
+      dv0 = mfma16(sdO[tile_idx(qq, i)], ad, dv0);
+      dv1 = mfma16(sdO[tile_idx(qq, 16 + i)], ad, dv1);
+      dk0 = mfma16(sQ[tile_idx(qq, i)], ds, dk0);
+      dk1 = mfma16(sQ[tile_idx(qq, 16 + i)], ds, dk1);
     }
   }
   if (klive) {
@@ -303,6 +322,8 @@ int check_common(const char* who, const float* qkv, const int64_t* mask, int B, 
   return B4R_OK;
 }
 
+inline int tile_rows(int Lp) { return Lp > ROWS_WG ? Lp : ROWS_WG; }  // a region must also hold a 128-row Q / dO tile
+
 }  // namespace
 
 extern "C" int b4r_attn_fwd(const float* qkv, const int64_t* input_mask, int32_t B, int32_t L, int32_t heads, float* ctx,
@@ -316,13 +337,15 @@ extern "C" int b4r_attn_fwd(const float* qkv, const int64_t* input_mask, int32_t
   const int KT = key_tiles(L);
   p.Lp = KT * 16;
   p.drop = b4r_make_drop(rng, drop_stream, drop_rate, 1);
-  const size_t sh = ((size_t)2 * p.Lp * LDH + 64 * LDH + p.Lp) * sizeof(float);
-  dim3 grid(b4r_cdiv(L, 64), heads, B);
+  // the K region must hold the 128-row query tile too; regions are laid out with stride Lp*32, so for short sequences the
+  // query tile spills into the V region, which is only filled after the query fragments have been read
+  const size_t sh = ((size_t)2 * p.Lp * 32 + p.Lp + (p.Lp < ROWS_WG ? (size_t)(ROWS_WG - p.Lp) * 32 : 0)) * sizeof(float);
+  dim3 grid(b4r_cdiv(L, ROWS_WG), heads, B);
 #define FWD_CASE(KT_)                                                                                   \
   case KT_:                                                                                             \
     rc = set_lds(attn_fwd_kernel<KT_>, sh);                                                             \
     if (rc) return rc;                                                                                  \
-    hipLaunchKernelGGL((attn_fwd_kernel<KT_>), grid, dim3(256), sh, (hipStream_t)stream, p);            \
+    hipLaunchKernelGGL((attn_fwd_kernel<KT_>), grid, dim3(64 * WAVES), sh, (hipStream_t)stream, p);     \
     break;
   switch (KT) {
     FWD_CASE(4) FWD_CASE(8) FWD_CASE(13) FWD_CASE(16)
@@ -344,16 +367,18 @@ extern "C" int b4r_attn_bwd(const float* qkv, const int64_t* input_mask, const f
   p.B = B; p.L = L; p.heads = heads; p.H = heads * 32; p.qscale = qscale;
   p.Lp = key_tiles(L) * 16;
   p.drop = b4r_make_drop(rng, drop_stream, drop_rate, 1);
-  dim3 grid(b4r_cdiv(L, 64), heads, B);
-  const size_t sh_dq = ((size_t)2 * p.Lp * LDH + 2 * 64 * LDH + p.Lp + 64) * sizeof(float);
+  dim3 grid(b4r_cdiv(L, ROWS_WG), heads, B);
+  // dQ: the K and V regions must each also hold a 128-row Q / dO tile
+  p.reg_rows = tile_rows(p.Lp);
+  const size_t sh_dq = ((size_t)2 * p.reg_rows * 32 + p.reg_rows + ROWS_WG) * sizeof(float);
   rc = set_lds(attn_bwd_dq_kernel, sh_dq);
   if (rc) return rc;
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), sh_dq, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(64 * WAVES), sh_dq, (hipStream_t)stream, p);
   B4R_CHECK_LAUNCH("b4r_attn_bwd dq");
-  const size_t sh_kv = ((size_t)2 * p.Lp * LDH + 2 * p.Lp) * sizeof(float);
+  const size_t sh_kv = ((size_t)2 * p.Lp * 32 + 2 * p.Lp) * sizeof(float);
   rc = set_lds(attn_bwd_dkv_kernel, sh_kv);
   if (rc) return rc;
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), sh_kv, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(64 * WAVES), sh_kv, (hipStream_t)stream, p);
   B4R_CHECK_LAUNCH("b4r_attn_bwd dkv");
   return B4R_OK;
 }

@@ -277,8 +277,133 @@ __global__ __launch_bounds__(256) void rx_gemm_nk_kernel(RxP p) {
   }
 }
 
+// ---- K > 64 (multiple of 64), N <= 32*NT: the K loop -----------------------------------------------------------------
+// Used by the products whose reduction dimension is the FFN inner size or 3H (FFN-out, d(FFN-in input), d(QKV input)): their
+// N is the hidden size, so a wave keeps all NT column tiles of its 32 rows in accumulators and streams K in chunks of 64:
+// A chunk = 8 x 16-byte fragment loads per lane (requested one chunk ahead); B chunk = NT tiles, either register
+// fragments of coalesced dword loads ([K,N]) or a workgroup-shared double-buffered bf16 hi/lo LDS tile ([N,K]).
+template <bool B_NK, int EPI, bool A_DROP, int NT>
+__global__ __launch_bounds__(256) void rx_gemm_kloop_kernel(RxP p) {
+  extern __shared__ __attribute__((aligned(16))) float s_lds[];
+  constexpr int BROW = 36, PLANE = NT * 32 * BROW * 4;     // B planes: [NT*32 rows][64 bf16 + pad]
+  constexpr int NLD = (NT * 32 * 16) / 256;                // float4 per thread per B chunk tile ([N,K] layout)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.x * 128 + wave * 32;
+  const bool live = m0 < p.M;
+  const int nchunks = p.K / 64;
+  DropCtx dctx = b4r_drop_ctx(p.drop);
+  float* stage = s_lds + wave * (32 * ST_LD);
+  char* bbuf = reinterpret_cast<char*>(s_lds + STAGE_FLOATS);
+  const int c4 = (lane & 7) * 4;
+  const int arow = min(m0 + r, p.M - 1);
+
+  f32x8 araw[4];
+  auto fetch_a = [&](int c) {
+    const float* ap = p.A + (int64_t)arow * p.lda + 64 * c + 8 * h;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) araw[kb] = load8_contig(ap + 16 * kb);
+  };
+  f32x4 braw[B_NK ? NLD : 1];
+  auto fetch_b = [&](int c) {
+    if constexpr (B_NK) {
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        const int f = i * 256 + tid;
+        const int trow = f >> 4, tc4 = (f & 15) * 4;
+        braw[i] = *reinterpret_cast<const f32x4*>(p.B + (int64_t)min(trow, p.N - 1) * p.ldb + 64 * c + tc4);
+      }
+    }
+  };
+  auto stash_b = [&](int buf) {
+    if constexpr (B_NK) {
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        const int f = i * 256 + tid;
+        const int trow = f >> 4, tc4 = (f & 15) * 4;
+        const bf16x4 hi = __builtin_convertvector(braw[i], bf16x4);
+        const bf16x4 lo = __builtin_convertvector(braw[i] - __builtin_convertvector(hi, f32x4), bf16x4);
+        char* dst = bbuf + buf * (2 * PLANE) + trow * (BROW * 4) + tc4 * 2;
+        *reinterpret_cast<bf16x4*>(dst) = hi;
+        *reinterpret_cast<bf16x4*>(dst + PLANE) = lo;
+      }
+    }
+  };
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+
+  fetch_a(0);
+  fetch_b(0);
+  stash_b(0);
+  if (B_NK) __syncthreads();
+
+  for (int c = 0; c < nchunks; ++c) {
+    bf16x8 ah[4], al[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      f32x8 x = araw[kb];
+      if (A_DROP) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = b4r_drop(dctx, x[j], (uint64_t)arow * (uint64_t)p.K + (uint64_t)(64 * c + 16 * kb + 8 * h + j));
+      }
+      split8(x, ah[kb], al[kb]);
+    }
+    const int cn = min(c + 1, nchunks - 1);   // unconditional look-ahead (the last chunk re-requests itself)
+    fetch_a(cn);
+    fetch_b(cn);
+    const int cur = c & 1;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        bf16x8 bh, bl;
+        if constexpr (B_NK) {
+          const char* src = bbuf + cur * (2 * PLANE) + (32 * j + r) * (BROW * 4) + 16 * h + 32 * kb;
+          bh = *reinterpret_cast<const bf16x8*>(src);
+          bl = *reinterpret_cast<const bf16x8*>(src + PLANE);
+        } else {
+          const int col = min(32 * j + r, p.N - 1);
+          split8(load8_strided(p.B + (int64_t)(64 * c + 16 * kb + 8 * h) * p.ldb + col, p.ldb), bh, bl);
+        }
+        acc[j] = mfma3(ah[kb], al[kb], bh, bl, acc[j]);
+      }
+    }
+    if (B_NK) {
+      stash_b(cur ^ 1);
+      __syncthreads();
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      if (32 * j < p.N) epilogue_tile<EPI>(p, dctx, acc[j], load_bias4<EPI>(p, 32 * j, c4), stage, m0, 32 * j, lane);
+    }
+  }
+}
+
+template <bool B_NK, int EPI, bool A_DROP>
+void launch_kloop(const RxP& p, hipStream_t s) {
+  dim3 grid((unsigned)b4r_cdiv(p.M, 128));
+  const int nt = b4r_cdiv(p.N, 32);
+  if (nt <= 2) {
+    const size_t lds = STAGE_FLOATS * sizeof(float) + (B_NK ? 2 * 2 * 2 * 32 * 36 * 4 : 0);
+    hipLaunchKernelGGL((rx_gemm_kloop_kernel<B_NK, EPI, A_DROP, 2>), grid, dim3(256), lds, s, p);
+  } else {
+    const size_t lds = STAGE_FLOATS * sizeof(float) + (B_NK ? 2 * 2 * 4 * 32 * 36 * 4 : 0);
+    if (lds > 48 * 1024)
+      (void)hipFuncSetAttribute((const void*)rx_gemm_kloop_kernel<B_NK, EPI, A_DROP, 4>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((rx_gemm_kloop_kernel<B_NK, EPI, A_DROP, 4>), grid, dim3(256), lds, s, p);
+  }
+}
+
 template <bool B_NK, int EPI, bool A_DROP>
 void launch_rx2(const RxP& p, dim3 grid, hipStream_t s) {
+  if (p.K > 64) { launch_kloop<B_NK, EPI, A_DROP>(p, s); return; }
   if (B_NK) {
     if (p.K == 64) hipLaunchKernelGGL((rx_gemm_nk_kernel<EPI, A_DROP, 4>), grid, dim3(256), NK_LDS_BYTES, s, p);
     else hipLaunchKernelGGL((rx_gemm_nk_kernel<EPI, A_DROP, 2>), grid, dim3(256), NK_LDS_BYTES, s, p);
@@ -317,7 +442,9 @@ inline int up4i(int x) { return (x + 3) & ~3; }
 
 // shape contract of the branch-free kernels; everything else runs on the exact-fp32 LDS-tiled path
 bool b4r_gemm_rx_supported(const b4r_gemm_desc* d) {
-  if (!(d->K == 64 || d->K == 32) || d->M % 32 != 0 || d->N < 4) return false;
+  const bool k_small = (d->K == 64 || d->K == 32);
+  const bool k_loop = (d->K > 64 && d->K % 64 == 0 && d->N <= 128);   // rx_gemm_kloop_kernel
+  if (!(k_small || k_loop) || d->M % 32 != 0 || d->N < 4) return false;
   if (!vec_ok(d->A, d->lda) || !vec_ok(d->C, d->ldc)) return false;
   if (d->b_is_nk && !vec_ok(d->B, d->ldb)) return false;
   const int ns = up4i(d->N);

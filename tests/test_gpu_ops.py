@@ -33,7 +33,7 @@ def gelu_grad(x):
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 70, 64), (128, 64, 32), (257, 192, 100), (64, 256, 256), (5, 3, 7), (512, 192, 64),
-                                   (96, 256, 64), (1024, 64, 64)])
+                                   (96, 256, 64), (1024, 64, 64), (256, 64, 256), (128, 64, 192), (160, 128, 512), (64, 100, 128)])
 def test_gemm_nn_epilogues(M, N, K):
     A, B, bias, R = rnd(M, K, seed=1), rnd(K, N, seed=2, scale=0.3), rnd(N, seed=3), rnd(M, N, seed=4)
     ref = A.double() @ B.double()
@@ -78,7 +78,8 @@ def test_gemm_dropout_epilogue_and_a_operand():
     assert T.maxdiff(c, ref) < 1e-4
 
 
-@pytest.mark.parametrize("M,N,K,ldc", [(256, 3709, 64, 3712), (130, 37, 16, 64), (96, 64, 192, 64)])
+@pytest.mark.parametrize("M,N,K,ldc", [(256, 3709, 64, 3712), (130, 37, 16, 64), (96, 64, 192, 64), (512, 64, 256, 64),
+                                       (128, 128, 128, 128)])
 def test_gemm_nt_vocab_projection(M, N, K, ldc):
     """C = A.B^T with B [N,K]: the tied projection T.E^T + b (tfm MaskedLM) incl. the padded leading dimension."""
     A, B, bias = rnd(M, K, seed=5), rnd(N, K, seed=6, scale=0.05), rnd(N, seed=7, scale=0.1)

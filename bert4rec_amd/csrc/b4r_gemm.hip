@@ -408,6 +408,9 @@ int b4r_launch_slab_reduce_full(const float* slab, int S, int Mo, int No, float*
 // ---- arithmetic mode of the dense layers ------------------------------------------------------------------------------
 int b4r_gemm_rx_launch(const b4r_gemm_desc* d, hipStream_t stream);
 bool b4r_gemm_rx_supported(const b4r_gemm_desc* d);
+bool b4r_gemm_rx_tn_supported(const b4r_gemm_tn_desc* d);
+int64_t b4r_gemm_rx_tn_scratch_floats(int R, int Mo, int No);
+int b4r_gemm_rx_tn_launch(const b4r_gemm_tn_desc* d, float* scratch, hipStream_t stream);
 static int g_gemm_mode = B4R_GEMM_BF16X3;
 extern "C" int b4r_set_gemm_mode(int mode) {
   B4R_CHECK_ARG(mode == B4R_GEMM_F32 || mode == B4R_GEMM_BF16X3, B4R_E_BADARG, "b4r_set_gemm_mode: unknown mode %d", mode);
@@ -483,7 +486,9 @@ int b4r_gemm_f32_splitk(const b4r_gemm_desc* d, int splits, float* scratch, hipS
 extern "C" int64_t b4r_gemm_tn_scratch_floats(int32_t R, int32_t Mo, int32_t No) {
   if (R <= 0 || Mo <= 0 || No <= 0) return 0;
   const int S = tn_split(R, Mo, No);
-  return (int64_t)S * Mo * No + (int64_t)S * No + (int64_t)S * Mo;
+  const int64_t a = (int64_t)S * Mo * No + (int64_t)S * No + (int64_t)S * Mo;
+  const int64_t b = b4r_gemm_rx_tn_scratch_floats(R, Mo, No);
+  return a > b ? a : b;  // large enough for either arithmetic mode
 }
 
 extern "C" int b4r_gemm_tn_f32(const b4r_gemm_tn_desc* d, float* scratch, b4r_stream_t stream) {
@@ -491,6 +496,7 @@ extern "C" int b4r_gemm_tn_f32(const b4r_gemm_tn_desc* d, float* scratch, b4r_st
   B4R_CHECK_ARG(d->A && d->B && d->out, B4R_E_BADARG, "b4r_gemm_tn_f32: null operand");
   B4R_CHECK_ARG(d->R > 0 && d->Mo > 0 && d->No > 0, B4R_E_SHAPE, "b4r_gemm_tn_f32: bad shape");
   B4R_CHECK_ARG(d->lda >= d->Mo && d->ldb >= d->No && d->ldo >= d->No, B4R_E_SHAPE, "b4r_gemm_tn_f32: bad leading dimension");
+  if (g_gemm_mode == B4R_GEMM_BF16X3 && b4r_gemm_rx_tn_supported(d)) return b4r_gemm_rx_tn_launch(d, scratch, (hipStream_t)stream);
   const int S = tn_split(d->R, d->Mo, d->No);
   TnP p;
   p.A = d->A; p.B = d->B; p.lda = d->lda; p.ldb = d->ldb;

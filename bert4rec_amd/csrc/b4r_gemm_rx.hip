@@ -435,6 +435,144 @@ int dispatch_rx(const RxP& p, int epi, bool a_drop, dim3 grid, hipStream_t s) {
   return B4R_OK;
 }
 
+
+// ---- weight gradients: out[Mo,No] = A[R,Mo]^T . B[R,No] --------------------------------------------------------------
+// k is the ROW index of both operands, so every fragment is 8 coalesced dword loads (32 lanes = one 128-byte line).  One
+// wave = one (64 x 64 output tile, slice of R) work item accumulating in registers; the next 16 rows are requested before
+// the MFMAs of the current 16; partial tiles go to slabs and are summed in a fixed order (bitwise reproducible).  Bias
+// gradients (column sums of B, or of A for the tied-table / output-bias pair) ride along on the loaded values.
+struct RxTnP {
+  const float* A; const float* B; float* slab; float* colsum_slab; float* colsum_a_slab;
+  int lda, ldb;
+  int R, Mo, No;
+  int tiles_i, tiles_j, S, chunk;  // chunk: rows per slice, multiple of 16
+  DropArgs drop;
+};
+
+template <bool B_DROP>
+__global__ __launch_bounds__(256) void rx_gemm_tn_kernel(RxTnP p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  __shared__ float s_red[3 * 64 * 64 + 3 * 256];   // partial tiles + column sums of waves 1..3
+  const int64_t item = blockIdx.x;                  // one workgroup = one (tile, slice); its 4 waves split the slice
+  const int z = (int)(item / ((int64_t)p.tiles_i * p.tiles_j));
+  const int t = (int)(item % ((int64_t)p.tiles_i * p.tiles_j));
+  const int ti = t / p.tiles_j, tj = t % p.tiles_j;
+  const int i0 = ti * 64, j0 = tj * 64;
+  const int sub = p.chunk / 4;                      // multiple of 16
+  const int r_begin = min(p.R, z * p.chunk + wave * sub), r_end = min(p.R, r_begin + sub);   // multiples of 16
+  const bool do_cs = p.colsum_slab != nullptr && ti == 0;
+  const bool do_csa = p.colsum_a_slab != nullptr && tj == 0;
+  DropCtx dctx = b4r_drop_ctx(p.drop);
+  // out-of-range columns are clamped (valid memory, results never stored)
+  const int ci0 = min(i0 + r, p.Mo - 1), ci1 = min(i0 + 32 + r, p.Mo - 1);
+  const int cj0 = min(j0 + r, p.No - 1), cj1 = min(j0 + 32 + r, p.No - 1);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+  float cs0 = 0.f, cs1 = 0.f, csa0 = 0.f, csa1 = 0.f;
+
+  f32x8 xa0, xa1, xb0, xb1;
+  auto fetch = [&](int k0) {
+    const int kk = k0 + 8 * h;
+    xa0 = load8_strided(p.A + (int64_t)kk * p.lda + ci0, p.lda);
+    xa1 = load8_strided(p.A + (int64_t)kk * p.lda + ci1, p.lda);
+    xb0 = load8_strided(p.B + (int64_t)kk * p.ldb + cj0, p.ldb);
+    xb1 = load8_strided(p.B + (int64_t)kk * p.ldb + cj1, p.ldb);
+  };
+  if (r_begin < r_end) fetch(r_begin);
+  for (int k0 = r_begin; k0 < r_end; k0 += 16) {
+    f32x8 ya0 = xa0, ya1 = xa1, yb0 = xb0, yb1 = xb1;
+    fetch(min(k0 + 16, r_end - 16));   // unconditional look-ahead
+    if (B_DROP) {
+      const int kk = k0 + 8 * h;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        yb0[j] = b4r_drop(dctx, yb0[j], (uint64_t)(kk + j) * (uint64_t)p.No + (uint64_t)cj0);
+        yb1[j] = b4r_drop(dctx, yb1[j], (uint64_t)(kk + j) * (uint64_t)p.No + (uint64_t)cj1);
+      }
+    }
+    if (do_cs) {
+      cs0 += ((yb0[0] + yb0[1]) + (yb0[2] + yb0[3])) + ((yb0[4] + yb0[5]) + (yb0[6] + yb0[7]));
+      cs1 += ((yb1[0] + yb1[1]) + (yb1[2] + yb1[3])) + ((yb1[4] + yb1[5]) + (yb1[6] + yb1[7]));
+    }
+    if (do_csa) {
+      csa0 += ((ya0[0] + ya0[1]) + (ya0[2] + ya0[3])) + ((ya0[4] + ya0[5]) + (ya0[6] + ya0[7]));
+      csa1 += ((ya1[0] + ya1[1]) + (ya1[2] + ya1[3])) + ((ya1[4] + ya1[5]) + (ya1[6] + ya1[7]));
+    }
+    bf16x8 ah0, al0, ah1, al1, bh0, bl0, bh1, bl1;
+    split8(ya0, ah0, al0); split8(ya1, ah1, al1); split8(yb0, bh0, bl0); split8(yb1, bh1, bl1);
+    acc[0][0] = mfma3(ah0, al0, bh0, bl0, acc[0][0]);
+    acc[0][1] = mfma3(ah0, al0, bh1, bl1, acc[0][1]);
+    acc[1][0] = mfma3(ah1, al1, bh0, bl0, acc[1][0]);
+    acc[1][1] = mfma3(ah1, al1, bh1, bl1, acc[1][1]);
+  }
+
+  // combine the 4 waves in a fixed order (wave 0 + 1 + 2 + 3), then one slab per workgroup
+  if (wave > 0) {
+    float* dst = s_red + (wave - 1) * 4096;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) dst[((a * 2 + b) * 16 + reg) * 64 + lane] = acc[a][b][reg];
+    float* dc = s_red + 3 * 4096 + (wave - 1) * 256;
+    dc[lane] = cs0; dc[64 + lane] = cs1; dc[128 + lane] = csa0; dc[192 + lane] = csa1;
+  }
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w) {
+    const float* src = s_red + w * 4096;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) acc[a][b][reg] += src[((a * 2 + b) * 16 + reg) * 64 + lane];
+    const float* sc = s_red + 3 * 4096 + w * 256;
+    cs0 += sc[lane]; cs1 += sc[64 + lane]; csa0 += sc[128 + lane]; csa1 += sc[192 + lane];
+  }
+  float* slab = p.slab + (int64_t)z * p.Mo * p.No;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int col = j0 + 32 * b + r;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = i0 + 32 * a + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        if (row < p.Mo && col < p.No) slab[(int64_t)row * p.No + col] = acc[a][b][reg];
+      }
+    }
+  if (do_cs) {
+    const float s0 = cs0 + __shfl_xor(cs0, 32, 64), s1 = cs1 + __shfl_xor(cs1, 32, 64);
+    if (h == 0 && j0 + r < p.No) p.colsum_slab[(int64_t)z * p.No + j0 + r] = s0;
+    if (h == 0 && j0 + 32 + r < p.No) p.colsum_slab[(int64_t)z * p.No + j0 + 32 + r] = s1;
+  }
+  if (do_csa) {
+    const float s0 = csa0 + __shfl_xor(csa0, 32, 64), s1 = csa1 + __shfl_xor(csa1, 32, 64);
+    if (h == 0 && i0 + r < p.Mo) p.colsum_a_slab[(int64_t)z * p.Mo + i0 + r] = s0;
+    if (h == 0 && i0 + 32 + r < p.Mo) p.colsum_a_slab[(int64_t)z * p.Mo + i0 + 32 + r] = s1;
+  }
+}
+
+int rx_tn_split(int R, int Mo, int No) {
+  const int tiles = b4r_cdiv(Mo, 64) * b4r_cdiv(No, 64);
+  int S = b4r_cdiv(768, tiles);   // workgroups of 4 waves: ~3 waves per SIMD over the whole chip
+  const int max_s = b4r_cdiv(R, 256);  // at least 64 rows per wave
+  if (S > max_s) S = max_s;
+  if (S > 256) S = 256;
+  if (S < 1) S = 1;
+  return S;
+}
+
 inline bool vec_ok(const void* ptr, int ld) { return ptr != nullptr && b4r_aligned16(ptr) && (ld % 4 == 0); }
 inline int up4i(int x) { return (x + 3) & ~3; }
 
@@ -480,4 +618,35 @@ int b4r_gemm_rx_launch(const b4r_gemm_desc* d, hipStream_t stream) {
   if (rc != B4R_OK) return rc;
   B4R_CHECK_LAUNCH("b4r_gemm_f32 (bf16x3)");
   return B4R_OK;
+}
+
+int b4r_launch_slab_reduce_full(const float* slab, int S, int Mo, int No, float* out, int ldo, int accumulate,
+                                const float* cslab, float* colsum, const float* caslab, float* colsum_a, hipStream_t stream);
+
+bool b4r_gemm_rx_tn_supported(const b4r_gemm_tn_desc* d) { return d->R % 16 == 0 && d->R >= 64; }
+
+int64_t b4r_gemm_rx_tn_scratch_floats(int R, int Mo, int No) {
+  const int S = rx_tn_split(R, Mo, No);
+  return (int64_t)S * Mo * No + (int64_t)S * No + (int64_t)S * Mo;
+}
+
+int b4r_gemm_rx_tn_launch(const b4r_gemm_tn_desc* d, float* scratch, hipStream_t stream) {
+  const int S = rx_tn_split(d->R, d->Mo, d->No);
+  RxTnP p;
+  p.A = d->A; p.B = d->B; p.lda = d->lda; p.ldb = d->ldb;
+  p.R = d->R; p.Mo = d->Mo; p.No = d->No;
+  p.tiles_i = b4r_cdiv(d->Mo, 64); p.tiles_j = b4r_cdiv(d->No, 64); p.S = S;
+  p.chunk = b4r_cdiv(b4r_cdiv(d->R, S), 64) * 64;   // each of the 4 waves takes a quarter (multiple of 16 rows)
+  p.slab = scratch;
+  p.colsum_slab = d->colsum ? scratch + (int64_t)S * d->Mo * d->No : nullptr;
+  p.colsum_a_slab = d->colsum_a ? scratch + (int64_t)S * d->Mo * d->No + (int64_t)S * d->No : nullptr;
+  p.drop = b4r_make_drop(d->rng, d->drop_stream, d->drop_rate, 1);
+  const bool b_drop = d->b_dropout && p.drop.rng != nullptr;
+  const int64_t items = (int64_t)p.tiles_i * p.tiles_j * S;
+  dim3 grid((unsigned)items);
+  if (b_drop) hipLaunchKernelGGL((rx_gemm_tn_kernel<true>), grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((rx_gemm_tn_kernel<false>), grid, dim3(256), 0, stream, p);
+  B4R_CHECK_LAUNCH("b4r_gemm_tn_f32 (bf16x3)");
+  return b4r_launch_slab_reduce_full(p.slab, S, d->Mo, d->No, d->out, d->ldo, d->accumulate, p.colsum_slab, d->colsum,
+                                     p.colsum_a_slab, d->colsum_a, stream);
 }

@@ -197,7 +197,7 @@ int ln_bwd_grid(int rows, int H) {
   int lpr = H / 4; if (lpr > 64) lpr = 64;
   const int rpb = 4 * (64 / lpr);
   int g = b4r_cdiv(rows, rpb);
-  if (g > 256) g = 256;
+  if (g > 1024) g = 1024;   // 4 workgroups per CU: enough bytes in flight for an HBM-bound pass
   if (g < 1) g = 1;
   return g;
 }
@@ -597,22 +597,22 @@ extern "C" int64_t b4r_ln_bwd_scratch_floats(int32_t rows, int32_t H) {
 }
 
 namespace {
-// dgamma[c] = sum_s partial[s][c], dbeta[c] = sum_s partial[s][H + c]; 16 columns x 16 slab lanes per workgroup,
+// dgamma[c] = sum_s partial[s][c], dbeta[c] = sum_s partial[s][H + c]; 4 columns x 64 slab lanes per workgroup,
 // combined in a fixed order
 __global__ __launch_bounds__(256) void ln_partial_reduce_kernel(const float* partial, int S, int H, float* dgamma, float* dbeta) {
-  __shared__ float sp[16][16];
-  const int cl = threadIdx.x & 15, zl = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
+  __shared__ float sp[64][4];
+  const int cl = threadIdx.x & 3, zl = threadIdx.x >> 2;
+  const int c = blockIdx.x * 4 + cl;
   float s = 0.f;
   if (c < 2 * H) {
-    for (int z = zl; z < S; z += 16) s += partial[(int64_t)z * 2 * H + c];
+    for (int z = zl; z < S; z += 64) s += partial[(int64_t)z * 2 * H + c];
   }
   sp[zl][cl] = s;
   __syncthreads();
   if (zl == 0 && c < 2 * H) {
     float t = 0.f;
 #pragma unroll
-    for (int z = 0; z < 16; ++z) t += sp[z][cl];
+    for (int z = 0; z < 64; ++z) t += sp[z][cl];
     if (c < H) dgamma[c] = t; else dbeta[c - H] = t;
   }
 }
@@ -629,7 +629,7 @@ int b4r_ln_bwd_launch(const float* dy, const float* z, const float* mean, const 
   int rc = ids ? launch_ln_bwd<true>(p, grid, stream) : launch_ln_bwd<false>(p, grid, stream);
   if (rc) return rc;
   B4R_CHECK_LAUNCH("ln_bwd");
-  hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3(b4r_cdiv(2 * H, 16)), dim3(256), 0, stream, scratch, grid, H,
+  hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3(b4r_cdiv(2 * H, 4)), dim3(256), 0, stream, scratch, grid, H,
                      dgamma, dbeta);
   B4R_CHECK_LAUNCH("ln_bwd reduce");
   return B4R_OK;

@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--config", default="ml1m", choices=list(CONFIGS))
     ap.add_argument("--cpu-steps", type=int, default=2, help="timed oracle steps for cpu_baseline (0 disables)")
     ap.add_argument("--phases", action="store_true", help="also print per-phase timings to stderr")
+    ap.add_argument("--no-dropout", action="store_true", help="diagnostic only: dropout 0 (NOT the headline configuration)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -85,6 +86,8 @@ def main():
     from bert4rec_amd.engine import Engine, make_adamw_config, make_model_config
 
     V, H, NL, NH, I, L, P, B, od, ad, rate = CONFIGS[args.config]
+    if args.no_dropout:
+        od = ad = 0.0
     cfg = make_model_config(V, H, NL, NH, L, I, od, ad)
     eng = Engine(cfg, device, seed=1234)
     eng.init_parameters(seed=3)

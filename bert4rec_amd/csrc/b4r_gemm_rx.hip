@@ -25,6 +25,8 @@
 // "three .s-level traps", (c)).  Hence the shape contract of b4r_gemm_rx_supported().
 // Epilogue: accumulators (row = register, column = lane) are transposed through a wave-private LDS tile so that every
 // global access (C, the GELU pre-activation copy, the residual) is a 16-byte piece of a full 128-byte line.
+#include <stdlib.h>
+
 #include "b4r_common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -565,7 +567,7 @@ __global__ __launch_bounds__(256) void rx_gemm_tn_kernel(RxTnP p) {
 
 int rx_tn_split(int R, int Mo, int No) {
   const int tiles = b4r_cdiv(Mo, 64) * b4r_cdiv(No, 64);
-  int S = b4r_cdiv(768, tiles);   // workgroups of 4 waves: ~3 waves per SIMD over the whole chip
+  int S = b4r_cdiv(192, tiles);   // workgroups of 4 waves; measured optimum on ML-1M shapes (96/192/384/768 tried)
   const int max_s = b4r_cdiv(R, 256);  // at least 64 rows per wave
   if (S > max_s) S = max_s;
   if (S > 256) S = 256;

@@ -157,7 +157,7 @@ def main():
         k_us = e0.elapsed_time(e1) * 1e3 / reps
         alg_bytes = M * V * 4 + M * H * 4 + V * H * 4 + V * 4 + M * 8
         achieved = alg_bytes / (k_us * 1e-6) / 1e9
-        roofline = {"kernel": "gemm_kernel<NT,BIAS> (mlm_logits = T.E^T + b)", "bound": "hbm", "achieved": round(achieved, 1),
+        roofline = {"kernel": "rx_gemm_nk_kernel<BIAS> (mlm_logits = T.E^T + b, bf16x3)", "bound": "hbm", "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                     "algorithmic_bytes": alg_bytes, "avg_launch_us": round(k_us, 2)}
 

@@ -292,6 +292,7 @@ __global__ __launch_bounds__(256) void rx_gemm_kloop_kernel(RxP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int m0 = blockIdx.x * 128 + wave * 32;
+  const int nb = blockIdx.y * (32 * NT);            // first column of this workgroup's pass over N
   const bool live = m0 < p.M;
   const int nchunks = p.K / 64;
   DropCtx dctx = b4r_drop_ctx(p.drop);
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(256) void rx_gemm_kloop_kernel(RxP p) {
       for (int i = 0; i < NLD; ++i) {
         const int f = i * 256 + tid;
         const int trow = f >> 4, tc4 = (f & 15) * 4;
-        braw[i] = *reinterpret_cast<const f32x4*>(p.B + (int64_t)min(trow, p.N - 1) * p.ldb + 64 * c + tc4);
+        braw[i] = *reinterpret_cast<const f32x4*>(p.B + (int64_t)min(nb + trow, p.N - 1) * p.ldb + 64 * c + tc4);
       }
     }
   };
@@ -368,7 +369,7 @@ __global__ __launch_bounds__(256) void rx_gemm_kloop_kernel(RxP p) {
           bh = *reinterpret_cast<const bf16x8*>(src);
           bl = *reinterpret_cast<const bf16x8*>(src + PLANE);
         } else {
-          const int col = min(32 * j + r, p.N - 1);
+          const int col = min(nb + 32 * j + r, p.N - 1);
           split8(load8_strided(p.B + (int64_t)(64 * c + 16 * kb + 8 * h) * p.ldb + col, p.ldb), bh, bl);
         }
         acc[j] = mfma3(ah[kb], al[kb], bh, bl, acc[j]);
@@ -382,15 +383,15 @@ __global__ __launch_bounds__(256) void rx_gemm_kloop_kernel(RxP p) {
   if (live) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      if (32 * j < p.N) epilogue_tile<EPI>(p, dctx, acc[j], load_bias4<EPI>(p, 32 * j, c4), stage, m0, 32 * j, lane);
+      if (nb + 32 * j < p.N) epilogue_tile<EPI>(p, dctx, acc[j], load_bias4<EPI>(p, nb + 32 * j, c4), stage, m0, nb + 32 * j, lane);
     }
   }
 }
 
 template <bool B_NK, int EPI, bool A_DROP>
 void launch_kloop(const RxP& p, hipStream_t s) {
-  dim3 grid((unsigned)b4r_cdiv(p.M, 128));
   const int nt = b4r_cdiv(p.N, 32);
+  dim3 grid((unsigned)b4r_cdiv(p.M, 128), (unsigned)(nt <= 2 ? 1 : b4r_cdiv(nt, 4)));
   if (nt <= 2) {
     const size_t lds = STAGE_FLOATS * sizeof(float) + (B_NK ? 2 * 2 * 2 * 32 * 36 * 4 : 0);
     hipLaunchKernelGGL((rx_gemm_kloop_kernel<B_NK, EPI, A_DROP, 2>), grid, dim3(256), lds, s, p);
@@ -583,7 +584,7 @@ inline int up4i(int x) { return (x + 3) & ~3; }
 // shape contract of the branch-free kernels; everything else runs on the exact-fp32 LDS-tiled path
 bool b4r_gemm_rx_supported(const b4r_gemm_desc* d) {
   const bool k_small = (d->K == 64 || d->K == 32);
-  const bool k_loop = (d->K > 64 && d->K % 64 == 0 && d->N <= 128);   // rx_gemm_kloop_kernel
+  const bool k_loop = (d->K > 64 && d->K % 64 == 0);   // rx_gemm_kloop_kernel (passes of 64 or 128 columns)
   if (!(k_small || k_loop) || d->M % 32 != 0 || d->N < 4) return false;
   if (!vec_ok(d->A, d->lda) || !vec_ok(d->C, d->ldc)) return false;
   if (d->b_is_nk && !vec_ok(d->B, d->ldb)) return false;

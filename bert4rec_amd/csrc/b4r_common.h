@@ -32,6 +32,25 @@ void b4r_set_error(const char* fmt, ...);
 static inline int b4r_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline bool b4r_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
+// ---------------------------------------------------------------------------------------------
+// deferred ordered reductions.  Every two-stage reduction of the backward pass (weight-gradient slabs, bias column
+// sums, LayerNorm gamma/beta partials) can be queued instead of launched: b4r_backward then sums ALL of them with one
+// kernel instead of ~18 tiny launches (each boundary costs ~1.5-2 us on this GPU whatever the kernel does).
+// ---------------------------------------------------------------------------------------------
+struct B4rReduceJob {
+  const float* slab; const float* cslab; const float* caslab;
+  float* out; float* colsum; float* colsum_a;
+  int S, Mo, No, ldo, accumulate;
+};
+constexpr int B4R_MAX_REDUCE_JOBS = 40;
+struct B4rReduceQueue {
+  B4rReduceJob jobs[B4R_MAX_REDUCE_JOBS];
+  int n;
+};
+void b4r_reduce_queue_begin(B4rReduceQueue* q);                 // queue reductions issued by this thread from now on
+int b4r_reduce_queue_flush(hipStream_t stream);                  // launch them all (one kernel) and stop queueing
+bool b4r_reduce_queue_push(const B4rReduceJob& job);             // false: no queue active (caller reduces immediately)
+
 // dropout sites (stream ids of the counter-hash RNG); restated in oracle/bert4rec_oracle.py
 #define B4R_STREAM_EMB 0u
 #define B4R_STREAM_ATTN_PROBS(layer) (1u + 4u * (uint32_t)(layer))

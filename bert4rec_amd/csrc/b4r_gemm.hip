@@ -397,8 +397,80 @@ int b4r_launch_slab_reduce(const float* slab, int S, int Mo, int No, float* out,
   return B4R_OK;
 }
 
+namespace {
+struct MultiReduceP {
+  B4rReduceJob jobs[B4R_MAX_REDUCE_JOBS];
+  int block_begin[B4R_MAX_REDUCE_JOBS + 1];
+  int n;
+};
+// all queued reductions in one launch: a workgroup looks up its job, then does what slab_reduce_kernel does
+__global__ __launch_bounds__(64 * RZ) void multi_slab_reduce_kernel(MultiReduceP p) {
+  __shared__ float sp[RZ][64];
+  int j = 0;
+  while (j + 1 < p.n && (int)blockIdx.x >= p.block_begin[j + 1]) ++j;
+  const B4rReduceJob job = p.jobs[j];
+  const int64_t total = (int64_t)job.Mo * job.No;
+  const int64_t n_cs = job.colsum ? job.No : 0, n_csa = job.colsum_a ? job.Mo : 0;
+  const int64_t e = (int64_t)((int)blockIdx.x - p.block_begin[j]) * 64 + (threadIdx.x & 63);
+  const int zl = threadIdx.x >> 6;
+  const float* src = nullptr;
+  int64_t stride = 0, idx = 0;
+  if (e < total) { src = job.slab; stride = total; idx = e; }
+  else if (e < total + n_cs) { src = job.cslab; stride = job.No; idx = e - total; }
+  else if (e < total + n_cs + n_csa) { src = job.caslab; stride = job.Mo; idx = e - total - n_cs; }
+  float s = 0.f;
+  if (src) {
+    for (int z = zl; z < job.S; z += RZ) s += src[(int64_t)z * stride + idx];
+  }
+  sp[zl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (zl == 0 && src) {
+    const int l = threadIdx.x;
+    s = 0.f;
+#pragma unroll
+    for (int z = 0; z < RZ; ++z) s += sp[z][l];
+    if (e < total) {
+      const int row = (int)(e / job.No), col = (int)(e % job.No);
+      float* o = job.out + (int64_t)row * job.ldo + col;
+      *o = job.accumulate ? (*o + s) : s;
+    } else if (e < total + n_cs) {
+      job.colsum[idx] = s;
+    } else {
+      job.colsum_a[idx] = s;
+    }
+  }
+}
+thread_local B4rReduceQueue* g_queue = nullptr;
+}  // namespace
+
+void b4r_reduce_queue_begin(B4rReduceQueue* q) { q->n = 0; g_queue = q; }
+bool b4r_reduce_queue_push(const B4rReduceJob& job) {
+  if (g_queue == nullptr || g_queue->n >= B4R_MAX_REDUCE_JOBS) return false;
+  g_queue->jobs[g_queue->n++] = job;
+  return true;
+}
+int b4r_reduce_queue_flush(hipStream_t stream) {
+  B4rReduceQueue* q = g_queue;
+  g_queue = nullptr;
+  if (q == nullptr || q->n == 0) return B4R_OK;
+  MultiReduceP p;
+  p.n = q->n;
+  int blocks = 0;
+  for (int j = 0; j < q->n; ++j) {
+    p.jobs[j] = q->jobs[j];
+    p.block_begin[j] = blocks;
+    blocks += slab_reduce_grid(q->jobs[j].Mo, q->jobs[j].No, q->jobs[j].colsum != nullptr, q->jobs[j].colsum_a != nullptr);
+  }
+  p.block_begin[q->n] = blocks;
+  hipLaunchKernelGGL(multi_slab_reduce_kernel, dim3(blocks), dim3(64 * RZ), 0, stream, p);
+  B4R_CHECK_LAUNCH("multi_slab_reduce");
+  return B4R_OK;
+}
+
 int b4r_launch_slab_reduce_full(const float* slab, int S, int Mo, int No, float* out, int ldo, int accumulate,
                                 const float* cslab, float* colsum, const float* caslab, float* colsum_a, hipStream_t stream) {
+  B4rReduceJob job{slab, cslab, caslab, out, colsum, colsum_a, S, Mo, No, ldo, accumulate};
+  if (b4r_reduce_queue_push(job)) return B4R_OK;
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(slab_reduce_grid(Mo, No, colsum != nullptr, colsum_a != nullptr)), dim3(64 * RZ),
                      0, stream, slab, S, Mo, No, out, ldo, accumulate, cslab, colsum, caslab, colsum_a);
   B4R_CHECK_LAUNCH("slab_reduce");
@@ -515,9 +587,6 @@ extern "C" int b4r_gemm_tn_f32(const b4r_gemm_tn_desc* d, float* scratch, b4r_st
   else
     hipLaunchKernelGGL((gemm_tn_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, p);
   B4R_CHECK_LAUNCH("b4r_gemm_tn_f32");
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(slab_reduce_grid(d->Mo, d->No, d->colsum != nullptr, d->colsum_a != nullptr)),
-                     dim3(64 * RZ), 0, (hipStream_t)stream, p.slab, S, d->Mo, d->No,
-                     d->out, d->ldo, d->accumulate, p.colsum_slab, d->colsum, p.colsum_a_slab, d->colsum_a);
-  B4R_CHECK_LAUNCH("b4r_gemm_tn_f32 reduce");
-  return B4R_OK;
+  return b4r_launch_slab_reduce_full(p.slab, S, d->Mo, d->No, d->out, d->ldo, d->accumulate, p.colsum_slab, d->colsum,
+                                     p.colsum_a_slab, d->colsum_a, (hipStream_t)stream);
 }

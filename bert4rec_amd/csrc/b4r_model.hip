@@ -170,21 +170,25 @@ WsLayout make_ws_layout(const b4r_model_config& c, int B, int L, int P) {
   w.t = take(M * H); w.logits = take(M * w.Vp); w.rowsc = take(4 * M); w.pooled = take((int64_t)B * H);
   w.dx = take(N * H); w.da = take(N * H); w.db = take(N * H); w.dctx = take(N * H);
   w.dqkv = take(N * 3 * H); w.df = take(N * I); w.dt = take(M * H); w.dg = take(M * H);
-  // scratch: the largest of every two-stage reduction that uses it (they run one after another on the stream)
+  // scratch: every two-stage reduction of the backward pass keeps its partials until the single deferred reduce launch,
+  // so the regions are summed (not max-ed); the two immediate reductions (split-K dT, position table) have their own
   int64_t s = 4096;
-  auto mx = [&](int64_t v) { if (v > s) s = v; };
-  mx(b4r_ln_bwd_scratch_floats((int)N, (int)H));
-  if (M > 0) mx(b4r_ln_bwd_scratch_floats((int)M, (int)H));
-  mx(b4r_gemm_tn_scratch_floats((int)N, (int)H, (int)(3 * H)));
-  mx(b4r_gemm_tn_scratch_floats((int)N, (int)H, (int)H));
-  mx(b4r_gemm_tn_scratch_floats((int)N, (int)H, (int)I));
-  mx(b4r_gemm_tn_scratch_floats((int)N, (int)I, (int)H));
-  if (M > 0) {
-    mx(b4r_gemm_tn_scratch_floats((int)M, (int)V, (int)H));
-    mx(b4r_gemm_tn_scratch_floats((int)M, (int)H, (int)H));
-    mx((int64_t)mlm_dt_splits(M, H, V) * M * H);
+  auto add = [&](int64_t v) { s += up4(v); };
+  for (int i = 0; i < c.num_layers; ++i) {
+    add(b4r_gemm_tn_scratch_floats((int)N, (int)H, (int)(3 * H)));
+    add(b4r_gemm_tn_scratch_floats((int)N, (int)H, (int)H));
+    add(b4r_gemm_tn_scratch_floats((int)N, (int)H, (int)I));
+    add(b4r_gemm_tn_scratch_floats((int)N, (int)I, (int)H));
+    add(2 * b4r_ln_bwd_scratch_floats((int)N, (int)H));
   }
-  mx((int64_t)b4r_cdiv(B, 16) * L * H);  // position-table gradient partials
+  add(b4r_ln_bwd_scratch_floats((int)N, (int)H));
+  if (M > 0) {
+    add(b4r_gemm_tn_scratch_floats((int)M, (int)V, (int)H));
+    add(b4r_gemm_tn_scratch_floats((int)M, (int)H, (int)H));
+    add(b4r_ln_bwd_scratch_floats((int)M, (int)H));
+    add((int64_t)mlm_dt_splits(M, H, V) * M * H);
+  }
+  add((int64_t)b4r_cdiv(B, 16) * L * H);  // position-table gradient partials
   w.scratch = take(s); w.scratch_floats = s;
   w.total = off;
   return w;
@@ -386,8 +390,12 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
   hipStream_t s = (hipStream_t)stream;
   const int H = cfg->hidden_size, I = cfg->inner_dim, V = cfg->vocab_size, N = B * L, M = B * P, Vp = (int)w.Vp;
   const float qscale = 1.0f / sqrtf(32.0f);
-  float* scratch = ws + w.scratch;
+  float* scratch_base = ws + w.scratch;
+  int64_t scratch_used = 0;
+  auto take = [&](int64_t n) { float* ptr = scratch_base + scratch_used; scratch_used += up4(n); return ptr; };
   const DropArgs nodrop = b4r_make_drop(nullptr, 0, 0.f, 0);
+  B4rReduceQueue queue;
+  b4r_reduce_queue_begin(&queue);   // every ordered reduction below is summed by ONE launch at the end
 
   if (hipMemsetAsync(grads, 0, (size_t)pl.total * sizeof(float), s) != hipSuccess ||
       hipMemsetAsync(ws + w.dx, 0, (size_t)N * H * sizeof(float), s) != hipSuccess) {
@@ -402,15 +410,17 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
     b4r_gemm_desc d{};
     d.A = dlog; d.lda = Vp; d.B = params + pl.word_emb; d.ldb = H; d.C = ws + w.dt; d.ldc = H;
     d.M = M; d.N = H; d.K = V; d.b_is_nk = 0; d.epilogue = B4R_EPI_NONE;
-    RC(b4r_gemm_f32_splitk(&d, mlm_dt_splits(M, H, V), scratch, s));
+    RC(b4r_gemm_f32_splitk(&d, mlm_dt_splits(M, H, V), take((int64_t)mlm_dt_splits(M, H, V) * M * H), s));
   }
   // dE = dlogits^T . T ; d output_bias = column sums of dlogits
-  RC(gemm_tn(dlog, Vp, ws + w.t, H, grads + pl.word_emb, H, M, V, H, nullptr, grads + pl.out_bias, nullptr, 0, 0.f, 0, scratch, s));
+  RC(gemm_tn(dlog, Vp, ws + w.t, H, grads + pl.word_emb, H, M, V, H, nullptr, grads + pl.out_bias, nullptr, 0, 0.f, 0,
+             take(b4r_gemm_tn_scratch_floats(M, V, H)), s));
   // LayerNorm of the transform
   RC(b4r_ln_bwd_launch(ws + w.dt, ws + w.u, ws + w.meanm, ws + w.rstdm, params + pl.lnm_g, M, H, ws + w.dt, grads + pl.lnm_g,
-                       grads + pl.lnm_b, scratch, nullptr, nullptr, nullptr, 1, 1, nodrop, s));
+                       grads + pl.lnm_b, take(b4r_ln_bwd_scratch_floats(M, H)), nullptr, nullptr, nullptr, 1, 1, nodrop, s));
   RC(b4r_mul_gelu_grad(ws + w.dt, ws + w.upre, (int64_t)M * H, s));
-  RC(gemm_tn(ws + w.gath, H, ws + w.dt, H, grads + pl.wd, H, M, H, H, grads + pl.bd, nullptr, nullptr, 0, 0.f, 0, scratch, s));
+  RC(gemm_tn(ws + w.gath, H, ws + w.dt, H, grads + pl.wd, H, M, H, H, grads + pl.bd, nullptr, nullptr, 0, 0.f, 0,
+             take(b4r_gemm_tn_scratch_floats(M, H, H)), s));
   RC(gemm(ws + w.dt, H, params + pl.wd, H, ws + w.dg, H, M, H, H, 1, B4R_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 1.f, 0,
           nullptr, 0, 0.f, 0, s));
   // scatter into d sequence_output (slots with y_true == 0 carry exactly zero gradient and are skipped)
@@ -421,24 +431,25 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
     const float* x_in = (i == 0) ? ws + w.x0 : ws + w.x2[i - 1];
     // output LayerNorm
     RC(b4r_ln_bwd_launch(ws + w.dx, ws + w.z2[i], ws + w.mean2[i], ws + w.rstd2[i], params + pl.ln2_g[i], N, H, ws + w.da,
-                         grads + pl.ln2_g[i], grads + pl.ln2_b[i], scratch, nullptr, nullptr, nullptr, 1, 1, nodrop, s));
+                         grads + pl.ln2_g[i], grads + pl.ln2_b[i], take(b4r_ln_bwd_scratch_floats(N, H)), nullptr, nullptr, nullptr, 1, 1, nodrop, s));
     // FFN: dFpre = (dropmask(dz2) . W2^T) * gelu'(fpre)
     RC(gemm(ws + w.da, H, params + pl.w2[i], H, ws + w.df, I, N, I, H, 1, B4R_EPI_GELU_BWD, nullptr, nullptr, 0, ws + w.fpre[i],
             I, 1.f, 0, rng, B4R_STREAM_FFN_OUT(i), od, 1, s));
     RC(gemm_tn(ws + w.f[i], I, ws + w.da, H, grads + pl.w2[i], H, N, I, H, grads + pl.b2[i], nullptr, rng, B4R_STREAM_FFN_OUT(i),
-               od, 1, scratch, s));
+               od, 1, take(b4r_gemm_tn_scratch_floats(N, I, H)), s));
     // dX1 = dFpre . W1^T + dz2
     RC(gemm(ws + w.df, I, params + pl.w1[i], I, ws + w.db, H, N, H, I, 1, B4R_EPI_ADD_RES, nullptr, nullptr, 0, ws + w.da, H, 1.f,
             0, nullptr, 0, 0.f, 0, s));
-    RC(gemm_tn(ws + w.x1[i], H, ws + w.df, I, grads + pl.w1[i], I, N, H, I, grads + pl.b1[i], nullptr, nullptr, 0, 0.f, 0, scratch, s));
+    RC(gemm_tn(ws + w.x1[i], H, ws + w.df, I, grads + pl.w1[i], I, N, H, I, grads + pl.b1[i], nullptr, nullptr, 0, 0.f, 0,
+               take(b4r_gemm_tn_scratch_floats(N, H, I)), s));
     // attention LayerNorm
     RC(b4r_ln_bwd_launch(ws + w.db, ws + w.z1[i], ws + w.mean1[i], ws + w.rstd1[i], params + pl.ln1_g[i], N, H, ws + w.db,
-                         grads + pl.ln1_g[i], grads + pl.ln1_b[i], scratch, nullptr, nullptr, nullptr, 1, 1, nodrop, s));
+                         grads + pl.ln1_g[i], grads + pl.ln1_b[i], take(b4r_ln_bwd_scratch_floats(N, H)), nullptr, nullptr, nullptr, 1, 1, nodrop, s));
     // attention output projection
     RC(gemm(ws + w.db, H, params + pl.wo[i], H, ws + w.dctx, H, N, H, H, 1, B4R_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 1.f, 0,
             rng, B4R_STREAM_ATTN_OUT(i), od, 1, s));
     RC(gemm_tn(ws + w.ctx[i], H, ws + w.db, H, grads + pl.wo[i], H, N, H, H, grads + pl.bo[i], nullptr, rng,
-               B4R_STREAM_ATTN_OUT(i), od, 1, scratch, s));
+               B4R_STREAM_ATTN_OUT(i), od, 1, take(b4r_gemm_tn_scratch_floats(N, H, H)), s));
     // attention core
     RC(b4r_attn_bwd(ws + w.qkv[i], batch->input_mask, ws + w.ctx[i], ws + w.lse[i], ws + w.dctx, B, L, cfg->num_heads, qscale,
                     ws + w.dqkv, rng, B4R_STREAM_ATTN_PROBS(i), adp, stream));
@@ -446,14 +457,18 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
     RC(gemm(ws + w.dqkv, 3 * H, params + pl.wqkv[i], 3 * H, ws + w.dx, H, N, H, 3 * H, 1, B4R_EPI_ADD_RES, nullptr, nullptr, 0,
             ws + w.db, H, 1.f, 0, nullptr, 0, 0.f, 0, s));
     RC(gemm_tn(x_in, H, ws + w.dqkv, 3 * H, grads + pl.wqkv[i], 3 * H, N, H, 3 * H, grads + pl.bqkv[i], nullptr, nullptr, 0, 0.f,
-               0, scratch, s));
+               0, take(b4r_gemm_tn_scratch_floats(N, H, 3 * H)), s));
   }
   // ---- embedding stage: dropout -> LayerNorm -> (word table scatter-add, position table batch sum) ---------------------
   RC(b4r_ln_bwd_launch(ws + w.dx, nullptr, ws + w.mean0, ws + w.rstd0, params + pl.emb_ln_g, N, H, ws + w.da, grads + pl.emb_ln_g,
-                       grads + pl.emb_ln_b, scratch, batch->input_word_ids, params + pl.word_emb, params + pl.pos_emb, L, V,
+                       grads + pl.emb_ln_b, take(b4r_ln_bwd_scratch_floats(N, H)), batch->input_word_ids, params + pl.word_emb, params + pl.pos_emb, L, V,
                        b4r_make_drop(rng, B4R_STREAM_EMB, od, 1), s));
+  // all queued ordered reductions (weight / bias / LayerNorm gradients) in one launch; the item-table gradient must be
+  // complete before the embedding rows are scatter-added on top of it
+  RC(b4r_reduce_queue_flush(s));
+  B4R_CHECK_ARG(scratch_used <= w.scratch_floats, B4R_E_NOMEM, "b4r_backward: internal scratch overflow");
   RC(b4r_scatter_add_rows_impl(ws + w.da, batch->input_word_ids, 0, 1, N, H, grads + pl.word_emb, H, nullptr, V, 3, s));
-  RC(b4r_batch_colsum(ws + w.da, B, L, H, grads + pl.pos_emb, scratch, s));
+  RC(b4r_batch_colsum(ws + w.da, B, L, H, grads + pl.pos_emb, take((int64_t)b4r_cdiv(B, 16) * L * H), s));
   return B4R_OK;
 }
 

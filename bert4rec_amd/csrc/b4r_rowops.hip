@@ -629,6 +629,10 @@ int b4r_ln_bwd_launch(const float* dy, const float* z, const float* mean, const 
   int rc = ids ? launch_ln_bwd<true>(p, grid, stream) : launch_ln_bwd<false>(p, grid, stream);
   if (rc) return rc;
   B4R_CHECK_LAUNCH("ln_bwd");
+  if (dbeta == dgamma + H) {   // gamma and beta adjacent (always so in the flat gradient buffer): one [1, 2H] strip
+    B4rReduceJob job{scratch, nullptr, nullptr, dgamma, nullptr, nullptr, grid, 1, 2 * H, 2 * H, 0};
+    if (b4r_reduce_queue_push(job)) return B4R_OK;
+  }
   hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3(b4r_cdiv(2 * H, 4)), dim3(256), 0, stream, scratch, grid, H,
                      dgamma, dbeta);
   B4R_CHECK_LAUNCH("ln_bwd reduce");

@@ -48,11 +48,14 @@ CONFIGS = {
     "tiny": (orc.OracleConfig(vocab_size=37, hidden_size=64, num_layers=2, num_attention_heads=2, max_sequence_length=20,
                               inner_dim=64), dict(B=4, L=16, P=5)),
     "ml1m_slice": (orc.OracleConfig(vocab_size=3709, hidden_size=64, num_layers=2, num_attention_heads=2,
-                                    max_sequence_length=200, inner_dim=256), dict(B=6, L=200, P=40)),
+                                    max_sequence_length=200, inner_dim=256), dict(B=8, L=200, P=40)),
     "h128": (orc.OracleConfig(vocab_size=500, hidden_size=128, num_layers=1, num_attention_heads=4, max_sequence_length=50,
-                              inner_dim=512), dict(B=5, L=50, P=20)),
+                              inner_dim=512), dict(B=8, L=48, P=20)),
     "h256": (orc.OracleConfig(vocab_size=1000, hidden_size=256, num_layers=2, num_attention_heads=8, max_sequence_length=64,
-                              inner_dim=1024), dict(B=3, L=40, P=8)),
+                              inner_dim=1024), dict(B=4, L=40, P=8)),
+    # token / slot counts that are NOT multiples of 32: the dense layers fall back to the exact-fp32 LDS-tiled kernels
+    "odd_rows": (orc.OracleConfig(vocab_size=301, hidden_size=64, num_layers=1, num_attention_heads=2, max_sequence_length=50,
+                                  inner_dim=256), dict(B=5, L=50, P=7)),
 }
 
 

@@ -89,8 +89,9 @@ PROTOTYPES = {
     "b4r_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _P]),
     "b4r_gemm_tn_scratch_floats": (_I64, [_I32, _I32, _I32]),
     "b4r_gemm_tn_f32": (C.c_int, [C.POINTER(GemmTnDesc), _P, _P]),
-    "b4r_attn_fwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P, _P, _U32, _F, _P]),
-    "b4r_attn_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _F, _P, _P, _U32, _F, _P]),
+    "b4r_attn_fwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P, _P, _U32, _F, _P, _P]),
+    "b4r_attn_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _F, _P, _P, _U32, _F, _P, _P]),
+    "b4r_attn_keep_words": (C.c_int64, [_I32, _I32, _I32]),
     "b4r_gather_rows": (C.c_int, [_P, _I32, _P, _I64, _I32, _I32, _I32, _P, _P]),
     "b4r_scatter_add_rows": (C.c_int, [_P, _P, _I64, _I32, _I32, _I32, _P, _I32, _P, _P]),
     "b4r_softmax_ce": (C.c_int, [_P, _I32, _I32, _I32, _P, _P, _P, _I32, _P]),

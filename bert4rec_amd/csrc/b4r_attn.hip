@@ -324,13 +324,40 @@ int check_common(const char* who, const float* qkv, const int64_t* mask, int B, 
 
 inline int tile_rows(int Lp) { return Lp > ROWS_WG ? Lp : ROWS_WG; }  // a region must also hold a 128-row Q / dO tile
 
+// the dropout decisions are only stored / consumed by the split-precision kernels; the fp32 kernels hash again
+int check_bits(const char* who, const DropArgs& drop, const uint32_t* keep_bits) {
+  if (drop.rng == nullptr) return B4R_OK;
+  B4R_CHECK_ARG(keep_bits != nullptr, B4R_E_BADARG, "%s: dropout in the bf16x3 mode needs the keep_bits buffer (b4r_attn_keep_words)", who);
+  B4R_CHECK_ARG(b4r_aligned16(keep_bits), B4R_E_ALIGN, "%s: keep_bits must be 16-byte aligned", who);
+  return B4R_OK;
+}
+
 }  // namespace
 
+int64_t b4r_attn_rx_keep_words(int B, int L, int heads);
+int b4r_attn_rx_fwd_launch(const float* qkv, const int64_t* mask, int B, int L, int heads, float* ctx, float* lse,
+                           const DropArgs& drop, uint32_t* keep_bits, hipStream_t stream);
+int b4r_attn_rx_bwd_launch(const float* qkv, const int64_t* mask, const float* ctx, const float* lse, const float* dctx,
+                           int B, int L, int heads, float qscale, float* dqkv, const DropArgs& drop,
+                           const uint32_t* keep_bits, hipStream_t stream);
+
+extern "C" int64_t b4r_attn_keep_words(int32_t B, int32_t L, int32_t heads) {
+  if (B <= 0 || L <= 0 || heads <= 0) return 0;
+  return b4r_attn_rx_keep_words(B, L, heads);
+}
+
 extern "C" int b4r_attn_fwd(const float* qkv, const int64_t* input_mask, int32_t B, int32_t L, int32_t heads, float* ctx,
-                            float* lse, const uint32_t* rng, uint32_t drop_stream, float drop_rate, b4r_stream_t stream) {
+                            float* lse, const uint32_t* rng, uint32_t drop_stream, float drop_rate, uint32_t* keep_bits,
+                            b4r_stream_t stream) {
   int rc = check_common("b4r_attn_fwd", qkv, input_mask, B, L, heads);
   if (rc) return rc;
   B4R_CHECK_ARG(ctx != nullptr, B4R_E_BADARG, "b4r_attn_fwd: null ctx");
+  if (b4r_get_gemm_mode() == B4R_GEMM_BF16X3) {
+    const DropArgs drop = b4r_make_drop(rng, drop_stream, drop_rate, 1);
+    rc = check_bits("b4r_attn_fwd", drop, keep_bits);
+    if (rc) return rc;
+    return b4r_attn_rx_fwd_launch(qkv, input_mask, B, L, heads, ctx, lse, drop, keep_bits, (hipStream_t)stream);
+  }
   AttnP p{};
   p.qkv = qkv; p.mask = input_mask; p.ctx_out = ctx; p.lse_out = lse;
   p.B = B; p.L = L; p.heads = heads; p.H = heads * 32;
@@ -358,10 +385,18 @@ extern "C" int b4r_attn_fwd(const float* qkv, const int64_t* input_mask, int32_t
 
 extern "C" int b4r_attn_bwd(const float* qkv, const int64_t* input_mask, const float* ctx, const float* lse,
                             const float* dctx, int32_t B, int32_t L, int32_t heads, float qscale, float* dqkv,
-                            const uint32_t* rng, uint32_t drop_stream, float drop_rate, b4r_stream_t stream) {
+                            const uint32_t* rng, uint32_t drop_stream, float drop_rate, const uint32_t* keep_bits,
+                            b4r_stream_t stream) {
   int rc = check_common("b4r_attn_bwd", qkv, input_mask, B, L, heads);
   if (rc) return rc;
   B4R_CHECK_ARG(ctx && lse && dctx && dqkv, B4R_E_BADARG, "b4r_attn_bwd: null argument");
+  B4R_CHECK_ARG(b4r_aligned16(ctx) && b4r_aligned16(dctx) && b4r_aligned16(dqkv), B4R_E_ALIGN, "b4r_attn_bwd: operands must be 16-byte aligned");
+  if (b4r_get_gemm_mode() == B4R_GEMM_BF16X3) {
+    const DropArgs drop = b4r_make_drop(rng, drop_stream, drop_rate, 1);
+    rc = check_bits("b4r_attn_bwd", drop, keep_bits);
+    if (rc) return rc;
+    return b4r_attn_rx_bwd_launch(qkv, input_mask, ctx, lse, dctx, B, L, heads, qscale, dqkv, drop, keep_bits, (hipStream_t)stream);
+  }
   AttnP p{};
   p.qkv = qkv; p.mask = input_mask; p.ctx = ctx; p.lse_in = lse; p.dctx = dctx; p.dqkv = dqkv;
   p.B = B; p.L = L; p.heads = heads; p.H = heads * 32; p.qscale = qscale;

@@ -1,0 +1,458 @@
+// Keras MultiHeadAttention core (head_dim 32), split-precision variant: every product runs on v_mfma_f32_16x16x32_bf16
+// with both operands split into bf16 hi + lo (x = hi + lo; A.B ~= Alo.Bhi + Ahi.Blo + Ahi.Bhi, fp32 accumulate), i.e. about
+// 2^-16 relative error per product at 5.3x the fp32-MFMA rate (b4r_gemm_rx.hip uses the same arithmetic).
+//
+// Same decomposition as the fp32 kernels of b4r_attn.hip (a wave owns 16 queries -- or 16 keys in the dK/dV kernel -- and
+// sweeps the other dimension in 16-row tiles; the score tile is computed in the orientation whose accumulator ROWS are the
+// index the following product sums over, so probabilities never move between lanes).  What changes:
+//   * K and V (or Q and dO) live in LDS as bf16 hi / lo IMAGES of [rows][32] with 64-byte rows, written once per
+//     workgroup.  One image serves both operand shapes: a row fragment (8 consecutive columns of one row, ds_read_b128)
+//     for the products that sum over the head dimension, and a transposed fragment (one column of 4 consecutive rows per
+//     lane, ds_read_b64_tr_b16) for the products that consume an accumulator tile.  The 16-byte chunk index of a row is
+//     XORed with (-(row>>2))&3, which makes both reads bank-conflict free without padding (MI355X_MICROARCH.md, LDS).
+//   * a 16x16x32 product that consumes accumulator tiles takes TWO of them per instruction: k-slot (g, j) is row
+//     16*t0 + 4g + j of tile t0 for j < 4 and row 16*t1 + 4g + (j-4) of tile t1 for j >= 4, on both operands.
+//   * the forward kernel stores the dropout decisions it hashed as bits (4 per lane and key tile); the two backward
+//     kernels read them back instead of hashing every (query, key) pair twice more.  Word layout: [b, head, query tile of
+//     16, key-tile group of 8][forward lane]; nibble (t & 7) of the word holds keys 16t + 4g .. +3 of query (lane & 15).
+#include "b4r_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int WAVES = 8;              // waves per workgroup
+constexpr int ROWS_WG = 16 * WAVES;   // queries (keys) per workgroup
+constexpr int TILE_BYTES = 16 * 64;   // 16 image rows
+
+struct AttnRxP {
+  const float* qkv; const int64_t* mask; const float* ctx; const float* lse_in; const float* dctx;
+  float* ctx_out; float* lse_out; float* dqkv;
+  uint32_t* bits_out; const uint32_t* bits_in;
+  int B, L, heads, H;
+  int KT, KTE;   // 16-row tiles covering L, and KT rounded up to even (the images hold KTE tiles, zero beyond L)
+  float qscale;
+  DropArgs drop;
+};
+
+__device__ __forceinline__ f32x4 mfma_bf(const bf16x8 a, const bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma3(const bf16x8 ah, const bf16x8 al, const bf16x8 bh, const bf16x8 bl, f32x4 c) {
+  c = mfma_bf(al, bh, c);
+  c = mfma_bf(ah, bl, c);
+  c = mfma_bf(ah, bh, c);
+  return c;
+}
+__device__ __forceinline__ void split8(const f32x8 x, bf16x8& hi, bf16x8& lo) {
+  hi = __builtin_convertvector(x, bf16x8);
+  lo = __builtin_convertvector(x - __builtin_convertvector(hi, f32x8), bf16x8);
+}
+__device__ __forceinline__ f32x8 load8(const float* ptr) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(ptr);
+  const f32x4 b = *reinterpret_cast<const f32x4*>(ptr + 4);
+  return (f32x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+__device__ __forceinline__ f32x8 cat(const f32x4 a, const f32x4 b) {
+  return (f32x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+
+// byte offset of 16-byte chunk `ch` (0..3) of row `row` in a [rows][32 bf16] image
+__device__ __forceinline__ int img_off(int row, int ch) { return row * 64 + 16 * (ch ^ ((0 - (row >> 2)) & 3)); }
+
+// rows [0,nrows) of a [*,32] fp32 head slice -> bf16 hi / lo images; rows beyond `valid` are zero
+__device__ __forceinline__ void stage_rows(char* hi, char* lo, const float* src, int64_t row0, int ld, int nrows, int valid) {
+  for (int f = threadIdx.x; f < nrows * 8; f += 64 * WAVES) {
+    const int r = f >> 3, c4 = f & 7;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r < valid) v = *reinterpret_cast<const f32x4*>(src + (row0 + r) * ld + 4 * c4);
+    const bf16x4 h = __builtin_convertvector(v, bf16x4);
+    const bf16x4 l = __builtin_convertvector(v - __builtin_convertvector(h, f32x4), bf16x4);
+    const int off = img_off(r, c4 >> 1) + 8 * (c4 & 1);
+    *reinterpret_cast<bf16x4*>(hi + off) = h;
+    *reinterpret_cast<bf16x4*>(lo + off) = l;
+  }
+}
+
+// lane constants of the two fragment reads (tile t adds TILE_BYTES * t)
+struct FragAddr {
+  int row;     // row fragment: row 16t + (lane & 15), columns 8g .. 8g+7
+  int tr[2];   // transposed fragment of column block db: this lane's address of the 4 x 16 block at rows 16t + 4g ..
+};
+__device__ __forceinline__ FragAddr frag_addr(int lane) {
+  const int i = lane & 15, g = lane >> 4, qq = i >> 2, pp = i & 3;
+  FragAddr a;
+  a.row = img_off(i, g);
+#pragma unroll
+  for (int db = 0; db < 2; ++db) a.tr[db] = img_off(4 * g + qq, 2 * db + (pp >> 1)) + 8 * (pp & 1);
+  return a;
+}
+__device__ __forceinline__ bf16x8 row_frag(const char* plane, int addr, int t) {
+  return *reinterpret_cast<const bf16x8*>(plane + addr + TILE_BYTES * t);
+}
+// element j < 4: image[16*t0 + 4g + j][16*db + (lane&15)], element j >= 4: the same of tile t1
+__device__ __forceinline__ bf16x8 tr_frag(const char* plane, int addr, int t0, int t1) {
+  typedef __attribute__((address_space(3))) s16x4* lds_ptr;
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(plane + addr + TILE_BYTES * t0));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(plane + addr + TILE_BYTES * t1));
+  const s16x8 r = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+// D[r] = sum_c dO[r][c] * O[r][c] over the 32 columns of this head, for rows [0,nrows); rows beyond valid -> 0
+__device__ __forceinline__ void rowdot_head(float* sD, const float* dO, const float* O, int64_t row0, int ld, int nrows, int valid) {
+  for (int base = 0; base < nrows; base += 16 * WAVES) {
+    const int r = base + (threadIdx.x >> 2), part = threadIdx.x & 3;
+    float s = 0.f;
+    if (r < valid) {
+      const float* a = dO + (row0 + r) * ld + part * 8;
+      const float* b = O + (row0 + r) * ld + part * 8;
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(a), a1 = *reinterpret_cast<const f32x4*>(a + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(b), b1 = *reinterpret_cast<const f32x4*>(b + 4);
+      s = (a0[0] * b0[0] + a0[1] * b0[1]) + (a0[2] * b0[2] + a0[3] * b0[3]) +
+          (a1[0] * b1[0] + a1[1] * b1[1]) + (a1[2] * b1[2] + a1[3] * b1[3]);
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    if (part == 0 && r < nrows) sD[r] = s;
+  }
+}
+
+// -----------------------------------------------------------------------------------------------------------
+// forward: workgroup = 128 queries of one (batch, head); wave = 16 queries x all keys
+// LDS: [K hi | K lo | V hi | V lo | sAdd]
+// -----------------------------------------------------------------------------------------------------------
+template <int KT>
+__global__ __launch_bounds__(64 * WAVES) void attn_rx_fwd_kernel(AttnRxP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_rx[];
+  constexpr int KTE = (KT + 1) & ~1, LPE = KTE * 16, PLANE = LPE * 64;
+  char* sKh = smem_rx;
+  char* sKl = sKh + PLANE;
+  char* sVh = sKl + PLANE;
+  char* sVl = sVh + PLANE;
+  float* sAdd = reinterpret_cast<float*>(sVl + PLANE);
+
+  const int b = blockIdx.z, hd = blockIdx.y, q0 = blockIdx.x * ROWS_WG;
+  const int L = p.L, H = p.H, ld3 = 3 * H;
+  const int64_t row0 = (int64_t)b * L;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+
+  const int q = q0 + 16 * wave + i;
+  const f32x8 qx = load8(p.qkv + (row0 + min(q, L - 1)) * ld3 + hd * 32 + 8 * g);   // in flight while K / V are staged
+  stage_rows(sKh, sKl, p.qkv + H + hd * 32, row0, ld3, LPE, L);
+  stage_rows(sVh, sVl, p.qkv + 2 * H + hd * 32, row0, ld3, LPE, L);
+  for (int k = threadIdx.x; k < LPE; k += 64 * WAVES)
+    sAdd[k] = (k < L) ? (1.0f - (float)p.mask[row0 + k]) * -1e9f : -INFINITY;
+  bf16x8 qh, ql;
+  split8(qx, qh, ql);
+  __syncthreads();
+  if (q0 + 16 * wave >= L) return;  // wave-uniform; no barrier below, and EXEC stays full for the transposed reads
+
+  const FragAddr fa = frag_addr(lane);
+  f32x4 acc[KTE];
+#pragma unroll
+  for (int t = 0; t < KTE; ++t) {
+    acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (t < KT) acc[t] = mfma3(row_frag(sKh, fa.row, t), row_frag(sKl, fa.row, t), qh, ql, acc[t]);   // S^T = K.Q^T
+  }
+  float m = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    const f32x4 ad = *reinterpret_cast<const f32x4*>(&sAdd[16 * t + 4 * g]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { acc[t][r] += ad[r]; m = fmaxf(m, acc[t][r]); }
+  }
+  m = fmaxf(m, __shfl_xor(m, 16, 64));
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const float e = __expf(acc[t][r] - m); acc[t][r] = e; sum += e; }
+  }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+  const int64_t bh = (int64_t)b * p.heads + hd;
+  if (g == 0 && q < L && p.lse_out) p.lse_out[bh * L + q] = m + __logf(sum);
+
+  const DropCtx dctx = b4r_drop_ctx(p.drop);
+  if (dctx.on) {
+    const uint64_t dbase = ((uint64_t)bh * L + (uint64_t)(q < L ? q : 0)) * (uint64_t)L;
+    uint32_t w[2] = {0u, 0u};
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bool keep = b4r_keep(dctx, dbase + (uint64_t)(16 * t + 4 * g + s));
+        acc[t][s] = keep ? acc[t][s] * (inv * dctx.scale) : 0.f;
+        w[t >> 3] |= (keep ? 1u : 0u) << (4 * (t & 7) + s);
+      }
+    }
+    uint32_t* wo = p.bits_out + ((bh * p.KT + (q0 >> 4) + wave) * 2) * 64 + lane;
+    wo[0] = w[0];
+    wo[64] = w[1];
+  } else {
+#pragma unroll
+    for (int t = 0; t < KT; ++t) acc[t] = acc[t] * inv;
+  }
+
+  f32x4 o[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+  for (int tp = 0; tp < KTE / 2; ++tp) {   // O^T[dd][query] += V^T[dd][keys of two tiles] . P^T[keys][query]
+    bf16x8 ph, pl;
+    split8(cat(acc[2 * tp], acc[2 * tp + 1]), ph, pl);
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+      o[db] = mfma3(tr_frag(sVh, fa.tr[db], 2 * tp, 2 * tp + 1), tr_frag(sVl, fa.tr[db], 2 * tp, 2 * tp + 1), ph, pl, o[db]);
+  }
+  if (q < L) {
+    float* dst = p.ctx_out + (row0 + q) * H + hd * 32 + 4 * g;
+    *reinterpret_cast<f32x4*>(dst) = o[0];
+    *reinterpret_cast<f32x4*>(dst + 16) = o[1];
+  }
+}
+
+// -----------------------------------------------------------------------------------------------------------
+// backward, dQ: same decomposition as the forward; probabilities recomputed from the saved log-sum-exp
+// LDS: [K hi | K lo | V hi | V lo | sAdd | sD]
+// -----------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * WAVES) void attn_rx_dq_kernel(AttnRxP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_rx[];
+  const int KTE = p.KTE, LPE = KTE * 16, PLANE = LPE * 64;
+  char* sKh = smem_rx;
+  char* sKl = sKh + PLANE;
+  char* sVh = sKl + PLANE;
+  char* sVl = sVh + PLANE;
+  float* sAdd = reinterpret_cast<float*>(sVl + PLANE);
+  float* sD = sAdd + LPE;
+
+  const int b = blockIdx.z, hd = blockIdx.y, q0 = blockIdx.x * ROWS_WG;
+  const int L = p.L, H = p.H, ld3 = 3 * H;
+  const int64_t row0 = (int64_t)b * L;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+
+  const int q = q0 + 16 * wave + i;
+  const bool qlive = q < L;
+  const int qc = min(q, L - 1);
+  const f32x8 qx = load8(p.qkv + (row0 + qc) * ld3 + hd * 32 + 8 * g);
+  const f32x8 dox = load8(p.dctx + (row0 + qc) * H + hd * 32 + 8 * g);
+  stage_rows(sKh, sKl, p.qkv + H + hd * 32, row0, ld3, LPE, L);
+  stage_rows(sVh, sVl, p.qkv + 2 * H + hd * 32, row0, ld3, LPE, L);
+  rowdot_head(sD, p.dctx + hd * 32, p.ctx + hd * 32, row0 + q0, H, ROWS_WG, L - q0);
+  for (int k = threadIdx.x; k < LPE; k += 64 * WAVES)
+    sAdd[k] = (k < L) ? (1.0f - (float)p.mask[row0 + k]) * -1e9f : -INFINITY;
+  bf16x8 qh, ql, doh, dol;
+  split8(qx, qh, ql);
+  split8(dox, doh, dol);
+  __syncthreads();
+  if (q0 + 16 * wave >= L) return;
+
+  const FragAddr fa = frag_addr(lane);
+  const int64_t bh = (int64_t)b * p.heads + hd;
+  const float Dq = sD[16 * wave + i];
+  const float lse = qlive ? p.lse_in[bh * L + q] : 0.f;
+  const DropCtx dctx = b4r_drop_ctx(p.drop);
+  uint32_t w[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+  if (dctx.on) {
+    const uint32_t* wi = p.bits_in + ((bh * p.KT + (q0 >> 4) + wave) * 2) * 64 + lane;
+    w[0] = wi[0];
+    w[1] = wi[64];
+  }
+  const float dscale = dctx.on ? dctx.scale : 1.0f;
+
+  f32x4 dq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  for (int tp = 0; tp < KTE / 2; ++tp) {
+    f32x4 ds[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int t = 2 * tp + u;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 sc = mfma3(row_frag(sKh, fa.row, t), row_frag(sKl, fa.row, t), qh, ql, z);     // S^T = K.Q^T
+      const f32x4 da = mfma3(row_frag(sVh, fa.row, t), row_frag(sVl, fa.row, t), doh, dol, z);   // dA^T = V.dO^T
+      const f32x4 ad = *reinterpret_cast<const f32x4*>(&sAdd[16 * t + 4 * g]);
+      const uint32_t nib = w[(t >> 3) & 1] >> (4 * (t & 7));
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float pr = __expf(sc[s] + ad[s] - lse);
+        const float dA = ((nib >> s) & 1u) ? da[s] * dscale : 0.f;
+        ds[u][s] = pr * (dA - Dq);
+      }
+    }
+    bf16x8 dsh, dsl;
+    split8(cat(ds[0], ds[1]), dsh, dsl);
+#pragma unroll
+    for (int db = 0; db < 2; ++db)   // dQ^T[dk][query] += K^T[dk][keys] . dS^T[keys][query]
+      dq[db] = mfma3(tr_frag(sKh, fa.tr[db], 2 * tp, 2 * tp + 1), tr_frag(sKl, fa.tr[db], 2 * tp, 2 * tp + 1), dsh, dsl, dq[db]);
+  }
+  if (qlive) {
+    float* dst = p.dqkv + (row0 + q) * ld3 + hd * 32 + 4 * g;
+    *reinterpret_cast<f32x4*>(dst) = dq[0] * p.qscale;
+    *reinterpret_cast<f32x4*>(dst + 16) = dq[1] * p.qscale;
+  }
+}
+
+// -----------------------------------------------------------------------------------------------------------
+// backward, dK / dV: workgroup = 128 keys of one (batch, head); wave = 16 keys x all queries
+// LDS: [Q hi | Q lo | dO hi | dO lo | sLse | sD]
+// -----------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * WAVES) void attn_rx_dkv_kernel(AttnRxP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_rx[];
+  const int KTE = p.KTE, LPE = KTE * 16, PLANE = LPE * 64;
+  char* sQh = smem_rx;
+  char* sQl = sQh + PLANE;
+  char* sOh = sQl + PLANE;
+  char* sOl = sOh + PLANE;
+  float* sLse = reinterpret_cast<float*>(sOl + PLANE);
+  float* sD = sLse + LPE;
+
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int L = p.L, H = p.H, ld3 = 3 * H;
+  const int64_t row0 = (int64_t)b * L;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+  const int64_t bh = (int64_t)b * p.heads + hd;
+
+  const int k0 = (blockIdx.x * WAVES + wave) * 16;
+  const int key = k0 + i;
+  const bool klive = key < L;
+  const int kc = min(key, L - 1);
+  const f32x8 kx = load8(p.qkv + (row0 + kc) * ld3 + H + hd * 32 + 8 * g);
+  const f32x8 vx = load8(p.qkv + (row0 + kc) * ld3 + 2 * H + hd * 32 + 8 * g);
+  stage_rows(sQh, sQl, p.qkv + hd * 32, row0, ld3, LPE, L);
+  stage_rows(sOh, sOl, p.dctx + hd * 32, row0, H, LPE, L);
+  rowdot_head(sD, p.dctx + hd * 32, p.ctx + hd * 32, row0, H, LPE, L);
+  for (int k = threadIdx.x; k < LPE; k += 64 * WAVES)
+    sLse[k] = (k < L) ? p.lse_in[bh * L + k] : INFINITY;   // +inf => probability 0 for pad queries
+  bf16x8 kh, kl, vh, vl;
+  split8(kx, kh, kl);
+  split8(vx, vh, vl);
+  __syncthreads();
+  if (k0 >= L) return;  // wave-uniform; no barrier below
+
+  const FragAddr fa = frag_addr(lane);
+  const float add = klive ? (1.0f - (float)p.mask[row0 + key]) * -1e9f : -INFINITY;
+  const DropCtx dctx = b4r_drop_ctx(p.drop);
+  const float dscale = dctx.on ? dctx.scale : 1.0f;
+  const int tk = k0 >> 4;
+  // the forward lane that hashed (query 16t + 4g + r, this key) is lane (4g + r) + 16 * (i >> 2): 4 consecutive words
+  const uint32_t* wbase = p.bits_in + ((bh * p.KT) * 2 + (tk >> 3)) * 64 + 4 * g + 16 * (i >> 2);
+  const int wshift = 4 * (tk & 7) + (i & 3);
+
+  f32x4 dk[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  for (int tp = 0; tp < KTE / 2; ++tp) {
+    f32x4 pd[2], ds[2];
+    u32x4 wq[2] = {{~0u, ~0u, ~0u, ~0u}, {~0u, ~0u, ~0u, ~0u}};
+    if (dctx.on) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u)   // query tiles beyond the forward's (odd KT) hold only pad queries: any word will do
+        wq[u] = *reinterpret_cast<const u32x4*>(wbase + (int64_t)min(2 * tp + u, p.KT - 1) * 128);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int t = 2 * tp + u;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 sc = mfma3(row_frag(sQh, fa.row, t), row_frag(sQl, fa.row, t), kh, kl, z);   // S = Q.K^T
+      const f32x4 da = mfma3(row_frag(sOh, fa.row, t), row_frag(sOl, fa.row, t), vh, vl, z);   // dA = dO.V^T
+      const f32x4 ls = *reinterpret_cast<const f32x4*>(&sLse[16 * t + 4 * g]);
+      const f32x4 dd = *reinterpret_cast<const f32x4*>(&sD[16 * t + 4 * g]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pr = __expf(sc[r] + add - ls[r]);
+        const bool keep = (wq[u][r] >> wshift) & 1u;
+        pd[u][r] = keep ? pr * dscale : 0.f;
+        const float dA = keep ? da[r] * dscale : 0.f;
+        ds[u][r] = pr * (dA - dd[r]);
+      }
+    }
+    bf16x8 pdh, pdl, dsh, dsl;
+    split8(cat(pd[0], pd[1]), pdh, pdl);
+    split8(cat(ds[0], ds[1]), dsh, dsl);
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      // dV^T[dd][key] += dO^T[dd][queries] . Pd[queries][key] ;  dK^T[dk][key] += Q^T[dk][queries] . dS[queries][key]
+      dv[db] = mfma3(tr_frag(sOh, fa.tr[db], 2 * tp, 2 * tp + 1), tr_frag(sOl, fa.tr[db], 2 * tp, 2 * tp + 1), pdh, pdl, dv[db]);
+      dk[db] = mfma3(tr_frag(sQh, fa.tr[db], 2 * tp, 2 * tp + 1), tr_frag(sQl, fa.tr[db], 2 * tp, 2 * tp + 1), dsh, dsl, dk[db]);
+    }
+  }
+  if (klive) {
+    float* ok = p.dqkv + (row0 + key) * ld3 + H + hd * 32 + 4 * g;
+    float* ov = p.dqkv + (row0 + key) * ld3 + 2 * H + hd * 32 + 4 * g;
+    *reinterpret_cast<f32x4*>(ok) = dk[0];
+    *reinterpret_cast<f32x4*>(ok + 16) = dk[1];
+    *reinterpret_cast<f32x4*>(ov) = dv[0];
+    *reinterpret_cast<f32x4*>(ov + 16) = dv[1];
+  }
+}
+
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+  if (bytes > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) { b4r_set_error("attention: cannot raise the LDS limit to %zu: %s", bytes, hipGetErrorString(e)); return B4R_E_HIP; }
+  }
+  return B4R_OK;
+}
+
+}  // namespace
+
+// dropout decisions of one layer: [B, heads, ceil(L/16) query tiles, 2 words, 64 lanes] uint32
+int64_t b4r_attn_rx_keep_words(int B, int L, int heads) { return (int64_t)B * heads * b4r_cdiv(L, 16) * 128; }
+
+// called by b4r_attn_fwd / b4r_attn_bwd (argument checks already done there) in the bf16x3 mode
+int b4r_attn_rx_fwd_launch(const float* qkv, const int64_t* mask, int B, int L, int heads, float* ctx, float* lse,
+                           const DropArgs& drop, uint32_t* keep_bits, hipStream_t stream) {
+  AttnRxP p{};
+  p.qkv = qkv; p.mask = mask; p.ctx_out = ctx; p.lse_out = lse; p.bits_out = keep_bits;
+  p.B = B; p.L = L; p.heads = heads; p.H = heads * 32;
+  p.KT = b4r_cdiv(L, 16);
+  p.drop = drop;
+  // the register-resident score row is a compile-time number of tiles; unused tiles cost one masked product each
+  const int KTt = p.KT <= 4 ? 4 : p.KT <= 8 ? 8 : p.KT <= 13 ? 13 : 16;
+  p.KT = b4r_cdiv(L, 16);
+  p.KTE = (KTt + 1) & ~1;
+  const size_t sh = (size_t)4 * p.KTE * 16 * 64 + (size_t)p.KTE * 16 * sizeof(float);
+  dim3 grid(b4r_cdiv(L, ROWS_WG), heads, B);
+  int rc;
+#define FWD_CASE(KT_)                                                                                      \
+  case KT_:                                                                                                \
+    rc = set_lds(attn_rx_fwd_kernel<KT_>, sh);                                                             \
+    if (rc) return rc;                                                                                     \
+    hipLaunchKernelGGL((attn_rx_fwd_kernel<KT_>), grid, dim3(64 * WAVES), sh, stream, p);                  \
+    break;
+  switch (KTt) {
+    FWD_CASE(4) FWD_CASE(8) FWD_CASE(13) FWD_CASE(16)
+    default: b4r_set_error("b4r_attn_fwd: internal"); return B4R_E_SHAPE;
+  }
+#undef FWD_CASE
+  B4R_CHECK_LAUNCH("b4r_attn_fwd (bf16x3)");
+  return B4R_OK;
+}
+
+int b4r_attn_rx_bwd_launch(const float* qkv, const int64_t* mask, const float* ctx, const float* lse, const float* dctx,
+                           int B, int L, int heads, float qscale, float* dqkv, const DropArgs& drop,
+                           const uint32_t* keep_bits, hipStream_t stream) {
+  AttnRxP p{};
+  p.qkv = qkv; p.mask = mask; p.ctx = ctx; p.lse_in = lse; p.dctx = dctx; p.dqkv = dqkv; p.bits_in = keep_bits;
+  p.B = B; p.L = L; p.heads = heads; p.H = heads * 32; p.qscale = qscale;
+  p.KT = b4r_cdiv(L, 16);
+  p.KTE = (p.KT + 1) & ~1;
+  p.drop = drop;
+  dim3 grid(b4r_cdiv(L, ROWS_WG), heads, B);
+  const size_t planes = (size_t)4 * p.KTE * 16 * 64;
+  const size_t sh_dq = planes + ((size_t)p.KTE * 16 + ROWS_WG) * sizeof(float);
+  int rc = set_lds(attn_rx_dq_kernel, sh_dq);
+  if (rc) return rc;
+  hipLaunchKernelGGL(attn_rx_dq_kernel, grid, dim3(64 * WAVES), sh_dq, stream, p);
+  B4R_CHECK_LAUNCH("b4r_attn_bwd dq (bf16x3)");
+  const size_t sh_kv = planes + (size_t)2 * p.KTE * 16 * sizeof(float);
+  rc = set_lds(attn_rx_dkv_kernel, sh_kv);
+  if (rc) return rc;
+  hipLaunchKernelGGL(attn_rx_dkv_kernel, grid, dim3(64 * WAVES), sh_kv, stream, p);
+  B4R_CHECK_LAUNCH("b4r_attn_bwd dkv (bf16x3)");
+  return B4R_OK;
+}

@@ -609,8 +609,11 @@ int b4r_gemm_rx_launch(const b4r_gemm_desc* d, hipStream_t stream) {
   const bool a_drop = d->a_dropout && p.drop.rng != nullptr;
   const int mblocks = b4r_cdiv(d->M, 128);
   const int total_steps = b4r_cdiv(d->N, 32);
-  // enough workgroups to cover the chip a few times, while keeping each A strip for as many n-steps as possible
-  int splits = b4r_cdiv(1536, mblocks);
+  // one resident round: 256 CUs x 4 workgroups (96 VGPRs -> 4 waves/SIMD).  A grid a little above that leaves a half-empty
+  // second round (measured on the MLM-head projection: 960 workgroups 31.7 us, 1360 36.2 us, 3120 40.6 us), so round the
+  // split count DOWN; B4R_RX_TARGET overrides the slot count for experiments
+  static const int wg_slots = getenv("B4R_RX_TARGET") ? atoi(getenv("B4R_RX_TARGET")) : 1024;
+  int splits = wg_slots / mblocks;
   if (splits > total_steps) splits = total_steps;
   if (splits < 1) splits = 1;
   p.steps_per_split = b4r_cdiv(total_steps, splits);

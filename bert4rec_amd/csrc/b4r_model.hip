@@ -144,7 +144,7 @@ struct WsLayout {
   int64_t total = 0;  // floats
   int64_t N = 0, M = 0, Vp = 0;
   int64_t x0, mean0, rstd0;
-  int64_t qkv[B4R_MAX_LAYERS], lse[B4R_MAX_LAYERS], ctx[B4R_MAX_LAYERS], z1[B4R_MAX_LAYERS], mean1[B4R_MAX_LAYERS],
+  int64_t qkv[B4R_MAX_LAYERS], lse[B4R_MAX_LAYERS], keep[B4R_MAX_LAYERS], ctx[B4R_MAX_LAYERS], z1[B4R_MAX_LAYERS], mean1[B4R_MAX_LAYERS],
       rstd1[B4R_MAX_LAYERS], x1[B4R_MAX_LAYERS], fpre[B4R_MAX_LAYERS], f[B4R_MAX_LAYERS], z2[B4R_MAX_LAYERS],
       mean2[B4R_MAX_LAYERS], rstd2[B4R_MAX_LAYERS], x2[B4R_MAX_LAYERS];
   int64_t gath, upre, u, meanm, rstdm, t, logits, rowsc, pooled;
@@ -161,7 +161,9 @@ WsLayout make_ws_layout(const b4r_model_config& c, int B, int L, int P) {
   auto take = [&](int64_t n) { int64_t o = off; off += up4(n); return o; };
   w.x0 = take(N * H); w.mean0 = take(N); w.rstd0 = take(N);
   for (int i = 0; i < c.num_layers; ++i) {
-    w.qkv[i] = take(N * 3 * H); w.lse[i] = take((int64_t)B * c.num_heads * L); w.ctx[i] = take(N * H);
+    w.qkv[i] = take(N * 3 * H); w.lse[i] = take((int64_t)B * c.num_heads * L);
+    w.keep[i] = take(b4r_attn_keep_words(B, L, c.num_heads));   // attention dropout decisions (uint32 words)
+    w.ctx[i] = take(N * H);
     w.z1[i] = take(N * H); w.mean1[i] = take(N); w.rstd1[i] = take(N); w.x1[i] = take(N * H);
     w.fpre[i] = take(N * I); w.f[i] = take(N * I);
     w.z2[i] = take(N * H); w.mean2[i] = take(N); w.rstd2[i] = take(N); w.x2[i] = take(N * H);
@@ -329,7 +331,7 @@ extern "C" int b4r_forward(const b4r_model_config* cfg, const b4r_batch* batch, 
     RC(gemm(x, H, params + pl.wqkv[i], 3 * H, ws + w.qkv[i], 3 * H, N, 3 * H, H, 0, B4R_EPI_BIAS_QSCALE, params + pl.bqkv[i],
             nullptr, 0, nullptr, 0, qscale, H, nullptr, 0, 0.f, 0, s));
     RC(b4r_attn_fwd(ws + w.qkv[i], batch->input_mask, B, L, cfg->num_heads, ws + w.ctx[i], ws + w.lse[i], rng,
-                    B4R_STREAM_ATTN_PROBS(i), adp, stream));
+                    B4R_STREAM_ATTN_PROBS(i), adp, reinterpret_cast<uint32_t*>(ws + w.keep[i]), stream));
     RC(gemm(ws + w.ctx[i], H, params + pl.wo[i], H, ws + w.z1[i], H, N, H, H, 0, B4R_EPI_BIAS_DROP_RES, params + pl.bo[i],
             nullptr, 0, x, H, 1.f, 0, rng, B4R_STREAM_ATTN_OUT(i), od, 0, s));
     RC(b4r_ln_fwd(ws + w.z1[i], N, H, params + pl.ln1_g[i], params + pl.ln1_b[i], cfg->ln_eps, ws + w.x1[i], ws + w.mean1[i],
@@ -452,7 +454,7 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
                B4R_STREAM_ATTN_OUT(i), od, 1, take(b4r_gemm_tn_scratch_floats(N, H, H)), s));
     // attention core
     RC(b4r_attn_bwd(ws + w.qkv[i], batch->input_mask, ws + w.ctx[i], ws + w.lse[i], ws + w.dctx, B, L, cfg->num_heads, qscale,
-                    ws + w.dqkv, rng, B4R_STREAM_ATTN_PROBS(i), adp, stream));
+                    ws + w.dqkv, rng, B4R_STREAM_ATTN_PROBS(i), adp, reinterpret_cast<const uint32_t*>(ws + w.keep[i]), stream));
     // QKV projection: dX_in = dqkv . Wqkv^T + dz1
     RC(gemm(ws + w.dqkv, 3 * H, params + pl.wqkv[i], 3 * H, ws + w.dx, H, N, H, 3 * H, 1, B4R_EPI_ADD_RES, nullptr, nullptr, 0,
             ws + w.db, H, 1.f, 0, nullptr, 0, 0.f, 0, s));

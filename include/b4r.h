@@ -228,11 +228,17 @@ int b4r_gemm_tn_f32(const b4r_gemm_tn_desc* d, float* scratch, b4r_stream_t stre
 /* Keras MultiHeadAttention core for one layer, head_dim 32: ctx = dropout(softmax(q k^T + (1-mask)*-1e9)) v
  * qkv [B*L, 3H] (q pre-scaled by 1/sqrt(d)), ctx [B*L, H], lse [B, heads, L]; input_mask int64 [B,L]. */
 int b4r_attn_fwd(const float* qkv, const int64_t* input_mask, int32_t B, int32_t L, int32_t heads, float* ctx,
-                 float* lse, const uint32_t* rng, uint32_t drop_stream, float drop_rate, b4r_stream_t stream);
+                 float* lse, const uint32_t* rng, uint32_t drop_stream, float drop_rate, uint32_t* keep_bits,
+                 b4r_stream_t stream);
 /* dqkv [B*L,3H] from dctx; dq is returned multiplied by qscale (gradient wrt the un-scaled query projection) */
 int b4r_attn_bwd(const float* qkv, const int64_t* input_mask, const float* ctx, const float* lse, const float* dctx,
                  int32_t B, int32_t L, int32_t heads, float qscale, float* dqkv, const uint32_t* rng,
-                 uint32_t drop_stream, float drop_rate, b4r_stream_t stream);
+                 uint32_t drop_stream, float drop_rate, const uint32_t* keep_bits, b4r_stream_t stream);
+/* keep_bits: uint32[b4r_attn_keep_words(B, L, heads)], 16-byte aligned.  In the B4R_GEMM_BF16X3 mode the forward stores
+ * its attention-probability dropout decisions there and the backward of the same step reads them back (required when
+ * dropout is active); the B4R_GEMM_F32 kernels regenerate the decisions from the hash and ignore the buffer.  Forward and
+ * backward of one step must run in the same mode. */
+int64_t b4r_attn_keep_words(int32_t B, int32_t L, int32_t heads);
 
 /* rows gather / scatter-add:  dst[i,:] = src[idx[i],:]   /   dst[idx[i],:] += src[i,:] (fp32 atomics) */
 int b4r_gather_rows(const float* src, int32_t src_ld, const int64_t* idx, int64_t idx_add_per, int32_t per,

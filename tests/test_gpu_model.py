@@ -99,10 +99,13 @@ def run_loss_and_grads(eng, batch, training, seed=0, step=0):
 
 def compare_grads(got, ref, count, rel=2e-3):
     worst = ("", 0.0)
+    # the key-bias gradient is analytically zero (softmax is shift invariant), so its reference is rounding noise: every
+    # tensor is measured against at least 1e-4 of the largest gradient magnitude in the model
+    floor = 1e-4 * max(float(g.abs().max()) for g in ref.values()) + 1e-7
     for n, g in ref.items():
         a = got[n].double() / count
         b = g.double().reshape(a.shape)
-        scale = float(b.abs().max()) + 1e-7
+        scale = max(float(b.abs().max()), floor)
         err = float((a - b).abs().max()) / scale
         if err > worst[1]:
             worst = (n, err)

@@ -206,15 +206,17 @@ def test_attention_fwd_bwd(B, L, heads, rate):
     qd, md = qkv.to(DEV), mask.to(DEV)
     ctx = torch.full((B * L, H), float("nan"), device=DEV)
     lse = torch.empty(B * heads * L, device=DEV)
-    _lib.check(lib.b4r_attn_fwd(P(qd), P(md), B, L, heads, P(ctx), P(lse), P(st), sid, rate, stream()))
-    assert T.maxdiff(ctx.view(B, L, heads, d), ctx_ref) < 5e-5
+    bits = torch.zeros(lib.b4r_attn_keep_words(B, L, heads), dtype=torch.int32, device=DEV)
+    x3 = lib.b4r_get_gemm_mode() == _lib.GEMM_BF16X3   # unit-variance inputs: scores of magnitude ~10, 2^-16 relative each
+    _lib.check(lib.b4r_attn_fwd(P(qd), P(md), B, L, heads, P(ctx), P(lse), P(st), sid, rate, P(bits), stream()))
+    assert T.maxdiff(ctx.view(B, L, heads, d), ctx_ref) < (3e-4 if x3 else 5e-5)
     dqkv = torch.full((B * L, 3 * H), float("nan"), device=DEV)
     qscale = 0.5
     dcd = dctx.to(DEV)
-    _lib.check(lib.b4r_attn_bwd(P(qd), P(md), P(ctx), P(lse), P(dcd), B, L, heads, qscale, P(dqkv), P(st), sid, rate, stream()))
+    _lib.check(lib.b4r_attn_bwd(P(qd), P(md), P(ctx), P(lse), P(dcd), B, L, heads, qscale, P(dqkv), P(st), sid, rate, P(bits), stream()))
     gref = x.grad.view(B * L, 3, H).clone()
     gref[:, 0] *= qscale
-    assert T.maxdiff(dqkv.view(B * L, 3, H), gref) < 2e-4
+    assert T.maxdiff(dqkv.view(B * L, 3, H), gref) < (1e-3 if x3 else 2e-4)
 
 
 def test_attention_fully_masked_row_is_uniform():
@@ -226,7 +228,7 @@ def test_attention_fully_masked_row_is_uniform():
     ctx = torch.empty(B * L, 32, device=DEV)
     lse = torch.empty(L, device=DEV)
     qd, md = qkv.to(DEV), mask.to(DEV)
-    _lib.check(lib.b4r_attn_fwd(P(qd), P(md), B, L, heads, P(ctx), P(lse), None, 0, 0.0, stream()))
+    _lib.check(lib.b4r_attn_fwd(P(qd), P(md), B, L, heads, P(ctx), P(lse), None, 0, 0.0, None, stream()))
     want = qkv[:, 64:96].double().mean(0, keepdim=True).expand(L, 32)
     assert T.maxdiff(ctx, want) < 1e-5
 

@@ -306,48 +306,80 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnP p) {
   }
 }
 
-// out[row*ldo+col] (+)= sum_z slab[z][row][col].  A workgroup owns 64 consecutive elements; its 16 waves each sum every
-// 16th slab (independent loads in flight), then the 16 partial sums are combined in a fixed order: bitwise reproducible.
-// The two optional column-sum strips ride along as extra "elements" behind the matrix.
+// out[row*ldo+col] (+)= sum_z slab[z][row][col].  A workgroup owns 256 consecutive elements of the matrix (a lane = 4 of
+// them, one 16-byte load per slab) or 256 elements of a column-sum strip (lanes 0..63 of each wave, scalar loads); its 16
+// waves each sum every 16th slab with independent loads in flight, then the 16 partial sums are combined in a fixed
+// order: bitwise reproducible.  16-byte loads need (Mo * No) % 4 == 0 and 16-byte aligned slabs (the model's scratch
+// regions are); otherwise the same lanes fall back to 4 scalar loads per slab (same summation order).
 constexpr int RZ = 16;
-__global__ __launch_bounds__(64 * RZ) void slab_reduce_kernel(const float* slab, int S, int Mo, int No, float* out, int ldo,
-                                                          int accumulate, const float* cslab, float* colsum,
-                                                          const float* caslab, float* colsum_a) {
-  __shared__ float sp[RZ][64];
-  const int64_t total = (int64_t)Mo * No;
-  const int64_t n_cs = colsum ? No : 0, n_csa = colsum_a ? Mo : 0;
-  const int64_t e = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);
-  const int zl = threadIdx.x >> 6;
+constexpr int RE = 256;   // elements per workgroup
+typedef B4rReduceJob ReduceJobView;
+__device__ __forceinline__ void slab_reduce_block(const ReduceJobView& job, int block, float (*sp)[RE]) {
+  const int64_t total = (int64_t)job.Mo * job.No;
+  const int mat_blocks = (int)((total + RE - 1) / RE);
+  const int lane = threadIdx.x & 63, zl = threadIdx.x >> 6;
+  if (block < mat_blocks) {
+    const int64_t e = (int64_t)block * RE + 4 * lane;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    const bool vec = (total % 4 == 0) && ((reinterpret_cast<uintptr_t>(job.slab) & 15) == 0);   // block-uniform
+    if (vec) {
+      if (e < total) {
+        const float* src = job.slab + e;
+#pragma unroll 4
+        for (int z = zl; z < job.S; z += RZ) s += *reinterpret_cast<const f32x4*>(src + (int64_t)z * total);
+      }
+    } else {
+      for (int z = zl; z < job.S; z += RZ) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (e + c < total) s[c] += job.slab[(int64_t)z * total + e + c];
+      }
+    }
+    *reinterpret_cast<f32x4*>(&sp[zl][4 * lane]) = s;
+    __syncthreads();
+    if (zl < 4) {                       // 4 waves x 64 lanes finish one element each
+      const int l = threadIdx.x;        // 0..255
+      const int64_t eo = (int64_t)block * RE + l;
+      if (eo < total) {
+        float r = 0.f;
+#pragma unroll
+        for (int z = 0; z < RZ; ++z) r += sp[z][l];
+        const int row = (int)(eo / job.No), col = (int)(eo % job.No);
+        float* o = job.out + (int64_t)row * job.ldo + col;
+        *o = job.accumulate ? (*o + r) : r;
+      }
+    }
+    return;
+  }
+  // column-sum strips: [No of cslab | Mo of caslab], 64 elements per wave-row, 4 wave-rows of the 16 x 64 layout unused
+  const int64_t n_cs = job.colsum ? job.No : 0, n_csa = job.colsum_a ? job.Mo : 0;
+  const int64_t e = (int64_t)(block - mat_blocks) * 64 + lane;
   const float* src = nullptr;
   int64_t stride = 0, idx = 0;
-  if (e < total) { src = slab; stride = total; idx = e; }
-  else if (e < total + n_cs) { src = cslab; stride = No; idx = e - total; }
-  else if (e < total + n_cs + n_csa) { src = caslab; stride = Mo; idx = e - total - n_cs; }
+  if (e < n_cs) { src = job.cslab; stride = job.No; idx = e; }
+  else if (e < n_cs + n_csa) { src = job.caslab; stride = job.Mo; idx = e - n_cs; }
   float s = 0.f;
   if (src) {
-    for (int z = zl; z < S; z += RZ) s += src[(int64_t)z * stride + idx];
+    for (int z = zl; z < job.S; z += RZ) s += src[(int64_t)z * stride + idx];
   }
-  sp[zl][threadIdx.x & 63] = s;
+  sp[zl][lane] = s;
   __syncthreads();
   if (zl == 0 && src) {
-    const int l = threadIdx.x;
-    s = 0.f;
+    float r = 0.f;
 #pragma unroll
-    for (int z = 0; z < RZ; ++z) s += sp[z][l];
-    if (e < total) {
-      const int row = (int)(e / No), col = (int)(e % No);
-      float* o = out + (int64_t)row * ldo + col;
-      *o = accumulate ? (*o + s) : s;
-    } else if (e < total + n_cs) {
-      colsum[idx] = s;
-    } else {
-      colsum_a[idx] = s;
-    }
+    for (int z = 0; z < RZ; ++z) r += sp[z][lane];
+    if (e < n_cs) job.colsum[idx] = r;
+    else job.colsum_a[idx] = r;
   }
 }
 
+__global__ __launch_bounds__(64 * RZ) void slab_reduce_kernel(ReduceJobView job) {
+  __shared__ __attribute__((aligned(16))) float sp[RZ][RE];
+  slab_reduce_block(job, (int)blockIdx.x, sp);
+}
+
 int slab_reduce_grid(int Mo, int No, bool cs, bool csa) {
-  return b4r_cdiv((int64_t)Mo * No + (cs ? No : 0) + (csa ? Mo : 0), 64);
+  return b4r_cdiv((int64_t)Mo * No, RE) + b4r_cdiv((int64_t)(cs ? No : 0) + (csa ? Mo : 0), 64);
 }
 
 int tn_split(int R, int Mo, int No) {
@@ -390,9 +422,8 @@ int dispatch_epi(const GemmP& p, int epi, int a_drop, dim3 grid, hipStream_t s) 
 
 int b4r_launch_slab_reduce(const float* slab, int S, int Mo, int No, float* out, int ldo, int accumulate,
                            hipStream_t stream) {
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(slab_reduce_grid(Mo, No, false, false)), dim3(64 * RZ), 0, stream, slab, S, Mo,
-                     No, out, ldo, accumulate,
-                     (const float*)nullptr, (float*)nullptr, (const float*)nullptr, (float*)nullptr);
+  ReduceJobView job{slab, nullptr, nullptr, out, nullptr, nullptr, S, Mo, No, ldo, accumulate};
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(slab_reduce_grid(Mo, No, false, false)), dim3(64 * RZ), 0, stream, job);
   B4R_CHECK_LAUNCH("slab_reduce");
   return B4R_OK;
 }
@@ -405,40 +436,12 @@ struct MultiReduceP {
 };
 // all queued reductions in one launch: a workgroup looks up its job, then does what slab_reduce_kernel does
 __global__ __launch_bounds__(64 * RZ) void multi_slab_reduce_kernel(MultiReduceP p) {
-  __shared__ float sp[RZ][64];
+  __shared__ __attribute__((aligned(16))) float sp[RZ][RE];
   int j = 0;
   while (j + 1 < p.n && (int)blockIdx.x >= p.block_begin[j + 1]) ++j;
-  const B4rReduceJob job = p.jobs[j];
-  const int64_t total = (int64_t)job.Mo * job.No;
-  const int64_t n_cs = job.colsum ? job.No : 0, n_csa = job.colsum_a ? job.Mo : 0;
-  const int64_t e = (int64_t)((int)blockIdx.x - p.block_begin[j]) * 64 + (threadIdx.x & 63);
-  const int zl = threadIdx.x >> 6;
-  const float* src = nullptr;
-  int64_t stride = 0, idx = 0;
-  if (e < total) { src = job.slab; stride = total; idx = e; }
-  else if (e < total + n_cs) { src = job.cslab; stride = job.No; idx = e - total; }
-  else if (e < total + n_cs + n_csa) { src = job.caslab; stride = job.Mo; idx = e - total - n_cs; }
-  float s = 0.f;
-  if (src) {
-    for (int z = zl; z < job.S; z += RZ) s += src[(int64_t)z * stride + idx];
-  }
-  sp[zl][threadIdx.x & 63] = s;
-  __syncthreads();
-  if (zl == 0 && src) {
-    const int l = threadIdx.x;
-    s = 0.f;
-#pragma unroll
-    for (int z = 0; z < RZ; ++z) s += sp[z][l];
-    if (e < total) {
-      const int row = (int)(e / job.No), col = (int)(e % job.No);
-      float* o = job.out + (int64_t)row * job.ldo + col;
-      *o = job.accumulate ? (*o + s) : s;
-    } else if (e < total + n_cs) {
-      job.colsum[idx] = s;
-    } else {
-      job.colsum_a[idx] = s;
-    }
-  }
+  const B4rReduceJob q = p.jobs[j];
+  const ReduceJobView job{q.slab, q.cslab, q.caslab, q.out, q.colsum, q.colsum_a, q.S, q.Mo, q.No, q.ldo, q.accumulate};
+  slab_reduce_block(job, (int)blockIdx.x - p.block_begin[j], sp);
 }
 thread_local B4rReduceQueue* g_queue = nullptr;
 }  // namespace
@@ -471,8 +474,9 @@ int b4r_launch_slab_reduce_full(const float* slab, int S, int Mo, int No, float*
                                 const float* cslab, float* colsum, const float* caslab, float* colsum_a, hipStream_t stream) {
   B4rReduceJob job{slab, cslab, caslab, out, colsum, colsum_a, S, Mo, No, ldo, accumulate};
   if (b4r_reduce_queue_push(job)) return B4R_OK;
+  ReduceJobView view{slab, cslab, caslab, out, colsum, colsum_a, S, Mo, No, ldo, accumulate};
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(slab_reduce_grid(Mo, No, colsum != nullptr, colsum_a != nullptr)), dim3(64 * RZ),
-                     0, stream, slab, S, Mo, No, out, ldo, accumulate, cslab, colsum, caslab, colsum_a);
+                     0, stream, view);
   B4R_CHECK_LAUNCH("slab_reduce");
   return B4R_OK;
 }

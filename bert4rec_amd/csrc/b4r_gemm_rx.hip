@@ -32,6 +32,7 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -440,136 +441,140 @@ int dispatch_rx(const RxP& p, int epi, bool a_drop, dim3 grid, hipStream_t s) {
 
 
 // ---- weight gradients: out[Mo,No] = A[R,Mo]^T . B[R,No] --------------------------------------------------------------
-// k is the ROW index of both operands, so every fragment is 8 coalesced dword loads (32 lanes = one 128-byte line).  One
-// wave = one (64 x 64 output tile, slice of R) work item accumulating in registers; the next 16 rows are requested before
-// the MFMAs of the current 16; partial tiles go to slabs and are summed in a fixed order (bitwise reproducible).  Bias
-// gradients (column sums of B, or of A for the tied-table / output-bias pair) ride along on the loaded values.
+// The reduction index k is the ROW index of both operands, so both MFMA operands are columns of row-major data.  A
+// workgroup (4 waves, one 32x32 quarter each) owns one (64 x 64 output tile, slice of R) item and walks its slice in
+// chunks of KS rows: every thread fetches full 16-byte pieces of whole 256-byte row segments (requested one chunk ahead,
+// KS*512 bytes in flight per workgroup), converts them once to bf16 hi / lo and writes two [KS][64] LDS images per
+// operand; fragments are then hardware-transposed reads (ds_read_b64_tr_b16: a lane gets one column of 4 consecutive
+// rows).  The 32-byte block index of an image row is XORed with 2*bit1(row), which spreads the 4 rows of a half-wave's
+// transposed read over all 64 banks.  Dropout of B (the masked upstream gradient) and the bias-gradient column sums
+// (of B, or of A for the tied-table / output-bias pair) ride on the staged values, whose column is fixed per thread.
+// Partial tiles go to slabs that are summed in a fixed order later (bitwise reproducible).
 struct RxTnP {
   const float* A; const float* B; float* slab; float* colsum_slab; float* colsum_a_slab;
   int lda, ldb;
   int R, Mo, No;
-  int tiles_i, tiles_j, S, chunk;  // chunk: rows per slice, multiple of 16
+  int a_lim, b_lim;                // first column that may not be fetched (Mo / No rounded up to 4), <= ld
+  int tiles_i, tiles_j, S, chunk;  // chunk: rows per slice
   DropArgs drop;
 };
 
-template <bool B_DROP>
+__device__ __forceinline__ int tn_img_off(int row, int c4) {   // bytes; c4 = float4 index (0..15) within the 64 columns
+  return row * 128 + 32 * ((c4 >> 2) ^ (row & 2)) + 8 * (c4 & 3);
+}
+
+template <int KS, bool B_DROP>
 __global__ __launch_bounds__(256) void rx_gemm_tn_kernel(RxTnP p) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int NLD = KS / 16;                       // float4 per thread per operand per chunk
+  constexpr int PLANE = KS * 128;                    // bytes per image
+  extern __shared__ __attribute__((aligned(16))) char s_tn[];   // [A hi | A lo | B hi | B lo]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  __shared__ float s_red[3 * 64 * 64 + 3 * 256];   // partial tiles + column sums of waves 1..3
-  const int64_t item = blockIdx.x;                  // one workgroup = one (tile, slice); its 4 waves split the slice
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t item = blockIdx.x;
   const int z = (int)(item / ((int64_t)p.tiles_i * p.tiles_j));
   const int t = (int)(item % ((int64_t)p.tiles_i * p.tiles_j));
   const int ti = t / p.tiles_j, tj = t % p.tiles_j;
   const int i0 = ti * 64, j0 = tj * 64;
-  const int sub = p.chunk / 4;                      // multiple of 16
-  const int r_begin = min(p.R, z * p.chunk + wave * sub), r_end = min(p.R, r_begin + sub);   // multiples of 16
+  const int r_begin = min(p.R, z * p.chunk), r_end = min(p.R, r_begin + p.chunk);
   const bool do_cs = p.colsum_slab != nullptr && ti == 0;
   const bool do_csa = p.colsum_a_slab != nullptr && tj == 0;
-  DropCtx dctx = b4r_drop_ctx(p.drop);
-  // out-of-range columns are clamped (valid memory, results never stored)
-  const int ci0 = min(i0 + r, p.Mo - 1), ci1 = min(i0 + 32 + r, p.Mo - 1);
-  const int cj0 = min(j0 + r, p.No - 1), cj1 = min(j0 + 32 + r, p.No - 1);
+  const DropCtx dctx = b4r_drop_ctx(p.drop);
 
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
-  float cs0 = 0.f, cs1 = 0.f, csa0 = 0.f, csa1 = 0.f;
-
-  f32x8 xa0, xa1, xb0, xb1;
+  // staging: thread -> (row tid/16 + 16*j, float4 column tid%16); columns beyond the matrix are clamped onto fetchable
+  // ones (their products land in output elements that are never stored)
+  const int c4 = tid & 15, srow = tid >> 4;
+  const int ca = min(i0 + 4 * c4, p.a_lim - 4), cb = min(j0 + 4 * c4, p.b_lim - 4);
+  f32x4 ra[NLD], rb[NLD];
   auto fetch = [&](int k0) {
-    const int kk = k0 + 8 * h;
-    xa0 = load8_strided(p.A + (int64_t)kk * p.lda + ci0, p.lda);
-    xa1 = load8_strided(p.A + (int64_t)kk * p.lda + ci1, p.lda);
-    xb0 = load8_strided(p.B + (int64_t)kk * p.ldb + cj0, p.ldb);
-    xb1 = load8_strided(p.B + (int64_t)kk * p.ldb + cj1, p.ldb);
-  };
-  if (r_begin < r_end) fetch(r_begin);
-  for (int k0 = r_begin; k0 < r_end; k0 += 16) {
-    f32x8 ya0 = xa0, ya1 = xa1, yb0 = xb0, yb1 = xb1;
-    fetch(min(k0 + 16, r_end - 16));   // unconditional look-ahead
-    if (B_DROP) {
-      const int kk = k0 + 8 * h;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        yb0[j] = b4r_drop(dctx, yb0[j], (uint64_t)(kk + j) * (uint64_t)p.No + (uint64_t)cj0);
-        yb1[j] = b4r_drop(dctx, yb1[j], (uint64_t)(kk + j) * (uint64_t)p.No + (uint64_t)cj1);
+    for (int j = 0; j < NLD; ++j) {
+      const int row = min(k0 + srow + 16 * j, p.R - 1);
+      ra[j] = *reinterpret_cast<const f32x4*>(p.A + (int64_t)row * p.lda + ca);
+      rb[j] = *reinterpret_cast<const f32x4*>(p.B + (int64_t)row * p.ldb + cb);
+    }
+  };
+  f32x4 cs = {0.f, 0.f, 0.f, 0.f}, csa = {0.f, 0.f, 0.f, 0.f};
+  auto stash = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int lrow = srow + 16 * j, row = k0 + lrow;
+      const bool live = row < r_end;
+      f32x4 va = ra[j], vb = rb[j];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        va[e] = live ? va[e] : 0.f;
+        vb[e] = live ? vb[e] : 0.f;
+        if (B_DROP) vb[e] = b4r_drop(dctx, vb[e], (uint64_t)row * (uint64_t)p.No + (uint64_t)(cb + e));
       }
+      cs += vb;
+      csa += va;
+      const int off = tn_img_off(lrow, c4);
+      const bf16x4 ah = __builtin_convertvector(va, bf16x4), bh = __builtin_convertvector(vb, bf16x4);
+      *reinterpret_cast<bf16x4*>(s_tn + off) = ah;
+      *reinterpret_cast<bf16x4*>(s_tn + PLANE + off) = __builtin_convertvector(va - __builtin_convertvector(ah, f32x4), bf16x4);
+      *reinterpret_cast<bf16x4*>(s_tn + 2 * PLANE + off) = bh;
+      *reinterpret_cast<bf16x4*>(s_tn + 3 * PLANE + off) = __builtin_convertvector(vb - __builtin_convertvector(bh, f32x4), bf16x4);
     }
-    if (do_cs) {
-      cs0 += ((yb0[0] + yb0[1]) + (yb0[2] + yb0[3])) + ((yb0[4] + yb0[5]) + (yb0[6] + yb0[7]));
-      cs1 += ((yb1[0] + yb1[1]) + (yb1[2] + yb1[3])) + ((yb1[4] + yb1[5]) + (yb1[6] + yb1[7]));
-    }
-    if (do_csa) {
-      csa0 += ((ya0[0] + ya0[1]) + (ya0[2] + ya0[3])) + ((ya0[4] + ya0[5]) + (ya0[6] + ya0[7]));
-      csa1 += ((ya1[0] + ya1[1]) + (ya1[2] + ya1[3])) + ((ya1[4] + ya1[5]) + (ya1[6] + ya1[7]));
-    }
-    bf16x8 ah0, al0, ah1, al1, bh0, bl0, bh1, bl1;
-    split8(ya0, ah0, al0); split8(ya1, ah1, al1); split8(yb0, bh0, bl0); split8(yb1, bh1, bl1);
-    acc[0][0] = mfma3(ah0, al0, bh0, bl0, acc[0][0]);
-    acc[0][1] = mfma3(ah0, al0, bh1, bl1, acc[0][1]);
-    acc[1][0] = mfma3(ah1, al1, bh0, bl0, acc[1][0]);
-    acc[1][1] = mfma3(ah1, al1, bh1, bl1, acc[1][1]);
+  };
+  // transposed fragment: 16-lane group G = lane>>4 reads the 4 x 16 block at rows 8h + 4s + (0..3) (+16*kb), columns
+  // 32*w + 16*(G&1) ..; lane 4q+pp of the group supplies the address of row q, columns 4pp..4pp+3
+  const int qq = (lane & 15) >> 2, pp = lane & 3, gb = (lane >> 4) & 1;
+  const int tr_a = tn_img_off(8 * h + qq, 4 * (2 * wm + gb) + pp);
+  const int tr_b = tn_img_off(8 * h + qq, 4 * (2 * wn + gb) + pp);
+  typedef __attribute__((address_space(3))) s16x4* lds_ptr;
+  auto tr8 = [&](int plane, int addr, int kb) {
+    const char* src = s_tn + plane * PLANE + addr + kb * (16 * 128);
+    const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(src));
+    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(src + 4 * 128));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  if (r_begin < r_end) fetch(r_begin);
+  for (int k0 = r_begin; k0 < r_end; k0 += KS) {
+    __syncthreads();                 // every wave is done with the previous chunk's images
+    stash(k0);
+    __syncthreads();
+    fetch(min(k0 + KS, p.R - 1));    // unconditional look-ahead (rows are clamped; unused after the last chunk)
+#pragma unroll
+    for (int kb = 0; kb < KS / 16; ++kb)
+      acc = mfma3(tr8(0, tr_a, kb), tr8(1, tr_a, kb), tr8(2, tr_b, kb), tr8(3, tr_b, kb), acc);
   }
 
-  // combine the 4 waves in a fixed order (wave 0 + 1 + 2 + 3), then one slab per workgroup
-  if (wave > 0) {
-    float* dst = s_red + (wave - 1) * 4096;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) dst[((a * 2 + b) * 16 + reg) * 64 + lane] = acc[a][b][reg];
-    float* dc = s_red + 3 * 4096 + (wave - 1) * 256;
-    dc[lane] = cs0; dc[64 + lane] = cs1; dc[128 + lane] = csa0; dc[192 + lane] = csa1;
-  }
-  __syncthreads();
-  if (wave > 0) return;
-#pragma unroll
-  for (int w = 0; w < 3; ++w) {
-    const float* src = s_red + w * 4096;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) acc[a][b][reg] += src[((a * 2 + b) * 16 + reg) * 64 + lane];
-    const float* sc = s_red + 3 * 4096 + w * 256;
-    cs0 += sc[lane]; cs1 += sc[64 + lane]; csa0 += sc[128 + lane]; csa1 += sc[192 + lane];
-  }
   float* slab = p.slab + (int64_t)z * p.Mo * p.No;
+  const int col = j0 + 32 * wn + r;
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int col = j0 + 32 * b + r;
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int row = i0 + 32 * a + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-        if (row < p.Mo && col < p.No) slab[(int64_t)row * p.No + col] = acc[a][b][reg];
-      }
-    }
-  if (do_cs) {
-    const float s0 = cs0 + __shfl_xor(cs0, 32, 64), s1 = cs1 + __shfl_xor(cs1, 32, 64);
-    if (h == 0 && j0 + r < p.No) p.colsum_slab[(int64_t)z * p.No + j0 + r] = s0;
-    if (h == 0 && j0 + 32 + r < p.No) p.colsum_slab[(int64_t)z * p.No + j0 + 32 + r] = s1;
+  for (int reg = 0; reg < 16; ++reg) {
+    const int row = i0 + 32 * wm + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    if (row < p.Mo && col < p.No) slab[(int64_t)row * p.No + col] = acc[reg];
   }
-  if (do_csa) {
-    const float s0 = csa0 + __shfl_xor(csa0, 32, 64), s1 = csa1 + __shfl_xor(csa1, 32, 64);
-    if (h == 0 && i0 + r < p.Mo) p.colsum_a_slab[(int64_t)z * p.Mo + i0 + r] = s0;
-    if (h == 0 && i0 + 32 + r < p.Mo) p.colsum_a_slab[(int64_t)z * p.Mo + i0 + 32 + r] = s1;
+  if (do_cs || do_csa) {             // 16 row groups per column quad, summed in a fixed order
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(s_tn);   // [2][16 row groups][64 columns]
+    *reinterpret_cast<f32x4*>(red + srow * 64 + 4 * c4) = cs;
+    *reinterpret_cast<f32x4*>(red + 1024 + srow * 64 + 4 * c4) = csa;
+    __syncthreads();
+    if (tid < 128) {
+      const int which = tid >> 6, c = tid & 63;
+      float sum = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) sum += red[which * 1024 + g * 64 + c];
+      if (which == 0 && do_cs && j0 + c < p.No) p.colsum_slab[(int64_t)z * p.No + j0 + c] = sum;
+      if (which == 1 && do_csa && i0 + c < p.Mo) p.colsum_a_slab[(int64_t)z * p.Mo + i0 + c] = sum;
+    }
   }
 }
 
+constexpr int TN_KS = 64;   // measured on the ML-1M shapes: 32 -> 1.185, 64 -> 1.173, 128 -> 1.197 ms/step
+
 int rx_tn_split(int R, int Mo, int No) {
+  static const int wg_target = getenv("B4R_TN_TARGET") ? atoi(getenv("B4R_TN_TARGET")) : 512;
   const int tiles = b4r_cdiv(Mo, 64) * b4r_cdiv(No, 64);
-  int S = b4r_cdiv(192, tiles);   // workgroups of 4 waves; measured optimum on ML-1M shapes (96/192/384/768 tried)
-  const int max_s = b4r_cdiv(R, 256);  // at least 64 rows per wave
+  int S = b4r_cdiv(wg_target, tiles);
+  const int max_s = b4r_cdiv(R, 2 * TN_KS);  // at least two chunks per workgroup
   if (S > max_s) S = max_s;
   if (S > 256) S = 256;
   if (S < 1) S = 1;
@@ -629,7 +634,10 @@ int b4r_gemm_rx_launch(const b4r_gemm_desc* d, hipStream_t stream) {
 int b4r_launch_slab_reduce_full(const float* slab, int S, int Mo, int No, float* out, int ldo, int accumulate,
                                 const float* cslab, float* colsum, const float* caslab, float* colsum_a, hipStream_t stream);
 
-bool b4r_gemm_rx_tn_supported(const b4r_gemm_tn_desc* d) { return d->R % 16 == 0 && d->R >= 64; }
+bool b4r_gemm_rx_tn_supported(const b4r_gemm_tn_desc* d) {
+  if (!vec_ok(d->A, d->lda) || !vec_ok(d->B, d->ldb)) return false;
+  return up4i(d->Mo) <= d->lda && up4i(d->No) <= d->ldb && d->Mo >= 4 && d->No >= 4;
+}
 
 int64_t b4r_gemm_rx_tn_scratch_floats(int R, int Mo, int No) {
   const int S = rx_tn_split(R, Mo, No);
@@ -642,7 +650,8 @@ int b4r_gemm_rx_tn_launch(const b4r_gemm_tn_desc* d, float* scratch, hipStream_t
   p.A = d->A; p.B = d->B; p.lda = d->lda; p.ldb = d->ldb;
   p.R = d->R; p.Mo = d->Mo; p.No = d->No;
   p.tiles_i = b4r_cdiv(d->Mo, 64); p.tiles_j = b4r_cdiv(d->No, 64); p.S = S;
-  p.chunk = b4r_cdiv(b4r_cdiv(d->R, S), 64) * 64;   // each of the 4 waves takes a quarter (multiple of 16 rows)
+  p.chunk = b4r_cdiv(b4r_cdiv(d->R, S), TN_KS) * TN_KS;
+  p.a_lim = up4i(d->Mo); p.b_lim = up4i(d->No);
   p.slab = scratch;
   p.colsum_slab = d->colsum ? scratch + (int64_t)S * d->Mo * d->No : nullptr;
   p.colsum_a_slab = d->colsum_a ? scratch + (int64_t)S * d->Mo * d->No + (int64_t)S * d->No : nullptr;
@@ -650,8 +659,15 @@ int b4r_gemm_rx_tn_launch(const b4r_gemm_tn_desc* d, float* scratch, hipStream_t
   const bool b_drop = d->b_dropout && p.drop.rng != nullptr;
   const int64_t items = (int64_t)p.tiles_i * p.tiles_j * S;
   dim3 grid((unsigned)items);
-  if (b_drop) hipLaunchKernelGGL((rx_gemm_tn_kernel<true>), grid, dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL((rx_gemm_tn_kernel<false>), grid, dim3(256), 0, stream, p);
+  constexpr size_t lds = (size_t)4 * TN_KS * 128;
+  static bool lds_raised = false;
+  if (lds > 48 * 1024 && !lds_raised) {
+    hipFuncSetAttribute((const void*)rx_gemm_tn_kernel<TN_KS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void*)rx_gemm_tn_kernel<TN_KS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    lds_raised = true;
+  }
+  if (b_drop) hipLaunchKernelGGL((rx_gemm_tn_kernel<TN_KS, true>), grid, dim3(256), lds, stream, p);
+  else hipLaunchKernelGGL((rx_gemm_tn_kernel<TN_KS, false>), grid, dim3(256), lds, stream, p);
   B4R_CHECK_LAUNCH("b4r_gemm_tn_f32 (bf16x3)");
   return b4r_launch_slab_reduce_full(p.slab, S, d->Mo, d->No, d->out, d->ldo, d->accumulate, p.colsum_slab, d->colsum,
                                      p.colsum_a_slab, d->colsum_a, stream);

@@ -138,10 +138,10 @@ __device__ __forceinline__ void epilogue_tile(const RxP& p, const DropCtx& dctx,
       if (EPI == B4R_EPI_NONE) y = a;
       else if (EPI == B4R_EPI_BIAS) y = a + bv[e];
       else if (EPI == B4R_EPI_BIAS_QSCALE) y = (a + bv[e]) * ((col + e < p.qcols) ? p.qscale : 1.0f);
-      else if (EPI == B4R_EPI_BIAS_GELU) { o2[e] = a + bv[e]; y = b4r_gelu(o2[e]); }
+      else if (EPI == B4R_EPI_BIAS_GELU) { o2[e] = a + bv[e]; y = b4r_gelu_fast(o2[e]); }
       else if (EPI == B4R_EPI_BIAS_DROP_RES)
         y = rr[i][e] + b4r_drop(dctx, a + bv[e], (uint64_t)row * (uint64_t)p.N + (uint64_t)(col + e));
-      else if (EPI == B4R_EPI_GELU_BWD) y = a * b4r_gelu_grad(rr[i][e]);
+      else if (EPI == B4R_EPI_GELU_BWD) y = a * b4r_gelu_grad_fast(rr[i][e]);
       else if (EPI == B4R_EPI_ADD_RES) y = a + rr[i][e];
       else y = tanhf(a + bv[e]);
       o[e] = y;

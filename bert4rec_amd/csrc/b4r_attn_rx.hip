@@ -65,17 +65,33 @@ __device__ __forceinline__ f32x8 cat(const f32x4 a, const f32x4 b) {
 // byte offset of 16-byte chunk `ch` (0..3) of row `row` in a [rows][32 bf16] image
 __device__ __forceinline__ int img_off(int row, int ch) { return row * 64 + 16 * (ch ^ ((0 - (row >> 2)) & 3)); }
 
-// rows [0,nrows) of a [*,32] fp32 head slice -> bf16 hi / lo images; rows beyond `valid` are zero
-__device__ __forceinline__ void stage_rows(char* hi, char* lo, const float* src, int64_t row0, int ld, int nrows, int valid) {
-  for (int f = threadIdx.x; f < nrows * 8; f += 64 * WAVES) {
-    const int r = f >> 3, c4 = f & 7;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (r < valid) v = *reinterpret_cast<const f32x4*>(src + (row0 + r) * ld + 4 * c4);
-    const bf16x4 h = __builtin_convertvector(v, bf16x4);
-    const bf16x4 l = __builtin_convertvector(v - __builtin_convertvector(h, f32x4), bf16x4);
-    const int off = img_off(r, c4 >> 1) + 8 * (c4 & 1);
-    *reinterpret_cast<bf16x4*>(hi + off) = h;
-    *reinterpret_cast<bf16x4*>(lo + off) = l;
+// rows [0,nrows) of two [*,32] fp32 head slices -> their bf16 hi / lo images; rows beyond `valid` are zero.  All loads are
+// issued before the first conversion (clamped addresses, no guard: a guarded load costs a branch and a full vmcnt(0) round
+// trip per iteration, which made this phase half of the kernel time); nrows <= 256 = 4 pieces per thread and tensor.
+struct StagedRows { f32x4 v0[4], v1[4]; };
+__device__ __forceinline__ void stage_fetch(StagedRows& st, const float* src0, int ld0, const float* src1, int ld1,
+                                            int64_t row0, int valid) {
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int f = threadIdx.x + 64 * WAVES * it, r = min(f >> 3, valid - 1), c4 = f & 7;
+    st.v0[it] = *reinterpret_cast<const f32x4*>(src0 + (row0 + r) * ld0 + 4 * c4);
+    st.v1[it] = *reinterpret_cast<const f32x4*>(src1 + (row0 + r) * ld1 + 4 * c4);
+  }
+}
+__device__ __forceinline__ void stage_write(const StagedRows& st, char* hi0, char* lo0, char* hi1, char* lo1, int nrows, int valid) {
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int f = threadIdx.x + 64 * WAVES * it, r = f >> 3, c4 = f & 7;
+    if (f < nrows * 8) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 a = r < valid ? st.v0[it] : z, b = r < valid ? st.v1[it] : z;
+      const bf16x4 ah = __builtin_convertvector(a, bf16x4), bh = __builtin_convertvector(b, bf16x4);
+      const int off = img_off(r, c4 >> 1) + 8 * (c4 & 1);
+      *reinterpret_cast<bf16x4*>(hi0 + off) = ah;
+      *reinterpret_cast<bf16x4*>(lo0 + off) = __builtin_convertvector(a - __builtin_convertvector(ah, f32x4), bf16x4);
+      *reinterpret_cast<bf16x4*>(hi1 + off) = bh;
+      *reinterpret_cast<bf16x4*>(lo1 + off) = __builtin_convertvector(b - __builtin_convertvector(bh, f32x4), bf16x4);
+    }
   }
 }
 
@@ -104,22 +120,26 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* plane, int addr, int t0, i
   return __builtin_bit_cast(bf16x8, r);
 }
 
-// D[r] = sum_c dO[r][c] * O[r][c] over the 32 columns of this head, for rows [0,nrows); rows beyond valid -> 0
+// D[r] = sum_c dO[r][c] * O[r][c] over the 32 columns of this head, for rows [0,nrows), nrows <= 256; rows beyond valid -> 0
 __device__ __forceinline__ void rowdot_head(float* sD, const float* dO, const float* O, int64_t row0, int ld, int nrows, int valid) {
-  for (int base = 0; base < nrows; base += 16 * WAVES) {
-    const int r = base + (threadIdx.x >> 2), part = threadIdx.x & 3;
-    float s = 0.f;
-    if (r < valid) {
-      const float* a = dO + (row0 + r) * ld + part * 8;
-      const float* b = O + (row0 + r) * ld + part * 8;
-      const f32x4 a0 = *reinterpret_cast<const f32x4*>(a), a1 = *reinterpret_cast<const f32x4*>(a + 4);
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(b), b1 = *reinterpret_cast<const f32x4*>(b + 4);
-      s = (a0[0] * b0[0] + a0[1] * b0[1]) + (a0[2] * b0[2] + a0[3] * b0[3]) +
-          (a1[0] * b1[0] + a1[1] * b1[1]) + (a1[2] * b1[2] + a1[3] * b1[3]);
-    }
+  const int part = threadIdx.x & 3;
+  f32x4 a0[2], a1[2], b0[2], b1[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int r = min(16 * WAVES * it + (int)(threadIdx.x >> 2), valid - 1);
+    const float* a = dO + (row0 + r) * ld + part * 8;
+    const float* b = O + (row0 + r) * ld + part * 8;
+    a0[it] = *reinterpret_cast<const f32x4*>(a); a1[it] = *reinterpret_cast<const f32x4*>(a + 4);
+    b0[it] = *reinterpret_cast<const f32x4*>(b); b1[it] = *reinterpret_cast<const f32x4*>(b + 4);
+  }
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int r = 16 * WAVES * it + (int)(threadIdx.x >> 2);
+    float s = (a0[it][0] * b0[it][0] + a0[it][1] * b0[it][1]) + (a0[it][2] * b0[it][2] + a0[it][3] * b0[it][3]) +
+              (a1[it][0] * b1[it][0] + a1[it][1] * b1[it][1]) + (a1[it][2] * b1[it][2] + a1[it][3] * b1[it][3]);
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
-    if (part == 0 && r < nrows) sD[r] = s;
+    if (part == 0 && r < nrows) sD[r] = r < valid ? s : 0.f;
   }
 }
 
@@ -144,10 +164,12 @@ __global__ __launch_bounds__(64 * WAVES) void attn_rx_fwd_kernel(AttnRxP p) {
 
   const int q = q0 + 16 * wave + i;
   const f32x8 qx = load8(p.qkv + (row0 + min(q, L - 1)) * ld3 + hd * 32 + 8 * g);   // in flight while K / V are staged
-  stage_rows(sKh, sKl, p.qkv + H + hd * 32, row0, ld3, LPE, L);
-  stage_rows(sVh, sVl, p.qkv + 2 * H + hd * 32, row0, ld3, LPE, L);
-  for (int k = threadIdx.x; k < LPE; k += 64 * WAVES)
-    sAdd[k] = (k < L) ? (1.0f - (float)p.mask[row0 + k]) * -1e9f : -INFINITY;
+  StagedRows st;
+  stage_fetch(st, p.qkv + H + hd * 32, ld3, p.qkv + 2 * H + hd * 32, ld3, row0, L);
+  const int kk = min((int)threadIdx.x, L - 1);   // LPE <= 256 < workgroup size
+  const float madd = (1.0f - (float)p.mask[row0 + kk]) * -1e9f;
+  stage_write(st, sKh, sKl, sVh, sVl, LPE, L);
+  if (threadIdx.x < LPE) sAdd[threadIdx.x] = (int)threadIdx.x < L ? madd : -INFINITY;
   bf16x8 qh, ql;
   split8(qx, qh, ql);
   __syncthreads();
@@ -242,11 +264,13 @@ __global__ __launch_bounds__(64 * WAVES) void attn_rx_dq_kernel(AttnRxP p) {
   const int qc = min(q, L - 1);
   const f32x8 qx = load8(p.qkv + (row0 + qc) * ld3 + hd * 32 + 8 * g);
   const f32x8 dox = load8(p.dctx + (row0 + qc) * H + hd * 32 + 8 * g);
-  stage_rows(sKh, sKl, p.qkv + H + hd * 32, row0, ld3, LPE, L);
-  stage_rows(sVh, sVl, p.qkv + 2 * H + hd * 32, row0, ld3, LPE, L);
+  StagedRows st;
+  stage_fetch(st, p.qkv + H + hd * 32, ld3, p.qkv + 2 * H + hd * 32, ld3, row0, L);
+  const int kk = min((int)threadIdx.x, L - 1);   // LPE <= 256 < workgroup size
+  const float madd = (1.0f - (float)p.mask[row0 + kk]) * -1e9f;
   rowdot_head(sD, p.dctx + hd * 32, p.ctx + hd * 32, row0 + q0, H, ROWS_WG, L - q0);
-  for (int k = threadIdx.x; k < LPE; k += 64 * WAVES)
-    sAdd[k] = (k < L) ? (1.0f - (float)p.mask[row0 + k]) * -1e9f : -INFINITY;
+  stage_write(st, sKh, sKl, sVh, sVl, LPE, L);
+  if (threadIdx.x < LPE) sAdd[threadIdx.x] = (int)threadIdx.x < L ? madd : -INFINITY;
   bf16x8 qh, ql, doh, dol;
   split8(qx, qh, ql);
   split8(dox, doh, dol);
@@ -323,11 +347,12 @@ __global__ __launch_bounds__(64 * WAVES) void attn_rx_dkv_kernel(AttnRxP p) {
   const int kc = min(key, L - 1);
   const f32x8 kx = load8(p.qkv + (row0 + kc) * ld3 + H + hd * 32 + 8 * g);
   const f32x8 vx = load8(p.qkv + (row0 + kc) * ld3 + 2 * H + hd * 32 + 8 * g);
-  stage_rows(sQh, sQl, p.qkv + hd * 32, row0, ld3, LPE, L);
-  stage_rows(sOh, sOl, p.dctx + hd * 32, row0, H, LPE, L);
+  StagedRows st;
+  stage_fetch(st, p.qkv + hd * 32, ld3, p.dctx + hd * 32, H, row0, L);
+  const float lse_k = p.lse_in[bh * L + min((int)threadIdx.x, L - 1)];   // LPE <= 256 < workgroup size
   rowdot_head(sD, p.dctx + hd * 32, p.ctx + hd * 32, row0, H, LPE, L);
-  for (int k = threadIdx.x; k < LPE; k += 64 * WAVES)
-    sLse[k] = (k < L) ? p.lse_in[bh * L + k] : INFINITY;   // +inf => probability 0 for pad queries
+  stage_write(st, sQh, sQl, sOh, sOl, LPE, L);
+  if (threadIdx.x < LPE) sLse[threadIdx.x] = (int)threadIdx.x < L ? lse_k : INFINITY;   // +inf => probability 0 for pad queries
   bf16x8 kh, kl, vh, vl;
   split8(kx, kh, kl);
   split8(vx, vh, vl);

@@ -535,8 +535,17 @@ extern "C" int b4r_gemm_f32(const b4r_gemm_desc* d, b4r_stream_t stream) {
 
 // C[M,N] = A.B with the K range split over `splits` workgroups per tile: partial products go to slabs in `scratch`
 // (>= splits*M*N floats) and are summed in a fixed order.  Used where M*N is small and K is long (dT = dlogits.E, K = V).
-int b4r_gemm_f32_splitk(const b4r_gemm_desc* d, int splits, float* scratch, hipStream_t stream) {
+bool b4r_gemm_rx_splitk_supported(const b4r_gemm_desc* d, int k_pad_ok);
+int b4r_gemm_rx_splitk_launch(const b4r_gemm_desc* d, int splits, float* slabs, int* slabs_used, hipStream_t stream);
+
+int b4r_gemm_f32_splitk(const b4r_gemm_desc* d, int splits, float* scratch, int k_pad_ok, hipStream_t stream) {
   B4R_CHECK_ARG(d && scratch && d->epilogue == B4R_EPI_NONE && !d->a_dropout, B4R_E_BADARG, "gemm_splitk: plain product only");
+  if (splits > 1 && g_gemm_mode == B4R_GEMM_BF16X3 && b4r_gemm_rx_splitk_supported(d, k_pad_ok)) {
+    int used = 0;
+    int rc = b4r_gemm_rx_splitk_launch(d, splits, scratch, &used, stream);
+    if (rc) return rc;
+    return b4r_launch_slab_reduce(scratch, used, d->M, d->N, d->C, d->ldc, 0, stream);
+  }
   if (splits <= 1) return b4r_gemm_f32(d, (b4r_stream_t)stream);
   GemmP p;
   p.A = d->A; p.B = d->B; p.C = scratch; p.bias = nullptr; p.C2 = nullptr; p.R = nullptr;

@@ -48,6 +48,8 @@ struct RxP {
   int M, N, K;
   int n_store;                    // columns that may be written: N rounded up to 4 (<= ldc; pad columns are scratch)
   int n_splits, steps_per_split;  // n-steps (32 columns each) per workgroup
+  int k_chunks_per_split;         // K-loop kernel: chunks of 64 per blockIdx.z (all of them when the grid has one z)
+  int64_t slab_stride;            // K-loop kernel with several z: partial products go to C + z * slab_stride
   float qscale; int qcols;
   DropArgs drop;
 };
@@ -295,7 +297,8 @@ __global__ __launch_bounds__(256) void rx_gemm_kloop_kernel(RxP p) {
   const int m0 = blockIdx.x * 128 + wave * 32;
   const int nb = blockIdx.y * (32 * NT);            // first column of this workgroup's pass over N
   const bool live = m0 < p.M;
-  const int nchunks = p.K / 64;
+  const int c_begin = blockIdx.z * p.k_chunks_per_split;
+  const int nchunks = min(p.K / 64, c_begin + p.k_chunks_per_split);   // end of this workgroup's chunk range
   DropCtx dctx = b4r_drop_ctx(p.drop);
   float* stage = s_lds + wave * (32 * ST_LD);
   char* bbuf = reinterpret_cast<char*>(s_lds + STAGE_FLOATS);
@@ -340,12 +343,12 @@ __global__ __launch_bounds__(256) void rx_gemm_kloop_kernel(RxP p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
 
-  fetch_a(0);
-  fetch_b(0);
-  stash_b(0);
+  fetch_a(c_begin);
+  fetch_b(c_begin);
+  stash_b(c_begin & 1);
   if (B_NK) __syncthreads();
 
-  for (int c = 0; c < nchunks; ++c) {
+  for (int c = c_begin; c < nchunks; ++c) {
     bf16x8 ah[4], al[4];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
@@ -382,9 +385,11 @@ __global__ __launch_bounds__(256) void rx_gemm_kloop_kernel(RxP p) {
     }
   }
   if (live) {
+    RxP q = p;
+    q.C = p.C + (int64_t)blockIdx.z * p.slab_stride;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      if (nb + 32 * j < p.N) epilogue_tile<EPI>(p, dctx, acc[j], load_bias4<EPI>(p, nb + 32 * j, c4), stage, m0, nb + 32 * j, lane);
+      if (nb + 32 * j < p.N) epilogue_tile<EPI>(q, dctx, acc[j], load_bias4<EPI>(p, nb + 32 * j, c4), stage, m0, nb + 32 * j, lane);
     }
   }
 }
@@ -392,7 +397,8 @@ __global__ __launch_bounds__(256) void rx_gemm_kloop_kernel(RxP p) {
 template <bool B_NK, int EPI, bool A_DROP>
 void launch_kloop(const RxP& p, hipStream_t s) {
   const int nt = b4r_cdiv(p.N, 32);
-  dim3 grid((unsigned)b4r_cdiv(p.M, 128), (unsigned)(nt <= 2 ? 1 : b4r_cdiv(nt, 4)));
+  dim3 grid((unsigned)b4r_cdiv(p.M, 128), (unsigned)(nt <= 2 ? 1 : b4r_cdiv(nt, 4)),
+            (unsigned)b4r_cdiv(p.K / 64, p.k_chunks_per_split));
   if (nt <= 2) {
     const size_t lds = STAGE_FLOATS * sizeof(float) + (B_NK ? 2 * 2 * 2 * 32 * 36 * 4 : 0);
     hipLaunchKernelGGL((rx_gemm_kloop_kernel<B_NK, EPI, A_DROP, 2>), grid, dim3(256), lds, s, p);
@@ -611,6 +617,7 @@ int b4r_gemm_rx_launch(const b4r_gemm_desc* d, hipStream_t stream) {
   p.n_store = up4i(d->N);
   p.qscale = d->qscale; p.qcols = d->qcols;
   p.drop = b4r_make_drop(d->rng, d->drop_stream, d->drop_rate, 1);
+  p.k_chunks_per_split = d->K / 64 > 0 ? d->K / 64 : 1; p.slab_stride = 0;
   const bool a_drop = d->a_dropout && p.drop.rng != nullptr;
   const int mblocks = b4r_cdiv(d->M, 128);
   const int total_steps = b4r_cdiv(d->N, 32);
@@ -628,6 +635,33 @@ int b4r_gemm_rx_launch(const b4r_gemm_desc* d, hipStream_t stream) {
                       : dispatch_rx<false>(p, d->epilogue, a_drop, grid, stream);
   if (rc != B4R_OK) return rc;
   B4R_CHECK_LAUNCH("b4r_gemm_f32 (bf16x3)");
+  return B4R_OK;
+}
+
+// plain product C = A.B with B as [K,N], N <= 128, reduced over `splits` ranges of K into slabs (the caller reduces them).
+// k_pad_ok: the caller guarantees that columns [K, roundup(K,64)) of A are readable zeros and rows [K, roundup(K,64)) of B
+// are readable finite values, so the reduction runs over whole chunks of 64.
+bool b4r_gemm_rx_splitk_supported(const b4r_gemm_desc* d, int k_pad_ok) {
+  const int Kp = (d->K + 63) & ~63;
+  if (d->b_is_nk || d->epilogue != B4R_EPI_NONE || d->a_dropout) return false;
+  if (Kp <= 64 || (Kp != d->K && (!k_pad_ok || d->lda < Kp))) return false;
+  if (d->M % 32 != 0 || d->N % 4 != 0 || d->N > 128) return false;
+  return vec_ok(d->A, d->lda) && d->B != nullptr;
+}
+
+int b4r_gemm_rx_splitk_launch(const b4r_gemm_desc* d, int splits, float* slabs, int* slabs_used, hipStream_t stream) {
+  RxP p{};
+  p.A = d->A; p.B = d->B; p.C = slabs; p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->N;
+  p.M = d->M; p.N = d->N; p.K = (d->K + 63) & ~63;
+  p.n_store = d->N;
+  p.qscale = 1.f;
+  p.drop = b4r_make_drop(nullptr, 0, 0.f, 0);
+  const int chunks = p.K / 64;
+  p.k_chunks_per_split = b4r_cdiv(chunks, splits < 1 ? 1 : splits);
+  p.slab_stride = (int64_t)d->M * d->N;
+  *slabs_used = b4r_cdiv(chunks, p.k_chunks_per_split);
+  launch_kloop<false, B4R_EPI_NONE, false>(p, stream);
+  B4R_CHECK_LAUNCH("gemm_splitk (bf16x3)");
   return B4R_OK;
 }
 

@@ -23,7 +23,7 @@ int b4r_scatter_add_rows_impl(const float* src, const int64_t* idx, int64_t idx_
                               hipStream_t stream);
 int b4r_batch_colsum(const float* x, int B, int L, int H, float* dpos, float* scratch, hipStream_t stream);
 int b4r_mul_gelu_grad(float* du, const float* pre, int64_t n, hipStream_t stream);
-int b4r_gemm_f32_splitk(const b4r_gemm_desc* d, int splits, float* scratch, hipStream_t stream);
+int b4r_gemm_f32_splitk(const b4r_gemm_desc* d, int splits, float* scratch, int k_pad_ok, hipStream_t stream);
 
 // ---- error message (thread local) ---------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -412,7 +412,10 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
     b4r_gemm_desc d{};
     d.A = dlog; d.lda = Vp; d.B = params + pl.word_emb; d.ldb = H; d.C = ws + w.dt; d.ldc = H;
     d.M = M; d.N = H; d.K = V; d.b_is_nk = 0; d.epilogue = B4R_EPI_NONE;
-    RC(b4r_gemm_f32_splitk(&d, mlm_dt_splits(M, H, V), take((int64_t)mlm_dt_splits(M, H, V) * M * H), s));
+    // the loss kernel zeroed columns [V, Vp) of dlogits, and the table is followed by the position table in the flat
+    // parameter buffer, so the reduction may run over whole chunks of 64 (rows V..Vp-1 of "E" meet zeros)
+    const int k_pad_ok = (pl.word_emb + (int64_t)Vp * H <= pl.total) ? 1 : 0;
+    RC(b4r_gemm_f32_splitk(&d, mlm_dt_splits(M, H, V), take((int64_t)mlm_dt_splits(M, H, V) * M * H), k_pad_ok, s));
   }
   // dE = dlogits^T . T ; d output_bias = column sums of dlogits
   RC(gemm_tn(dlog, Vp, ws + w.t, H, grads + pl.word_emb, H, M, V, H, nullptr, grads + pl.out_bias, nullptr, 0, 0.f, 0,

@@ -133,15 +133,16 @@ __global__ __launch_bounds__(64 * WAVES) void attn_fwd_kernel(AttnP p) {
   if (g == 0 && q < L && p.lse_out) p.lse_out[((int64_t)b * p.heads + hd) * L + q] = m + __logf(sum);
 
   DropCtx dctx = b4r_drop_ctx(p.drop);
-  const uint64_t dbase = (((uint64_t)b * p.heads + hd) * L + (uint64_t)(q < L ? q : 0)) * (uint64_t)L;
+  const uint64_t dbase = (((uint64_t)b * p.heads + hd) * L + (uint64_t)(q < L ? q : 0)) * (uint64_t)B4R_ATTN_PITCH;
   f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < KT; ++t) {
+    const uint32_t k4 = dctx.on ? b4r_keep4(dctx, dbase + (uint64_t)(16 * t + 4 * g)) : 15u;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int key = 16 * t + 4 * g + s;
       float pv = acc[t][s] * inv;
-      if (dctx.on) pv = b4r_keep(dctx, dbase + (uint64_t)key) ? pv * dctx.scale : 0.f;
+      if (dctx.on) pv = ((k4 >> s) & 1u) ? pv * dctx.scale : 0.f;
       o0 = mfma16(sV[tile_idx(key, i)], pv, o0);
       o1 = mfma16(sV[tile_idx(key, 16 + i)], pv, o1);
     }
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_dq_kernel(AttnP p) {
   const bool qlive = q < L;
   const float lse = qlive ? p.lse_in[((int64_t)b * p.heads + hd) * L + q] : 0.f;
   DropCtx dctx = b4r_drop_ctx(p.drop);
-  const uint64_t dbase = (((uint64_t)b * p.heads + hd) * L + (uint64_t)(qlive ? q : 0)) * (uint64_t)L;
+  const uint64_t dbase = (((uint64_t)b * p.heads + hd) * L + (uint64_t)(qlive ? q : 0)) * (uint64_t)B4R_ATTN_PITCH;
 
   f32x4 dq0 = {0.f, 0.f, 0.f, 0.f}, dq1 = {0.f, 0.f, 0.f, 0.f};
   for (int t = 0; t < KT; ++t) {
@@ -204,12 +205,13 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_dq_kernel(AttnP p) {
       da = mfma16(sV[tile_idx(16 * t + i, 4 * s + g)], dof[s], da);
     }
     const f32x4 ad = *reinterpret_cast<const f32x4*>(&sAdd[16 * t + 4 * g]);
+    const uint32_t k4 = dctx.on ? b4r_keep4(dctx, dbase + (uint64_t)(16 * t + 4 * g)) : 15u;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int key = 16 * t + 4 * g + s;
       const float pr = __expf(sc[s] + ad[s] - lse);
       float dA = da[s];
-      if (dctx.on) dA = b4r_keep(dctx, dbase + (uint64_t)key) ? dA * dctx.scale : 0.f;
+      if (dctx.on) dA = ((k4 >> s) & 1u) ? dA * dctx.scale : 0.f;
       const float ds = pr * (dA - Dq);
       dq0 = mfma16(sK[tile_idx(key, i)], ds, dq0);
       dq1 = mfma16(sK[tile_idx(key, 16 + i)], ds, dq1);
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_dkv_kernel(AttnP p) {
       const float pr = __expf(sc[s] + add - ls[s]);
       float ad = pr, dA = da[s];
       if (dctx.on) {
-        const bool keep = b4r_keep(dctx, (hbase + (uint64_t)(qq < L ? qq : 0)) * (uint64_t)L + (uint64_t)(klive ? key : 0));
+        const bool keep = b4r_keep(dctx, (hbase + (uint64_t)(qq < L ? qq : 0)) * (uint64_t)B4R_ATTN_PITCH + (uint64_t)(klive ? key : 0));
         ad = keep ? pr * dctx.scale : 0.f;
         dA = keep ? dA * dctx.scale : 0.f;
       }

@@ -205,16 +205,14 @@ __global__ __launch_bounds__(64 * WAVES) void attn_rx_fwd_kernel(AttnRxP p) {
 
   const DropCtx dctx = b4r_drop_ctx(p.drop);
   if (dctx.on) {
-    const uint64_t dbase = ((uint64_t)bh * L + (uint64_t)(q < L ? q : 0)) * (uint64_t)L;
+    const uint64_t dbase = ((uint64_t)bh * L + (uint64_t)(q < L ? q : 0)) * (uint64_t)B4R_ATTN_PITCH;
     uint32_t w[2] = {0u, 0u};
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
+      const uint32_t k4 = b4r_keep4(dctx, dbase + (uint64_t)(16 * t + 4 * g));   // one hash for the lane's 4 keys
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const bool keep = b4r_keep(dctx, dbase + (uint64_t)(16 * t + 4 * g + s));
-        acc[t][s] = keep ? acc[t][s] * (inv * dctx.scale) : 0.f;
-        w[t >> 3] |= (keep ? 1u : 0u) << (4 * (t & 7) + s);
-      }
+      for (int s = 0; s < 4; ++s) acc[t][s] = ((k4 >> s) & 1u) ? acc[t][s] * (inv * dctx.scale) : 0.f;
+      w[t >> 3] |= k4 << (4 * (t & 7));
     }
     uint32_t* wo = p.bits_out + ((bh * p.KT + (q0 >> 4) + wave) * 2) * 64 + lane;
     wo[0] = w[0];

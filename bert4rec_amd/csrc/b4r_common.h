@@ -60,11 +60,18 @@ bool b4r_reduce_queue_push(const B4rReduceJob& job);             // false: no qu
 // ---------------------------------------------------------------------------------------------
 // counter-hash dropout.  keep(idx) is a pure function of (seed, step, stream, idx) so forward and backward
 // regenerate the same mask without storing it.  Restated in oracle/bert4rec_oracle.py::dropout_keep_mask.
+// One 2-round integer hash serves the GROUP of 4 consecutive elements idx>>2: the hash and one xorshift32 step of it give
+// four 16-bit uniforms (v_mul_lo_u32 is a quarter-rate instruction and the hash was the dominant VALU cost of the
+// attention kernels).  The drop probability is floor(rate * 65536) / 65536.  Element indices are laid out so that the 4
+// elements a lane holds are one group: row-major [rows, N] tensors with N % 4 == 0, and attention probabilities indexed
+// ((b*heads + h) * L + query) * 256 + key (B4R_ATTN_PITCH).
 // ---------------------------------------------------------------------------------------------
+constexpr int B4R_ATTN_PITCH = 256;
+
 struct DropArgs {
   const uint32_t* rng;  // device: rng[0] = seed, rng[1] = step (low 32 bits); nullptr => dropout disabled
   uint32_t stream;      // dropout site id (B4R_STREAM_*)
-  uint32_t thr;         // drop if hash < thr;  thr = (uint32)(rate * 2^32)
+  uint32_t thr;         // drop if u16 < thr;  thr = (uint32)(rate * 2^16)
   float scale;          // 1 / (1 - rate)
 };
 
@@ -73,7 +80,7 @@ static inline DropArgs b4r_make_drop(const uint32_t* rng, uint32_t stream, float
   d.rng = nullptr; d.stream = stream; d.thr = 0; d.scale = 1.0f;
   if (training && rate > 0.0f && rng != nullptr) {
     d.rng = rng;
-    d.thr = (uint32_t)((double)rate * 4294967296.0);
+    d.thr = (uint32_t)((double)rate * 65536.0);
     d.scale = 1.0f / (1.0f - rate);
   }
   return d;
@@ -101,17 +108,51 @@ __device__ __forceinline__ DropCtx b4r_drop_ctx(const DropArgs& a) {
   return c;
 }
 
-__device__ __forceinline__ bool b4r_keep(const DropCtx& c, uint64_t idx) {
-  uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+// the two 32-bit words of group g: uniforms of elements 4g+0 / 4g+1 are the low / high half of h1, 4g+2 / 4g+3 of h2
+__device__ __forceinline__ void b4r_group_hash(const DropCtx& c, uint64_t g, uint32_t& h1, uint32_t& h2) {
+  const uint32_t lo = (uint32_t)g, hi = (uint32_t)(g >> 32);
   uint32_t h = b4r_hash32(lo ^ c.seed);
-  h = b4r_hash32((h ^ (hi * 0x85EBCA6Bu)) + c.key);
-  return h >= c.thr;
+  h = b4r_hash32((h ^ hi) + c.key);
+  h1 = h;
+  h ^= h << 13; h ^= h >> 17; h ^= h << 5;
+  h2 = h;
+}
+
+// bit e of the result = keep(idx4 + e); idx4 must be a multiple of 4
+__device__ __forceinline__ uint32_t b4r_keep4(const DropCtx& c, uint64_t idx4) {
+  uint32_t h1, h2;
+  b4r_group_hash(c, idx4 >> 2, h1, h2);
+  return ((h1 & 0xFFFFu) >= c.thr ? 1u : 0u) | ((h1 >> 16) >= c.thr ? 2u : 0u) |
+         ((h2 & 0xFFFFu) >= c.thr ? 4u : 0u) | ((h2 >> 16) >= c.thr ? 8u : 0u);
+}
+
+__device__ __forceinline__ bool b4r_keep(const DropCtx& c, uint64_t idx) {
+  uint32_t h1, h2;
+  b4r_group_hash(c, idx >> 2, h1, h2);
+  const uint32_t w = (idx & 2) ? h2 : h1;
+  const uint32_t u = (idx & 1) ? (w >> 16) : (w & 0xFFFFu);
+  return u >= c.thr;
 }
 
 // x -> dropout(x)
 __device__ __forceinline__ float b4r_drop(const DropCtx& c, float x, uint64_t idx) {
   if (!c.on) return x;
   return b4r_keep(c, idx) ? x * c.scale : 0.0f;
+}
+
+// 4 consecutive elements idx .. idx+3 of one row.  One hash when they are one group (idx % 4 == 0, which holds at every
+// call site whenever the row length is a multiple of 4), the per-element path otherwise; same decisions either way.
+__device__ __forceinline__ f32x4 b4r_drop4(const DropCtx& c, f32x4 x, uint64_t idx) {
+  if (!c.on) return x;
+  if ((idx & 3) == 0) {
+    const uint32_t k = b4r_keep4(c, idx);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = ((k >> e) & 1u) ? x[e] * c.scale : 0.0f;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = b4r_keep(c, idx + e) ? x[e] * c.scale : 0.0f;
+  }
+  return x;
 }
 
 // ---------------------------------------------------------------------------------------------

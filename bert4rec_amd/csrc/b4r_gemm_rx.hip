@@ -79,6 +79,13 @@ __device__ __forceinline__ f32x8 load8_strided(const float* ptr, int ld) {
   return x;
 }
 
+// 8 consecutive elements of one row (two hash groups when idx % 4 == 0)
+__device__ __forceinline__ f32x8 drop8(const DropCtx& c, const f32x8 x, uint64_t idx) {
+  const f32x4 a = b4r_drop4(c, (f32x4){x[0], x[1], x[2], x[3]}, idx);
+  const f32x4 b = b4r_drop4(c, (f32x4){x[4], x[5], x[6], x[7]}, idx + 4);
+  return (f32x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+
 constexpr bool epi_has_bias(int e) {
   return e == B4R_EPI_BIAS || e == B4R_EPI_BIAS_QSCALE || e == B4R_EPI_BIAS_GELU || e == B4R_EPI_BIAS_DROP_RES ||
          e == B4R_EPI_BIAS_TANH;
@@ -92,10 +99,7 @@ __device__ __forceinline__ void load_a_strip(const RxP& p, const DropCtx& dctx, 
 #pragma unroll
   for (int kb = 0; kb < NKB; ++kb) {
     f32x8 x = load8_contig(arow + 16 * kb);
-    if (A_DROP) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) x[j] = b4r_drop(dctx, x[j], (uint64_t)row * (uint64_t)p.K + (uint64_t)(16 * kb + 8 * h + j));
-    }
+    if (A_DROP) x = drop8(dctx, x, (uint64_t)row * (uint64_t)p.K + (uint64_t)(16 * kb + 8 * h));
     split8(x, ah[kb], al[kb]);
   }
 }
@@ -132,7 +136,8 @@ __device__ __forceinline__ void epilogue_tile(const RxP& p, const DropCtx& dctx,
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = m0 + rsub + 8 * i;
-    f32x4 o, o2 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 o, o2 = {0.f, 0.f, 0.f, 0.f}, dz = {0.f, 0.f, 0.f, 0.f};
+    if (EPI == B4R_EPI_BIAS_DROP_RES) dz = b4r_drop4(dctx, vin[i] + bv, (uint64_t)row * (uint64_t)p.N + (uint64_t)col);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float a = vin[i][e];
@@ -141,8 +146,7 @@ __device__ __forceinline__ void epilogue_tile(const RxP& p, const DropCtx& dctx,
       else if (EPI == B4R_EPI_BIAS) y = a + bv[e];
       else if (EPI == B4R_EPI_BIAS_QSCALE) y = (a + bv[e]) * ((col + e < p.qcols) ? p.qscale : 1.0f);
       else if (EPI == B4R_EPI_BIAS_GELU) { o2[e] = a + bv[e]; y = b4r_gelu_fast(o2[e]); }
-      else if (EPI == B4R_EPI_BIAS_DROP_RES)
-        y = rr[i][e] + b4r_drop(dctx, a + bv[e], (uint64_t)row * (uint64_t)p.N + (uint64_t)(col + e));
+      else if (EPI == B4R_EPI_BIAS_DROP_RES) y = rr[i][e] + dz[e];
       else if (EPI == B4R_EPI_GELU_BWD) y = a * b4r_gelu_grad_fast(rr[i][e]);
       else if (EPI == B4R_EPI_ADD_RES) y = a + rr[i][e];
       else y = tanhf(a + bv[e]);
@@ -353,10 +357,7 @@ __global__ __launch_bounds__(256) void rx_gemm_kloop_kernel(RxP p) {
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
       f32x8 x = araw[kb];
-      if (A_DROP) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = b4r_drop(dctx, x[j], (uint64_t)arow * (uint64_t)p.K + (uint64_t)(64 * c + 16 * kb + 8 * h + j));
-      }
+      if (A_DROP) x = drop8(dctx, x, (uint64_t)arow * (uint64_t)p.K + (uint64_t)(64 * c + 16 * kb + 8 * h));
       split8(x, ah[kb], al[kb]);
     }
     const int cn = min(c + 1, nchunks - 1);   // unconditional look-ahead (the last chunk re-requests itself)
@@ -511,8 +512,8 @@ __global__ __launch_bounds__(256) void rx_gemm_tn_kernel(RxTnP p) {
       for (int e = 0; e < 4; ++e) {
         va[e] = live ? va[e] : 0.f;
         vb[e] = live ? vb[e] : 0.f;
-        if (B_DROP) vb[e] = b4r_drop(dctx, vb[e], (uint64_t)row * (uint64_t)p.No + (uint64_t)(cb + e));
       }
+      if (B_DROP) vb = b4r_drop4(dctx, vb, (uint64_t)row * (uint64_t)p.No + (uint64_t)cb);
       cs += vb;
       csa += va;
       const int off = tn_img_off(lrow, c4);

@@ -84,10 +84,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdP p) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float inv = rstd * g[e];
-      float yv = x[v][e] * inv + (b[e] - mean * inv);
-      yv = b4r_drop(dctx, yv, (uint64_t)row * (uint64_t)p.H + (uint64_t)(c + e));
-      o[e] = yv;
+      o[e] = x[v][e] * inv + (b[e] - mean * inv);
     }
+    o = b4r_drop4(dctx, o, (uint64_t)row * (uint64_t)p.H + (uint64_t)c);
     *reinterpret_cast<f32x4*>(p.y + row * p.H + c) = o;
   }
   if (sub == 0) {
@@ -148,10 +147,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdP p) {
       } else {
         zz = *reinterpret_cast<const f32x4*>(p.z + rr * p.H + c);
       }
+      if (EMBED) d = b4r_drop4(dctx, d, (uint64_t)rr * (uint64_t)p.H + (uint64_t)c);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float de = d[e];
-        if (EMBED) de = b4r_drop(dctx, de, (uint64_t)rr * (uint64_t)p.H + (uint64_t)(c + e));
         if (!live) de = 0.f;
         const float xhat = (zz[e] - mean) * rstd;
         const float g = de * g4[v][e];

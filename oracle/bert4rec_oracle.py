@@ -168,23 +168,43 @@ def _hash32_int(x: int) -> int:
     return x
 
 
-def dropout_keep_mask(numel_shape: Sequence[int], rate: float, seed: int, step: int, stream: int) -> torch.Tensor:
-    """keep[idx] for idx = flat row-major index of a tensor of ``numel_shape`` (DESIGN.md 'dropout')."""
-    n = int(np.prod(numel_shape))
-    idx = torch.arange(n, dtype=torch.int64)
-    lo, hi = idx & _M32, idx >> 32
+ATTN_PITCH = 256   # B4R_ATTN_PITCH: attention-probability rows are indexed with this pitch so that they start a hash group
+
+
+def dropout_keep_mask(numel_shape: Sequence[int], rate: float, seed: int, step: int, stream: int,
+                      row_pitch: Optional[int] = None) -> torch.Tensor:
+    """keep[idx] (DESIGN.md 'dropout').  idx is the flat row-major index of a tensor of ``numel_shape`` or, with
+    ``row_pitch``, (flat index of the leading dims) * row_pitch + last index (attention probabilities: ATTN_PITCH).
+    One 2-round hash per group of 4 consecutive indices; it and one xorshift32 step of it hold four 16-bit uniforms."""
+    shape = tuple(int(s) for s in numel_shape)
+    n = int(np.prod(shape))
+    flat = torch.arange(n, dtype=torch.int64)
+    if row_pitch is None:
+        idx = flat
+    else:
+        last = shape[-1]
+        assert last <= row_pitch
+        idx = (flat // last) * row_pitch + (flat % last)
+    grp, e = idx >> 2, idx & 3
+    lo, hi = grp & _M32, grp >> 32
     key = _hash32_int((stream * 0x9E3779B9 + step) & _M32)
-    h = _hash32(lo ^ (seed & _M32))
-    h = _hash32(((h ^ ((hi * 0x85EBCA6B) & _M32)) + key) & _M32)
-    thr = int(rate * 4294967296.0)
-    return (h >= thr).reshape(tuple(numel_shape))
+    h1 = _hash32(lo ^ (seed & _M32))
+    h1 = _hash32(((h1 ^ hi) + key) & _M32)
+    h2 = h1 ^ ((h1 << 13) & _M32)
+    h2 = h2 ^ (h2 >> 17)
+    h2 = h2 ^ ((h2 << 5) & _M32)
+    w = torch.where(e >= 2, h2, h1)
+    u = torch.where((e & 1) == 1, w >> 16, w & 0xFFFF)
+    thr = int(rate * 65536.0)
+    return (u >= thr).reshape(shape)
 
 
-def _dropout(x: torch.Tensor, rate: float, training: bool, rng: Optional[Tuple[int, int]], stream: int) -> torch.Tensor:
+def _dropout(x: torch.Tensor, rate: float, training: bool, rng: Optional[Tuple[int, int]], stream: int,
+             row_pitch: Optional[int] = None) -> torch.Tensor:
     if not training or rate <= 0.0:
         return x
     assert rng is not None, "training with dropout needs rng=(seed, step)"
-    keep = dropout_keep_mask(x.shape, rate, rng[0], rng[1], stream)
+    keep = dropout_keep_mask(x.shape, rate, rng[0], rng[1], stream, row_pitch)
     scale = torch.tensor(1.0 / (1.0 - rate), dtype=torch.float32)
     return torch.where(keep, x * scale, torch.zeros((), dtype=x.dtype))
 
@@ -241,7 +261,7 @@ def encoder_forward(params: Dict[str, torch.Tensor], input_word_ids: torch.Tenso
         q = q * torch.tensor(1.0 / math.sqrt(float(d)), dtype=torch.float32)
         s = torch.einsum("bqhd,bkhd->bhqk", q, k) + adder
         a = torch.softmax(s, dim=-1)
-        a = _dropout(a, cfg.attention_dropout, training, rng, stream_attn_probs(i))
+        a = _dropout(a, cfg.attention_dropout, training, rng, stream_attn_probs(i), ATTN_PITCH)
         ctx = torch.einsum("bhqk,bkhd->bqhd", a, v)
         y = torch.einsum("bqhd,hdH->bqH", ctx, params[f"{p}/self_attention/attention_output/kernel"]) \
             + params[f"{p}/self_attention/attention_output/bias"]

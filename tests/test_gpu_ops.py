@@ -199,7 +199,7 @@ def test_attention_fwd_bwd(B, L, heads, rate):
         mask[1, 0] = 0  # an interior hole: the mask is per key, not a length
     dctx = rnd(B * L, H, seed=23)
     x = qkv.double().view(B, L, 3, heads, d).clone().requires_grad_(True)
-    keep = orc.dropout_keep_mask((B, heads, L, L), rate, seed, step, sid) if rate > 0 else None
+    keep = orc.dropout_keep_mask((B, heads, L, L), rate, seed, step, sid, orc.ATTN_PITCH) if rate > 0 else None
     ctx_ref = attention_reference(x[:, :, 0], x[:, :, 1], x[:, :, 2], mask, rate, keep)
     ctx_ref.backward(dctx.double().view(B, L, heads, d))
     st = T.new_state(seed, step)

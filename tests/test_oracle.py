@@ -236,3 +236,21 @@ def test_dropout_hash_statistics_and_determinism():
     assert torch.equal(k1, k2) and abs(float(k1.float().mean()) - 0.8) < 0.005
     assert not torch.equal(k1, orc.dropout_keep_mask((200000,), 0.2, 1234, 6, 3))      # new step, new mask
     assert not torch.equal(k1, orc.dropout_keep_mask((200000,), 0.2, 1234, 5, 7))      # other site, other mask
+
+
+def test_dropout_group_fields_are_unbiased_and_uncorrelated():
+    """one hash serves 4 consecutive elements (two halves of the hash and of one xorshift32 step of it): every field must
+    keep with probability 1 - rate, fields must not be correlated with each other, nor with the neighbouring group, nor
+    with the same element of the next step; the attention pitch only changes which index an element has"""
+    n, rate = 400000, 0.2
+    k = orc.dropout_keep_mask((n,), rate, 99, 7, 5).float().view(-1, 4)
+    sigma = (rate * (1 - rate) / (n / 4)) ** 0.5
+    assert float((k.mean(0) - (1 - rate)).abs().max()) < 4.5 * sigma
+    c = torch.corrcoef(torch.cat([k[:-1], k[1:]], dim=1).T)          # 8 x 8: fields of a group and of its neighbour
+    off = c - torch.eye(8)
+    assert float(off.abs().max()) < 0.02
+    nxt = orc.dropout_keep_mask((n,), rate, 99, 8, 5).float().view(-1, 4)
+    assert abs(float(torch.corrcoef(torch.stack([k.flatten(), nxt.flatten()]))[0, 1])) < 0.01
+    a = orc.dropout_keep_mask((3, 2, 10, 10), rate, 1, 2, 3, row_pitch=orc.ATTN_PITCH)
+    flat = orc.dropout_keep_mask((3 * 2 * 10 * orc.ATTN_PITCH,), rate, 1, 2, 3).view(3, 2, 10, orc.ATTN_PITCH)
+    assert torch.equal(a, flat[..., :10])

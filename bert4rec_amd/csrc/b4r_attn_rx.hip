@@ -10,6 +10,8 @@
 //     for the products that sum over the head dimension, and a transposed fragment (one column of 4 consecutive rows per
 //     lane, ds_read_b64_tr_b16) for the products that consume an accumulator tile.  The 16-byte chunk index of a row is
 //     XORed with (-(row>>2))&3, which makes both reads bank-conflict free without padding (MI355X_MICROARCH.md, LDS).
+//     The four images of a kernel are interleaved per 16-row tile ([tile][image][16 rows]) so that an image is a
+//     compile-time offset and every LDS address of a loop iteration is one lane constant + one tile offset + immediate.
 //   * a 16x16x32 product that consumes accumulator tiles takes TWO of them per instruction: k-slot (g, j) is row
 //     16*t0 + 4g + j of tile t0 for j < 4 and row 16*t1 + 4g + (j-4) of tile t1 for j >= 4, on both operands.
 //   * the forward kernel stores the dropout decisions it hashed as bits (4 per lane and key tile); the two backward
@@ -28,7 +30,8 @@ namespace {
 
 constexpr int WAVES = 8;              // waves per workgroup
 constexpr int ROWS_WG = 16 * WAVES;   // queries (keys) per workgroup
-constexpr int TILE_BYTES = 16 * 64;   // 16 image rows
+constexpr int IMG_BYTES = 16 * 64;       // 16 rows of one image
+constexpr int TILE_BYTES = 4 * IMG_BYTES;  // one 16-row tile of the four interleaved images
 
 struct AttnRxP {
   const float* qkv; const int64_t* mask; const float* ctx; const float* lse_in; const float* dctx;
@@ -49,10 +52,7 @@ __device__ __forceinline__ f32x4 mfma3(const bf16x8 ah, const bf16x8 al, const b
   c = mfma_bf(ah, bh, c);
   return c;
 }
-__device__ __forceinline__ void split8(const f32x8 x, bf16x8& hi, bf16x8& lo) {
-  hi = __builtin_convertvector(x, bf16x8);
-  lo = __builtin_convertvector(x - __builtin_convertvector(hi, f32x8), bf16x8);
-}
+__device__ __forceinline__ void split8(const f32x8 x, bf16x8& hi, bf16x8& lo) { b4r_split8(x, hi, lo); }
 __device__ __forceinline__ f32x8 load8(const float* ptr) {
   const f32x4 a = *reinterpret_cast<const f32x4*>(ptr);
   const f32x4 b = *reinterpret_cast<const f32x4*>(ptr + 4);
@@ -62,8 +62,10 @@ __device__ __forceinline__ f32x8 cat(const f32x4 a, const f32x4 b) {
   return (f32x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
 
-// byte offset of 16-byte chunk `ch` (0..3) of row `row` in a [rows][32 bf16] image
-__device__ __forceinline__ int img_off(int row, int ch) { return row * 64 + 16 * (ch ^ ((0 - (row >> 2)) & 3)); }
+// byte offset of 16-byte chunk `ch` (0..3) of row `row` of image 0; image k of the same tile is IMG_BYTES * k further
+__device__ __forceinline__ int img_off(int row, int ch) {
+  return (row >> 4) * TILE_BYTES + (row & 15) * 64 + 16 * (ch ^ ((0 - (row >> 2)) & 3));
+}
 
 // rows [0,nrows) of two [*,32] fp32 head slices -> their bf16 hi / lo images; rows beyond `valid` are zero.  All loads are
 // issued before the first conversion (clamped addresses, no guard: a guarded load costs a branch and a full vmcnt(0) round
@@ -78,19 +80,22 @@ __device__ __forceinline__ void stage_fetch(StagedRows& st, const float* src0, i
     st.v1[it] = *reinterpret_cast<const f32x4*>(src1 + (row0 + r) * ld1 + 4 * c4);
   }
 }
-__device__ __forceinline__ void stage_write(const StagedRows& st, char* hi0, char* lo0, char* hi1, char* lo1, int nrows, int valid) {
+// images: tensor 0 -> (0 = hi, 1 = lo), tensor 1 -> (2 = hi, 3 = lo)
+__device__ __forceinline__ void stage_write(const StagedRows& st, char* img, int nrows, int valid) {
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int f = threadIdx.x + 64 * WAVES * it, r = f >> 3, c4 = f & 7;
     if (f < nrows * 8) {
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
       const f32x4 a = r < valid ? st.v0[it] : z, b = r < valid ? st.v1[it] : z;
-      const bf16x4 ah = __builtin_convertvector(a, bf16x4), bh = __builtin_convertvector(b, bf16x4);
-      const int off = img_off(r, c4 >> 1) + 8 * (c4 & 1);
-      *reinterpret_cast<bf16x4*>(hi0 + off) = ah;
-      *reinterpret_cast<bf16x4*>(lo0 + off) = __builtin_convertvector(a - __builtin_convertvector(ah, f32x4), bf16x4);
-      *reinterpret_cast<bf16x4*>(hi1 + off) = bh;
-      *reinterpret_cast<bf16x4*>(lo1 + off) = __builtin_convertvector(b - __builtin_convertvector(bh, f32x4), bf16x4);
+      bf16x4 ah, al, bh, bl;
+      b4r_split4(a, ah, al);
+      b4r_split4(b, bh, bl);
+      char* dst = img + img_off(r, c4 >> 1) + 8 * (c4 & 1);
+      *reinterpret_cast<bf16x4*>(dst) = ah;
+      *reinterpret_cast<bf16x4*>(dst + IMG_BYTES) = al;
+      *reinterpret_cast<bf16x4*>(dst + 2 * IMG_BYTES) = bh;
+      *reinterpret_cast<bf16x4*>(dst + 3 * IMG_BYTES) = bl;
     }
   }
 }
@@ -108,14 +113,17 @@ __device__ __forceinline__ FragAddr frag_addr(int lane) {
   for (int db = 0; db < 2; ++db) a.tr[db] = img_off(4 * g + qq, 2 * db + (pp >> 1)) + 8 * (pp & 1);
   return a;
 }
-__device__ __forceinline__ bf16x8 row_frag(const char* plane, int addr, int t) {
-  return *reinterpret_cast<const bf16x8*>(plane + addr + TILE_BYTES * t);
+// `tile` = image base + lane constant + TILE_BYTES * t, computed once per tile by the caller; IMG = image index
+template <int IMG>
+__device__ __forceinline__ bf16x8 row_frag(const char* tile) {
+  return *reinterpret_cast<const bf16x8*>(tile + IMG * IMG_BYTES);
 }
-// element j < 4: image[16*t0 + 4g + j][16*db + (lane&15)], element j >= 4: the same of tile t1
-__device__ __forceinline__ bf16x8 tr_frag(const char* plane, int addr, int t0, int t1) {
+// element j < 4: image[16*t0 + 4g + j][16*db + (lane&15)], element j >= 4: the same of the next tile (t0 + 1)
+template <int IMG>
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile) {
   typedef __attribute__((address_space(3))) s16x4* lds_ptr;
-  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(plane + addr + TILE_BYTES * t0));
-  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(plane + addr + TILE_BYTES * t1));
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(tile + IMG * IMG_BYTES));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(tile + IMG * IMG_BYTES + TILE_BYTES));
   const s16x8 r = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
   return __builtin_bit_cast(bf16x8, r);
 }
@@ -150,12 +158,9 @@ __device__ __forceinline__ void rowdot_head(float* sD, const float* dO, const fl
 template <int KT>
 __global__ __launch_bounds__(64 * WAVES) void attn_rx_fwd_kernel(AttnRxP p) {
   extern __shared__ __attribute__((aligned(16))) char smem_rx[];
-  constexpr int KTE = (KT + 1) & ~1, LPE = KTE * 16, PLANE = LPE * 64;
-  char* sKh = smem_rx;
-  char* sKl = sKh + PLANE;
-  char* sVh = sKl + PLANE;
-  char* sVl = sVh + PLANE;
-  float* sAdd = reinterpret_cast<float*>(sVl + PLANE);
+  constexpr int KTE = (KT + 1) & ~1, LPE = KTE * 16;
+  char* img = smem_rx;                                    // images 0/1 = K hi/lo, 2/3 = V hi/lo
+  float* sAdd = reinterpret_cast<float*>(img + KTE * TILE_BYTES);
 
   const int b = blockIdx.z, hd = blockIdx.y, q0 = blockIdx.x * ROWS_WG;
   const int L = p.L, H = p.H, ld3 = 3 * H;
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_rx_fwd_kernel(AttnRxP p) {
   stage_fetch(st, p.qkv + H + hd * 32, ld3, p.qkv + 2 * H + hd * 32, ld3, row0, L);
   const int kk = min((int)threadIdx.x, L - 1);   // LPE <= 256 < workgroup size
   const float madd = (1.0f - (float)p.mask[row0 + kk]) * -1e9f;
-  stage_write(st, sKh, sKl, sVh, sVl, LPE, L);
+  stage_write(st, img, LPE, L);
   if (threadIdx.x < LPE) sAdd[threadIdx.x] = (int)threadIdx.x < L ? madd : -INFINITY;
   bf16x8 qh, ql;
   split8(qx, qh, ql);
@@ -180,7 +185,8 @@ __global__ __launch_bounds__(64 * WAVES) void attn_rx_fwd_kernel(AttnRxP p) {
 #pragma unroll
   for (int t = 0; t < KTE; ++t) {
     acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (t < KT) acc[t] = mfma3(row_frag(sKh, fa.row, t), row_frag(sKl, fa.row, t), qh, ql, acc[t]);   // S^T = K.Q^T
+    const char* tile = img + fa.row + TILE_BYTES * t;
+    if (t < KT) acc[t] = mfma3(row_frag<0>(tile), row_frag<1>(tile), qh, ql, acc[t]);   // S^T = K.Q^T
   }
   float m = -INFINITY;
 #pragma unroll
@@ -192,6 +198,8 @@ __global__ __launch_bounds__(64 * WAVES) void attn_rx_fwd_kernel(AttnRxP p) {
   m = fmaxf(m, __shfl_xor(m, 16, 64));
   m = fmaxf(m, __shfl_xor(m, 32, 64));
   float sum = 0.f;
+  // (score - max) first: with Keras' -1e9 mask a fully masked row has scores and max of magnitude 1e9, and folding log2(e)
+  // into separately rounded terms would lose the exact cancellation (same in the backward kernels)
 #pragma unroll
   for (int t = 0; t < KT; ++t) {
 #pragma unroll
@@ -228,8 +236,10 @@ __global__ __launch_bounds__(64 * WAVES) void attn_rx_fwd_kernel(AttnRxP p) {
     bf16x8 ph, pl;
     split8(cat(acc[2 * tp], acc[2 * tp + 1]), ph, pl);
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
-      o[db] = mfma3(tr_frag(sVh, fa.tr[db], 2 * tp, 2 * tp + 1), tr_frag(sVl, fa.tr[db], 2 * tp, 2 * tp + 1), ph, pl, o[db]);
+    for (int db = 0; db < 2; ++db) {
+      const char* tile = img + fa.tr[db] + TILE_BYTES * 2 * tp;
+      o[db] = mfma3(tr_frag<2>(tile), tr_frag<3>(tile), ph, pl, o[db]);
+    }
   }
   if (q < L) {
     float* dst = p.ctx_out + (row0 + q) * H + hd * 32 + 4 * g;
@@ -244,12 +254,9 @@ __global__ __launch_bounds__(64 * WAVES) void attn_rx_fwd_kernel(AttnRxP p) {
 // -----------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * WAVES) void attn_rx_dq_kernel(AttnRxP p) {
   extern __shared__ __attribute__((aligned(16))) char smem_rx[];
-  const int KTE = p.KTE, LPE = KTE * 16, PLANE = LPE * 64;
-  char* sKh = smem_rx;
-  char* sKl = sKh + PLANE;
-  char* sVh = sKl + PLANE;
-  char* sVl = sVh + PLANE;
-  float* sAdd = reinterpret_cast<float*>(sVl + PLANE);
+  const int KTE = p.KTE, LPE = KTE * 16;
+  char* img = smem_rx;                                    // images 0/1 = K hi/lo, 2/3 = V hi/lo
+  float* sAdd = reinterpret_cast<float*>(img + KTE * TILE_BYTES);
   float* sD = sAdd + LPE;
 
   const int b = blockIdx.z, hd = blockIdx.y, q0 = blockIdx.x * ROWS_WG;
@@ -267,7 +274,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_rx_dq_kernel(AttnRxP p) {
   const int kk = min((int)threadIdx.x, L - 1);   // LPE <= 256 < workgroup size
   const float madd = (1.0f - (float)p.mask[row0 + kk]) * -1e9f;
   rowdot_head(sD, p.dctx + hd * 32, p.ctx + hd * 32, row0 + q0, H, ROWS_WG, L - q0);
-  stage_write(st, sKh, sKl, sVh, sVl, LPE, L);
+  stage_write(st, img, LPE, L);
   if (threadIdx.x < LPE) sAdd[threadIdx.x] = (int)threadIdx.x < L ? madd : -INFINITY;
   bf16x8 qh, ql, doh, dol;
   split8(qx, qh, ql);
@@ -295,8 +302,9 @@ __global__ __launch_bounds__(64 * WAVES) void attn_rx_dq_kernel(AttnRxP p) {
     for (int u = 0; u < 2; ++u) {
       const int t = 2 * tp + u;
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      const f32x4 sc = mfma3(row_frag(sKh, fa.row, t), row_frag(sKl, fa.row, t), qh, ql, z);     // S^T = K.Q^T
-      const f32x4 da = mfma3(row_frag(sVh, fa.row, t), row_frag(sVl, fa.row, t), doh, dol, z);   // dA^T = V.dO^T
+      const char* tile = img + fa.row + TILE_BYTES * t;
+      const f32x4 sc = mfma3(row_frag<0>(tile), row_frag<1>(tile), qh, ql, z);     // S^T = K.Q^T
+      const f32x4 da = mfma3(row_frag<2>(tile), row_frag<3>(tile), doh, dol, z);   // dA^T = V.dO^T
       const f32x4 ad = *reinterpret_cast<const f32x4*>(&sAdd[16 * t + 4 * g]);
       const uint32_t nib = w[(t >> 3) & 1] >> (4 * (t & 7));
 #pragma unroll
@@ -309,8 +317,10 @@ __global__ __launch_bounds__(64 * WAVES) void attn_rx_dq_kernel(AttnRxP p) {
     bf16x8 dsh, dsl;
     split8(cat(ds[0], ds[1]), dsh, dsl);
 #pragma unroll
-    for (int db = 0; db < 2; ++db)   // dQ^T[dk][query] += K^T[dk][keys] . dS^T[keys][query]
-      dq[db] = mfma3(tr_frag(sKh, fa.tr[db], 2 * tp, 2 * tp + 1), tr_frag(sKl, fa.tr[db], 2 * tp, 2 * tp + 1), dsh, dsl, dq[db]);
+    for (int db = 0; db < 2; ++db) {   // dQ^T[dk][query] += K^T[dk][keys] . dS^T[keys][query]
+      const char* tile = img + fa.tr[db] + TILE_BYTES * 2 * tp;
+      dq[db] = mfma3(tr_frag<0>(tile), tr_frag<1>(tile), dsh, dsl, dq[db]);
+    }
   }
   if (qlive) {
     float* dst = p.dqkv + (row0 + q) * ld3 + hd * 32 + 4 * g;
@@ -325,12 +335,9 @@ __global__ __launch_bounds__(64 * WAVES) void attn_rx_dq_kernel(AttnRxP p) {
 // -----------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * WAVES) void attn_rx_dkv_kernel(AttnRxP p) {
   extern __shared__ __attribute__((aligned(16))) char smem_rx[];
-  const int KTE = p.KTE, LPE = KTE * 16, PLANE = LPE * 64;
-  char* sQh = smem_rx;
-  char* sQl = sQh + PLANE;
-  char* sOh = sQl + PLANE;
-  char* sOl = sOh + PLANE;
-  float* sLse = reinterpret_cast<float*>(sOl + PLANE);
+  const int KTE = p.KTE, LPE = KTE * 16;
+  char* img = smem_rx;                                    // images 0/1 = Q hi/lo, 2/3 = dO hi/lo
+  float* sLse = reinterpret_cast<float*>(img + KTE * TILE_BYTES);
   float* sD = sLse + LPE;
 
   const int b = blockIdx.z, hd = blockIdx.y;
@@ -349,7 +356,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_rx_dkv_kernel(AttnRxP p) {
   stage_fetch(st, p.qkv + hd * 32, ld3, p.dctx + hd * 32, H, row0, L);
   const float lse_k = p.lse_in[bh * L + min((int)threadIdx.x, L - 1)];   // LPE <= 256 < workgroup size
   rowdot_head(sD, p.dctx + hd * 32, p.ctx + hd * 32, row0, H, LPE, L);
-  stage_write(st, sQh, sQl, sOh, sOl, LPE, L);
+  stage_write(st, img, LPE, L);
   if (threadIdx.x < LPE) sLse[threadIdx.x] = (int)threadIdx.x < L ? lse_k : INFINITY;   // +inf => probability 0 for pad queries
   bf16x8 kh, kl, vh, vl;
   split8(kx, kh, kl);
@@ -367,28 +374,41 @@ __global__ __launch_bounds__(64 * WAVES) void attn_rx_dkv_kernel(AttnRxP p) {
   const int wshift = 4 * (tk & 7) + (i & 3);
 
   f32x4 dk[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dv[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  for (int tp = 0; tp < KTE / 2; ++tp) {
-    f32x4 pd[2], ds[2];
-    u32x4 wq[2] = {{~0u, ~0u, ~0u, ~0u}, {~0u, ~0u, ~0u, ~0u}};
-    if (dctx.on) {
+  // software pipeline: the two products that only need LDS operands (S, dA) and the dropout words of pair tp+1 are
+  // issued before the exp / select / split work of pair tp, so the matrix pipe and the LDS reads overlap that VALU work
+  // inside one wave (3 waves per SIMD cannot hide them otherwise).  The look-ahead of the last pair recomputes itself.
+  f32x4 sc_n[2], da_n[2];
+  u32x4 wq_n[2] = {{~0u, ~0u, ~0u, ~0u}, {~0u, ~0u, ~0u, ~0u}};
+  auto lookahead = [&](int tpn) {
 #pragma unroll
-      for (int u = 0; u < 2; ++u)   // query tiles beyond the forward's (odd KT) hold only pad queries: any word will do
-        wq[u] = *reinterpret_cast<const u32x4*>(wbase + (int64_t)min(2 * tp + u, p.KT - 1) * 128);
+    for (int u = 0; u < 2; ++u) {
+      const int t = 2 * tpn + u;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      if (dctx.on)   // query tiles beyond the forward's (odd KT) hold only pad queries: any word will do
+        wq_n[u] = *reinterpret_cast<const u32x4*>(wbase + (int64_t)min(t, p.KT - 1) * 128);
+      const char* tile = img + fa.row + TILE_BYTES * t;
+      sc_n[u] = mfma3(row_frag<0>(tile), row_frag<1>(tile), kh, kl, z);   // S = Q.K^T
+      da_n[u] = mfma3(row_frag<2>(tile), row_frag<3>(tile), vh, vl, z);   // dA = dO.V^T
     }
+  };
+  lookahead(0);
+  const int NP = KTE / 2;
+  for (int tp = 0; tp < NP; ++tp) {
+    f32x4 pd[2], ds[2];
+    const f32x4 sc[2] = {sc_n[0], sc_n[1]}, da[2] = {da_n[0], da_n[1]};
+    const u32x4 wq[2] = {wq_n[0], wq_n[1]};
+    lookahead(min(tp + 1, NP - 1));
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int t = 2 * tp + u;
-      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      const f32x4 sc = mfma3(row_frag(sQh, fa.row, t), row_frag(sQl, fa.row, t), kh, kl, z);   // S = Q.K^T
-      const f32x4 da = mfma3(row_frag(sOh, fa.row, t), row_frag(sOl, fa.row, t), vh, vl, z);   // dA = dO.V^T
       const f32x4 ls = *reinterpret_cast<const f32x4*>(&sLse[16 * t + 4 * g]);
       const f32x4 dd = *reinterpret_cast<const f32x4*>(&sD[16 * t + 4 * g]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float pr = __expf(sc[r] + add - ls[r]);
+        const float pr = __expf(sc[u][r] + add - ls[r]);
         const bool keep = (wq[u][r] >> wshift) & 1u;
         pd[u][r] = keep ? pr * dscale : 0.f;
-        const float dA = keep ? da[r] * dscale : 0.f;
+        const float dA = keep ? da[u][r] * dscale : 0.f;
         ds[u][r] = pr * (dA - dd[r]);
       }
     }
@@ -398,8 +418,9 @@ __global__ __launch_bounds__(64 * WAVES) void attn_rx_dkv_kernel(AttnRxP p) {
 #pragma unroll
     for (int db = 0; db < 2; ++db) {
       // dV^T[dd][key] += dO^T[dd][queries] . Pd[queries][key] ;  dK^T[dk][key] += Q^T[dk][queries] . dS[queries][key]
-      dv[db] = mfma3(tr_frag(sOh, fa.tr[db], 2 * tp, 2 * tp + 1), tr_frag(sOl, fa.tr[db], 2 * tp, 2 * tp + 1), pdh, pdl, dv[db]);
-      dk[db] = mfma3(tr_frag(sQh, fa.tr[db], 2 * tp, 2 * tp + 1), tr_frag(sQl, fa.tr[db], 2 * tp, 2 * tp + 1), dsh, dsl, dk[db]);
+      const char* tile = img + fa.tr[db] + TILE_BYTES * 2 * tp;
+      dv[db] = mfma3(tr_frag<2>(tile), tr_frag<3>(tile), pdh, pdl, dv[db]);
+      dk[db] = mfma3(tr_frag<0>(tile), tr_frag<1>(tile), dsh, dsl, dk[db]);
     }
   }
   if (klive) {

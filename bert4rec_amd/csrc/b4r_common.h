@@ -156,6 +156,47 @@ __device__ __forceinline__ f32x4 b4r_drop4(const DropCtx& c, f32x4 x, uint64_t i
 }
 
 // ---------------------------------------------------------------------------------------------
+// split precision: x = hi + lo with hi = bf16(x), lo = bf16(x - hi).  Written on packed pairs: hipcc's own lowering of
+// convert(x - convert(hi)) converts every element a second time on its own (32 VALU instructions per 8 elements, 20 here)
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 b4r_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b4r_bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 b4r_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float b4r_f32x8 __attribute__((ext_vector_type(8)));
+typedef float b4r_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int b4r_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int b4r_u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void b4r_split_pair(float a, float b, uint32_t& hw, uint32_t& lw) {
+  const b4r_bf16x2 h = __builtin_convertvector((b4r_f32x2){a, b}, b4r_bf16x2);
+  hw = __builtin_bit_cast(uint32_t, h);
+  const float h0 = __builtin_bit_cast(float, hw << 16), h1 = __builtin_bit_cast(float, hw & 0xFFFF0000u);
+  lw = __builtin_bit_cast(uint32_t, __builtin_convertvector((b4r_f32x2){a - h0, b - h1}, b4r_bf16x2));
+}
+__device__ __forceinline__ void b4r_split8(const b4r_f32x8 x, b4r_bf16x8& hi, b4r_bf16x8& lo) {
+  b4r_u32x4 hw, lw;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    uint32_t h, l;
+    b4r_split_pair(x[2 * j], x[2 * j + 1], h, l);
+    hw[j] = h; lw[j] = l;
+  }
+  hi = __builtin_bit_cast(b4r_bf16x8, hw);
+  lo = __builtin_bit_cast(b4r_bf16x8, lw);
+}
+__device__ __forceinline__ void b4r_split4(const f32x4 x, b4r_bf16x4& hi, b4r_bf16x4& lo) {
+  b4r_u32x2 hw, lw;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    uint32_t h, l;
+    b4r_split_pair(x[2 * j], x[2 * j + 1], h, l);
+    hw[j] = h; lw[j] = l;
+  }
+  hi = __builtin_bit_cast(b4r_bf16x4, hw);
+  lo = __builtin_bit_cast(b4r_bf16x4, lw);
+}
+
+// ---------------------------------------------------------------------------------------------
 // math
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float b4r_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

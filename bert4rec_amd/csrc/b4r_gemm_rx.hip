@@ -54,10 +54,7 @@ struct RxP {
   DropArgs drop;
 };
 
-__device__ __forceinline__ void split8(const f32x8 x, bf16x8& hi, bf16x8& lo) {
-  hi = __builtin_convertvector(x, bf16x8);
-  lo = __builtin_convertvector(x - __builtin_convertvector(hi, f32x8), bf16x8);
-}
+__device__ __forceinline__ void split8(const f32x8 x, bf16x8& hi, bf16x8& lo) { b4r_split8(x, hi, lo); }
 
 __device__ __forceinline__ f32x16 mfma3(const bf16x8 ah, const bf16x8 al, const bf16x8 bh, const bf16x8 bl, f32x16 acc) {
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
@@ -247,8 +244,8 @@ __global__ __launch_bounds__(256) void rx_gemm_nk_kernel(RxP p) {
     for (int i = 0; i < NLD; ++i) {
       const int f = i * 256 + tid;
       const int trow = f / F4_PER_ROW, tc4 = (f % F4_PER_ROW) * 4;
-      const bf16x4 hi = __builtin_convertvector(raw[i], bf16x4);
-      const bf16x4 lo = __builtin_convertvector(raw[i] - __builtin_convertvector(hi, f32x4), bf16x4);
+      bf16x4 hi, lo;
+      b4r_split4(raw[i], hi, lo);
       char* dst = bbuf + buf * (2 * PLANE) + trow * (BROW * 4) + tc4 * 2;
       *reinterpret_cast<bf16x4*>(dst) = hi;
       *reinterpret_cast<bf16x4*>(dst + PLANE) = lo;
@@ -332,8 +329,8 @@ __global__ __launch_bounds__(256) void rx_gemm_kloop_kernel(RxP p) {
       for (int i = 0; i < NLD; ++i) {
         const int f = i * 256 + tid;
         const int trow = f >> 4, tc4 = (f & 15) * 4;
-        const bf16x4 hi = __builtin_convertvector(braw[i], bf16x4);
-        const bf16x4 lo = __builtin_convertvector(braw[i] - __builtin_convertvector(hi, f32x4), bf16x4);
+        bf16x4 hi, lo;
+        b4r_split4(braw[i], hi, lo);
         char* dst = bbuf + buf * (2 * PLANE) + trow * (BROW * 4) + tc4 * 2;
         *reinterpret_cast<bf16x4*>(dst) = hi;
         *reinterpret_cast<bf16x4*>(dst + PLANE) = lo;
@@ -517,11 +514,13 @@ __global__ __launch_bounds__(256) void rx_gemm_tn_kernel(RxTnP p) {
       cs += vb;
       csa += va;
       const int off = tn_img_off(lrow, c4);
-      const bf16x4 ah = __builtin_convertvector(va, bf16x4), bh = __builtin_convertvector(vb, bf16x4);
+      bf16x4 ah, al, bh, bl;
+      b4r_split4(va, ah, al);
+      b4r_split4(vb, bh, bl);
       *reinterpret_cast<bf16x4*>(s_tn + off) = ah;
-      *reinterpret_cast<bf16x4*>(s_tn + PLANE + off) = __builtin_convertvector(va - __builtin_convertvector(ah, f32x4), bf16x4);
+      *reinterpret_cast<bf16x4*>(s_tn + PLANE + off) = al;
       *reinterpret_cast<bf16x4*>(s_tn + 2 * PLANE + off) = bh;
-      *reinterpret_cast<bf16x4*>(s_tn + 3 * PLANE + off) = __builtin_convertvector(vb - __builtin_convertvector(bh, f32x4), bf16x4);
+      *reinterpret_cast<bf16x4*>(s_tn + 3 * PLANE + off) = bl;
     }
   };
   // transposed fragment: 16-lane group G = lane>>4 reads the 4 x 16 block at rows 8h + 4s + (0..3) (+16*kb), columns

@@ -54,7 +54,8 @@ ST_SEED, ST_STEP_LO, ST_STEP = 0, 1, 2  # step is int64 at words 2..3
 ST_LOSS_SUM, ST_VALID, ST_CORRECT_MASKED, ST_CORRECT_ALL, ST_SLOTS_ALL, ST_SQNORM, ST_GRAD_NORM, ST_LR = range(4, 12)
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_QSCALE, EPI_BIAS_GELU, EPI_BIAS_DROP_RES, EPI_GELU_BWD, EPI_ADD_RES, EPI_BIAS_TANH = range(8)
-FLAG_TRAINING, FLAG_POOLER = 1, 2
+FLAG_TRAINING, FLAG_POOLER, FLAG_FUSED_HEAD = 1, 2, 4
+LOSS_FUSED_HEAD = 2
 GEMM_F32, GEMM_BF16X3 = 0, 1
 
 _P, _I32, _I64, _F, _U32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint32
@@ -72,6 +73,7 @@ PROTOTYPES = {
     "b4r_workspace_bytes": (_I64, [C.POINTER(ModelConfig), _I32, _I32, _I32]),
     "b4r_workspace_region": (C.c_int, [C.POINTER(ModelConfig), _I32, _I32, _I32, C.c_char_p, C.POINTER(_I64),
                                        C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32)]),
+    "b4r_fused_head_supported": (_I32, [C.POINTER(ModelConfig)]),
     "b4r_forward": (C.c_int, [C.POINTER(ModelConfig), C.POINTER(Batch), _P, _P, _P, _I64, _P, _I32, _P]),
     "b4r_loss": (C.c_int, [C.POINTER(ModelConfig), C.POINTER(Batch), _P, _I64, _P, _I32, _P]),
     "b4r_backward": (C.c_int, [C.POINTER(ModelConfig), C.POINTER(Batch), _P, _P, _P, _I64, _P, _I32, _P]),

@@ -1,0 +1,325 @@
+// Masked-LM head of a TRAIN step without materialising the [M, V] logits (split-precision arithmetic, hidden size 64).
+//
+//   logits x[m,v] = T[m,:].E[v,:] + b[v]      (T = transform output [M,64], E = tied item table [V,64])
+//   loss_m = logsumexp_v x[m,v] - x[m,y_m] ;  g[m,v] = softmax(x[m,:])[v] - [v == y_m]   (rows with y_m == 0 ignored)
+//   dT = g.E ;  dE = g^T.T ;  db = column sums of g
+//
+// The materialising path (b4r_gemm_rx.hip + softmax_ce_kernel + two more passes over the 152 MB of dlogits at ML-1M)
+// moves ~760 MB per step through HBM; here the logits only ever exist as accumulator tiles:
+//   head_fwd_kernel   "attention" over the vocabulary (b4r_attn_rx.hip's forward with E as both keys and values): a wave
+//                     owns 16 rows of T, sweeps a slice of V in 16-row tiles of E held in LDS as bf16 hi / lo images,
+//                     keeps a running max / sum (online softmax) and accumulates sum_v exp(x - max) E[v,:] with the
+//                     probability tiles fed back as MFMA operands; also argmax and the label logit for the metrics.
+//   head_combine_kernel merges the V slices of a row (flash-decoding style), writes loss rows, lse and dT = acc/sum - E[y].
+//   head_dE_kernel    the other orientation (a wave owns 16 rows of E, sweeps slices of M): recomputes the logit tiles
+//                     with the same arithmetic, g = exp(x - lse) - onehot, dE^T += T^T.g, db += column sums; partial
+//                     tiles per M slice go to slabs that the backward's deferred ordered reduction sums.
+// Tile / image mechanics are those of b4r_rx_tiles.h: the 64 columns of E (or T) are two 32-column images (hi, lo each).
+#include "b4r_rx_tiles.h"
+
+namespace {
+
+constexpr int HEAD_CH = 10;    // 16-row tiles per LDS chunk: 40 KB of images, three workgroups per CU
+constexpr int PART_LD = 72;    // floats per (V slice, row): 64 accumulators, max, sum, best logit, best index, label logit
+
+struct HeadP {
+  const float* T; const float* E; const float* bias; const int64_t* y;
+  float* part;                    // forward: [slices][M][PART_LD]
+  const float* lse; const int32_t* ylab;
+  float* slab; float* bslab;      // dE: [slices][V][64], [slices][V]
+  int M, V;
+  int tiles_per_slice;            // even number of 16-row tiles per slice (of V in the forward, of M in dE)
+};
+
+__device__ __forceinline__ f32x4 logit_tile(const char* tile, const bf16x8 (&bh)[2], const bf16x8 (&bl)[2]) {
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  s = mfma3(row_frag<0>(tile), row_frag<1>(tile), bh[0], bl[0], s);
+  s = mfma3(row_frag<2>(tile), row_frag<3>(tile), bh[1], bl[1], s);
+  return s;
+}
+
+// acc[2*kh + db] += image(kh)^T[16 columns of block db][rows of the tile pair] . (ph, pl)
+__device__ __forceinline__ void feed_pair(const char* img, const FragAddr& fa, int pair_tile, const bf16x8 ph, const bf16x8 pl,
+                                          f32x4 (&acc)[4]) {
+#pragma unroll
+  for (int db = 0; db < 2; ++db) {
+    const char* tile = img + fa.tr[db] + TILE_BYTES * pair_tile;
+    acc[db] = mfma3(tr_frag<0>(tile), tr_frag<1>(tile), ph, pl, acc[db]);
+    acc[2 + db] = mfma3(tr_frag<2>(tile), tr_frag<3>(tile), ph, pl, acc[2 + db]);
+  }
+}
+
+// -----------------------------------------------------------------------------------------------------------
+// forward: grid (row blocks of 128, V slices); wave = 16 rows of T x the slice's rows of E
+// LDS: [E chunk images | bias chunk]
+// -----------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * WAVES) void head_fwd_kernel(HeadP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_head[];
+  char* img = smem_head;
+  float* sBias = reinterpret_cast<float*>(img + HEAD_CH * TILE_BYTES);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+  const int m = blockIdx.x * ROWS_WG + 16 * wave + i;
+  const int mc = min(m, p.M - 1);
+  bf16x8 th[2], tl[2];
+#pragma unroll
+  for (int kh = 0; kh < 2; ++kh) split8(load8(p.T + (int64_t)mc * 64 + 32 * kh + 8 * g), th[kh], tl[kh]);
+  const int64_t y64 = p.y[mc];
+  const int yv = (y64 >= 0 && y64 < p.V) ? (int)y64 : -1;
+  const int v_begin = blockIdx.y * p.tiles_per_slice * 16;
+  const int v_end = min(((p.V + 31) >> 5) << 5, v_begin + p.tiles_per_slice * 16);   // multiples of 32; v_begin < V
+  const FragAddr fa = frag_addr(lane);
+
+  float mx = -INFINITY, sum = 0.f, best = -INFINITY, xl = -INFINITY;
+  int bidx = 0x7fffffff;
+  f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+
+  for (int c0 = v_begin; c0 < v_end; c0 += HEAD_CH * 16) {
+    const int nrows = min(HEAD_CH * 16, v_end - c0);            // multiple of 32
+    const int valid = min(nrows, p.V - c0);                     // >= 1: every chunk starts below V
+    StagedRows st;
+    stage_fetch(st, p.E + (int64_t)c0 * 64, 64, p.E + (int64_t)c0 * 64 + 32, 64, 0, valid);
+    const float bz = p.bias[min(c0 + (int)threadIdx.x, p.V - 1)];
+    __syncthreads();                                            // the previous chunk has been consumed
+    stage_write(st, img, nrows, valid);
+    if ((int)threadIdx.x < nrows) sBias[threadIdx.x] = (c0 + (int)threadIdx.x < p.V) ? bz : -INFINITY;
+    __syncthreads();
+    for (int tp = 0; tp < nrows / 32; ++tp) {
+      f32x4 x[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        x[u] = logit_tile(img + fa.row + TILE_BYTES * (2 * tp + u), th, tl) +
+               *reinterpret_cast<const f32x4*>(&sBias[16 * (2 * tp + u) + 4 * g]);
+      float pm = fmaxf(fmaxf(fmaxf(x[0][0], x[0][1]), fmaxf(x[0][2], x[0][3])), fmaxf(fmaxf(x[1][0], x[1][1]), fmaxf(x[1][2], x[1][3])));
+      pm = fmaxf(pm, __shfl_xor(pm, 16, 64));
+      pm = fmaxf(pm, __shfl_xor(pm, 32, 64));
+      const float mnew = fmaxf(mx, pm);                         // finite: the first pair of a slice holds real columns
+      const float alpha = (mx == mnew) ? 1.0f : __expf(mx - mnew);
+      mx = mnew;
+      sum *= alpha;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) acc[kb] = acc[kb] * alpha;
+      f32x4 pr[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int v = c0 + 16 * (2 * tp + u) + 4 * g + r;
+          const float xv = x[u][r];
+          if (xv > best) { best = xv; bidx = v; }               // increasing v within a lane: the lowest index wins ties
+          if (v == yv) xl = xv;
+          const float e = __expf(xv - mnew);
+          pr[u][r] = e;
+          sum += e;
+        }
+      }
+      bf16x8 ph, pl;
+      split8(cat(pr[0], pr[1]), ph, pl);
+      feed_pair(img, fa, 2 * tp, ph, pl, acc);                  // acc^T[k][row] += E^T[k][v pair] . p^T[v pair][row]
+    }
+  }
+  // the four g lanes of a row hold disjoint columns: combine
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  xl = fmaxf(xl, __shfl_xor(xl, 16, 64));
+  xl = fmaxf(xl, __shfl_xor(xl, 32, 64));
+#pragma unroll
+  for (int o = 16; o <= 32; o <<= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bidx, o, 64);
+    if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+  }
+  if (m < p.M) {
+    float* dst = p.part + ((int64_t)blockIdx.y * p.M + m) * PART_LD;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) *reinterpret_cast<f32x4*>(dst + 16 * kb + 4 * g) = acc[kb];
+    if (g == 0) {
+      dst[64] = mx; dst[65] = sum; dst[66] = best; dst[67] = __int_as_float(bidx); dst[68] = xl;
+    }
+  }
+}
+
+// merge the V slices of every row; 16 threads per row (4 columns each)
+__global__ __launch_bounds__(256) void head_combine_kernel(const float* part, int slices, int M, int V, const float* E,
+                                                           const int64_t* y, float* dT, float* row_out, float* lse_out,
+                                                           int32_t* ylab) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  const int m = idx >> 4, c4 = idx & 15;
+  if (m >= M) return;
+  float mx = -INFINITY;
+  for (int s = 0; s < slices; ++s) mx = fmaxf(mx, part[((int64_t)s * M + m) * PART_LD + 64]);
+  float sum = 0.f, best = -INFINITY, xl = -INFINITY;
+  int bidx = 0x7fffffff;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < slices; ++s) {                            // slices in increasing column order: lowest index wins ties
+    const float* src = part + ((int64_t)s * M + m) * PART_LD;
+    const float w = __expf(src[64] - mx);
+    sum += src[65] * w;
+    acc += *reinterpret_cast<const f32x4*>(src + 4 * c4) * w;
+    if (src[66] > best) { best = src[66]; bidx = __float_as_int(src[67]); }
+    xl = fmaxf(xl, src[68]);
+  }
+  const int64_t y64 = y[m];
+  const bool valid = (y64 != 0), y_ok = (y64 >= 0 && y64 < V);
+  f32x4 d = {0.f, 0.f, 0.f, 0.f};
+  if (valid) {
+    d = acc * (1.0f / sum);
+    if (y_ok) d -= *reinterpret_cast<const f32x4*>(E + y64 * 64 + 4 * c4);
+  }
+  *reinterpret_cast<f32x4*>(dT + (int64_t)m * 64 + 4 * c4) = d;
+  if (c4 == 0) {
+    const float lse = mx + __logf(sum);
+    row_out[4 * (int64_t)m + 0] = (valid && y_ok) ? (lse - xl) : 0.f;
+    row_out[4 * (int64_t)m + 1] = valid ? 1.f : 0.f;
+    row_out[4 * (int64_t)m + 2] = (valid && (int64_t)bidx == y64) ? 1.f : 0.f;
+    row_out[4 * (int64_t)m + 3] = ((int64_t)bidx == y64) ? 1.f : 0.f;
+    lse_out[m] = valid ? lse : INFINITY;                        // +inf => zero gradient rows in head_dE_kernel
+    ylab[m] = (valid && y_ok) ? (int32_t)y64 : -1;
+  }
+}
+
+// -----------------------------------------------------------------------------------------------------------
+// dE / db: grid (blocks of 128 rows of E, M slices); wave = 16 rows of E x the slice's rows of T
+// LDS: [T chunk images | lse chunk | label chunk]
+// -----------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * WAVES) void head_dE_kernel(HeadP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_head[];
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  char* img = smem_head;
+  float* sLse = reinterpret_cast<float*>(img + HEAD_CH * TILE_BYTES);
+  int* sY = reinterpret_cast<int*>(sLse + HEAD_CH * 16);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+  const int v = blockIdx.x * ROWS_WG + 16 * wave + i;
+  const bool vlive = v < p.V;
+  const int vc = min(v, p.V - 1);
+  bf16x8 eh[2], el[2];
+#pragma unroll
+  for (int kh = 0; kh < 2; ++kh) split8(load8(p.E + (int64_t)vc * 64 + 32 * kh + 8 * g), eh[kh], el[kh]);
+  const float bv = vlive ? p.bias[vc] : -INFINITY;              // -inf => zero probability, and no label equals v >= V
+  const int m_begin = blockIdx.y * p.tiles_per_slice * 16;
+  const int m_end = min(((p.M + 31) >> 5) << 5, m_begin + p.tiles_per_slice * 16);
+  const FragAddr fa = frag_addr(lane);
+
+  float dbsum = 0.f;
+  f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  for (int c0 = m_begin; c0 < m_end; c0 += HEAD_CH * 16) {
+    const int nrows = min(HEAD_CH * 16, m_end - c0);
+    const int valid = min(nrows, p.M - c0);
+    StagedRows st;
+    stage_fetch(st, p.T + (int64_t)c0 * 64, 64, p.T + (int64_t)c0 * 64 + 32, 64, 0, valid);
+    const int mr = min(c0 + (int)threadIdx.x, p.M - 1);
+    const float lz = p.lse[mr];
+    const int yz = p.ylab[mr];
+    __syncthreads();
+    stage_write(st, img, nrows, valid);
+    if ((int)threadIdx.x < nrows) {
+      const bool in = c0 + (int)threadIdx.x < p.M;
+      sLse[threadIdx.x] = in ? lz : INFINITY;
+      sY[threadIdx.x] = in ? yz : -1;
+    }
+    __syncthreads();
+    for (int tp = 0; tp < nrows / 32; ++tp) {
+      f32x4 gv[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int t = 2 * tp + u;
+        const f32x4 x = logit_tile(img + fa.row + TILE_BYTES * t, eh, el);   // rows = T rows, column = this lane's v
+        const f32x4 ls = *reinterpret_cast<const f32x4*>(&sLse[16 * t + 4 * g]);
+        const i32x4 yy = *reinterpret_cast<const i32x4*>(&sY[16 * t + 4 * g]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float gg = __expf(x[r] + bv - ls[r]) - (yy[r] == v ? 1.0f : 0.0f);
+          gv[u][r] = gg;
+          dbsum += gg;
+        }
+      }
+      bf16x8 gh, gl;
+      split8(cat(gv[0], gv[1]), gh, gl);
+      feed_pair(img, fa, 2 * tp, gh, gl, acc);                  // dE^T[k][v] += T^T[k][row pair] . g[row pair][v]
+    }
+  }
+  dbsum += __shfl_xor(dbsum, 16, 64);
+  dbsum += __shfl_xor(dbsum, 32, 64);
+  if (vlive) {
+    float* dst = p.slab + ((int64_t)blockIdx.y * p.V + v) * 64;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) *reinterpret_cast<f32x4*>(dst + 16 * kb + 4 * g) = acc[kb];
+    if (g == 0) p.bslab[(int64_t)blockIdx.y * p.V + v] = dbsum;
+  }
+}
+
+int even_tiles(int rows, int slices) {
+  const int tiles = b4r_cdiv(rows, 16);
+  int per = b4r_cdiv(tiles, slices < 1 ? 1 : slices);
+  per = (per + 1) & ~1;
+  return per < 2 ? 2 : per;
+}
+
+int fwd_slices_wanted(int M) {
+  static const int target = getenv("B4R_HEAD_FWD_WGS") ? atoi(getenv("B4R_HEAD_FWD_WGS")) : 512;
+  int s = b4r_cdiv(target, b4r_cdiv(M, ROWS_WG));
+  return s < 1 ? 1 : (s > 16 ? 16 : s);
+}
+int dE_slices_wanted(int V) {
+  static const int target = getenv("B4R_HEAD_DE_WGS") ? atoi(getenv("B4R_HEAD_DE_WGS")) : 512;
+  int s = b4r_cdiv(target, b4r_cdiv(V, ROWS_WG));
+  return s < 1 ? 1 : (s > 32 ? 32 : s);
+}
+
+constexpr size_t HEAD_LDS = (size_t)HEAD_CH * TILE_BYTES + 2 * HEAD_CH * 16 * sizeof(float);
+
+}  // namespace
+
+// number of V slices the forward uses / M slices the dE kernel uses, and the scratch they need (floats)
+int b4r_head_rx_fwd_slices(int M, int V) {
+  const int per = even_tiles(V, fwd_slices_wanted(M));
+  return b4r_cdiv(b4r_cdiv(V, 16), per);
+}
+int64_t b4r_head_rx_fwd_scratch_floats(int M, int V) { return (int64_t)b4r_head_rx_fwd_slices(M, V) * M * PART_LD; }
+int b4r_head_rx_dE_slices(int M, int V) {
+  const int per = even_tiles(M, dE_slices_wanted(V));
+  return b4r_cdiv(b4r_cdiv(M, 16), per);
+}
+int64_t b4r_head_rx_dE_scratch_floats(int M, int V) { return (int64_t)b4r_head_rx_dE_slices(M, V) * ((int64_t)V * 64 + V); }
+
+// loss rows (as b4r_softmax_ce writes them), lse, labels and dT from T, E, bias, y; hidden size 64 only
+int b4r_head_rx_fwd_launch(const float* T, const float* E, const float* bias, const int64_t* y, int M, int V, float* scratch,
+                           float* dT, float* row_out, float* lse, int32_t* ylab, hipStream_t stream) {
+  HeadP p{};
+  p.T = T; p.E = E; p.bias = bias; p.y = y; p.part = scratch; p.M = M; p.V = V;
+  const int slices = b4r_head_rx_fwd_slices(M, V);
+  p.tiles_per_slice = even_tiles(V, fwd_slices_wanted(M));
+  static bool raised = false;
+  if (!raised) {
+    (void)hipFuncSetAttribute((const void*)head_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEAD_LDS);
+    (void)hipFuncSetAttribute((const void*)head_dE_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEAD_LDS);
+    raised = true;
+  }
+  hipLaunchKernelGGL(head_fwd_kernel, dim3(b4r_cdiv(M, ROWS_WG), slices), dim3(64 * WAVES), HEAD_LDS, stream, p);
+  B4R_CHECK_LAUNCH("masked-LM head forward (fused)");
+  hipLaunchKernelGGL(head_combine_kernel, dim3(b4r_cdiv(M * 16, 256)), dim3(256), 0, stream, (const float*)scratch, slices, M, V, E,
+                     y, dT, row_out, lse, ylab);
+  B4R_CHECK_LAUNCH("masked-LM head combine");
+  return B4R_OK;
+}
+
+int b4r_launch_slab_reduce_full(const float* slab, int S, int Mo, int No, float* out, int ldo, int accumulate,
+                                const float* cslab, float* colsum, const float* caslab, float* colsum_a, hipStream_t stream);
+
+// dE [V,64] and db [V] (overwritten, through the ordered slab reduction) from T, E, bias and the forward's lse / labels
+int b4r_head_rx_dE_launch(const float* T, const float* E, const float* bias, const float* lse, const int32_t* ylab, int M, int V,
+                          float* scratch, float* dE, float* db, hipStream_t stream) {
+  HeadP p{};
+  p.T = T; p.E = E; p.bias = bias; p.lse = lse; p.ylab = ylab; p.M = M; p.V = V;
+  const int slices = b4r_head_rx_dE_slices(M, V);
+  p.tiles_per_slice = even_tiles(M, dE_slices_wanted(V));
+  p.slab = scratch;
+  p.bslab = scratch + (int64_t)slices * V * 64;
+  static bool raised = false;
+  if (!raised) {
+    (void)hipFuncSetAttribute((const void*)head_dE_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEAD_LDS);
+    raised = true;
+  }
+  hipLaunchKernelGGL(head_dE_kernel, dim3(b4r_cdiv(V, ROWS_WG), slices), dim3(64 * WAVES), HEAD_LDS, stream, p);
+  B4R_CHECK_LAUNCH("masked-LM head dE (fused)");
+  return b4r_launch_slab_reduce_full(p.slab, slices, V, 64, dE, 64, 0, nullptr, nullptr, p.bslab, db, stream);
+}

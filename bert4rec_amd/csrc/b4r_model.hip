@@ -24,6 +24,14 @@ int b4r_scatter_add_rows_impl(const float* src, const int64_t* idx, int64_t idx_
 int b4r_batch_colsum(const float* x, int B, int L, int H, float* dpos, float* scratch, hipStream_t stream);
 int b4r_mul_gelu_grad(float* du, const float* pre, int64_t n, hipStream_t stream);
 int b4r_gemm_f32_splitk(const b4r_gemm_desc* d, int splits, float* scratch, int k_pad_ok, hipStream_t stream);
+// b4r_head_rx.hip: masked-LM head of a train step without materialised logits (hidden size 64, bf16x3 mode)
+int64_t b4r_head_rx_fwd_scratch_floats(int M, int V);
+int64_t b4r_head_rx_dE_scratch_floats(int M, int V);
+int b4r_head_rx_fwd_launch(const float* T, const float* E, const float* bias, const int64_t* y, int M, int V, float* scratch,
+                           float* dT, float* row_out, float* lse, int32_t* ylab, hipStream_t stream);
+int b4r_head_rx_dE_launch(const float* T, const float* E, const float* bias, const float* lse, const int32_t* ylab, int M, int V,
+                          float* scratch, float* dE, float* db, hipStream_t stream);
+int b4r_ce_finalize_launch(const float* row_scratch, int M, b4r_train_state* state, hipStream_t stream);
 
 // ---- error message (thread local) ---------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -147,7 +155,7 @@ struct WsLayout {
   int64_t qkv[B4R_MAX_LAYERS], lse[B4R_MAX_LAYERS], keep[B4R_MAX_LAYERS], ctx[B4R_MAX_LAYERS], z1[B4R_MAX_LAYERS], mean1[B4R_MAX_LAYERS],
       rstd1[B4R_MAX_LAYERS], x1[B4R_MAX_LAYERS], fpre[B4R_MAX_LAYERS], f[B4R_MAX_LAYERS], z2[B4R_MAX_LAYERS],
       mean2[B4R_MAX_LAYERS], rstd2[B4R_MAX_LAYERS], x2[B4R_MAX_LAYERS];
-  int64_t gath, upre, u, meanm, rstdm, t, logits, rowsc, pooled;
+  int64_t gath, upre, u, meanm, rstdm, t, logits, rowsc, pooled, head_lse, head_ylab;
   int64_t dx, da, db, dctx, dqkv, df, dt, dg;
   int64_t scratch, scratch_floats;
 };
@@ -170,6 +178,7 @@ WsLayout make_ws_layout(const b4r_model_config& c, int B, int L, int P) {
   }
   w.gath = take(M * H); w.upre = take(M * H); w.u = take(M * H); w.meanm = take(M); w.rstdm = take(M);
   w.t = take(M * H); w.logits = take(M * w.Vp); w.rowsc = take(4 * M); w.pooled = take((int64_t)B * H);
+  w.head_lse = take(M); w.head_ylab = take(M);
   w.dx = take(N * H); w.da = take(N * H); w.db = take(N * H); w.dctx = take(N * H);
   w.dqkv = take(N * 3 * H); w.df = take(N * I); w.dt = take(M * H); w.dg = take(M * H);
   // scratch: every two-stage reduction of the backward pass keeps its partials until the single deferred reduce launch,
@@ -189,8 +198,11 @@ WsLayout make_ws_layout(const b4r_model_config& c, int B, int L, int P) {
     add(b4r_gemm_tn_scratch_floats((int)M, (int)H, (int)H));
     add(b4r_ln_bwd_scratch_floats((int)M, (int)H));
     add((int64_t)mlm_dt_splits(M, H, V) * M * H);
+    if (H == 64) add(b4r_head_rx_dE_scratch_floats((int)M, (int)V));
   }
   add((int64_t)b4r_cdiv(B, 16) * L * H);  // position-table gradient partials
+  // the fused head's forward partials live at the start of the scratch region (consumed before the backward starts)
+  if (M > 0 && H == 64 && s < b4r_head_rx_fwd_scratch_floats((int)M, (int)V)) s = up4(b4r_head_rx_fwd_scratch_floats((int)M, (int)V));
   w.scratch = take(s); w.scratch_floats = s;
   w.total = off;
   return w;
@@ -302,6 +314,10 @@ extern "C" int b4r_workspace_region(const b4r_model_config* cfg, int32_t B, int3
 }
 
 // ===============================================================================================================
+extern "C" int32_t b4r_fused_head_supported(const b4r_model_config* cfg) {
+  return (cfg != nullptr && cfg->hidden_size == 64 && b4r_get_gemm_mode() == B4R_GEMM_BF16X3) ? 1 : 0;
+}
+
 extern "C" int b4r_forward(const b4r_model_config* cfg, const b4r_batch* batch, const float* params, const float* pooler,
                            void* workspace, int64_t workspace_bytes, b4r_train_state* state, int32_t flags,
                            b4r_stream_t stream) {
@@ -355,8 +371,16 @@ extern "C" int b4r_forward(const b4r_model_config* cfg, const b4r_batch* batch, 
     RC(gemm(ws + w.gath, H, params + pl.wd, H, ws + w.u, H, M, H, H, 0, B4R_EPI_BIAS_GELU, params + pl.bd, ws + w.upre, H,
             nullptr, 0, 1.f, 0, nullptr, 0, 0.f, 0, s));
     RC(b4r_ln_fwd(ws + w.u, M, H, params + pl.lnm_g, params + pl.lnm_b, cfg->ln_eps, ws + w.t, ws + w.meanm, ws + w.rstdm, stream));
-    RC(gemm(ws + w.t, H, params + pl.word_emb, H, ws + w.logits, (int)w.Vp, M, V, H, 1, B4R_EPI_BIAS, params + pl.out_bias,
-            nullptr, 0, nullptr, 0, 1.f, 0, nullptr, 0, 0.f, 0, s));
+    if (flags & B4R_FLAG_FUSED_HEAD) {
+      // no [M,V] tensor: loss rows, log-sum-exp and d loss_sum / d T straight from T, E and the bias
+      B4R_CHECK_ARG(b4r_fused_head_supported(cfg), B4R_E_BADARG, "b4r_forward: B4R_FLAG_FUSED_HEAD needs hidden size 64 and the bf16x3 mode");
+      B4R_CHECK_ARG(batch->masked_lm_ids != nullptr, B4R_E_BADARG, "b4r_forward: B4R_FLAG_FUSED_HEAD needs masked_lm_ids");
+      RC(b4r_head_rx_fwd_launch(ws + w.t, params + pl.word_emb, params + pl.out_bias, batch->masked_lm_ids, M, V, ws + w.scratch,
+                                ws + w.dt, ws + w.rowsc, ws + w.head_lse, reinterpret_cast<int32_t*>(ws + w.head_ylab), s));
+    } else {
+      RC(gemm(ws + w.t, H, params + pl.word_emb, H, ws + w.logits, (int)w.Vp, M, V, H, 1, B4R_EPI_BIAS, params + pl.out_bias,
+              nullptr, 0, nullptr, 0, 1.f, 0, nullptr, 0, 0.f, 0, s));
+    }
   }
   return B4R_OK;
 }
@@ -369,8 +393,10 @@ extern "C" int b4r_loss(const b4r_model_config* cfg, const b4r_batch* batch, voi
   const WsLayout w = make_ws_layout(*cfg, batch->B, batch->L, batch->P);
   B4R_CHECK_ARG(workspace_bytes >= w.total * (int64_t)sizeof(float), B4R_E_NOMEM, "b4r_loss: workspace too small");
   float* ws = static_cast<float*>(workspace);
+  if (want_grad & B4R_LOSS_FUSED_HEAD)   // the forward (B4R_FLAG_FUSED_HEAD) already produced the loss rows and dT
+    return b4r_ce_finalize_launch(ws + w.rowsc, (int)w.M, state, (hipStream_t)stream);
   return b4r_softmax_ce(ws + w.logits, (int)w.M, cfg->vocab_size, (int)w.Vp, batch->masked_lm_ids, ws + w.rowsc, state,
-                        want_grad, stream);
+                        want_grad & 1, stream);
 }
 
 extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch, const float* params, float* grads,
@@ -407,6 +433,14 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
 
   // ---- masked-LM head (logits buffer holds d loss_sum / d logits, pad columns zero) --------------------------------
   float* dlog = ws + w.logits;
+  const bool fused_head = (flags & B4R_FLAG_FUSED_HEAD) != 0;
+  B4R_CHECK_ARG(!fused_head || b4r_fused_head_supported(cfg), B4R_E_BADARG, "b4r_backward: B4R_FLAG_FUSED_HEAD needs hidden size 64 and the bf16x3 mode");
+  if (fused_head) {
+    // dT came with the forward; dE / d output_bias recompute the logit tiles (b4r_head_rx.hip)
+    RC(b4r_head_rx_dE_launch(ws + w.t, params + pl.word_emb, params + pl.out_bias, ws + w.head_lse,
+                             reinterpret_cast<const int32_t*>(ws + w.head_ylab), M, V, take(b4r_head_rx_dE_scratch_floats(M, V)),
+                             grads + pl.word_emb, grads + pl.out_bias, s));
+  } else {
   // dT = dlogits . E   (K = V is long and the output small: split K so that the whole chip streams dlogits)
   {
     b4r_gemm_desc d{};
@@ -420,6 +454,7 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
   // dE = dlogits^T . T ; d output_bias = column sums of dlogits
   RC(gemm_tn(dlog, Vp, ws + w.t, H, grads + pl.word_emb, H, M, V, H, nullptr, grads + pl.out_bias, nullptr, 0, 0.f, 0,
              take(b4r_gemm_tn_scratch_floats(M, V, H)), s));
+  }
   // LayerNorm of the transform
   RC(b4r_ln_bwd_launch(ws + w.dt, ws + w.u, ws + w.meanm, ws + w.rstdm, params + pl.lnm_g, M, H, ws + w.dt, grads + pl.lnm_g,
                        grads + pl.lnm_b, take(b4r_ln_bwd_scratch_floats(M, H)), nullptr, nullptr, nullptr, 1, 1, nodrop, s));
@@ -495,10 +530,13 @@ extern "C" int b4r_optimizer_step(const b4r_model_config* cfg, const b4r_adamw_c
 extern "C" int b4r_train_step(const b4r_model_config* cfg, const b4r_adamw_config* hp, const b4r_batch* batch, float* params,
                               float* grads, float* adam_m, float* adam_v, void* workspace, int64_t workspace_bytes,
                               b4r_train_state* state, b4r_stream_t stream) {
+  const int fused = b4r_fused_head_supported(cfg) ? 1 : 0;   // the train step never needs the logits themselves
   RC(b4r_state_begin_step(state, stream));
-  RC(b4r_forward(cfg, batch, params, nullptr, workspace, workspace_bytes, state, B4R_FLAG_TRAINING, stream));
-  RC(b4r_loss(cfg, batch, workspace, workspace_bytes, state, 1, stream));
-  RC(b4r_backward(cfg, batch, params, grads, workspace, workspace_bytes, state, B4R_FLAG_TRAINING, stream));
+  RC(b4r_forward(cfg, batch, params, nullptr, workspace, workspace_bytes, state,
+                 B4R_FLAG_TRAINING | (fused ? B4R_FLAG_FUSED_HEAD : 0), stream));
+  RC(b4r_loss(cfg, batch, workspace, workspace_bytes, state, 1 | (fused ? B4R_LOSS_FUSED_HEAD : 0), stream));
+  RC(b4r_backward(cfg, batch, params, grads, workspace, workspace_bytes, state,
+                  B4R_FLAG_TRAINING | (fused ? B4R_FLAG_FUSED_HEAD : 0), stream));
   RC(b4r_optimizer_step(cfg, hp, params, grads, adam_m, adam_v, workspace, workspace_bytes, state, stream));
   return B4R_OK;
 }

@@ -712,6 +712,13 @@ extern "C" int b4r_softmax_ce(float* logits, int32_t M, int32_t V, int32_t ld, c
   return B4R_OK;
 }
 
+int b4r_ce_finalize_launch(const float* row_scratch, int M, b4r_train_state* state, hipStream_t stream) {
+  B4R_CHECK_ARG(row_scratch && state && M > 0, B4R_E_BADARG, "ce_finalize: bad argument");
+  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1024), 0, stream, row_scratch, M, state);
+  B4R_CHECK_LAUNCH("b4r_loss finalize");
+  return B4R_OK;
+}
+
 extern "C" int b4r_state_begin_step(b4r_train_state* state, b4r_stream_t stream) {
   B4R_CHECK_ARG(state, B4R_E_BADARG, "b4r_state_begin_step: null state");
   hipLaunchKernelGGL(state_begin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state);

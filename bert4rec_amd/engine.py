@@ -243,26 +243,34 @@ class Engine:
         return cb, keep
 
     # ---- compute --------------------------------------------------------------------------------------------------
-    def forward(self, cb: Batch, training: bool = False, pooler: bool = True) -> None:
+    def fused_head_supported(self) -> bool:
+        """train-step masked-LM head that never materialises the logits (include/b4r.h, B4R_FLAG_FUSED_HEAD)"""
+        return bool(self.lib.b4r_fused_head_supported(C.byref(self.cfg)))
+
+    def forward(self, cb: Batch, training: bool = False, pooler: bool = True, fused_head: bool = False) -> None:
+        """fused_head: the loss / backward of the same step must be called with fused_head=True as well, and the
+        "mlm_logits" region is not written"""
         ws = self.workspace(cb.B, cb.L, cb.P)
-        flags = (_lib.FLAG_TRAINING if training else 0) | (_lib.FLAG_POOLER if pooler else 0)
+        flags = (_lib.FLAG_TRAINING if training else 0) | (_lib.FLAG_POOLER if pooler else 0) | \
+                (_lib.FLAG_FUSED_HEAD if fused_head else 0)
         _lib.check(self.lib.b4r_forward(C.byref(self.cfg), C.byref(cb), _ptr(self.params), _ptr(self.pooler), _ptr(ws),
                                         ws.numel() * 4, _ptr(self.state), flags, _stream(self.device)), "b4r_forward")
 
     def begin_step(self) -> None:
         _lib.check(self.lib.b4r_state_begin_step(_ptr(self.state), _stream(self.device)), "b4r_state_begin_step")
 
-    def loss(self, cb: Batch, want_grad: bool) -> None:
+    def loss(self, cb: Batch, want_grad: bool, fused_head: bool = False) -> None:
         ws = self.workspace(cb.B, cb.L, cb.P)
         _lib.check(self.lib.b4r_loss(C.byref(self.cfg), C.byref(cb), _ptr(ws), ws.numel() * 4, _ptr(self.state),
-                                     1 if want_grad else 0, _stream(self.device)), "b4r_loss")
+                                     (1 if want_grad else 0) | (_lib.LOSS_FUSED_HEAD if fused_head else 0),
+                                     _stream(self.device)), "b4r_loss")
 
-    def backward(self, cb: Batch, training: bool = True) -> None:
+    def backward(self, cb: Batch, training: bool = True, fused_head: bool = False) -> None:
         self.ensure_training_buffers()
         ws = self.workspace(cb.B, cb.L, cb.P)
+        flags = (_lib.FLAG_TRAINING if training else 0) | (_lib.FLAG_FUSED_HEAD if fused_head else 0)
         _lib.check(self.lib.b4r_backward(C.byref(self.cfg), C.byref(cb), _ptr(self.params), _ptr(self.grads), _ptr(ws),
-                                         ws.numel() * 4, _ptr(self.state), _lib.FLAG_TRAINING if training else 0,
-                                         _stream(self.device)), "b4r_backward")
+                                         ws.numel() * 4, _ptr(self.state), flags, _stream(self.device)), "b4r_backward")
 
     def optimizer_step(self, hp: AdamWConfig, cb: Batch) -> None:
         self.ensure_training_buffers()
@@ -284,10 +292,11 @@ class Engine:
         [grads | loss sums], then the clip + AdamW step on the reduced buffer (identical on every rank)."""
         from .distributed import allreduce_step
         self.ensure_training_buffers()
+        fused = self.fused_head_supported()
         self.begin_step()
-        self.forward(cb, training=True, pooler=False)
-        self.loss(cb, want_grad=True)
-        self.backward(cb, training=True)
+        self.forward(cb, training=True, pooler=False, fused_head=fused)
+        self.loss(cb, want_grad=True, fused_head=fused)
+        self.backward(cb, training=True, fused_head=fused)
         allreduce_step(self.grad_ext, self.state, self.n_params, group)
         self.optimizer_step(hp, cb)
 

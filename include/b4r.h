@@ -126,6 +126,13 @@ int b4r_workspace_region(const b4r_model_config* cfg, int32_t B, int32_t L, int3
  * flags: bit0 = training (dropout on), bit1 = also compute pooled_output. */
 #define B4R_FLAG_TRAINING 1
 #define B4R_FLAG_POOLER 2
+/* Train-step variant of the masked-LM head that never materialises the [B*P, V] logits (hidden size 64, B4R_GEMM_BF16X3;
+ * ask b4r_fused_head_supported).  b4r_forward with this flag needs masked_lm_ids and leaves the per-slot loss terms and
+ * d loss_sum / d transform in the workspace instead of "mlm_logits"; b4r_loss must then be called with
+ * want_grad | B4R_LOSS_FUSED_HEAD and b4r_backward with the same flag.  b4r_train_step uses it whenever it is supported. */
+#define B4R_FLAG_FUSED_HEAD 4
+#define B4R_LOSS_FUSED_HEAD 2
+int32_t b4r_fused_head_supported(const b4r_model_config* cfg);
 int b4r_forward(const b4r_model_config* cfg, const b4r_batch* batch, const float* params, const float* pooler,
                 void* workspace, int64_t workspace_bytes, b4r_train_state* state, int32_t flags, b4r_stream_t stream);
 int b4r_loss(const b4r_model_config* cfg, const b4r_batch* batch, void* workspace, int64_t workspace_bytes,

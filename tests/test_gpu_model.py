@@ -84,14 +84,14 @@ def test_forward_matches_oracle(name, ragged):
     assert d < 2e-4, d
 
 
-def run_loss_and_grads(eng, batch, training, seed=0, step=0):
+def run_loss_and_grads(eng, batch, training, seed=0, step=0, fused_head=False):
     cb, keep = eng.prepare_batch(batch)
     eng.set_seed(seed)
     eng.set_step(step)
     eng.begin_step()
-    eng.forward(cb, training=training, pooler=False)
-    eng.loss(cb, want_grad=True)
-    eng.backward(cb, training=training)
+    eng.forward(cb, training=training, pooler=False, fused_head=fused_head)
+    eng.loss(cb, want_grad=True, fused_head=fused_head)
+    eng.backward(cb, training=training, fused_head=fused_head)
     torch.cuda.synchronize()
     st = eng.read_state()
     return st, eng.export_named(eng.grads)
@@ -123,6 +123,13 @@ def test_loss_and_gradients_match_autograd(name):
     assert st["valid_count"] == float((batch["masked_lm_ids"] != 0).sum())
     assert abs(st["loss_sum"] / st["valid_count"] - float(loss_ref)) < LOGIT_TOL
     compare_grads(grads, grads_ref, st["valid_count"])
+    if eng.fused_head_supported():
+        # the train-step head that never materialises the logits: same loss, metrics and gradients
+        st2, grads2 = run_loss_and_grads(eng, batch, training=False, fused_head=True)
+        assert st2["valid_count"] == st["valid_count"]
+        assert abs(st2["loss_sum"] / st2["valid_count"] - float(loss_ref)) < LOGIT_TOL
+        assert st2["correct_masked"] == st["correct_masked"] and st2["correct_all"] == st["correct_all"]
+        compare_grads(grads2, grads_ref, st2["valid_count"])
 
 
 def test_train_mode_with_dropout_matches_oracle_mask_for_mask():

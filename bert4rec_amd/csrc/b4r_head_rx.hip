@@ -255,12 +255,12 @@ int even_tiles(int rows, int slices) {
 }
 
 int fwd_slices_wanted(int M) {
-  static const int target = getenv("B4R_HEAD_FWD_WGS") ? atoi(getenv("B4R_HEAD_FWD_WGS")) : 512;
+  static const int target = getenv("B4R_HEAD_FWD_WGS") ? atoi(getenv("B4R_HEAD_FWD_WGS")) : 768;
   int s = b4r_cdiv(target, b4r_cdiv(M, ROWS_WG));
   return s < 1 ? 1 : (s > 16 ? 16 : s);
 }
 int dE_slices_wanted(int V) {
-  static const int target = getenv("B4R_HEAD_DE_WGS") ? atoi(getenv("B4R_HEAD_DE_WGS")) : 512;
+  static const int target = getenv("B4R_HEAD_DE_WGS") ? atoi(getenv("B4R_HEAD_DE_WGS")) : 768;
   int s = b4r_cdiv(target, b4r_cdiv(V, ROWS_WG));
   return s < 1 ? 1 : (s > 32 ? 32 : s);
 }
@@ -281,9 +281,17 @@ int b4r_head_rx_dE_slices(int M, int V) {
 }
 int64_t b4r_head_rx_dE_scratch_floats(int M, int V) { return (int64_t)b4r_head_rx_dE_slices(M, V) * ((int64_t)V * 64 + V); }
 
+int b4r_head_rx_fwd_launch2(const float* T, const float* E, const float* bias, const int64_t* y, int M, int V, float* scratch,
+                            float* dT, float* row_out, float* lse, int32_t* ylab, int only_sweep, hipStream_t stream);
+
 // loss rows (as b4r_softmax_ce writes them), lse, labels and dT from T, E, bias, y; hidden size 64 only
 int b4r_head_rx_fwd_launch(const float* T, const float* E, const float* bias, const int64_t* y, int M, int V, float* scratch,
                            float* dT, float* row_out, float* lse, int32_t* ylab, hipStream_t stream) {
+  return b4r_head_rx_fwd_launch2(T, E, bias, y, M, V, scratch, dT, row_out, lse, ylab, 0, stream);
+}
+
+int b4r_head_rx_fwd_launch2(const float* T, const float* E, const float* bias, const int64_t* y, int M, int V, float* scratch,
+                            float* dT, float* row_out, float* lse, int32_t* ylab, int only_sweep, hipStream_t stream) {
   HeadP p{};
   p.T = T; p.E = E; p.bias = bias; p.y = y; p.part = scratch; p.M = M; p.V = V;
   const int slices = b4r_head_rx_fwd_slices(M, V);
@@ -296,6 +304,7 @@ int b4r_head_rx_fwd_launch(const float* T, const float* E, const float* bias, co
   }
   hipLaunchKernelGGL(head_fwd_kernel, dim3(b4r_cdiv(M, ROWS_WG), slices), dim3(64 * WAVES), HEAD_LDS, stream, p);
   B4R_CHECK_LAUNCH("masked-LM head forward (fused)");
+  if (only_sweep) return B4R_OK;
   hipLaunchKernelGGL(head_combine_kernel, dim3(b4r_cdiv(M * 16, 256)), dim3(256), 0, stream, (const float*)scratch, slices, M, V, E,
                      y, dT, row_out, lse, ylab);
   B4R_CHECK_LAUNCH("masked-LM head combine");
@@ -322,4 +331,30 @@ int b4r_head_rx_dE_launch(const float* T, const float* E, const float* bias, con
   hipLaunchKernelGGL(head_dE_kernel, dim3(b4r_cdiv(V, ROWS_WG), slices), dim3(64 * WAVES), HEAD_LDS, stream, p);
   B4R_CHECK_LAUNCH("masked-LM head dE (fused)");
   return b4r_launch_slab_reduce_full(p.slab, slices, V, 64, dE, 64, 0, nullptr, nullptr, p.bslab, db, stream);
+}
+
+extern "C" int64_t b4r_mlm_head_fused_scratch_floats(int32_t M, int32_t V) {
+  if (M <= 0 || V <= 0) return 0;
+  const int64_t a = b4r_head_rx_fwd_scratch_floats(M, V), b = b4r_head_rx_dE_scratch_floats(M, V);
+  return a > b ? a : b;
+}
+
+extern "C" int b4r_mlm_head_fused_fwd(const float* T, const float* E, const float* bias, const int64_t* y_true, int32_t M,
+                                      int32_t V, float* scratch, float* dT, float* row_scratch, float* lse, int32_t* labels,
+                                      int32_t only_sweep, b4r_stream_t stream) {
+  B4R_CHECK_ARG(T && E && bias && y_true && scratch, B4R_E_BADARG, "b4r_mlm_head_fused_fwd: null argument");
+  B4R_CHECK_ARG(only_sweep || (dT && row_scratch && lse && labels), B4R_E_BADARG, "b4r_mlm_head_fused_fwd: null output");
+  B4R_CHECK_ARG(M > 0 && V > 0, B4R_E_SHAPE, "b4r_mlm_head_fused_fwd: bad shape");
+  B4R_CHECK_ARG(b4r_aligned16(T) && b4r_aligned16(E) && b4r_aligned16(scratch) && (only_sweep || b4r_aligned16(dT)), B4R_E_ALIGN,
+                "b4r_mlm_head_fused_fwd: T, E, scratch and dT must be 16-byte aligned");
+  return b4r_head_rx_fwd_launch2(T, E, bias, y_true, M, V, scratch, dT, row_scratch, lse, labels, only_sweep, (hipStream_t)stream);
+}
+
+extern "C" int b4r_mlm_head_fused_bwd(const float* T, const float* E, const float* bias, const float* lse, const int32_t* labels,
+                                     int32_t M, int32_t V, float* scratch, float* dE, float* dbias, b4r_stream_t stream) {
+  B4R_CHECK_ARG(T && E && bias && lse && labels && scratch && dE && dbias, B4R_E_BADARG, "b4r_mlm_head_fused_bwd: null argument");
+  B4R_CHECK_ARG(M > 0 && V > 0, B4R_E_SHAPE, "b4r_mlm_head_fused_bwd: bad shape");
+  B4R_CHECK_ARG(b4r_aligned16(T) && b4r_aligned16(E) && b4r_aligned16(scratch), B4R_E_ALIGN,
+                "b4r_mlm_head_fused_bwd: T, E and scratch must be 16-byte aligned");
+  return b4r_head_rx_dE_launch(T, E, bias, lse, labels, M, V, scratch, dE, dbias, (hipStream_t)stream);
 }

@@ -8,8 +8,11 @@ B=256 per GPU, L=200, P=40, H=64, 2 layers, 2 heads, inner 256, V=3709, dropout 
         bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0.  `value` = masked positions (slots with masked_lm_ids != 0) consumed per second by the
-whole job, inputs resident in HBM.  `roofline` is measured on the materialising masked-LM-head projection kernel
-(logits[M,V] = T.E^T + b), replayed stand-alone on the same buffers between two HIP events on the launch stream.
+whole job, inputs resident in HBM.  `roofline` is measured on the longest kernel of the step, replayed stand-alone on the
+live buffers between two HIP events on the launch stream: with hidden size 64 that is the vocabulary sweep of the fused
+masked-LM head (head_fwd_kernel: logits tiles -> online softmax -> sum_v p E[v], nothing of size [M,V] touches HBM, so
+the bound is the matrix pipe); `roofline_materialising` reports the HBM-bound logits[M,V] = T.E^T + b kernel that the
+forward / evaluation API still uses (and that larger hidden sizes train with).
 `cpu_baseline` is the oracle (CPU restatement of the reference math; TF2 is not installed anywhere) timed on the host.
 """
 import argparse
@@ -35,6 +38,7 @@ CONFIGS = {
 }
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); 6.29 TB/s is the measured copy rate
+BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md); the split-precision kernels run on it
 
 
 def synthetic_batch(B, L, P, V, rate, seed):
@@ -157,9 +161,32 @@ def main():
         k_us = e0.elapsed_time(e1) * 1e3 / reps
         alg_bytes = M * V * 4 + M * H * 4 + V * H * 4 + V * 4 + M * 8
         achieved = alg_bytes / (k_us * 1e-6) / 1e9
-        roofline = {"kernel": "rx_gemm_nk_kernel<BIAS> (mlm_logits = T.E^T + b, bf16x3)", "bound": "hbm", "achieved": round(achieved, 1),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                    "algorithmic_bytes": alg_bytes, "avg_launch_us": round(k_us, 2)}
+        roofline_mat = {"kernel": "rx_gemm_nk_kernel<BIAS> (mlm_logits = T.E^T + b, bf16x3)", "bound": "hbm",
+                        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes": alg_bytes,
+                        "avg_launch_us": round(k_us, 2), "in_timed_region": not eng.fused_head_supported()}
+        roofline = roofline_mat
+        if eng.fused_head_supported():
+            # the train step's head: replay the vocabulary sweep (the longest kernel of the step) on the live buffers
+            _, keep0 = prepared[0]
+            scratch = torch.empty(lib.b4r_mlm_head_fused_scratch_floats(M, V), dtype=torch.float32, device=device)
+            hargs = (t_h.data_ptr(), eng.view("word_embeddings/embeddings").data_ptr(),
+                    eng.view("cls/predictions/output_bias/bias").data_ptr(), keep0["masked_lm_ids"].data_ptr(), M, V,
+                    scratch.data_ptr(), None, None, None, None, 1, stream)
+            for _ in range(5):
+                _lib.check(lib.b4r_mlm_head_fused_fwd(*hargs))
+            e0.record()
+            for _ in range(reps):
+                _lib.check(lib.b4r_mlm_head_fused_fwd(*hargs))
+            e1.record()
+            torch.cuda.synchronize()
+            h_us = e0.elapsed_time(e1) * 1e3 / reps
+            alg_flops = 2 * (2 * M * V * H)          # x = T.E^T and sum_v p[m,v] E[v,:], fp32-equivalent multiply-adds
+            tf = alg_flops / (h_us * 1e-6) / 1e12
+            roofline = {"kernel": "head_fwd_kernel (masked-LM head: logit tiles -> online softmax -> p.E, bf16x3)",
+                        "bound": "mfma", "achieved": round(tf, 1), "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(tf / BF16_PEAK_TFLOPS, 4), "traffic": None, "algorithmic_flops": alg_flops,
+                        "executed_mfma_flops": 3 * alg_flops, "avg_launch_us": round(h_us, 2)}
 
         if args.phases:
             def timed(fn, n=20):
@@ -214,7 +241,7 @@ def main():
                                          f"masked positions/GPU/step",
                              "global_batch": B * world, "seq_len": L, "parallelism": f"dp{world}"},
                   "per_gpu": round(value / world, 1), "final_loss": round(loss, 5),
-                  "roofline": roofline, "cpu_baseline": cpu}
+                  "roofline": roofline, "roofline_materialising": roofline_mat, "cpu_baseline": cpu}
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

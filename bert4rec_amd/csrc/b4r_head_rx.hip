@@ -20,7 +20,11 @@
 namespace {
 
 constexpr int HEAD_CH = 10;    // 16-row tiles per LDS chunk: 40 KB of images, three workgroups per CU
-constexpr int PART_LD = 72;    // floats per (V slice, row): 64 accumulators, max, sum, best logit, best index, label logit
+constexpr int PART_LD = 72;    // floats per (V slice, row): 64 accumulators, max, sum, best logit, best index
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+// The sweeps work in log2 units: T (or E) is scaled by log2(e) before it is split, so that the softmax exponential is the
+// bare v_exp_f32 (2^x) -- the kernels are bound by VALU issue, every instruction per logit counts.
+__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 struct HeadP {
   const float* T; const float* E; const float* bias; const int64_t* y;
@@ -62,14 +66,12 @@ __global__ __launch_bounds__(64 * WAVES) void head_fwd_kernel(HeadP p) {
   const int mc = min(m, p.M - 1);
   bf16x8 th[2], tl[2];
 #pragma unroll
-  for (int kh = 0; kh < 2; ++kh) split8(load8(p.T + (int64_t)mc * 64 + 32 * kh + 8 * g), th[kh], tl[kh]);
-  const int64_t y64 = p.y[mc];
-  const int yv = (y64 >= 0 && y64 < p.V) ? (int)y64 : -1;
+  for (int kh = 0; kh < 2; ++kh) split8(load8(p.T + (int64_t)mc * 64 + 32 * kh + 8 * g) * LOG2E, th[kh], tl[kh]);
   const int v_begin = blockIdx.y * p.tiles_per_slice * 16;
   const int v_end = min(((p.V + 31) >> 5) << 5, v_begin + p.tiles_per_slice * 16);   // multiples of 32; v_begin < V
   const FragAddr fa = frag_addr(lane);
 
-  float mx = -INFINITY, sum = 0.f, best = -INFINITY, xl = -INFINITY;
+  float mx = -INFINITY, sum = 0.f, best = -INFINITY;   // log2 units
   int bidx = 0x7fffffff;
   f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(64 * WAVES) void head_fwd_kernel(HeadP p) {
     const float bz = p.bias[min(c0 + (int)threadIdx.x, p.V - 1)];
     __syncthreads();                                            // the previous chunk has been consumed
     stage_write(st, img, nrows, valid);
-    if ((int)threadIdx.x < nrows) sBias[threadIdx.x] = (c0 + (int)threadIdx.x < p.V) ? bz : -INFINITY;
+    if ((int)threadIdx.x < nrows) sBias[threadIdx.x] = (c0 + (int)threadIdx.x < p.V) ? bz * LOG2E : -INFINITY;
     __syncthreads();
     for (int tp = 0; tp < nrows / 32; ++tp) {
       f32x4 x[2];
@@ -89,25 +91,30 @@ __global__ __launch_bounds__(64 * WAVES) void head_fwd_kernel(HeadP p) {
       for (int u = 0; u < 2; ++u)
         x[u] = logit_tile(img + fa.row + TILE_BYTES * (2 * tp + u), th, tl) +
                *reinterpret_cast<const f32x4*>(&sBias[16 * (2 * tp + u) + 4 * g]);
-      float pm = fmaxf(fmaxf(fmaxf(x[0][0], x[0][1]), fmaxf(x[0][2], x[0][3])), fmaxf(fmaxf(x[1][0], x[1][1]), fmaxf(x[1][2], x[1][3])));
-      pm = fmaxf(pm, __shfl_xor(pm, 16, 64));
+      const float pl8 = fmaxf(fmaxf(fmaxf(x[0][0], x[0][1]), fmaxf(x[0][2], x[0][3])), fmaxf(fmaxf(x[1][0], x[1][1]), fmaxf(x[1][2], x[1][3])));
+      if (pl8 > best) {                                         // rare after the first tiles: argmax of this lane's columns
+        best = pl8;
+        int j = 7;                                              // lowest of the 8 positions that holds the maximum
+#pragma unroll
+        for (int jj = 6; jj >= 0; --jj) j = (x[jj >> 2][jj & 3] == pl8) ? jj : j;
+        bidx = c0 + 16 * (2 * tp + (j >> 2)) + 4 * g + (j & 3);   // columns grow with the pair: earlier maxima win ties
+      }
+      float pm = fmaxf(pl8, __shfl_xor(pl8, 16, 64));
       pm = fmaxf(pm, __shfl_xor(pm, 32, 64));
       const float mnew = fmaxf(mx, pm);                         // finite: the first pair of a slice holds real columns
-      const float alpha = (mx == mnew) ? 1.0f : __expf(mx - mnew);
-      mx = mnew;
-      sum *= alpha;
+      if (__builtin_amdgcn_ballot_w64(mnew != mx) != 0) {       // wave-uniform; the running maxima settle after a few tiles
+        const float alpha = (mx == mnew) ? 1.0f : ex2(mx - mnew);
+        sum *= alpha;
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb) acc[kb] = acc[kb] * alpha;
+        for (int kb = 0; kb < 4; ++kb) acc[kb] = acc[kb] * alpha;
+      }
+      mx = mnew;
       f32x4 pr[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int v = c0 + 16 * (2 * tp + u) + 4 * g + r;
-          const float xv = x[u][r];
-          if (xv > best) { best = xv; bidx = v; }               // increasing v within a lane: the lowest index wins ties
-          if (v == yv) xl = xv;
-          const float e = __expf(xv - mnew);
+          const float e = ex2(x[u][r] - mnew);
           pr[u][r] = e;
           sum += e;
         }
@@ -120,8 +127,6 @@ __global__ __launch_bounds__(64 * WAVES) void head_fwd_kernel(HeadP p) {
   // the four g lanes of a row hold disjoint columns: combine
   sum += __shfl_xor(sum, 16, 64);
   sum += __shfl_xor(sum, 32, 64);
-  xl = fmaxf(xl, __shfl_xor(xl, 16, 64));
-  xl = fmaxf(xl, __shfl_xor(xl, 32, 64));
 #pragma unroll
   for (int o = 16; o <= 32; o <<= 1) {
     const float ov = __shfl_xor(best, o, 64);
@@ -133,41 +138,44 @@ __global__ __launch_bounds__(64 * WAVES) void head_fwd_kernel(HeadP p) {
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) *reinterpret_cast<f32x4*>(dst + 16 * kb + 4 * g) = acc[kb];
     if (g == 0) {
-      dst[64] = mx; dst[65] = sum; dst[66] = best; dst[67] = __int_as_float(bidx); dst[68] = xl;
+      dst[64] = mx; dst[65] = sum; dst[66] = best; dst[67] = __int_as_float(bidx);
     }
   }
 }
 
 // merge the V slices of every row; 16 threads per row (4 columns each)
-__global__ __launch_bounds__(256) void head_combine_kernel(const float* part, int slices, int M, int V, const float* E,
-                                                           const int64_t* y, float* dT, float* row_out, float* lse_out,
-                                                           int32_t* ylab) {
+__global__ __launch_bounds__(256) void head_combine_kernel(const float* part, int slices, int M, int V, const float* T,
+                                                           const float* E, const float* bias, const int64_t* y, float* dT,
+                                                           float* row_out, float* lse_out, int32_t* ylab) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  const int m = idx >> 4, c4 = idx & 15;
-  if (m >= M) return;
+  const int m = min(idx >> 4, M - 1), c4 = idx & 15;           // M*16 is a multiple of 16: whole 16-lane groups are in range
+  if ((idx >> 4) >= M) return;
   float mx = -INFINITY;
   for (int s = 0; s < slices; ++s) mx = fmaxf(mx, part[((int64_t)s * M + m) * PART_LD + 64]);
-  float sum = 0.f, best = -INFINITY, xl = -INFINITY;
+  float sum = 0.f, best = -INFINITY;
   int bidx = 0x7fffffff;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int s = 0; s < slices; ++s) {                            // slices in increasing column order: lowest index wins ties
     const float* src = part + ((int64_t)s * M + m) * PART_LD;
-    const float w = __expf(src[64] - mx);
+    const float w = ex2(src[64] - mx);                          // the sweep's maxima are in log2 units
     sum += src[65] * w;
     acc += *reinterpret_cast<const f32x4*>(src + 4 * c4) * w;
     if (src[66] > best) { best = src[66]; bidx = __float_as_int(src[67]); }
-    xl = fmaxf(xl, src[68]);
   }
   const int64_t y64 = y[m];
   const bool valid = (y64 != 0), y_ok = (y64 >= 0 && y64 < V);
-  f32x4 d = {0.f, 0.f, 0.f, 0.f};
-  if (valid) {
-    d = acc * (1.0f / sum);
-    if (y_ok) d -= *reinterpret_cast<const f32x4*>(E + y64 * 64 + 4 * c4);
-  }
+  f32x4 d = {0.f, 0.f, 0.f, 0.f}, ey = {0.f, 0.f, 0.f, 0.f};
+  if (y_ok) ey = *reinterpret_cast<const f32x4*>(E + y64 * 64 + 4 * c4);
+  if (valid) d = acc * (1.0f / sum) - ey;
   *reinterpret_cast<f32x4*>(dT + (int64_t)m * 64 + 4 * c4) = d;
+  // the label's logit in plain fp32 (the loss needs its value, the metrics only the argmax index): 16 lanes x 4 columns
+  const f32x4 tv = *reinterpret_cast<const f32x4*>(T + (int64_t)m * 64 + 4 * c4);
+  float xl = (tv[0] * ey[0] + tv[1] * ey[1]) + (tv[2] * ey[2] + tv[3] * ey[3]);
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) xl += __shfl_xor(xl, o, 64);
   if (c4 == 0) {
-    const float lse = mx + __logf(sum);
+    if (y_ok) xl += bias[y64];
+    const float lse = (mx + __log2f(sum)) * LN2;
     row_out[4 * (int64_t)m + 0] = (valid && y_ok) ? (lse - xl) : 0.f;
     row_out[4 * (int64_t)m + 1] = valid ? 1.f : 0.f;
     row_out[4 * (int64_t)m + 2] = (valid && (int64_t)bidx == y64) ? 1.f : 0.f;
@@ -193,8 +201,8 @@ __global__ __launch_bounds__(64 * WAVES) void head_dE_kernel(HeadP p) {
   const int vc = min(v, p.V - 1);
   bf16x8 eh[2], el[2];
 #pragma unroll
-  for (int kh = 0; kh < 2; ++kh) split8(load8(p.E + (int64_t)vc * 64 + 32 * kh + 8 * g), eh[kh], el[kh]);
-  const float bv = vlive ? p.bias[vc] : -INFINITY;              // -inf => zero probability, and no label equals v >= V
+  for (int kh = 0; kh < 2; ++kh) split8(load8(p.E + (int64_t)vc * 64 + 32 * kh + 8 * g) * LOG2E, eh[kh], el[kh]);
+  const float bv = vlive ? p.bias[vc] * LOG2E : -INFINITY;      // -inf => zero probability, and no label equals v >= V
   const int m_begin = blockIdx.y * p.tiles_per_slice * 16;
   const int m_end = min(((p.M + 31) >> 5) << 5, m_begin + p.tiles_per_slice * 16);
   const FragAddr fa = frag_addr(lane);
@@ -213,7 +221,7 @@ __global__ __launch_bounds__(64 * WAVES) void head_dE_kernel(HeadP p) {
     stage_write(st, img, nrows, valid);
     if ((int)threadIdx.x < nrows) {
       const bool in = c0 + (int)threadIdx.x < p.M;
-      sLse[threadIdx.x] = in ? lz : INFINITY;
+      sLse[threadIdx.x] = in ? lz * LOG2E : INFINITY;
       sY[threadIdx.x] = in ? yz : -1;
     }
     __syncthreads();
@@ -227,7 +235,7 @@ __global__ __launch_bounds__(64 * WAVES) void head_dE_kernel(HeadP p) {
         const i32x4 yy = *reinterpret_cast<const i32x4*>(&sY[16 * t + 4 * g]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float gg = __expf(x[r] + bv - ls[r]) - (yy[r] == v ? 1.0f : 0.0f);
+          const float gg = ex2(x[r] + (bv - ls[r])) - (yy[r] == v ? 1.0f : 0.0f);
           gv[u][r] = gg;
           dbsum += gg;
         }
@@ -305,8 +313,8 @@ int b4r_head_rx_fwd_launch2(const float* T, const float* E, const float* bias, c
   hipLaunchKernelGGL(head_fwd_kernel, dim3(b4r_cdiv(M, ROWS_WG), slices), dim3(64 * WAVES), HEAD_LDS, stream, p);
   B4R_CHECK_LAUNCH("masked-LM head forward (fused)");
   if (only_sweep) return B4R_OK;
-  hipLaunchKernelGGL(head_combine_kernel, dim3(b4r_cdiv(M * 16, 256)), dim3(256), 0, stream, (const float*)scratch, slices, M, V, E,
-                     y, dT, row_out, lse, ylab);
+  hipLaunchKernelGGL(head_combine_kernel, dim3(b4r_cdiv(M * 16, 256)), dim3(256), 0, stream, (const float*)scratch, slices, M, V, T, E,
+                     bias, y, dT, row_out, lse, ylab);
   B4R_CHECK_LAUNCH("masked-LM head combine");
   return B4R_OK;
 }

@@ -20,7 +20,8 @@ int b4r_ln_bwd_launch(const float* dy, const float* z, const float* mean, const 
                       const float* table, const float* pos_table, int L, int V, DropArgs drop, hipStream_t stream);
 int b4r_scatter_add_rows_impl(const float* src, const int64_t* idx, int64_t idx_add_per, int per, int n, int H,
                               float* dst, int dst_ld, const int64_t* skip_if_zero, int64_t dst_rows, int hot_rows,
-                              hipStream_t stream);
+                              float* hot_scratch, hipStream_t stream);
+int64_t b4r_scatter_hot_scratch_floats(int hot_rows, int H);
 int b4r_batch_colsum(const float* x, int B, int L, int H, float* dpos, float* scratch, hipStream_t stream);
 int b4r_mul_gelu_grad(float* du, const float* pre, int64_t n, hipStream_t stream);
 int b4r_gemm_f32_splitk(const b4r_gemm_desc* d, int splits, float* scratch, int k_pad_ok, hipStream_t stream);
@@ -201,6 +202,7 @@ WsLayout make_ws_layout(const b4r_model_config& c, int B, int L, int P) {
     if (H == 64) add(b4r_head_rx_dE_scratch_floats((int)M, (int)V));
   }
   add((int64_t)b4r_cdiv(B, 16) * L * H);  // position-table gradient partials
+  add(b4r_scatter_hot_scratch_floats(3, (int)H));   // per-workgroup sums of the special-token rows of the table gradient
   // the fused head's forward partials live at the start of the scratch region (consumed before the backward starts)
   if (M > 0 && H == 64 && s < b4r_head_rx_fwd_scratch_floats((int)M, (int)V)) s = up4(b4r_head_rx_fwd_scratch_floats((int)M, (int)V));
   w.scratch = take(s); w.scratch_floats = s;
@@ -464,7 +466,7 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
   RC(gemm(ws + w.dt, H, params + pl.wd, H, ws + w.dg, H, M, H, H, 1, B4R_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 1.f, 0,
           nullptr, 0, 0.f, 0, s));
   // scatter into d sequence_output (slots with y_true == 0 carry exactly zero gradient and are skipped)
-  RC(b4r_scatter_add_rows_impl(ws + w.dg, batch->masked_lm_positions, L, P, M, H, ws + w.dx, H, batch->masked_lm_ids, N, 0, s));
+  RC(b4r_scatter_add_rows_impl(ws + w.dg, batch->masked_lm_positions, L, P, M, H, ws + w.dx, H, batch->masked_lm_ids, N, 0, nullptr, s));
 
   // ---- encoder layers, last to first ---------------------------------------------------------------------------------
   for (int i = cfg->num_layers - 1; i >= 0; --i) {
@@ -506,9 +508,13 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
   // all queued ordered reductions (weight / bias / LayerNorm gradients) in one launch; the item-table gradient must be
   // complete before the embedding rows are scatter-added on top of it
   RC(b4r_reduce_queue_flush(s));
-  B4R_CHECK_ARG(scratch_used <= w.scratch_floats, B4R_E_NOMEM, "b4r_backward: internal scratch overflow");
-  RC(b4r_scatter_add_rows_impl(ws + w.da, batch->input_word_ids, 0, 1, N, H, grads + pl.word_emb, H, nullptr, V, 3, s));
+  B4rReduceQueue tail_queue;
+  b4r_reduce_queue_begin(&tail_queue);   // the two small reductions below share one launch as well
+  RC(b4r_scatter_add_rows_impl(ws + w.da, batch->input_word_ids, 0, 1, N, H, grads + pl.word_emb, H, nullptr, V, 3,
+                               take(b4r_scatter_hot_scratch_floats(3, H)), s));
   RC(b4r_batch_colsum(ws + w.da, B, L, H, grads + pl.pos_emb, take((int64_t)b4r_cdiv(B, 16) * L * H), s));
+  RC(b4r_reduce_queue_flush(s));
+  B4R_CHECK_ARG(scratch_used <= w.scratch_floats, B4R_E_NOMEM, "b4r_backward: internal scratch overflow");
   return B4R_OK;
 }
 

@@ -6,6 +6,8 @@
 // xor-shuffle reductions inside the LPR-lane group.
 #include "b4r_common.h"
 
+int b4r_launch_slab_reduce_full(const float* slab, int S, int Mo, int No, float* out, int ldo, int accumulate,
+                                const float* cslab, float* colsum, const float* caslab, float* colsum_a, hipStream_t stream);
 int b4r_launch_slab_reduce(const float* slab, int S, int Mo, int No, float* out, int ldo, int accumulate,
                            hipStream_t stream);
 
@@ -259,15 +261,19 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* src, int 
   }
 }
 
+constexpr int HOT_SLOTS = 64;
 // one lane per float: a wave-instruction adds 64 consecutive dwords (256 contiguous bytes of one or a few rows), the
 // shape at which global float atomics run at full rate (MI355X_MICROARCH.md 'Global float atomics')
 __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* src, const int64_t* idx, int64_t idx_add_per,
                                                                int per, int n, int H, float* dst, int dst_ld,
                                                                const int64_t* skip_if_zero, int64_t dst_rows,
-                                                               int hot_rows) {
+                                                               int hot_rows, float* hot_slab) {
   // hot_rows > 0: destination rows [0, hot_rows) (the special tokens PAD/MASK/UNK of the item table: [MASK] alone is
-  // ~20 % of all tokens) are first summed in LDS and flushed once per workgroup, instead of thousands of global
-  // atomics queueing on the same 256 bytes.
+  // ~20 % of all tokens) are first summed in LDS and leave the workgroup once, instead of thousands of global atomics
+  // queueing on the same 256 bytes.  Even one flush per workgroup is 1024 same-address atomics per float, which the L2
+  // serialises (that was most of this kernel's 39 us): with hot_slab the per-workgroup sums go to HOT_SLOTS slabs
+  // [HOT_SLOTS][hot_rows*H] (workgroup % HOT_SLOTS: 16 atomics per address instead of 1024) that a slab reduction adds
+  // to dst afterwards.
   extern __shared__ float s_hot[];
   for (int k = threadIdx.x; k < hot_rows * H; k += 256) s_hot[k] = 0.f;
   if (hot_rows > 0) __syncthreads();
@@ -287,7 +293,9 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* src,
     __syncthreads();
     for (int k = threadIdx.x; k < hot_rows * H; k += 256) {
       const float v = s_hot[k];
-      if (v != 0.f) atomicAdd(dst + (int64_t)(k / H) * dst_ld + (k % H), v);
+      if (v == 0.f) continue;
+      if (hot_slab) atomicAdd(hot_slab + (int64_t)(blockIdx.x % HOT_SLOTS) * hot_rows * H + k, v);
+      else atomicAdd(dst + (int64_t)(k / H) * dst_ld + (k % H), v);
     }
   }
 }
@@ -660,15 +668,25 @@ extern "C" int b4r_gather_rows(const float* src, int32_t src_ld, const int64_t* 
   return B4R_OK;
 }
 
+// hot_scratch (optional, with hot_rows > 0): b4r_scatter_hot_scratch_floats(hot_rows, H) floats
+int64_t b4r_scatter_hot_scratch_floats(int hot_rows, int H) { return (int64_t)HOT_SLOTS * hot_rows * H; }
+
 int b4r_scatter_add_rows_impl(const float* src, const int64_t* idx, int64_t idx_add_per, int per, int n, int H,
                               float* dst, int dst_ld, const int64_t* skip_if_zero, int64_t dst_rows, int hot_rows,
-                              hipStream_t stream) {
+                              float* hot_scratch, hipStream_t stream) {
   int grid = b4r_cdiv((int64_t)n * H, 256);
   const int cap = hot_rows > 0 ? 1024 : 8192;
   if (grid > cap) grid = cap;
+  if (hot_rows <= 0) hot_scratch = nullptr;
+  if (hot_scratch && hipMemsetAsync(hot_scratch, 0, (size_t)HOT_SLOTS * hot_rows * H * sizeof(float), stream) != hipSuccess) {
+    b4r_set_error("b4r_scatter_add_rows: hipMemsetAsync failed");
+    return B4R_E_HIP;
+  }
   hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid), dim3(256), (size_t)hot_rows * H * sizeof(float), stream, src, idx,
-                     idx_add_per, per, n, H, dst, dst_ld, skip_if_zero, dst_rows, hot_rows);
+                     idx_add_per, per, n, H, dst, dst_ld, skip_if_zero, dst_rows, hot_rows, hot_scratch);
   B4R_CHECK_LAUNCH("b4r_scatter_add_rows");
+  if (hot_scratch)   // joins the caller's reduce queue when one is active
+    return b4r_launch_slab_reduce_full(hot_scratch, HOT_SLOTS, hot_rows, H, dst, dst_ld, 1, nullptr, nullptr, nullptr, nullptr, stream);
   return B4R_OK;
 }
 
@@ -677,7 +695,7 @@ extern "C" int b4r_scatter_add_rows(const float* src, const int64_t* idx, int64_
                                     b4r_stream_t stream) {
   B4R_CHECK_ARG(src && idx && dst, B4R_E_BADARG, "b4r_scatter_add_rows: null argument");
   B4R_CHECK_ARG(n > 0 && H > 0 && H % 4 == 0 && per > 0 && dst_ld % 4 == 0, B4R_E_SHAPE, "b4r_scatter_add_rows: bad shape");
-  return b4r_scatter_add_rows_impl(src, idx, idx_add_per, per, n, H, dst, dst_ld, skip_if_zero, (int64_t)1 << 62, 0,
+  return b4r_scatter_add_rows_impl(src, idx, idx_add_per, per, n, H, dst, dst_ld, skip_if_zero, (int64_t)1 << 62, 0, nullptr,
                                    (hipStream_t)stream);
 }
 
@@ -696,7 +714,7 @@ int b4r_batch_colsum(const float* x, int B, int L, int H, float* dpos, float* sc
   dim3 grid(b4r_cdiv((int64_t)L * (H / 4), 256), S);
   hipLaunchKernelGGL(batch_colsum_kernel, grid, dim3(256), 0, stream, x, B, L, H, bchunk, scratch);
   B4R_CHECK_LAUNCH("batch_colsum");
-  return b4r_launch_slab_reduce(scratch, S, L, H, dpos, H, 0, stream);
+  return b4r_launch_slab_reduce_full(scratch, S, L, H, dpos, H, 0, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int b4r_softmax_ce(float* logits, int32_t M, int32_t V, int32_t ld, const int64_t* y_true,

@@ -32,7 +32,9 @@ int b4r_head_rx_fwd_launch(const float* T, const float* E, const float* bias, co
                            float* dT, float* row_out, float* lse, int32_t* ylab, hipStream_t stream);
 int b4r_head_rx_dE_launch(const float* T, const float* E, const float* bias, const float* lse, const int32_t* ylab, int M, int V,
                           float* scratch, float* dE, float* db, hipStream_t stream);
-int b4r_ce_finalize_launch(const float* row_scratch, int M, b4r_train_state* state, hipStream_t stream);
+int b4r_ce_finalize_launch(const float* row_scratch, int M, b4r_train_state* state, int overwrite, hipStream_t stream);
+int b4r_optimizer_fused(const b4r_adamw_config* hp, float* params, const float* grads, float* adam_m, float* adam_v, int64_t n,
+                        int64_t n_decay, float* scratch, b4r_train_state* state, hipStream_t stream);
 
 // ---- error message (thread local) ---------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -396,9 +398,9 @@ extern "C" int b4r_loss(const b4r_model_config* cfg, const b4r_batch* batch, voi
   B4R_CHECK_ARG(workspace_bytes >= w.total * (int64_t)sizeof(float), B4R_E_NOMEM, "b4r_loss: workspace too small");
   float* ws = static_cast<float*>(workspace);
   if (want_grad & B4R_LOSS_FUSED_HEAD)   // the forward (B4R_FLAG_FUSED_HEAD) already produced the loss rows and dT
-    return b4r_ce_finalize_launch(ws + w.rowsc, (int)w.M, state, (hipStream_t)stream);
+    return b4r_ce_finalize_launch(ws + w.rowsc, (int)w.M, state, (want_grad & B4R_LOSS_OVERWRITE) ? 1 : 0, (hipStream_t)stream);
   return b4r_softmax_ce(ws + w.logits, (int)w.M, cfg->vocab_size, (int)w.Vp, batch->masked_lm_ids, ws + w.rowsc, state,
-                        want_grad & 1, stream);
+                        want_grad & (1 | B4R_LOSS_OVERWRITE), stream);
 }
 
 extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch, const float* params, float* grads,
@@ -528,19 +530,17 @@ extern "C" int b4r_optimizer_step(const b4r_model_config* cfg, const b4r_adamw_c
   // the scratch region sits at the END of the workspace; any 4096-float area works, use the start of the buffer the
   // backward no longer needs: the first floats of the workspace hold x0 which is dead after backward.
   float* scratch = static_cast<float*>(workspace);
-  RC(b4r_global_sqnorm(grads, pl.total, scratch, state, stream));
-  RC(b4r_adamw_step(hp, params, grads, adam_m, adam_v, pl.total, pl.n_decay, state, stream));
-  return B4R_OK;
+  return b4r_optimizer_fused(hp, params, grads, adam_m, adam_v, pl.total, pl.n_decay, scratch, state, (hipStream_t)stream);
 }
 
 extern "C" int b4r_train_step(const b4r_model_config* cfg, const b4r_adamw_config* hp, const b4r_batch* batch, float* params,
                               float* grads, float* adam_m, float* adam_v, void* workspace, int64_t workspace_bytes,
                               b4r_train_state* state, b4r_stream_t stream) {
   const int fused = b4r_fused_head_supported(cfg) ? 1 : 0;   // the train step never needs the logits themselves
-  RC(b4r_state_begin_step(state, stream));
+  // no b4r_state_begin_step launch: the loss reduction overwrites the sums (B4R_LOSS_OVERWRITE)
   RC(b4r_forward(cfg, batch, params, nullptr, workspace, workspace_bytes, state,
                  B4R_FLAG_TRAINING | (fused ? B4R_FLAG_FUSED_HEAD : 0), stream));
-  RC(b4r_loss(cfg, batch, workspace, workspace_bytes, state, 1 | (fused ? B4R_LOSS_FUSED_HEAD : 0), stream));
+  RC(b4r_loss(cfg, batch, workspace, workspace_bytes, state, 1 | B4R_LOSS_OVERWRITE | (fused ? B4R_LOSS_FUSED_HEAD : 0), stream));
   RC(b4r_backward(cfg, batch, params, grads, workspace, workspace_bytes, state,
                   B4R_FLAG_TRAINING | (fused ? B4R_FLAG_FUSED_HEAD : 0), stream));
   RC(b4r_optimizer_step(cfg, hp, params, grads, adam_m, adam_v, workspace, workspace_bytes, state, stream));

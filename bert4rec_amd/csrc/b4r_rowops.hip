@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(float* logits, int V, i
 }
 
 // ordered reduction of the per-row scalars into the state (single workgroup => fixed summation order)
-__global__ __launch_bounds__(1024) void ce_finalize_kernel(const float* row_out, int M, b4r_train_state* st) {
+__global__ __launch_bounds__(1024) void ce_finalize_kernel(const float* row_out, int M, b4r_train_state* st, int overwrite) {
   __shared__ float s[4][1024];
   const int tid = threadIdx.x;
   float a[4] = {0.f, 0.f, 0.f, 0.f};
@@ -415,6 +415,10 @@ __global__ __launch_bounds__(1024) void ce_finalize_kernel(const float* row_out,
     __syncthreads();
   }
   if (tid == 0) {
+    if (overwrite) {   // what b4r_state_begin_step + accumulation would leave (b4r_train_step saves that launch)
+      st->loss_sum = 0.f; st->valid_count = 0.f; st->correct_masked = 0.f; st->correct_all = 0.f; st->slots_all = 0.f;
+      st->grad_sqnorm = 0.f; st->grad_norm = 0.f;
+    }
     st->loss_sum += s[0][0];
     st->valid_count += s[1][0];
     st->correct_masked += s[2][0];
@@ -515,6 +519,62 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamP a) {
     *reinterpret_cast<f32x4*>(a.v + 4 * i) = v;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) { a.st->grad_norm = gnorm; a.st->lr = lr_t; }
+}
+
+// clip + decay + Adam + step advance in ONE launch after sqnorm_partial_kernel (b4r_optimizer_step): every workgroup sums the
+// np partial norms itself (same order, same value everywhere), the last one to finish (ticket) publishes norm / lr and
+// advances the step -- the other workgroups have read the state by then.
+__global__ __launch_bounds__(256) void adamw_fused_kernel(AdamP a, const float* partial, int np, unsigned int* ticket) {
+  __shared__ float s_red[256];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < np; i += 256) acc += partial[i];
+  s_red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) s_red[threadIdx.x] += s_red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const float sqnorm = s_red[0];
+  const int64_t step = a.st->step;
+  const float cnt = a.st->valid_count;
+  const float inv_cnt = cnt > 0.f ? 1.0f / cnt : 1.0f;
+  const float gnorm = sqrtf(sqnorm) * inv_cnt;
+  const float clip_scale = a.hp.clip_norm > 0.f ? a.hp.clip_norm / fmaxf(gnorm, a.hp.clip_norm) : 1.0f;
+  const float lr_t = lr_schedule(a.hp, step);
+  const float t = (float)(step + 1);
+  const float b1p = powf(a.hp.beta_1, t), b2p = powf(a.hp.beta_2, t);
+  const float alpha = lr_t * sqrtf(1.0f - b2p) / (1.0f - b1p);
+  const float omb1 = 1.0f - a.hp.beta_1, omb2 = 1.0f - a.hp.beta_2;
+  const float wd = a.hp.weight_decay_rate, eps = a.hp.epsilon;
+  const int64_t n4 = a.n / 4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 p = *reinterpret_cast<f32x4*>(a.p + 4 * i);
+    const f32x4 g = *reinterpret_cast<const f32x4*>(a.g + 4 * i);
+    f32x4 m = *reinterpret_cast<f32x4*>(a.m + 4 * i);
+    f32x4 v = *reinterpret_cast<f32x4*>(a.v + 4 * i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float ge = (g[e] * inv_cnt) * clip_scale;
+      float pe = p[e];
+      if (wd != 0.f && 4 * i + e < a.n_decay) pe -= lr_t * pe * wd;   // _decay_weights_op, before Adam
+      m[e] += (ge - m[e]) * omb1;
+      v[e] += (ge * ge - v[e]) * omb2;
+      pe -= (m[e] * alpha) / (sqrtf(v[e]) + eps);
+      p[e] = pe;
+    }
+    *reinterpret_cast<f32x4*>(a.p + 4 * i) = p;
+    *reinterpret_cast<f32x4*>(a.m + 4 * i) = m;
+    *reinterpret_cast<f32x4*>(a.v + 4 * i) = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+      a.st->grad_sqnorm = sqnorm; a.st->grad_norm = gnorm; a.st->lr = lr_t;
+      a.st->step = step + 1; a.st->step_lo = (uint32_t)(step + 1);
+      *ticket = 0u;   // ready for the next step
+    }
+  }
 }
 
 __global__ void state_advance_kernel(b4r_train_state* st) {
@@ -723,16 +783,16 @@ extern "C" int b4r_softmax_ce(float* logits, int32_t M, int32_t V, int32_t ld, c
   B4R_CHECK_ARG(M > 0 && V > 0 && ld >= V, B4R_E_SHAPE, "b4r_softmax_ce: bad shape");
   B4R_CHECK_ARG(ld % 4 == 0 && b4r_aligned16(logits), B4R_E_ALIGN, "b4r_softmax_ce: logits need ld %% 4 == 0 and 16-byte alignment");
   hipLaunchKernelGGL(softmax_ce_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, logits, V, ld, y_true, row_scratch,
-                     want_grad);
+                     want_grad & 1);
   B4R_CHECK_LAUNCH("b4r_softmax_ce");
-  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, row_scratch, M, state);
+  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, row_scratch, M, state, (want_grad >> 2) & 1);
   B4R_CHECK_LAUNCH("b4r_softmax_ce finalize");
   return B4R_OK;
 }
 
-int b4r_ce_finalize_launch(const float* row_scratch, int M, b4r_train_state* state, hipStream_t stream) {
+int b4r_ce_finalize_launch(const float* row_scratch, int M, b4r_train_state* state, int overwrite, hipStream_t stream) {
   B4R_CHECK_ARG(row_scratch && state && M > 0, B4R_E_BADARG, "ce_finalize: bad argument");
-  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1024), 0, stream, row_scratch, M, state);
+  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1024), 0, stream, row_scratch, M, state, overwrite);
   B4R_CHECK_LAUNCH("b4r_loss finalize");
   return B4R_OK;
 }
@@ -755,6 +815,25 @@ extern "C" int b4r_global_sqnorm(const float* g, int64_t n, float* scratch, b4r_
   B4R_CHECK_LAUNCH("b4r_global_sqnorm");
   hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, np, state);
   B4R_CHECK_LAUNCH("b4r_global_sqnorm final");
+  return B4R_OK;
+}
+
+// model-level optimizer step: global norm partials, then everything else in one launch.  scratch: >= 1024 floats.  The
+// ticket is reserved[0] of the state (zero-initialised by the caller like the rest of the state, reset by the kernel).
+int b4r_optimizer_fused(const b4r_adamw_config* hp, float* params, const float* grads, float* adam_m, float* adam_v, int64_t n,
+                        int64_t n_decay, float* scratch, b4r_train_state* state, hipStream_t stream) {
+  int np = (int)((n / 4 + 1023) / 1024);
+  if (np > 1024) np = 1024;
+  if (np < 1) np = 1;
+  unsigned int* ticket = reinterpret_cast<unsigned int*>(&state->reserved[0]);
+  hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(np), dim3(256), 0, stream, grads, n, scratch);
+  B4R_CHECK_LAUNCH("global norm");
+  AdamP a;
+  a.p = params; a.g = grads; a.m = adam_m; a.v = adam_v; a.n = n; a.n_decay = n_decay; a.hp = *hp; a.st = state;
+  int grid = (int)((n / 4 + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(adamw_fused_kernel, dim3(grid), dim3(256), 0, stream, a, (const float*)scratch, np, ticket);
+  B4R_CHECK_LAUNCH("optimizer step");
   return B4R_OK;
 }
 

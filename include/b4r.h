@@ -82,7 +82,7 @@ typedef struct b4r_train_state {
   float grad_sqnorm;    /* [9]  sum g^2 of the (summed, un-normalised) gradient buffer                */
   float grad_norm;      /* [10] global norm of the mean gradient as clip_by_global_norm sees it      */
   float lr;             /* [11] lr_t used by the last optimizer step                                  */
-  float reserved[4];
+  float reserved[4];    /* [12..15] zero-initialise; [12] is the optimizer kernel's completion ticket          */
 } b4r_train_state;
 
 /* ------------------------------------------------------------------------------------------------------------ */
@@ -132,6 +132,7 @@ int b4r_workspace_region(const b4r_model_config* cfg, int32_t B, int32_t L, int3
  * want_grad | B4R_LOSS_FUSED_HEAD and b4r_backward with the same flag.  b4r_train_step uses it whenever it is supported. */
 #define B4R_FLAG_FUSED_HEAD 4
 #define B4R_LOSS_FUSED_HEAD 2
+#define B4R_LOSS_OVERWRITE 4 /* b4r_loss: set the state's sums instead of adding to them (= b4r_state_begin_step first) */
 int32_t b4r_fused_head_supported(const b4r_model_config* cfg);
 int b4r_forward(const b4r_model_config* cfg, const b4r_batch* batch, const float* params, const float* pooler,
                 void* workspace, int64_t workspace_bytes, b4r_train_state* state, int32_t flags, b4r_stream_t stream);

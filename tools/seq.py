@@ -4,9 +4,9 @@ f = glob.glob(sys.argv[1] + '/*/*_kernel_trace.csv')[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 names = [r['Kernel_Name'] for r in rows]
-# one step = from a state_begin_kernel to the next
-idx = [i for i, n in enumerate(names) if 'state_begin_kernel' in n]
-a, b = idx[-3], idx[-2]
+# one step = from the kernel after an optimizer launch to the next optimizer launch (inclusive)
+idx = [i for i, n in enumerate(names) if 'adamw' in n]
+a, b = idx[-3] + 1, idx[-2] + 1
 tot = 0
 prev_end = None
 for r in rows[a:b]:

@@ -856,6 +856,80 @@ extern "C" int b4r_adamw_step(const b4r_adamw_config* hp, float* params, const f
   return B4R_OK;
 }
 
+// -----------------------------------------------------------------------------------------------------------
+// negative sampling for the evaluator: one workgroup per ranked slot
+// -----------------------------------------------------------------------------------------------------------
+// Weighted sampling without replacement (what np.random.choice(vocab, size, False, p) followed by dropping the excluded
+// items draws: successive picks proportional to p among what is left) as Gumbel top-k: key_v = log p_v + G_v with
+// G_v = -log(-log u_v); the C largest keys, in descending order, are the sample in draw order.  u_v comes from a counter
+// hash of (seed, row, v) with 24 bits, so it lies strictly inside (0, 1).
+__global__ __launch_bounds__(256) void sample_candidates_kernel(const float* logp, int V, const int64_t* exclude, int E,
+                                                                const int64_t* gt, int C, uint32_t seed_lo,
+                                                                uint32_t seed_hi, int64_t* cand) {
+  extern __shared__ float s_key[];            // [V]
+  __shared__ float s_v[4];
+  __shared__ int s_i[4];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t rk = b4r_hash32((uint32_t)row * 0x9E3779B9u + seed_hi);
+  for (int v = tid; v < V; v += 256) {
+    uint32_t h = b4r_hash32((uint32_t)v ^ seed_lo);
+    h = b4r_hash32(h + rk);
+    const float u = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    s_key[v] = logp[v] - __logf(-__logf(u));  // -inf + finite = -inf: zero-probability items are never drawn
+  }
+  __syncthreads();
+  for (int e = tid; e < E; e += 256) {
+    const int64_t id = exclude[(int64_t)row * E + e];
+    if (id >= 0 && id < V) s_key[id] = -INFINITY;
+  }
+  const int64_t g = gt ? gt[row] : -1;
+  if (tid == 0 && g >= 0 && g < V) s_key[g] = -INFINITY;
+  __syncthreads();
+  int64_t* out = cand + (int64_t)row * (C + 1);
+  for (int c = 0; c < C; ++c) {
+    float best = -INFINITY; int bidx = 0x7fffffff;
+    for (int v = tid; v < V; v += 256) {
+      const float k = s_key[v];
+      if (k > best) { best = k; bidx = v; }    // increasing v per thread: the lowest index wins ties
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bidx, o, 64);
+      if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+    }
+    if (lane == 0) { s_v[wave] = best; s_i[wave] = bidx; }
+    __syncthreads();
+    if (tid == 0) {
+      best = s_v[0]; bidx = s_i[0];
+#pragma unroll
+      for (int w = 1; w < 4; ++w)
+        if (s_v[w] > best || (s_v[w] == best && s_i[w] < bidx)) { best = s_v[w]; bidx = s_i[w]; }
+      const bool ok = best > -INFINITY;
+      out[c] = ok ? (int64_t)bidx : -1;        // -1: fewer than C items with non-zero probability are left
+      if (ok) s_key[bidx] = -INFINITY;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) out[C] = g;
+}
+
+extern "C" int b4r_sample_candidates(const float* logp, int32_t V, const int64_t* exclude, int32_t E, const int64_t* gt,
+                                     int32_t R, int32_t C, uint64_t seed, int64_t* cand, b4r_stream_t stream) {
+  B4R_CHECK_ARG(logp && cand && (exclude || E == 0), B4R_E_BADARG, "b4r_sample_candidates: null argument");
+  B4R_CHECK_ARG(V > 0 && R > 0 && C > 0 && E >= 0 && C <= V, B4R_E_SHAPE, "b4r_sample_candidates: bad shape");
+  const size_t lds = (size_t)V * sizeof(float);
+  B4R_CHECK_ARG(lds <= 150 * 1024, B4R_E_SHAPE, "b4r_sample_candidates: vocabulary %d does not fit the 160 KB of LDS", V);
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)sample_candidates_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { b4r_set_error("b4r_sample_candidates: cannot raise the LDS limit: %s", hipGetErrorString(e)); return B4R_E_HIP; }
+  }
+  hipLaunchKernelGGL(sample_candidates_kernel, dim3(R), dim3(256), lds, (hipStream_t)stream, logp, V, exclude, E, gt, C,
+                     (uint32_t)seed, (uint32_t)(seed >> 32), cand);
+  B4R_CHECK_LAUNCH("b4r_sample_candidates");
+  return B4R_OK;
+}
+
 extern "C" int b4r_rank_candidates(const float* hidden, int32_t hidden_ld, const int64_t* hidden_row, const float* table,
                                    const float* bias, int32_t H, const int64_t* cand, int32_t R, int32_t C,
                                    const int64_t* gt, int64_t* ranking, int32_t* gt_rank, float* scores,

@@ -300,6 +300,23 @@ class Engine:
         allreduce_step(self.grad_ext, self.state, self.n_params, group)
         self.optimizer_step(hp, cb)
 
+    def sample_candidates(self, logp: torch.Tensor, exclude: torch.Tensor, gt: torch.Tensor, n_samples: int,
+                          seed: int) -> torch.Tensor:
+        """b4r_sample_candidates: exclude [R,E] int64 (-1 padded), gt [R] int64 -> cand [R, n_samples+1] int64 (device);
+        raises ValueError when a row has fewer than n_samples drawable items (popular_random_sampler.py:56-58)."""
+        logp = logp.to(device=self.device, dtype=torch.float32).contiguous()
+        exclude = exclude.to(device=self.device, dtype=torch.int64).contiguous()
+        gt = gt.to(device=self.device, dtype=torch.int64).contiguous()
+        R, E = exclude.shape
+        cand = torch.empty((R, n_samples + 1), dtype=torch.int64, device=self.device)
+        _lib.check(self.lib.b4r_sample_candidates(_ptr(logp), logp.numel(), _ptr(exclude), E, _ptr(gt), R, n_samples,
+                                                  int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(cand), _stream(self.device)),
+                   "b4r_sample_candidates")
+        if bool((cand[:, :n_samples] < 0).any()):
+            raise ValueError(f"The exclusion lists reduce the vocab too much to take a sample of size {n_samples} "
+                             f"(since no duplicates are allowed).")
+        return cand
+
     def rank_candidates(self, hidden: torch.Tensor, hidden_rows: Optional[torch.Tensor], cand: torch.Tensor,
                         gt: Optional[torch.Tensor], want_ranking: bool = True, want_scores: bool = False):
         """b4r_rank_candidates on `hidden` [*,H] (ld = stride(0)); cand [R,C] int64; gt [R] int64 or None."""

@@ -151,6 +151,18 @@ int b4r_train_step(const b4r_model_config* cfg, const b4r_adamw_config* hp, cons
                    float* grads, float* adam_m, float* adam_v, void* workspace, int64_t workspace_bytes,
                    b4r_train_state* state, b4r_stream_t stream);
 
+/* ---- evaluator negatives -------------------------------------------------------------------
+ * replaces the per-slot sampler call of bert4rec_evaluator.py:84-104 (PopularRandomSampler.sample:
+ * np.random.choice(vocab, 100 + |without|, replace=False, p=popularity), drop `without`, keep 100) for ALL ranked slots of
+ * a batch in one launch.  Same distribution (successive draws proportional to p among the remaining allowed items,
+ * realised as Gumbel top-k on log p), own counter-hash random stream (numpy's stream cannot be reproduced).
+ * logp [V] = log popularity (-inf where p = 0); exclude [R,E] item ids that must not be drawn for row r (out-of-range
+ * entries such as -1 are ignored; gt[r] is excluded as well); cand [R, C+1]: the C draws in draw order, then gt[r] as the
+ * last candidate (bert4rec_evaluator.py:103).  A row with fewer than C drawable items gets -1 entries (the reference
+ * raises ValueError there; the Python layer does too). */
+int b4r_sample_candidates(const float* logp, int32_t V, const int64_t* exclude, int32_t E, const int64_t* gt, int32_t R,
+                          int32_t C, uint64_t seed, int64_t* cand, b4r_stream_t stream);
+
 /* ---- ranking ------------------------------------------------------------------------------------------------
  * replaces BERT4RecModel.rank_items bert4rec_model.py:224-239 (gather candidate logits, tf.argsort DESCENDING,
  * gather candidates) and the rank lookup of bert4rec_evaluator.py:113-117.

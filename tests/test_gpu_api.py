@@ -168,3 +168,35 @@ def test_evaluator_ranks_equal_oracle_ranks_for_given_candidates():
         om.update(int(r))
     for k, v in om.results().items():
         assert ev.get_metrics_results()[k] == pytest.approx(v, abs=1e-12)
+
+
+def test_evaluator_device_sampling_matches_host_sampling_in_distribution():
+    """one b4r_sample_candidates launch per batch instead of one np.random.choice per slot.  Same law,
+    other random stream: candidate lists obey the same constraints and the metrics agree statistically."""
+    V, B, L = 400, 64, 20
+    model = make_model(V, seed=13)
+    rng = np.random.default_rng(3)
+    pop = rng.zipf(1.3, size=20000) % (V - 3) + 3                       # skewed item popularity over real items
+    smp = dataloaders.samplers.get("pop_random", source=pop.tolist(), vocab=list(range(V)), sample_size=100, seed=7)
+    batches = [orc.synthetic_batch(B, L, 4, V, seed=50 + i, ragged=True, finetune=True) for i in range(6)]
+    ev_dev = evaluation.get(sampler=smp, device_sampling=True, seed=1)
+    assert ev_dev._device_sampler_ready(model)
+    cand, gt = ev_dev.sample_candidates_device(model, batches[0])
+    cand, gt = cand.cpu().numpy(), gt.cpu().numpy()
+    assert cand.shape == (B, 101) and np.array_equal(cand[:, 100], gt)
+    p = np.asarray(smp.probability_distribution)
+    for b in range(B):
+        neg = cand[b, :100]
+        assert len(set(neg.tolist())) == 100 and (p[neg] > 0).all()
+        assert not (set(neg.tolist()) & (set(batches[0]["labels"][b].tolist()) | {int(gt[b])}))
+    # popular items are drawn more often: mean popularity of the negatives far above the uniform mean
+    assert p[cand[:, :100]].mean() > 2 * p[p > 0].mean()
+    ev_host = evaluation.get(sampler=smp, device_sampling=False)
+    for bt in batches:
+        ev_dev.evaluate_batch(model, bt)
+        ev_host.evaluate_batch(model, bt)
+    rd, rh = ev_dev.get_metrics_results(), ev_host.get_metrics_results()
+    assert rd["Valid Ranks"] == rh["Valid Ranks"] == 6 * B
+    # an untrained model ranks the ground truth anywhere among 101: both estimates of HR@10 sit near 10/101, within noise
+    for k in ("HR@10", "NDCG@10", "MAP"):
+        assert abs(rd[k] - rh[k]) < 0.06, (k, rd[k], rh[k])

@@ -386,3 +386,46 @@ def test_fused_mlm_head_matches_materialised_math(M, V):
     _lib.check(lib.b4r_mlm_head_fused_bwd(P(Td), P(Ed), P(bd), P(lse), P(lab), M, V, P(scratch), P(dE), P(db), stream()))
     assert T.maxdiff(dE, Er.grad) < 1e-3 * float(Er.grad.abs().max())
     assert T.maxdiff(db, br.grad) < 1e-3 * float(br.grad.abs().max())
+
+
+def test_sample_candidates_draws_like_numpy_choice_without_replacement():
+    """b4r_sample_candidates vs the law of PopularRandomSampler.sample (popular_random_sampler.py:48-63: np.random.choice
+    without replacement by popularity, excluded items dropped): ordered triples must follow the successive-draw
+    probabilities p_a/S * p_b/(S-p_a) * p_c/(S-p_a-p_b) over the allowed items"""
+    import itertools
+    lib = _lib.load()
+    V, C, R = 12, 3, 200000
+    p = np.array([0.0, 0.0, 0.0, 0.20, 0.05, 0.15, 0.10, 0.02, 0.18, 0.0, 0.25, 0.05])   # specials and one unseen item: 0
+    excl = [5, 11, -1, 40]                                      # two real exclusions, padding, out of range
+    gt = 6
+    with np.errstate(divide="ignore"):
+        logp = torch.from_numpy(np.log(p).astype(np.float32)).to(DEV)
+    ex = torch.tensor(excl, dtype=torch.int64).repeat(R, 1).to(DEV)
+    gtd = torch.full((R,), gt, dtype=torch.int64, device=DEV)
+    cand = torch.empty((R, C + 1), dtype=torch.int64, device=DEV)
+    _lib.check(lib.b4r_sample_candidates(P(logp), V, P(ex), len(excl), P(gtd), R, C, 12345, P(cand), stream()))
+    c = cand.cpu().numpy()
+    assert (c[:, C] == gt).all()
+    allowed = [v for v in range(V) if p[v] > 0 and v not in (5, 11, gt)]
+    assert np.isin(c[:, :C], allowed).all()
+    assert (c[:, 0] != c[:, 1]).all() and (c[:, 0] != c[:, 2]).all() and (c[:, 1] != c[:, 2]).all()
+    S = sum(p[v] for v in allowed)
+    code = c[:, 0] * V * V + c[:, 1] * V + c[:, 2]
+    counts = np.bincount(code, minlength=V ** 3)
+    worst = 0.0
+    for a, b, d in itertools.permutations(allowed, 3):
+        prob = p[a] / S * p[b] / (S - p[a]) * p[d] / (S - p[a] - p[b])
+        exp = R * prob
+        z = abs(counts[a * V * V + b * V + d] - exp) / np.sqrt(exp * (1 - prob) + 1.0)
+        worst = max(worst, z)
+    assert worst < 5.0, worst                                   # 336 cells, 5 sigma
+    # determinism per seed, new draws per seed
+    cand2 = torch.empty_like(cand)
+    _lib.check(lib.b4r_sample_candidates(P(logp), V, P(ex), len(excl), P(gtd), R, C, 12345, P(cand2), stream()))
+    assert torch.equal(cand, cand2)
+    _lib.check(lib.b4r_sample_candidates(P(logp), V, P(ex), len(excl), P(gtd), R, C, 12346, P(cand2), stream()))
+    assert not torch.equal(cand, cand2)
+    # not enough drawable items: -1 entries (the Python layer raises like the reference)
+    few = torch.empty((2, 8), dtype=torch.int64, device=DEV)
+    _lib.check(lib.b4r_sample_candidates(P(logp), V, P(ex), len(excl), P(gtd), 2, 7, 1, P(few), stream()))
+    assert int((few[:, :7] < 0).sum()) == 2 * (7 - len(allowed))

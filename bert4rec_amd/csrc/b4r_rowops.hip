@@ -857,6 +857,94 @@ extern "C" int b4r_adamw_step(const b4r_adamw_config* hp, float* params, const f
 }
 
 // -----------------------------------------------------------------------------------------------------------
+// batch construction: the masked-LM task of the preprocessor for a whole batch, one wave per sequence
+// -----------------------------------------------------------------------------------------------------------
+// tokens [B,L]: ids right-padded with 0.  Restates apply_dynamic_masking_task (dataloader_utils.py:186-261) with a
+// counter-hash stream instead of python's random: n = tokens that are neither PAD (0) nor UNK (2);
+// num = min(P, max(1, int(n * rate))) positions are a uniform subset of [0, n) (random keys, the num smallest win), visited
+// in ascending order; each becomes [MASK] (1) with probability mask_rate, a uniform id of the vocabulary minus {PAD, UNK}
+// with probability random_rate, else stays.  finetune != 0 restates mask_last_token_only (:264-269).
+__global__ __launch_bounds__(64) void mask_batch_kernel(const int64_t* tokens, int L, int P, int V, double rate, float mask_rate,
+                                                        float random_rate, int finetune, uint32_t seed_lo, uint32_t seed_hi,
+                                                        int64_t* ids_out, int64_t* mask_out, int64_t* labels_out,
+                                                        int64_t* pos_out, int64_t* mids_out, int64_t* w_out) {
+  __shared__ uint32_t s_key[256];
+  __shared__ int s_sel[256];
+  const int row = blockIdx.x, lane = threadIdx.x;
+  const int64_t* src = tokens + (int64_t)row * L;
+  int len = 0, n = 0;
+  for (int i = lane; i < L; i += 64) {
+    const int64_t t = src[i];
+    len += (t != 0) ? 1 : 0;
+    n += (t != 0 && t != 2) ? 1 : 0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { len += __shfl_xor(len, o, 64); n += __shfl_xor(n, o, 64); }
+  const uint32_t rk = b4r_hash32((uint32_t)row * 0x9E3779B9u + seed_hi);
+  int num;
+  if (finetune) num = len > 0 ? 1 : 0;
+  else num = n > 0 ? min(P, max(1, (int)((double)n * rate))) : 0;
+  for (int i = lane; i < L; i += 64) {
+    s_key[i] = b4r_hash32(b4r_hash32((uint32_t)i ^ seed_lo) + rk);
+    s_sel[i] = 0;
+  }
+  __syncthreads();
+  for (int i = lane; i < L; i += 64) {
+    int sel = 0;
+    if (finetune) sel = (i == len - 1) ? 1 : 0;
+    else if (i < n) {
+      int rank = 0;
+      const uint32_t ki = s_key[i];
+      for (int j = 0; j < n; ++j) { const uint32_t kj = s_key[j]; rank += (kj < ki || (kj == ki && j < i)) ? 1 : 0; }
+      sel = rank < num ? 1 : 0;
+    }
+    s_sel[i] = sel;
+  }
+  __syncthreads();
+  for (int i = lane; i < L; i += 64) {
+    const int64_t t = src[i];
+    int64_t out = t;
+    if (s_sel[i]) {
+      int slot = 0;
+      for (int j = 0; j < i; ++j) slot += s_sel[j];
+      pos_out[(int64_t)row * P + slot] = i;
+      mids_out[(int64_t)row * P + slot] = t;
+      w_out[(int64_t)row * P + slot] = 1;
+      if (finetune) out = 1;
+      else {
+        const uint32_t h = b4r_hash32(s_key[i] ^ 0x68E31DA4u);
+        const float rn = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        if (rn < mask_rate) out = 1;
+        else if (rn < mask_rate + random_rate) {
+          const uint32_t k = b4r_hash32(h + 0x9E3779B9u) % (uint32_t)(V - 2);   // selectable vocab: every id but PAD, UNK
+          out = (k == 0) ? 1 : (int64_t)k + 2;
+        }
+      }
+    }
+    ids_out[(int64_t)row * L + i] = out;
+    mask_out[(int64_t)row * L + i] = (i < len) ? 1 : 0;
+    labels_out[(int64_t)row * L + i] = t;
+  }
+  for (int s = num + lane; s < P; s += 64) {
+    pos_out[(int64_t)row * P + s] = 0; mids_out[(int64_t)row * P + s] = 0; w_out[(int64_t)row * P + s] = 0;
+  }
+}
+
+extern "C" int b4r_mask_batch(const int64_t* tokens, int32_t B, int32_t L, int32_t P, int32_t V, double selection_rate,
+                              float mask_token_rate, float random_token_rate, int32_t finetune, uint64_t seed,
+                              int64_t* input_word_ids, int64_t* input_mask, int64_t* labels, int64_t* masked_lm_positions,
+                              int64_t* masked_lm_ids, int64_t* masked_lm_weights, b4r_stream_t stream) {
+  B4R_CHECK_ARG(tokens && input_word_ids && input_mask && labels && masked_lm_positions && masked_lm_ids && masked_lm_weights,
+                B4R_E_BADARG, "b4r_mask_batch: null argument");
+  B4R_CHECK_ARG(B > 0 && L > 0 && L <= 256 && P > 0 && V > 3, B4R_E_SHAPE, "b4r_mask_batch: bad shape (L <= 256)");
+  hipLaunchKernelGGL(mask_batch_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, tokens, L, P, V, selection_rate,
+                     mask_token_rate, random_token_rate, finetune, (uint32_t)seed, (uint32_t)(seed >> 32), input_word_ids,
+                     input_mask, labels, masked_lm_positions, masked_lm_ids, masked_lm_weights);
+  B4R_CHECK_LAUNCH("b4r_mask_batch");
+  return B4R_OK;
+}
+
+// -----------------------------------------------------------------------------------------------------------
 // negative sampling for the evaluator: one workgroup per ranked slot
 // -----------------------------------------------------------------------------------------------------------
 // Weighted sampling without replacement (what np.random.choice(vocab, size, False, p) followed by dropping the excluded

@@ -300,6 +300,27 @@ class Engine:
         allreduce_step(self.grad_ext, self.state, self.n_params, group)
         self.optimizer_step(hp, cb)
 
+    def mask_batch(self, tokens: torch.Tensor, max_predictions: int, selection_rate: float = 0.2,
+                   mask_token_rate: float = 1.0, random_token_rate: float = 0.0, finetune: bool = False,
+                   seed: int = 0) -> Dict[str, torch.Tensor]:
+        """b4r_mask_batch: tokens [B,L] int64 (right-padded with 0) -> the six-tensor batch dict on the device
+        (bert4rec_preprocessor.py:48-116 for a whole batch; defaults of BERT4RecPreprocessor: rate 0.2, always [MASK])."""
+        tokens = torch.as_tensor(tokens).to(device=self.device, dtype=torch.int64).contiguous()
+        if tokens.dim() != 2:
+            raise ValueError(f"tokens must be rank 2 [batch, length], got shape {tuple(tokens.shape)}")
+        B, L = tokens.shape
+        P = int(max_predictions)
+        out = {k: torch.empty((B, L), dtype=torch.int64, device=self.device) for k in ("input_word_ids", "input_mask", "labels")}
+        out.update({k: torch.empty((B, P), dtype=torch.int64, device=self.device)
+                    for k in ("masked_lm_positions", "masked_lm_ids", "masked_lm_weights")})
+        _lib.check(self.lib.b4r_mask_batch(_ptr(tokens), B, L, P, self.cfg.vocab_size, float(selection_rate),
+                                           float(mask_token_rate), float(random_token_rate), 1 if finetune else 0,
+                                           int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(out["input_word_ids"]),
+                                           _ptr(out["input_mask"]), _ptr(out["labels"]), _ptr(out["masked_lm_positions"]),
+                                           _ptr(out["masked_lm_ids"]), _ptr(out["masked_lm_weights"]),
+                                           _stream(self.device)), "b4r_mask_batch")
+        return out
+
     def sample_candidates(self, logp: torch.Tensor, exclude: torch.Tensor, gt: torch.Tensor, n_samples: int,
                           seed: int) -> torch.Tensor:
         """b4r_sample_candidates: exclude [R,E] int64 (-1 padded), gt [R] int64 -> cand [R, n_samples+1] int64 (device);

@@ -151,6 +151,18 @@ int b4r_train_step(const b4r_model_config* cfg, const b4r_adamw_config* hp, cons
                    float* grads, float* adam_m, float* adam_v, void* workspace, int64_t workspace_bytes,
                    b4r_train_state* state, b4r_stream_t stream);
 
+/* ---- batch construction ----------------------------------------------------------------------
+ * replaces BERT4RecPreprocessor.process_element bert4rec_preprocessor.py:48-116 on already truncated, right-padded token
+ * rows for a whole batch: apply_dynamic_masking_task dataloader_utils.py:186-261 (or mask_last_token_only :264-269 when
+ * finetune != 0) + the padding of the six [B,.] int64 tensors of bert4rec_model.py:15-22.  Same law as the reference
+ * (uniform subset of min(P, max(1, int(n*rate))) of the first n positions, ascending; [MASK] / random id / unchanged by
+ * mask_token_rate / random_token_rate), own counter-hash random stream: a dataset can be re-masked every epoch on the
+ * device instead of being masked `duplication_factor` times on the host. */
+int b4r_mask_batch(const int64_t* tokens, int32_t B, int32_t L, int32_t P, int32_t V, double selection_rate,
+                   float mask_token_rate, float random_token_rate, int32_t finetune, uint64_t seed, int64_t* input_word_ids,
+                   int64_t* input_mask, int64_t* labels, int64_t* masked_lm_positions, int64_t* masked_lm_ids,
+                   int64_t* masked_lm_weights, b4r_stream_t stream);
+
 /* ---- evaluator negatives -------------------------------------------------------------------
  * replaces the per-slot sampler call of bert4rec_evaluator.py:84-104 (PopularRandomSampler.sample:
  * np.random.choice(vocab, 100 + |without|, replace=False, p=popularity), drop `without`, keep 100) for ALL ranked slots of

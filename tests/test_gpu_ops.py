@@ -429,3 +429,61 @@ def test_sample_candidates_draws_like_numpy_choice_without_replacement():
     few = torch.empty((2, 8), dtype=torch.int64, device=DEV)
     _lib.check(lib.b4r_sample_candidates(P(logp), V, P(ex), len(excl), P(gtd), 2, 7, 1, P(few), stream()))
     assert int((few[:, :7] < 0).sum()) == 2 * (7 - len(allowed))
+
+
+def test_mask_batch_follows_the_preprocessor_law():
+    """b4r_mask_batch vs apply_dynamic_masking_task / process_element (dataloader_utils.py:186-261,
+    bert4rec_preprocessor.py:48-116): per-row invariants for every length, the reference's count formula, uniform choice
+    of positions and the [MASK] / random / unchanged proportions"""
+    from bert4rec_amd.engine import Engine, make_model_config
+    V, L, P = 500, 40, 12
+    eng = Engine(make_model_config(V, 64, 1, 2, L, 64, 0.0, 0.0), "cuda")
+    g = torch.Generator().manual_seed(0)
+    B = 4000
+    lens = torch.randint(1, L + 1, (B,), generator=g)
+    lens[:L] = torch.arange(1, L + 1)                                  # every length at least once
+    toks = torch.randint(3, V, (B, L), generator=g)
+    toks[torch.arange(L)[None, :] >= lens[:, None]] = 0
+    out = {k: v.cpu() for k, v in eng.mask_batch(toks, P, selection_rate=0.2, seed=11).items()}
+    assert torch.equal(out["labels"], toks)
+    assert torch.equal(out["input_mask"], (toks != 0).long())
+    for b in range(0, B, 7):
+        n = int(lens[b])
+        num = min(P, max(1, int(n * 0.2)))                             # dataloader_utils.py:214-215
+        w = out["masked_lm_weights"][b]
+        assert int(w.sum()) == num and bool((w[:num] == 1).all())
+        pos = out["masked_lm_positions"][b, :num]
+        assert bool((pos[1:] > pos[:-1]).all()) and int(pos.max()) < n   # ascending, inside the sequence
+        assert torch.equal(out["masked_lm_ids"][b, :num], toks[b, pos])
+        assert bool((out["masked_lm_positions"][b, num:] == 0).all()) and bool((out["masked_lm_ids"][b, num:] == 0).all())
+        changed = out["input_word_ids"][b] != toks[b]
+        assert int(changed.sum()) == num and bool((out["input_word_ids"][b, pos] == 1).all())   # always [MASK] by default
+    # uniform choice: full-length rows, 8 of 40 positions each -> every position ~ 20 %
+    full = lens == L
+    hits = torch.zeros(L)
+    for b in torch.nonzero(full).flatten().tolist():
+        hits[out["masked_lm_positions"][b, :8]] += 1
+    nfull = int(full.sum())
+    assert float((hits / nfull - 0.2).abs().max()) < 5 * (0.2 * 0.8 / nfull) ** 0.5
+    # 80 / 10 / 10 replacement
+    out2 = {k: v.cpu() for k, v in eng.mask_batch(toks, P, 0.2, 0.8, 0.1, seed=12).items()}
+    w2 = out2["masked_lm_weights"] == 1
+    rows = torch.arange(B)[:, None].expand(B, P)[w2]
+    posv = out2["masked_lm_positions"][w2]
+    new, old = out2["input_word_ids"][rows, posv], toks[rows, posv]
+    total = float(new.numel())
+    frac_mask, frac_same = float((new == 1).sum()) / total, float((new == old).sum()) / total
+    assert abs(frac_mask - 0.8) < 0.02 and abs(frac_same - 0.1) < 0.015 and bool(((new != 0) & (new != 2)).all())
+    # another seed, another mask; same seed, same mask
+    assert not torch.equal(out["masked_lm_positions"], eng.mask_batch(toks, P, 0.2, seed=13)["masked_lm_positions"].cpu())
+    assert torch.equal(out["masked_lm_positions"], eng.mask_batch(toks, P, 0.2, seed=11)["masked_lm_positions"].cpu())
+    # fine-tuning / evaluation rows: the last real token (mask_last_token_only)
+    ft = {k: v.cpu() for k, v in eng.mask_batch(toks, P, finetune=True, seed=1).items()}
+    assert torch.equal(ft["masked_lm_positions"][:, 0], lens - 1) and bool((ft["masked_lm_weights"].sum(1) == 1).all())
+    assert torch.equal(ft["masked_lm_ids"][:, 0], toks[torch.arange(B), lens - 1])
+    assert bool((ft["input_word_ids"][torch.arange(B), lens - 1] == 1).all())
+    # the product of the kernel is a valid batch for the model
+    cb, keep = eng.prepare_batch({k: v[:8] for k, v in out.items()})
+    eng.init_parameters(seed=1)
+    eng.forward(cb)
+    torch.cuda.synchronize()

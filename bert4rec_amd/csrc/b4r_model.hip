@@ -17,7 +17,8 @@
 // ---- internal launchers defined in the other translation units --------------------------------------------------
 int b4r_ln_bwd_launch(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
                       int rows, int H, float* dz, float* dgamma, float* dbeta, float* scratch, const int64_t* ids,
-                      const float* table, const float* pos_table, int L, int V, DropArgs drop, hipStream_t stream);
+                      const float* table, const float* pos_table, int L, int V, DropArgs drop, hipStream_t stream,
+                      const float* gelu_pre = nullptr);
 int b4r_scatter_add_rows_impl(const float* src, const int64_t* idx, int64_t idx_add_per, int per, int n, int H,
                               float* dst, int dst_ld, const int64_t* skip_if_zero, int64_t dst_rows, int hot_rows,
                               float* hot_scratch, hipStream_t stream);
@@ -461,8 +462,8 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
   }
   // LayerNorm of the transform
   RC(b4r_ln_bwd_launch(ws + w.dt, ws + w.u, ws + w.meanm, ws + w.rstdm, params + pl.lnm_g, M, H, ws + w.dt, grads + pl.lnm_g,
-                       grads + pl.lnm_b, take(b4r_ln_bwd_scratch_floats(M, H)), nullptr, nullptr, nullptr, 1, 1, nodrop, s));
-  RC(b4r_mul_gelu_grad(ws + w.dt, ws + w.upre, (int64_t)M * H, s));
+                       grads + pl.lnm_b, take(b4r_ln_bwd_scratch_floats(M, H)), nullptr, nullptr, nullptr, 1, 1, nodrop, s,
+                       ws + w.upre));   // ... and straight through the GELU of the transform's dense layer
   RC(gemm_tn(ws + w.gath, H, ws + w.dt, H, grads + pl.wd, H, M, H, H, grads + pl.bd, nullptr, nullptr, 0, 0.f, 0,
              take(b4r_gemm_tn_scratch_floats(M, H, H)), s));
   RC(gemm(ws + w.dt, H, params + pl.wd, H, ws + w.dg, H, M, H, H, 1, B4R_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 1.f, 0,

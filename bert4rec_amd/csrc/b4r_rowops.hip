@@ -107,6 +107,7 @@ struct LnBwdP {
   float* dz; float* partial;  // partial[gridDim.x][2][H]
   int rows, H;
   DropArgs drop;
+  const float* gelu_pre;      // optional [rows,H]: dz is further multiplied by gelu'(gelu_pre) (dense+GELU before the LN)
 };
 
 template <int LPR, int NV, bool EMBED>
@@ -171,6 +172,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdP p) {
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = rstd * (gg[v][e] - c1 - xh[v][e] * c2);
+        if (p.gelu_pre) {
+          const f32x4 pre = *reinterpret_cast<const f32x4*>(p.gelu_pre + row * p.H + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] *= b4r_gelu_grad(pre[e]);
+        }
         *reinterpret_cast<f32x4*>(p.dz + row * p.H + c) = o;
       }
     }
@@ -689,8 +695,10 @@ __global__ __launch_bounds__(256) void ln_partial_reduce_kernel(const float* par
 
 int b4r_ln_bwd_launch(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
                       int rows, int H, float* dz, float* dgamma, float* dbeta, float* scratch, const int64_t* ids,
-                      const float* table, const float* pos_table, int L, int V, DropArgs drop, hipStream_t stream) {
+                      const float* table, const float* pos_table, int L, int V, DropArgs drop, hipStream_t stream,
+                      const float* gelu_pre) {
   LnBwdP p{};
+  p.gelu_pre = gelu_pre;
   p.dy = dy; p.z = z; p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.dz = dz; p.partial = scratch;
   p.ids = ids; p.table = table; p.pos_table = pos_table; p.L = L; p.V = V;
   p.rows = rows; p.H = H; p.drop = drop;
@@ -715,7 +723,7 @@ extern "C" int b4r_ln_bwd(const float* dy, const float* z, const float* mean, co
                 "b4r_ln_bwd: null argument");
   B4R_CHECK_ARG(rows > 0, B4R_E_SHAPE, "b4r_ln_bwd: bad shape");
   return b4r_ln_bwd_launch(dy, z, mean, rstd, gamma, rows, H, dz, dgamma, dbeta, scratch, nullptr, nullptr, nullptr, 1,
-                           1, b4r_make_drop(nullptr, 0, 0.f, 0), (hipStream_t)stream);
+                           1, b4r_make_drop(nullptr, 0, 0.f, 0), (hipStream_t)stream, nullptr);
 }
 
 extern "C" int b4r_gather_rows(const float* src, int32_t src_ld, const int64_t* idx, int64_t idx_add_per, int32_t per,

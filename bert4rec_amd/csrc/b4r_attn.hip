@@ -341,7 +341,7 @@ int b4r_attn_rx_fwd_launch(const float* qkv, const int64_t* mask, int B, int L, 
                            const DropArgs& drop, uint32_t* keep_bits, hipStream_t stream);
 int b4r_attn_rx_bwd_launch(const float* qkv, const int64_t* mask, const float* ctx, const float* lse, const float* dctx,
                            int B, int L, int heads, float qscale, float* dqkv, const DropArgs& drop,
-                           const uint32_t* keep_bits, hipStream_t stream);
+                           const uint32_t* keep_bits, hipStream_t stream, hipStream_t stream_dkv);
 
 extern "C" int64_t b4r_attn_keep_words(int32_t B, int32_t L, int32_t heads) {
   if (B <= 0 || L <= 0 || heads <= 0) return 0;
@@ -385,10 +385,24 @@ extern "C" int b4r_attn_fwd(const float* qkv, const int64_t* input_mask, int32_t
   return B4R_OK;
 }
 
+int b4r_attn_bwd_streams(const float* qkv, const int64_t* input_mask, const float* ctx, const float* lse, const float* dctx,
+                         int32_t B, int32_t L, int32_t heads, float qscale, float* dqkv, const uint32_t* rng,
+                         uint32_t drop_stream, float drop_rate, const uint32_t* keep_bits, hipStream_t stream,
+                         hipStream_t stream_dkv);
+
 extern "C" int b4r_attn_bwd(const float* qkv, const int64_t* input_mask, const float* ctx, const float* lse,
                             const float* dctx, int32_t B, int32_t L, int32_t heads, float qscale, float* dqkv,
                             const uint32_t* rng, uint32_t drop_stream, float drop_rate, const uint32_t* keep_bits,
                             b4r_stream_t stream) {
+  return b4r_attn_bwd_streams(qkv, input_mask, ctx, lse, dctx, B, L, heads, qscale, dqkv, rng, drop_stream, drop_rate,
+                              keep_bits, (hipStream_t)stream, (hipStream_t)stream);
+}
+
+// stream_dkv: where the dK/dV kernel goes (the backward pass overlaps it with dQ); the caller orders the two streams
+int b4r_attn_bwd_streams(const float* qkv, const int64_t* input_mask, const float* ctx, const float* lse, const float* dctx,
+                         int32_t B, int32_t L, int32_t heads, float qscale, float* dqkv, const uint32_t* rng,
+                         uint32_t drop_stream, float drop_rate, const uint32_t* keep_bits, hipStream_t stream,
+                         hipStream_t stream_dkv) {
   int rc = check_common("b4r_attn_bwd", qkv, input_mask, B, L, heads);
   if (rc) return rc;
   B4R_CHECK_ARG(ctx && lse && dctx && dqkv, B4R_E_BADARG, "b4r_attn_bwd: null argument");
@@ -397,7 +411,7 @@ extern "C" int b4r_attn_bwd(const float* qkv, const int64_t* input_mask, const f
     const DropArgs drop = b4r_make_drop(rng, drop_stream, drop_rate, 1);
     rc = check_bits("b4r_attn_bwd", drop, keep_bits);
     if (rc) return rc;
-    return b4r_attn_rx_bwd_launch(qkv, input_mask, ctx, lse, dctx, B, L, heads, qscale, dqkv, drop, keep_bits, (hipStream_t)stream);
+    return b4r_attn_rx_bwd_launch(qkv, input_mask, ctx, lse, dctx, B, L, heads, qscale, dqkv, drop, keep_bits, stream, stream_dkv);
   }
   AttnP p{};
   p.qkv = qkv; p.mask = input_mask; p.ctx = ctx; p.lse_in = lse; p.dctx = dctx; p.dqkv = dqkv;
@@ -415,7 +429,7 @@ extern "C" int b4r_attn_bwd(const float* qkv, const int64_t* input_mask, const f
   const size_t sh_kv = ((size_t)2 * p.Lp * 32 + 2 * p.Lp) * sizeof(float);
   rc = set_lds(attn_bwd_dkv_kernel, sh_kv);
   if (rc) return rc;
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(64 * WAVES), sh_kv, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(64 * WAVES), sh_kv, stream_dkv, p);
   B4R_CHECK_LAUNCH("b4r_attn_bwd dkv");
   return B4R_OK;
 }

@@ -382,7 +382,8 @@ int b4r_attn_rx_fwd_launch(const float* qkv, const int64_t* mask, int B, int L, 
 
 int b4r_attn_rx_bwd_launch(const float* qkv, const int64_t* mask, const float* ctx, const float* lse, const float* dctx,
                            int B, int L, int heads, float qscale, float* dqkv, const DropArgs& drop,
-                           const uint32_t* keep_bits, hipStream_t stream) {
+                           const uint32_t* keep_bits, hipStream_t stream, hipStream_t stream_dkv) {
+  // stream_dkv: the dK/dV kernel may run on another stream (it writes other columns of dqkv than dQ does)
   AttnRxP p{};
   p.qkv = qkv; p.mask = mask; p.ctx = ctx; p.lse_in = lse; p.dctx = dctx; p.dqkv = dqkv; p.bits_in = keep_bits;
   p.B = B; p.L = L; p.heads = heads; p.H = heads * 32; p.qscale = qscale;
@@ -399,7 +400,7 @@ int b4r_attn_rx_bwd_launch(const float* qkv, const int64_t* mask, const float* c
   const size_t sh_kv = planes + (size_t)2 * p.KTE * 16 * sizeof(float);
   rc = set_lds(attn_rx_dkv_kernel, sh_kv);
   if (rc) return rc;
-  hipLaunchKernelGGL(attn_rx_dkv_kernel, grid, dim3(64 * WAVES), sh_kv, stream, p);
+  hipLaunchKernelGGL(attn_rx_dkv_kernel, grid, dim3(64 * WAVES), sh_kv, stream_dkv ? stream_dkv : stream, p);
   B4R_CHECK_LAUNCH("b4r_attn_bwd dkv (bf16x3)");
   return B4R_OK;
 }

@@ -34,6 +34,10 @@ int b4r_head_rx_fwd_launch(const float* T, const float* E, const float* bias, co
 int b4r_head_rx_dE_launch(const float* T, const float* E, const float* bias, const float* lse, const int32_t* ylab, int M, int V,
                           float* scratch, float* dE, float* db, hipStream_t stream);
 int b4r_ce_finalize_launch(const float* row_scratch, int M, b4r_train_state* state, int overwrite, hipStream_t stream);
+int b4r_attn_bwd_streams(const float* qkv, const int64_t* input_mask, const float* ctx, const float* lse, const float* dctx,
+                         int32_t B, int32_t L, int32_t heads, float qscale, float* dqkv, const uint32_t* rng,
+                         uint32_t drop_stream, float drop_rate, const uint32_t* keep_bits, hipStream_t stream,
+                         hipStream_t stream_dkv);
 int b4r_optimizer_fused(const b4r_adamw_config* hp, float* params, const float* grads, float* adam_m, float* adam_v, int64_t n,
                         int64_t n_decay, float* scratch, b4r_train_state* state, hipStream_t stream);
 
@@ -240,6 +244,48 @@ int gemm(const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, i
   return b4r_gemm_f32(&d, (b4r_stream_t)s);
 }
 
+// ---- a second stream for the branches of the backward pass that nothing downstream waits for -------------------------
+// (weight-gradient products, the dE sweep of the fused head, dK/dV next to dQ).  The idea: every kernel of this workload
+// leaves part of the chip idle at its start and tail, a concurrent independent kernel could fill those holes.  MEASURED
+// (ML-1M step, one MI355X, same box, ms per step): single stream 0.943 | head dE only 0.958 | + dK/dV 0.970 | + all weight
+// gradients 0.990 -- the event hand-offs between streams cost more than the overlap returns, and the concurrent kernels
+// mostly take each other's CUs.  So it is OFF by default; B4R_SIDE_STREAM=1|2|3 re-enables the three levels.
+struct SideStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[64];
+  int next = 0, device = -1;
+};
+thread_local SideStream g_side;
+
+int side_level() {   // 0: off; 1: everything independent; 2: head dE + dK/dV; 3: head dE only
+  static const int lv = getenv("B4R_SIDE_STREAM") ? atoi(getenv("B4R_SIDE_STREAM")) : 0;
+  return lv;
+}
+
+hipStream_t side_stream() {
+  if (side_level() == 0) return nullptr;
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  if (g_side.stream == nullptr || g_side.device != dev) {
+    if (hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking) != hipSuccess) { g_side.stream = nullptr; return nullptr; }
+    for (int i = 0; i < 64; ++i)
+      if (hipEventCreateWithFlags(&g_side.ev[i], hipEventDisableTiming) != hipSuccess) { g_side.stream = nullptr; return nullptr; }
+    g_side.device = dev;
+  }
+  return g_side.stream;
+}
+
+// work enqueued on `to` after this call starts only when everything enqueued on `from` so far has finished
+int order_after(hipStream_t from, hipStream_t to) {
+  if (from == to) return B4R_OK;
+  hipEvent_t e = g_side.ev[(g_side.next++) & 63];
+  if (hipEventRecord(e, from) != hipSuccess || hipStreamWaitEvent(to, e, 0) != hipSuccess) {
+    b4r_set_error("b4r_backward: stream ordering failed");
+    return B4R_E_HIP;
+  }
+  return B4R_OK;
+}
+
 int gemm_tn(const float* A, int lda, const float* Bm, int ldb, float* out, int ldo, int R, int Mo, int No, float* colsum,
             float* colsum_a, const uint32_t* rng, uint32_t stream_id, float rate, int b_dropout, float* scratch,
             hipStream_t s) {
@@ -437,6 +483,13 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
   }
 
   // ---- masked-LM head (logits buffer holds d loss_sum / d logits, pad columns zero) --------------------------------
+  // s2: independent branches (see SideStream); it is ordered after the memsets here, joined before every reuse of a buffer
+  // a branch reads (top of each layer) and before the final reductions
+  hipStream_t s2 = side_stream();
+  if (s2 == nullptr) s2 = s;
+  hipStream_t s_tn = side_level() == 1 ? s2 : s;                          // weight-gradient products
+  hipStream_t s_kv = (side_level() == 1 || side_level() == 2) ? s2 : s;  // dK/dV
+  RC(order_after(s, s2));
   float* dlog = ws + w.logits;
   const bool fused_head = (flags & B4R_FLAG_FUSED_HEAD) != 0;
   B4R_CHECK_ARG(!fused_head || b4r_fused_head_supported(cfg), B4R_E_BADARG, "b4r_backward: B4R_FLAG_FUSED_HEAD needs hidden size 64 and the bf16x3 mode");
@@ -444,7 +497,7 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
     // dT came with the forward; dE / d output_bias recompute the logit tiles (b4r_head_rx.hip)
     RC(b4r_head_rx_dE_launch(ws + w.t, params + pl.word_emb, params + pl.out_bias, ws + w.head_lse,
                              reinterpret_cast<const int32_t*>(ws + w.head_ylab), M, V, take(b4r_head_rx_dE_scratch_floats(M, V)),
-                             grads + pl.word_emb, grads + pl.out_bias, s));
+                             grads + pl.word_emb, grads + pl.out_bias, s2));
   } else {
   // dT = dlogits . E   (K = V is long and the output small: split K so that the whole chip streams dlogits)
   {
@@ -464,8 +517,9 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
   RC(b4r_ln_bwd_launch(ws + w.dt, ws + w.u, ws + w.meanm, ws + w.rstdm, params + pl.lnm_g, M, H, ws + w.dt, grads + pl.lnm_g,
                        grads + pl.lnm_b, take(b4r_ln_bwd_scratch_floats(M, H)), nullptr, nullptr, nullptr, 1, 1, nodrop, s,
                        ws + w.upre));   // ... and straight through the GELU of the transform's dense layer
+  RC(order_after(s, s_tn));
   RC(gemm_tn(ws + w.gath, H, ws + w.dt, H, grads + pl.wd, H, M, H, H, grads + pl.bd, nullptr, nullptr, 0, 0.f, 0,
-             take(b4r_gemm_tn_scratch_floats(M, H, H)), s));
+             take(b4r_gemm_tn_scratch_floats(M, H, H)), s_tn));
   RC(gemm(ws + w.dt, H, params + pl.wd, H, ws + w.dg, H, M, H, H, 1, B4R_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 1.f, 0,
           nullptr, 0, 0.f, 0, s));
   // scatter into d sequence_output (slots with y_true == 0 carry exactly zero gradient and are skipped)
@@ -474,35 +528,43 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
   // ---- encoder layers, last to first ---------------------------------------------------------------------------------
   for (int i = cfg->num_layers - 1; i >= 0; --i) {
     const float* x_in = (i == 0) ? ws + w.x0 : ws + w.x2[i - 1];
+    RC(order_after(s_tn, s));   // the branches of the previous layer still read da / df / db / dqkv, which this layer rewrites
     // output LayerNorm
     RC(b4r_ln_bwd_launch(ws + w.dx, ws + w.z2[i], ws + w.mean2[i], ws + w.rstd2[i], params + pl.ln2_g[i], N, H, ws + w.da,
                          grads + pl.ln2_g[i], grads + pl.ln2_b[i], take(b4r_ln_bwd_scratch_floats(N, H)), nullptr, nullptr, nullptr, 1, 1, nodrop, s));
     // FFN: dFpre = (dropmask(dz2) . W2^T) * gelu'(fpre)
     RC(gemm(ws + w.da, H, params + pl.w2[i], H, ws + w.df, I, N, I, H, 1, B4R_EPI_GELU_BWD, nullptr, nullptr, 0, ws + w.fpre[i],
             I, 1.f, 0, rng, B4R_STREAM_FFN_OUT(i), od, 1, s));
+    RC(order_after(s, s_tn));
     RC(gemm_tn(ws + w.f[i], I, ws + w.da, H, grads + pl.w2[i], H, N, I, H, grads + pl.b2[i], nullptr, rng, B4R_STREAM_FFN_OUT(i),
-               od, 1, take(b4r_gemm_tn_scratch_floats(N, I, H)), s));
+               od, 1, take(b4r_gemm_tn_scratch_floats(N, I, H)), s_tn));
     // dX1 = dFpre . W1^T + dz2
     RC(gemm(ws + w.df, I, params + pl.w1[i], I, ws + w.db, H, N, H, I, 1, B4R_EPI_ADD_RES, nullptr, nullptr, 0, ws + w.da, H, 1.f,
             0, nullptr, 0, 0.f, 0, s));
+    RC(order_after(s, s_tn));
     RC(gemm_tn(ws + w.x1[i], H, ws + w.df, I, grads + pl.w1[i], I, N, H, I, grads + pl.b1[i], nullptr, nullptr, 0, 0.f, 0,
-               take(b4r_gemm_tn_scratch_floats(N, H, I)), s));
+               take(b4r_gemm_tn_scratch_floats(N, H, I)), s_tn));
     // attention LayerNorm
     RC(b4r_ln_bwd_launch(ws + w.db, ws + w.z1[i], ws + w.mean1[i], ws + w.rstd1[i], params + pl.ln1_g[i], N, H, ws + w.db,
                          grads + pl.ln1_g[i], grads + pl.ln1_b[i], take(b4r_ln_bwd_scratch_floats(N, H)), nullptr, nullptr, nullptr, 1, 1, nodrop, s));
     // attention output projection
     RC(gemm(ws + w.db, H, params + pl.wo[i], H, ws + w.dctx, H, N, H, H, 1, B4R_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 1.f, 0,
             rng, B4R_STREAM_ATTN_OUT(i), od, 1, s));
+    RC(order_after(s, s_tn));
     RC(gemm_tn(ws + w.ctx[i], H, ws + w.db, H, grads + pl.wo[i], H, N, H, H, grads + pl.bo[i], nullptr, rng,
-               B4R_STREAM_ATTN_OUT(i), od, 1, take(b4r_gemm_tn_scratch_floats(N, H, H)), s));
-    // attention core
-    RC(b4r_attn_bwd(ws + w.qkv[i], batch->input_mask, ws + w.ctx[i], ws + w.lse[i], ws + w.dctx, B, L, cfg->num_heads, qscale,
-                    ws + w.dqkv, rng, B4R_STREAM_ATTN_PROBS(i), adp, reinterpret_cast<const uint32_t*>(ws + w.keep[i]), stream));
+               B4R_STREAM_ATTN_OUT(i), od, 1, take(b4r_gemm_tn_scratch_floats(N, H, H)), s_tn));
+    // attention core: dQ on the main stream, dK/dV on the other (both need dctx; the QKV product below needs both)
+    RC(order_after(s, s_kv));
+    RC(b4r_attn_bwd_streams(ws + w.qkv[i], batch->input_mask, ws + w.ctx[i], ws + w.lse[i], ws + w.dctx, B, L, cfg->num_heads,
+                            qscale, ws + w.dqkv, rng, B4R_STREAM_ATTN_PROBS(i), adp,
+                            reinterpret_cast<const uint32_t*>(ws + w.keep[i]), s, s_kv));
+    RC(order_after(s_kv, s));
     // QKV projection: dX_in = dqkv . Wqkv^T + dz1
     RC(gemm(ws + w.dqkv, 3 * H, params + pl.wqkv[i], 3 * H, ws + w.dx, H, N, H, 3 * H, 1, B4R_EPI_ADD_RES, nullptr, nullptr, 0,
             ws + w.db, H, 1.f, 0, nullptr, 0, 0.f, 0, s));
+    RC(order_after(s, s_tn));
     RC(gemm_tn(x_in, H, ws + w.dqkv, 3 * H, grads + pl.wqkv[i], 3 * H, N, H, 3 * H, grads + pl.bqkv[i], nullptr, nullptr, 0, 0.f,
-               0, take(b4r_gemm_tn_scratch_floats(N, H, 3 * H)), s));
+               0, take(b4r_gemm_tn_scratch_floats(N, H, 3 * H)), s_tn));
   }
   // ---- embedding stage: dropout -> LayerNorm -> (word table scatter-add, position table batch sum) ---------------------
   RC(b4r_ln_bwd_launch(ws + w.dx, nullptr, ws + w.mean0, ws + w.rstd0, params + pl.emb_ln_g, N, H, ws + w.da, grads + pl.emb_ln_g,
@@ -510,6 +572,7 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
                        b4r_make_drop(rng, B4R_STREAM_EMB, od, 1), s));
   // all queued ordered reductions (weight / bias / LayerNorm gradients) in one launch; the item-table gradient must be
   // complete before the embedding rows are scatter-added on top of it
+  RC(order_after(s2, s));
   RC(b4r_reduce_queue_flush(s));
   B4rReduceQueue tail_queue;
   b4r_reduce_queue_begin(&tail_queue);   // the two small reductions below share one launch as well

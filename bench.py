@@ -41,6 +41,27 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); 6.29 TB/s is t
 BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md); the split-precision kernels run on it
 
 
+def profiled_traffic(kernel_prefix):
+    """HBM bytes per launch of a kernel from the newest committed PMC summary (profiles/r01_*_pmc_ml1m*.txt: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench, gfx950 x2 fetch correction applied by tools/pmc.py).
+    bench.py cannot collect PMC counters itself; None when no summary names the kernel."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_*_pmc_ml1m*.txt")), reverse=True):
+        try:
+            lines = open(path).read().splitlines()
+            hdr = lines[0].split()
+            i_rd, i_wr = hdr.index("rdMB"), hdr.index("wrMB")
+            for ln in lines[1:]:
+                if kernel_prefix in ln:
+                    cols = ln.split()
+                    off = len(cols) - len(hdr)          # the kernel name may contain blanks
+                    return {"bytes": round((float(cols[i_rd + off]) + float(cols[i_wr + off])) * 1e6),
+                            "source": os.path.relpath(path, ROOT)}
+        except (OSError, ValueError, IndexError):
+            continue
+    return None
+
+
 def synthetic_batch(B, L, P, V, rate, seed):
     """S-full rows of SURVEY.md §8(d): every row has length L, n = min(P, max(1, int(L*rate))) masked positions."""
     rng = np.random.default_rng(seed)
@@ -165,6 +186,9 @@ def main():
                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes": alg_bytes,
                         "avg_launch_us": round(k_us, 2), "in_timed_region": not eng.fused_head_supported()}
+        tr = profiled_traffic("rx_gemm_nk_kernel<1, false, 4>") if args.config == "ml1m" else None
+        if tr:
+            roofline_mat["traffic"], roofline_mat["traffic_source"] = tr["bytes"], tr["source"]
         roofline = roofline_mat
         if eng.fused_head_supported():
             # the train step's head: replay the vocabulary sweep (the longest kernel of the step) on the live buffers
@@ -187,6 +211,9 @@ def main():
                         "bound": "mfma", "achieved": round(tf, 1), "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(tf / BF16_PEAK_TFLOPS, 4), "traffic": None, "algorithmic_flops": alg_flops,
                         "executed_mfma_flops": 3 * alg_flops, "avg_launch_us": round(h_us, 2)}
+            tr = profiled_traffic("head_fwd_kernel") if args.config == "ml1m" else None
+            if tr:
+                roofline["traffic"], roofline["traffic_source"] = tr["bytes"], tr["source"]
 
         if args.phases:
             def timed(fn, n=20):

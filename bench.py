@@ -3,7 +3,7 @@
 [+ RCCL all-reduce]) on the ML-1M configuration of BASELINE.json (configs[1]):
 B=256 per GPU, L=200, P=40, H=64, 2 layers, 2 heads, inner 256, V=3709, dropout 0.2/0.2, full-vocab masked-LM head.
 
-    python bench.py --gpus 1 --steps 50 --warmup 10
+    python bench.py --gpus 1 --steps 200 --warmup 30
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -84,8 +84,8 @@ def synthetic_batch(B, L, P, V, rate, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--config", default="ml1m", choices=list(CONFIGS))
     ap.add_argument("--cpu-steps", type=int, default=2, help="timed oracle steps for cpu_baseline (0 disables)")
     ap.add_argument("--phases", action="store_true", help="also print per-phase timings to stderr")

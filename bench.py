@@ -193,9 +193,9 @@ def main():
         if eng.fused_head_supported():
             # the train step's head: replay the vocabulary sweep (the longest kernel of the step) on the live buffers
             _, keep0 = prepared[0]
-            scratch = torch.empty(lib.b4r_mlm_head_fused_scratch_floats(M, V), dtype=torch.float32, device=device)
+            scratch = torch.empty(lib.b4r_mlm_head_fused_scratch_floats(M, V, H), dtype=torch.float32, device=device)
             hargs = (t_h.data_ptr(), eng.view("word_embeddings/embeddings").data_ptr(),
-                    eng.view("cls/predictions/output_bias/bias").data_ptr(), keep0["masked_lm_ids"].data_ptr(), M, V,
+                    eng.view("cls/predictions/output_bias/bias").data_ptr(), keep0["masked_lm_ids"].data_ptr(), M, V, H,
                     scratch.data_ptr(), None, None, None, None, 1, stream)
             for _ in range(5):
                 _lib.check(lib.b4r_mlm_head_fused_fwd(*hargs))

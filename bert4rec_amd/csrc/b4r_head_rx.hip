@@ -1,4 +1,5 @@
-// Masked-LM head of a TRAIN step without materialising the [M, V] logits (split-precision arithmetic, hidden size 64).
+// Masked-LM head of a TRAIN step without materialising the [M, V] logits (split-precision arithmetic; hidden size 64, 128
+// or 256 = NKH column groups of 32, the kernels are templates over NKH).
 //
 //   logits x[m,v] = T[m,:].E[v,:] + b[v]      (T = transform output [M,64], E = tied item table [V,64])
 //   loss_m = logsumexp_v x[m,v] - x[m,y_m] ;  g[m,v] = softmax(x[m,:])[v] - [v == y_m]   (rows with y_m == 0 ignored)
@@ -14,13 +15,15 @@
 //   head_dE_kernel    the other orientation (a wave owns 16 rows of E, sweeps slices of M): recomputes the logit tiles
 //                     with the same arithmetic, g = exp(x - lse) - onehot, dE^T += T^T.g, db += column sums; partial
 //                     tiles per M slice go to slabs that the backward's deferred ordered reduction sums.
-// Tile / image mechanics are those of b4r_rx_tiles.h: the 64 columns of E (or T) are two 32-column images (hi, lo each).
+// Tile / image mechanics are those of b4r_rx_tiles.h: the H columns of E (or T) are NKH 32-column images (hi, lo each),
+// interleaved per 16-row tile.
 #include "b4r_rx_tiles.h"
 
 namespace {
 
-constexpr int HEAD_CH = 10;    // 16-row tiles per LDS chunk: 40 KB of images, three workgroups per CU
-constexpr int PART_LD = 72;    // floats per (V slice, row): 64 accumulators, max, sum, best logit, best index
+// 16-row tiles per LDS chunk (even): 40 KB of images at H = 64 (three workgroups per CU), 48 KB at 128, 64 KB at 256
+constexpr int head_ch(int nkh) { return nkh == 2 ? 10 : nkh == 4 ? 6 : 4; }
+constexpr int part_ld(int nkh) { return 32 * nkh + 8; }   // floats per (V slice, row): H accumulators, max, sum, best logit, best index
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 // The sweeps work in log2 units: T (or E) is scaled by log2(e) before it is split, so that the softmax exponential is the
 // bare v_exp_f32 (2^x) -- the kernels are bound by VALU issue, every instruction per logit counts.
@@ -35,61 +38,92 @@ struct HeadP {
   int tiles_per_slice;            // even number of 16-row tiles per slice (of V in the forward, of M in dE)
 };
 
-__device__ __forceinline__ f32x4 logit_tile(const char* tile, const bf16x8 (&bh)[2], const bf16x8 (&bl)[2]) {
+// image index as a function argument: it is a constant after unrolling, so the offset still folds into the instruction
+__device__ __forceinline__ bf16x8 row_frag_at(const char* tile, int img) {
+  return *reinterpret_cast<const bf16x8*>(tile + img * IMG_BYTES);
+}
+template <int TB>
+__device__ __forceinline__ bf16x8 tr_frag_at(const char* tile, int img) {
+  typedef __attribute__((address_space(3))) s16x4* lds_ptr;
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(tile + img * IMG_BYTES));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(tile + img * IMG_BYTES + TB));
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+template <int NKH>
+__device__ __forceinline__ f32x4 logit_tile(const char* tile, const bf16x8 (&bh)[NKH], const bf16x8 (&bl)[NKH]) {
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  s = mfma3(row_frag<0>(tile), row_frag<1>(tile), bh[0], bl[0], s);
-  s = mfma3(row_frag<2>(tile), row_frag<3>(tile), bh[1], bl[1], s);
+#pragma unroll
+  for (int kh = 0; kh < NKH; ++kh) s = mfma3(row_frag_at(tile, 2 * kh), row_frag_at(tile, 2 * kh + 1), bh[kh], bl[kh], s);
   return s;
 }
 
 // acc[2*kh + db] += image(kh)^T[16 columns of block db][rows of the tile pair] . (ph, pl)
+template <int NKH>
 __device__ __forceinline__ void feed_pair(const char* img, const FragAddr& fa, int pair_tile, const bf16x8 ph, const bf16x8 pl,
-                                          f32x4 (&acc)[4]) {
+                                          f32x4 (&acc)[2 * NKH]) {
+  constexpr int TB = 2 * NKH * IMG_BYTES;
 #pragma unroll
   for (int db = 0; db < 2; ++db) {
-    const char* tile = img + fa.tr[db] + TILE_BYTES * pair_tile;
-    acc[db] = mfma3(tr_frag<0>(tile), tr_frag<1>(tile), ph, pl, acc[db]);
-    acc[2 + db] = mfma3(tr_frag<2>(tile), tr_frag<3>(tile), ph, pl, acc[2 + db]);
+    const char* tile = img + fa.tr[db] + TB * pair_tile;
+#pragma unroll
+    for (int kh = 0; kh < NKH; ++kh)
+      acc[2 * kh + db] = mfma3(tr_frag_at<TB>(tile, 2 * kh), tr_frag_at<TB>(tile, 2 * kh + 1), ph, pl, acc[2 * kh + db]);
   }
+}
+
+// one chunk of `nrows` rows (row c0 onwards of a [*, 32*NKH] fp32 matrix) -> the chunk's images; rows >= valid are zero
+template <int NKH>
+__device__ __forceinline__ void stage_chunk(char* img, const float* src, int c0, int nrows, int valid) {
+  constexpr int H = 32 * NKH, TB = 2 * NKH * IMG_BYTES, CH = head_ch(NKH);
+  constexpr int NIT = (CH * 16 * 8 + 64 * WAVES - 1) / (64 * WAVES);   // float4 pieces per thread and 32-column group
+  StagedRowsT<NIT> st[NKH / 2];
+#pragma unroll
+  for (int j = 0; j < NKH / 2; ++j)
+    stage_fetch<NIT>(st[j], src + (int64_t)c0 * H + 64 * j, H, src + (int64_t)c0 * H + 64 * j + 32, H, 0, valid);
+  __syncthreads();                                              // the previous chunk has been consumed
+#pragma unroll
+  for (int j = 0; j < NKH / 2; ++j) stage_write<NIT, TB>(st[j], img + 4 * j * IMG_BYTES, nrows, valid);
 }
 
 // -----------------------------------------------------------------------------------------------------------
 // forward: grid (row blocks of 128, V slices); wave = 16 rows of T x the slice's rows of E
 // LDS: [E chunk images | bias chunk]
 // -----------------------------------------------------------------------------------------------------------
+template <int NKH>
 __global__ __launch_bounds__(64 * WAVES) void head_fwd_kernel(HeadP p) {
   extern __shared__ __attribute__((aligned(16))) char smem_head[];
+  constexpr int H = 32 * NKH, TB = 2 * NKH * IMG_BYTES, HEAD_CH = head_ch(NKH), PART_LD = part_ld(NKH);
   char* img = smem_head;
-  float* sBias = reinterpret_cast<float*>(img + HEAD_CH * TILE_BYTES);
+  float* sBias = reinterpret_cast<float*>(img + HEAD_CH * TB);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
   const int m = blockIdx.x * ROWS_WG + 16 * wave + i;
   const int mc = min(m, p.M - 1);
-  bf16x8 th[2], tl[2];
+  bf16x8 th[NKH], tl[NKH];
 #pragma unroll
-  for (int kh = 0; kh < 2; ++kh) split8(load8(p.T + (int64_t)mc * 64 + 32 * kh + 8 * g) * LOG2E, th[kh], tl[kh]);
+  for (int kh = 0; kh < NKH; ++kh) split8(load8(p.T + (int64_t)mc * H + 32 * kh + 8 * g) * LOG2E, th[kh], tl[kh]);
   const int v_begin = blockIdx.y * p.tiles_per_slice * 16;
   const int v_end = min(((p.V + 31) >> 5) << 5, v_begin + p.tiles_per_slice * 16);   // multiples of 32; v_begin < V
   const FragAddr fa = frag_addr(lane);
 
   float mx = -INFINITY, sum = 0.f, best = -INFINITY;   // log2 units
   int bidx = 0x7fffffff;
-  f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  f32x4 acc[2 * NKH];
+#pragma unroll
+  for (int kb = 0; kb < 2 * NKH; ++kb) acc[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   for (int c0 = v_begin; c0 < v_end; c0 += HEAD_CH * 16) {
     const int nrows = min(HEAD_CH * 16, v_end - c0);            // multiple of 32
     const int valid = min(nrows, p.V - c0);                     // >= 1: every chunk starts below V
-    StagedRows st;
-    stage_fetch(st, p.E + (int64_t)c0 * 64, 64, p.E + (int64_t)c0 * 64 + 32, 64, 0, valid);
     const float bz = p.bias[min(c0 + (int)threadIdx.x, p.V - 1)];
-    __syncthreads();                                            // the previous chunk has been consumed
-    stage_write(st, img, nrows, valid);
+    stage_chunk<NKH>(img, p.E, c0, nrows, valid);
     if ((int)threadIdx.x < nrows) sBias[threadIdx.x] = (c0 + (int)threadIdx.x < p.V) ? bz * LOG2E : -INFINITY;
     __syncthreads();
     for (int tp = 0; tp < nrows / 32; ++tp) {
       f32x4 x[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u)
-        x[u] = logit_tile(img + fa.row + TILE_BYTES * (2 * tp + u), th, tl) +
+        x[u] = logit_tile<NKH>(img + fa.row + TB * (2 * tp + u), th, tl) +
                *reinterpret_cast<const f32x4*>(&sBias[16 * (2 * tp + u) + 4 * g]);
       const float pl8 = fmaxf(fmaxf(fmaxf(x[0][0], x[0][1]), fmaxf(x[0][2], x[0][3])), fmaxf(fmaxf(x[1][0], x[1][1]), fmaxf(x[1][2], x[1][3])));
       if (pl8 > best) {                                         // rare after the first tiles: argmax of this lane's columns
@@ -106,7 +140,7 @@ __global__ __launch_bounds__(64 * WAVES) void head_fwd_kernel(HeadP p) {
         const float alpha = (mx == mnew) ? 1.0f : ex2(mx - mnew);
         sum *= alpha;
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) acc[kb] = acc[kb] * alpha;
+        for (int kb = 0; kb < 2 * NKH; ++kb) acc[kb] = acc[kb] * alpha;
       }
       mx = mnew;
       f32x4 pr[2];
@@ -121,7 +155,7 @@ __global__ __launch_bounds__(64 * WAVES) void head_fwd_kernel(HeadP p) {
       }
       bf16x8 ph, pl;
       split8(cat(pr[0], pr[1]), ph, pl);
-      feed_pair(img, fa, 2 * tp, ph, pl, acc);                  // acc^T[k][row] += E^T[k][v pair] . p^T[v pair][row]
+      feed_pair<NKH>(img, fa, 2 * tp, ph, pl, acc);             // acc^T[k][row] += E^T[k][v pair] . p^T[v pair][row]
     }
   }
   // the four g lanes of a row hold disjoint columns: combine
@@ -136,43 +170,45 @@ __global__ __launch_bounds__(64 * WAVES) void head_fwd_kernel(HeadP p) {
   if (m < p.M) {
     float* dst = p.part + ((int64_t)blockIdx.y * p.M + m) * PART_LD;
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) *reinterpret_cast<f32x4*>(dst + 16 * kb + 4 * g) = acc[kb];
+    for (int kb = 0; kb < 2 * NKH; ++kb) *reinterpret_cast<f32x4*>(dst + 16 * kb + 4 * g) = acc[kb];
     if (g == 0) {
-      dst[64] = mx; dst[65] = sum; dst[66] = best; dst[67] = __int_as_float(bidx);
+      dst[H] = mx; dst[H + 1] = sum; dst[H + 2] = best; dst[H + 3] = __int_as_float(bidx);
     }
   }
 }
 
-// merge the V slices of every row; 16 threads per row (4 columns each)
+// merge the V slices of every row; H/4 threads per row (4 columns each)
+template <int NKH>
 __global__ __launch_bounds__(256) void head_combine_kernel(const float* part, int slices, int M, int V, const float* T,
                                                            const float* E, const float* bias, const int64_t* y, float* dT,
                                                            float* row_out, float* lse_out, int32_t* ylab) {
+  constexpr int H = 32 * NKH, TPR = 8 * NKH, PART_LD = part_ld(NKH);   // TPR = threads per row: 16, 32 or 64
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  const int m = min(idx >> 4, M - 1), c4 = idx & 15;           // M*16 is a multiple of 16: whole 16-lane groups are in range
-  if ((idx >> 4) >= M) return;
+  const int m = min(idx / TPR, M - 1), c4 = idx % TPR;         // whole TPR-lane groups are in or out of range together
+  if (idx / TPR >= M) return;
   float mx = -INFINITY;
-  for (int s = 0; s < slices; ++s) mx = fmaxf(mx, part[((int64_t)s * M + m) * PART_LD + 64]);
+  for (int s = 0; s < slices; ++s) mx = fmaxf(mx, part[((int64_t)s * M + m) * PART_LD + H]);
   float sum = 0.f, best = -INFINITY;
   int bidx = 0x7fffffff;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   for (int s = 0; s < slices; ++s) {                            // slices in increasing column order: lowest index wins ties
     const float* src = part + ((int64_t)s * M + m) * PART_LD;
-    const float w = ex2(src[64] - mx);                          // the sweep's maxima are in log2 units
-    sum += src[65] * w;
+    const float w = ex2(src[H] - mx);                           // the sweep's maxima are in log2 units
+    sum += src[H + 1] * w;
     acc += *reinterpret_cast<const f32x4*>(src + 4 * c4) * w;
-    if (src[66] > best) { best = src[66]; bidx = __float_as_int(src[67]); }
+    if (src[H + 2] > best) { best = src[H + 2]; bidx = __float_as_int(src[H + 3]); }
   }
   const int64_t y64 = y[m];
   const bool valid = (y64 != 0), y_ok = (y64 >= 0 && y64 < V);
   f32x4 d = {0.f, 0.f, 0.f, 0.f}, ey = {0.f, 0.f, 0.f, 0.f};
-  if (y_ok) ey = *reinterpret_cast<const f32x4*>(E + y64 * 64 + 4 * c4);
+  if (y_ok) ey = *reinterpret_cast<const f32x4*>(E + y64 * H + 4 * c4);
   if (valid) d = acc * (1.0f / sum) - ey;
-  *reinterpret_cast<f32x4*>(dT + (int64_t)m * 64 + 4 * c4) = d;
-  // the label's logit in plain fp32 (the loss needs its value, the metrics only the argmax index): 16 lanes x 4 columns
-  const f32x4 tv = *reinterpret_cast<const f32x4*>(T + (int64_t)m * 64 + 4 * c4);
+  *reinterpret_cast<f32x4*>(dT + (int64_t)m * H + 4 * c4) = d;
+  // the label's logit in plain fp32 (the loss needs its value, the metrics only the argmax index): TPR lanes x 4 columns
+  const f32x4 tv = *reinterpret_cast<const f32x4*>(T + (int64_t)m * H + 4 * c4);
   float xl = (tv[0] * ey[0] + tv[1] * ey[1]) + (tv[2] * ey[2] + tv[3] * ey[3]);
 #pragma unroll
-  for (int o = 1; o < 16; o <<= 1) xl += __shfl_xor(xl, o, 64);
+  for (int o = 1; o < TPR; o <<= 1) xl += __shfl_xor(xl, o, 64);
   if (c4 == 0) {
     if (y_ok) xl += bias[y64];
     const float lse = (mx + __log2f(sum)) * LN2;
@@ -189,36 +225,37 @@ __global__ __launch_bounds__(256) void head_combine_kernel(const float* part, in
 // dE / db: grid (blocks of 128 rows of E, M slices); wave = 16 rows of E x the slice's rows of T
 // LDS: [T chunk images | lse chunk | label chunk]
 // -----------------------------------------------------------------------------------------------------------
+template <int NKH>
 __global__ __launch_bounds__(64 * WAVES) void head_dE_kernel(HeadP p) {
   extern __shared__ __attribute__((aligned(16))) char smem_head[];
   typedef int i32x4 __attribute__((ext_vector_type(4)));
+  constexpr int H = 32 * NKH, TB = 2 * NKH * IMG_BYTES, HEAD_CH = head_ch(NKH);
   char* img = smem_head;
-  float* sLse = reinterpret_cast<float*>(img + HEAD_CH * TILE_BYTES);
+  float* sLse = reinterpret_cast<float*>(img + HEAD_CH * TB);
   int* sY = reinterpret_cast<int*>(sLse + HEAD_CH * 16);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
   const int v = blockIdx.x * ROWS_WG + 16 * wave + i;
   const bool vlive = v < p.V;
   const int vc = min(v, p.V - 1);
-  bf16x8 eh[2], el[2];
+  bf16x8 eh[NKH], el[NKH];
 #pragma unroll
-  for (int kh = 0; kh < 2; ++kh) split8(load8(p.E + (int64_t)vc * 64 + 32 * kh + 8 * g) * LOG2E, eh[kh], el[kh]);
+  for (int kh = 0; kh < NKH; ++kh) split8(load8(p.E + (int64_t)vc * H + 32 * kh + 8 * g) * LOG2E, eh[kh], el[kh]);
   const float bv = vlive ? p.bias[vc] * LOG2E : -INFINITY;      // -inf => zero probability, and no label equals v >= V
   const int m_begin = blockIdx.y * p.tiles_per_slice * 16;
   const int m_end = min(((p.M + 31) >> 5) << 5, m_begin + p.tiles_per_slice * 16);
   const FragAddr fa = frag_addr(lane);
 
   float dbsum = 0.f;
-  f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  f32x4 acc[2 * NKH];
+#pragma unroll
+  for (int kb = 0; kb < 2 * NKH; ++kb) acc[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
   for (int c0 = m_begin; c0 < m_end; c0 += HEAD_CH * 16) {
     const int nrows = min(HEAD_CH * 16, m_end - c0);
     const int valid = min(nrows, p.M - c0);
-    StagedRows st;
-    stage_fetch(st, p.T + (int64_t)c0 * 64, 64, p.T + (int64_t)c0 * 64 + 32, 64, 0, valid);
     const int mr = min(c0 + (int)threadIdx.x, p.M - 1);
     const float lz = p.lse[mr];
     const int yz = p.ylab[mr];
-    __syncthreads();
-    stage_write(st, img, nrows, valid);
+    stage_chunk<NKH>(img, p.T, c0, nrows, valid);
     if ((int)threadIdx.x < nrows) {
       const bool in = c0 + (int)threadIdx.x < p.M;
       sLse[threadIdx.x] = in ? lz * LOG2E : INFINITY;
@@ -230,7 +267,7 @@ __global__ __launch_bounds__(64 * WAVES) void head_dE_kernel(HeadP p) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int t = 2 * tp + u;
-        const f32x4 x = logit_tile(img + fa.row + TILE_BYTES * t, eh, el);   // rows = T rows, column = this lane's v
+        const f32x4 x = logit_tile<NKH>(img + fa.row + TB * t, eh, el);   // rows = T rows, column = this lane's v
         const f32x4 ls = *reinterpret_cast<const f32x4*>(&sLse[16 * t + 4 * g]);
         const i32x4 yy = *reinterpret_cast<const i32x4*>(&sY[16 * t + 4 * g]);
 #pragma unroll
@@ -242,15 +279,15 @@ __global__ __launch_bounds__(64 * WAVES) void head_dE_kernel(HeadP p) {
       }
       bf16x8 gh, gl;
       split8(cat(gv[0], gv[1]), gh, gl);
-      feed_pair(img, fa, 2 * tp, gh, gl, acc);                  // dE^T[k][v] += T^T[k][row pair] . g[row pair][v]
+      feed_pair<NKH>(img, fa, 2 * tp, gh, gl, acc);             // dE^T[k][v] += T^T[k][row pair] . g[row pair][v]
     }
   }
   dbsum += __shfl_xor(dbsum, 16, 64);
   dbsum += __shfl_xor(dbsum, 32, 64);
   if (vlive) {
-    float* dst = p.slab + ((int64_t)blockIdx.y * p.V + v) * 64;
+    float* dst = p.slab + ((int64_t)blockIdx.y * p.V + v) * H;
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) *reinterpret_cast<f32x4*>(dst + 16 * kb + 4 * g) = acc[kb];
+    for (int kb = 0; kb < 2 * NKH; ++kb) *reinterpret_cast<f32x4*>(dst + 16 * kb + 4 * g) = acc[kb];
     if (g == 0) p.bslab[(int64_t)blockIdx.y * p.V + v] = dbsum;
   }
 }
@@ -273,96 +310,119 @@ int dE_slices_wanted(int V) {
   return s < 1 ? 1 : (s > 32 ? 32 : s);
 }
 
-constexpr size_t HEAD_LDS = (size_t)HEAD_CH * TILE_BYTES + 2 * HEAD_CH * 16 * sizeof(float);
+constexpr size_t head_lds(int nkh) { return (size_t)head_ch(nkh) * 2 * nkh * IMG_BYTES + 2 * head_ch(nkh) * 16 * sizeof(float); }
+
+template <int NKH>
+int launch_fwd(const HeadP& p, int slices, float* dT, float* row_out, float* lse, int32_t* ylab, int only_sweep, hipStream_t stream) {
+  static bool raised = false;
+  if (!raised) {
+    (void)hipFuncSetAttribute((const void*)head_fwd_kernel<NKH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)head_lds(NKH));
+    raised = true;
+  }
+  hipLaunchKernelGGL(head_fwd_kernel<NKH>, dim3(b4r_cdiv(p.M, ROWS_WG), slices), dim3(64 * WAVES), head_lds(NKH), stream, p);
+  B4R_CHECK_LAUNCH("masked-LM head forward (fused)");
+  if (only_sweep) return B4R_OK;
+  hipLaunchKernelGGL(head_combine_kernel<NKH>, dim3(b4r_cdiv((int64_t)p.M * 8 * NKH, 256)), dim3(256), 0, stream,
+                     (const float*)p.part, slices, p.M, p.V, p.T, p.E, p.bias, p.y, dT, row_out, lse, ylab);
+  B4R_CHECK_LAUNCH("masked-LM head combine");
+  return B4R_OK;
+}
+
+template <int NKH>
+int launch_dE(const HeadP& p, int slices, hipStream_t stream) {
+  static bool raised = false;
+  if (!raised) {
+    (void)hipFuncSetAttribute((const void*)head_dE_kernel<NKH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)head_lds(NKH));
+    raised = true;
+  }
+  hipLaunchKernelGGL(head_dE_kernel<NKH>, dim3(b4r_cdiv(p.V, ROWS_WG), slices), dim3(64 * WAVES), head_lds(NKH), stream, p);
+  B4R_CHECK_LAUNCH("masked-LM head dE (fused)");
+  return B4R_OK;
+}
 
 }  // namespace
+
+bool b4r_head_rx_hidden_ok(int H) { return H == 64 || H == 128 || H == 256; }
 
 // number of V slices the forward uses / M slices the dE kernel uses, and the scratch they need (floats)
 int b4r_head_rx_fwd_slices(int M, int V) {
   const int per = even_tiles(V, fwd_slices_wanted(M));
   return b4r_cdiv(b4r_cdiv(V, 16), per);
 }
-int64_t b4r_head_rx_fwd_scratch_floats(int M, int V) { return (int64_t)b4r_head_rx_fwd_slices(M, V) * M * PART_LD; }
+int64_t b4r_head_rx_fwd_scratch_floats(int M, int V, int H) { return (int64_t)b4r_head_rx_fwd_slices(M, V) * M * (H + 8); }
 int b4r_head_rx_dE_slices(int M, int V) {
   const int per = even_tiles(M, dE_slices_wanted(V));
   return b4r_cdiv(b4r_cdiv(M, 16), per);
 }
-int64_t b4r_head_rx_dE_scratch_floats(int M, int V) { return (int64_t)b4r_head_rx_dE_slices(M, V) * ((int64_t)V * 64 + V); }
+int64_t b4r_head_rx_dE_scratch_floats(int M, int V, int H) { return (int64_t)b4r_head_rx_dE_slices(M, V) * ((int64_t)V * H + V); }
 
-int b4r_head_rx_fwd_launch2(const float* T, const float* E, const float* bias, const int64_t* y, int M, int V, float* scratch,
-                            float* dT, float* row_out, float* lse, int32_t* ylab, int only_sweep, hipStream_t stream);
-
-// loss rows (as b4r_softmax_ce writes them), lse, labels and dT from T, E, bias, y; hidden size 64 only
-int b4r_head_rx_fwd_launch(const float* T, const float* E, const float* bias, const int64_t* y, int M, int V, float* scratch,
-                           float* dT, float* row_out, float* lse, int32_t* ylab, hipStream_t stream) {
-  return b4r_head_rx_fwd_launch2(T, E, bias, y, M, V, scratch, dT, row_out, lse, ylab, 0, stream);
-}
-
-int b4r_head_rx_fwd_launch2(const float* T, const float* E, const float* bias, const int64_t* y, int M, int V, float* scratch,
-                            float* dT, float* row_out, float* lse, int32_t* ylab, int only_sweep, hipStream_t stream) {
+int b4r_head_rx_fwd_launch2(const float* T, const float* E, const float* bias, const int64_t* y, int M, int V, int H,
+                            float* scratch, float* dT, float* row_out, float* lse, int32_t* ylab, int only_sweep,
+                            hipStream_t stream) {
   HeadP p{};
   p.T = T; p.E = E; p.bias = bias; p.y = y; p.part = scratch; p.M = M; p.V = V;
   const int slices = b4r_head_rx_fwd_slices(M, V);
   p.tiles_per_slice = even_tiles(V, fwd_slices_wanted(M));
-  static bool raised = false;
-  if (!raised) {
-    (void)hipFuncSetAttribute((const void*)head_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEAD_LDS);
-    (void)hipFuncSetAttribute((const void*)head_dE_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEAD_LDS);
-    raised = true;
+  switch (H) {
+    case 64: return launch_fwd<2>(p, slices, dT, row_out, lse, ylab, only_sweep, stream);
+    case 128: return launch_fwd<4>(p, slices, dT, row_out, lse, ylab, only_sweep, stream);
+    case 256: return launch_fwd<8>(p, slices, dT, row_out, lse, ylab, only_sweep, stream);
+    default: b4r_set_error("fused masked-LM head: hidden size %d not supported (64, 128, 256)", H); return B4R_E_SHAPE;
   }
-  hipLaunchKernelGGL(head_fwd_kernel, dim3(b4r_cdiv(M, ROWS_WG), slices), dim3(64 * WAVES), HEAD_LDS, stream, p);
-  B4R_CHECK_LAUNCH("masked-LM head forward (fused)");
-  if (only_sweep) return B4R_OK;
-  hipLaunchKernelGGL(head_combine_kernel, dim3(b4r_cdiv(M * 16, 256)), dim3(256), 0, stream, (const float*)scratch, slices, M, V, T, E,
-                     bias, y, dT, row_out, lse, ylab);
-  B4R_CHECK_LAUNCH("masked-LM head combine");
-  return B4R_OK;
+}
+
+// loss rows (as b4r_softmax_ce writes them), lse, labels and dT from T, E, bias, y
+int b4r_head_rx_fwd_launch(const float* T, const float* E, const float* bias, const int64_t* y, int M, int V, int H,
+                           float* scratch, float* dT, float* row_out, float* lse, int32_t* ylab, hipStream_t stream) {
+  return b4r_head_rx_fwd_launch2(T, E, bias, y, M, V, H, scratch, dT, row_out, lse, ylab, 0, stream);
 }
 
 int b4r_launch_slab_reduce_full(const float* slab, int S, int Mo, int No, float* out, int ldo, int accumulate,
                                 const float* cslab, float* colsum, const float* caslab, float* colsum_a, hipStream_t stream);
 
-// dE [V,64] and db [V] (overwritten, through the ordered slab reduction) from T, E, bias and the forward's lse / labels
+// dE [V,H] and db [V] (overwritten, through the ordered slab reduction) from T, E, bias and the forward's lse / labels
 int b4r_head_rx_dE_launch(const float* T, const float* E, const float* bias, const float* lse, const int32_t* ylab, int M, int V,
-                          float* scratch, float* dE, float* db, hipStream_t stream) {
+                          int H, float* scratch, float* dE, float* db, hipStream_t stream) {
   HeadP p{};
   p.T = T; p.E = E; p.bias = bias; p.lse = lse; p.ylab = ylab; p.M = M; p.V = V;
   const int slices = b4r_head_rx_dE_slices(M, V);
   p.tiles_per_slice = even_tiles(M, dE_slices_wanted(V));
   p.slab = scratch;
-  p.bslab = scratch + (int64_t)slices * V * 64;
-  static bool raised = false;
-  if (!raised) {
-    (void)hipFuncSetAttribute((const void*)head_dE_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)HEAD_LDS);
-    raised = true;
+  p.bslab = scratch + (int64_t)slices * V * H;
+  int rc;
+  switch (H) {
+    case 64: rc = launch_dE<2>(p, slices, stream); break;
+    case 128: rc = launch_dE<4>(p, slices, stream); break;
+    case 256: rc = launch_dE<8>(p, slices, stream); break;
+    default: b4r_set_error("fused masked-LM head: hidden size %d not supported (64, 128, 256)", H); return B4R_E_SHAPE;
   }
-  hipLaunchKernelGGL(head_dE_kernel, dim3(b4r_cdiv(V, ROWS_WG), slices), dim3(64 * WAVES), HEAD_LDS, stream, p);
-  B4R_CHECK_LAUNCH("masked-LM head dE (fused)");
-  return b4r_launch_slab_reduce_full(p.slab, slices, V, 64, dE, 64, 0, nullptr, nullptr, p.bslab, db, stream);
+  if (rc) return rc;
+  return b4r_launch_slab_reduce_full(p.slab, slices, V, H, dE, H, 0, nullptr, nullptr, p.bslab, db, stream);
 }
 
-extern "C" int64_t b4r_mlm_head_fused_scratch_floats(int32_t M, int32_t V) {
-  if (M <= 0 || V <= 0) return 0;
-  const int64_t a = b4r_head_rx_fwd_scratch_floats(M, V), b = b4r_head_rx_dE_scratch_floats(M, V);
+extern "C" int64_t b4r_mlm_head_fused_scratch_floats(int32_t M, int32_t V, int32_t H) {
+  if (M <= 0 || V <= 0 || !b4r_head_rx_hidden_ok(H)) return 0;
+  const int64_t a = b4r_head_rx_fwd_scratch_floats(M, V, H), b = b4r_head_rx_dE_scratch_floats(M, V, H);
   return a > b ? a : b;
 }
 
 extern "C" int b4r_mlm_head_fused_fwd(const float* T, const float* E, const float* bias, const int64_t* y_true, int32_t M,
-                                      int32_t V, float* scratch, float* dT, float* row_scratch, float* lse, int32_t* labels,
-                                      int32_t only_sweep, b4r_stream_t stream) {
+                                      int32_t V, int32_t H, float* scratch, float* dT, float* row_scratch, float* lse,
+                                      int32_t* labels, int32_t only_sweep, b4r_stream_t stream) {
   B4R_CHECK_ARG(T && E && bias && y_true && scratch, B4R_E_BADARG, "b4r_mlm_head_fused_fwd: null argument");
   B4R_CHECK_ARG(only_sweep || (dT && row_scratch && lse && labels), B4R_E_BADARG, "b4r_mlm_head_fused_fwd: null output");
-  B4R_CHECK_ARG(M > 0 && V > 0, B4R_E_SHAPE, "b4r_mlm_head_fused_fwd: bad shape");
+  B4R_CHECK_ARG(M > 0 && V > 0 && b4r_head_rx_hidden_ok(H), B4R_E_SHAPE, "b4r_mlm_head_fused_fwd: bad shape (H = 64, 128 or 256)");
   B4R_CHECK_ARG(b4r_aligned16(T) && b4r_aligned16(E) && b4r_aligned16(scratch) && (only_sweep || b4r_aligned16(dT)), B4R_E_ALIGN,
                 "b4r_mlm_head_fused_fwd: T, E, scratch and dT must be 16-byte aligned");
-  return b4r_head_rx_fwd_launch2(T, E, bias, y_true, M, V, scratch, dT, row_scratch, lse, labels, only_sweep, (hipStream_t)stream);
+  return b4r_head_rx_fwd_launch2(T, E, bias, y_true, M, V, H, scratch, dT, row_scratch, lse, labels, only_sweep, (hipStream_t)stream);
 }
 
 extern "C" int b4r_mlm_head_fused_bwd(const float* T, const float* E, const float* bias, const float* lse, const int32_t* labels,
-                                     int32_t M, int32_t V, float* scratch, float* dE, float* dbias, b4r_stream_t stream) {
+                                     int32_t M, int32_t V, int32_t H, float* scratch, float* dE, float* dbias,
+                                     b4r_stream_t stream) {
   B4R_CHECK_ARG(T && E && bias && lse && labels && scratch && dE && dbias, B4R_E_BADARG, "b4r_mlm_head_fused_bwd: null argument");
-  B4R_CHECK_ARG(M > 0 && V > 0, B4R_E_SHAPE, "b4r_mlm_head_fused_bwd: bad shape");
+  B4R_CHECK_ARG(M > 0 && V > 0 && b4r_head_rx_hidden_ok(H), B4R_E_SHAPE, "b4r_mlm_head_fused_bwd: bad shape (H = 64, 128 or 256)");
   B4R_CHECK_ARG(b4r_aligned16(T) && b4r_aligned16(E) && b4r_aligned16(scratch), B4R_E_ALIGN,
                 "b4r_mlm_head_fused_bwd: T, E and scratch must be 16-byte aligned");
-  return b4r_head_rx_dE_launch(T, E, bias, lse, labels, M, V, scratch, dE, dbias, (hipStream_t)stream);
+  return b4r_head_rx_dE_launch(T, E, bias, lse, labels, M, V, H, scratch, dE, dbias, (hipStream_t)stream);
 }

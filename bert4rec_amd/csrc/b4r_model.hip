@@ -27,12 +27,13 @@ int b4r_batch_colsum(const float* x, int B, int L, int H, float* dpos, float* sc
 int b4r_mul_gelu_grad(float* du, const float* pre, int64_t n, hipStream_t stream);
 int b4r_gemm_f32_splitk(const b4r_gemm_desc* d, int splits, float* scratch, int k_pad_ok, hipStream_t stream);
 // b4r_head_rx.hip: masked-LM head of a train step without materialised logits (hidden size 64, bf16x3 mode)
-int64_t b4r_head_rx_fwd_scratch_floats(int M, int V);
-int64_t b4r_head_rx_dE_scratch_floats(int M, int V);
-int b4r_head_rx_fwd_launch(const float* T, const float* E, const float* bias, const int64_t* y, int M, int V, float* scratch,
-                           float* dT, float* row_out, float* lse, int32_t* ylab, hipStream_t stream);
+bool b4r_head_rx_hidden_ok(int H);
+int64_t b4r_head_rx_fwd_scratch_floats(int M, int V, int H);
+int64_t b4r_head_rx_dE_scratch_floats(int M, int V, int H);
+int b4r_head_rx_fwd_launch(const float* T, const float* E, const float* bias, const int64_t* y, int M, int V, int H,
+                           float* scratch, float* dT, float* row_out, float* lse, int32_t* ylab, hipStream_t stream);
 int b4r_head_rx_dE_launch(const float* T, const float* E, const float* bias, const float* lse, const int32_t* ylab, int M, int V,
-                          float* scratch, float* dE, float* db, hipStream_t stream);
+                          int H, float* scratch, float* dE, float* db, hipStream_t stream);
 int b4r_ce_finalize_launch(const float* row_scratch, int M, b4r_train_state* state, int overwrite, hipStream_t stream);
 int b4r_attn_bwd_streams(const float* qkv, const int64_t* input_mask, const float* ctx, const float* lse, const float* dctx,
                          int32_t B, int32_t L, int32_t heads, float qscale, float* dqkv, const uint32_t* rng,
@@ -206,12 +207,13 @@ WsLayout make_ws_layout(const b4r_model_config& c, int B, int L, int P) {
     add(b4r_gemm_tn_scratch_floats((int)M, (int)H, (int)H));
     add(b4r_ln_bwd_scratch_floats((int)M, (int)H));
     add((int64_t)mlm_dt_splits(M, H, V) * M * H);
-    if (H == 64) add(b4r_head_rx_dE_scratch_floats((int)M, (int)V));
+    if (b4r_head_rx_hidden_ok((int)H)) add(b4r_head_rx_dE_scratch_floats((int)M, (int)V, (int)H));
   }
   add((int64_t)b4r_cdiv(B, 16) * L * H);  // position-table gradient partials
   add(b4r_scatter_hot_scratch_floats(3, (int)H));   // per-workgroup sums of the special-token rows of the table gradient
   // the fused head's forward partials live at the start of the scratch region (consumed before the backward starts)
-  if (M > 0 && H == 64 && s < b4r_head_rx_fwd_scratch_floats((int)M, (int)V)) s = up4(b4r_head_rx_fwd_scratch_floats((int)M, (int)V));
+  if (M > 0 && b4r_head_rx_hidden_ok((int)H) && s < b4r_head_rx_fwd_scratch_floats((int)M, (int)V, (int)H))
+    s = up4(b4r_head_rx_fwd_scratch_floats((int)M, (int)V, (int)H));
   w.scratch = take(s); w.scratch_floats = s;
   w.total = off;
   return w;
@@ -366,7 +368,7 @@ extern "C" int b4r_workspace_region(const b4r_model_config* cfg, int32_t B, int3
 
 // ===============================================================================================================
 extern "C" int32_t b4r_fused_head_supported(const b4r_model_config* cfg) {
-  return (cfg != nullptr && cfg->hidden_size == 64 && b4r_get_gemm_mode() == B4R_GEMM_BF16X3) ? 1 : 0;
+  return (cfg != nullptr && b4r_head_rx_hidden_ok(cfg->hidden_size) && b4r_get_gemm_mode() == B4R_GEMM_BF16X3) ? 1 : 0;
 }
 
 extern "C" int b4r_forward(const b4r_model_config* cfg, const b4r_batch* batch, const float* params, const float* pooler,
@@ -424,9 +426,9 @@ extern "C" int b4r_forward(const b4r_model_config* cfg, const b4r_batch* batch, 
     RC(b4r_ln_fwd(ws + w.u, M, H, params + pl.lnm_g, params + pl.lnm_b, cfg->ln_eps, ws + w.t, ws + w.meanm, ws + w.rstdm, stream));
     if (flags & B4R_FLAG_FUSED_HEAD) {
       // no [M,V] tensor: loss rows, log-sum-exp and d loss_sum / d T straight from T, E and the bias
-      B4R_CHECK_ARG(b4r_fused_head_supported(cfg), B4R_E_BADARG, "b4r_forward: B4R_FLAG_FUSED_HEAD needs hidden size 64 and the bf16x3 mode");
+      B4R_CHECK_ARG(b4r_fused_head_supported(cfg), B4R_E_BADARG, "b4r_forward: B4R_FLAG_FUSED_HEAD needs hidden size 64 / 128 / 256 and the bf16x3 mode");
       B4R_CHECK_ARG(batch->masked_lm_ids != nullptr, B4R_E_BADARG, "b4r_forward: B4R_FLAG_FUSED_HEAD needs masked_lm_ids");
-      RC(b4r_head_rx_fwd_launch(ws + w.t, params + pl.word_emb, params + pl.out_bias, batch->masked_lm_ids, M, V, ws + w.scratch,
+      RC(b4r_head_rx_fwd_launch(ws + w.t, params + pl.word_emb, params + pl.out_bias, batch->masked_lm_ids, M, V, H, ws + w.scratch,
                                 ws + w.dt, ws + w.rowsc, ws + w.head_lse, reinterpret_cast<int32_t*>(ws + w.head_ylab), s));
     } else {
       RC(gemm(ws + w.t, H, params + pl.word_emb, H, ws + w.logits, (int)w.Vp, M, V, H, 1, B4R_EPI_BIAS, params + pl.out_bias,
@@ -492,11 +494,11 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
   RC(order_after(s, s2));
   float* dlog = ws + w.logits;
   const bool fused_head = (flags & B4R_FLAG_FUSED_HEAD) != 0;
-  B4R_CHECK_ARG(!fused_head || b4r_fused_head_supported(cfg), B4R_E_BADARG, "b4r_backward: B4R_FLAG_FUSED_HEAD needs hidden size 64 and the bf16x3 mode");
+  B4R_CHECK_ARG(!fused_head || b4r_fused_head_supported(cfg), B4R_E_BADARG, "b4r_backward: B4R_FLAG_FUSED_HEAD needs hidden size 64 / 128 / 256 and the bf16x3 mode");
   if (fused_head) {
     // dT came with the forward; dE / d output_bias recompute the logit tiles (b4r_head_rx.hip)
     RC(b4r_head_rx_dE_launch(ws + w.t, params + pl.word_emb, params + pl.out_bias, ws + w.head_lse,
-                             reinterpret_cast<const int32_t*>(ws + w.head_ylab), M, V, take(b4r_head_rx_dE_scratch_floats(M, V)),
+                             reinterpret_cast<const int32_t*>(ws + w.head_ylab), M, V, H, take(b4r_head_rx_dE_scratch_floats(M, V, H)),
                              grads + pl.word_emb, grads + pl.out_bias, s2));
   } else {
   // dT = dlogits . E   (K = V is long and the output small: split K so that the whole chip streams dlogits)

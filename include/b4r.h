@@ -126,7 +126,7 @@ int b4r_workspace_region(const b4r_model_config* cfg, int32_t B, int32_t L, int3
  * flags: bit0 = training (dropout on), bit1 = also compute pooled_output. */
 #define B4R_FLAG_TRAINING 1
 #define B4R_FLAG_POOLER 2
-/* Train-step variant of the masked-LM head that never materialises the [B*P, V] logits (hidden size 64, B4R_GEMM_BF16X3;
+/* Train-step variant of the masked-LM head that never materialises the [B*P, V] logits (hidden size 64/128/256, B4R_GEMM_BF16X3;
  * ask b4r_fused_head_supported).  b4r_forward with this flag needs masked_lm_ids and leaves the per-slot loss terms and
  * d loss_sum / d transform in the workspace instead of "mlm_logits"; b4r_loss must then be called with
  * want_grad | B4R_LOSS_FUSED_HEAD and b4r_backward with the same flag.  b4r_train_step uses it whenever it is supported. */
@@ -278,20 +278,21 @@ int b4r_gather_rows(const float* src, int32_t src_ld, const int64_t* idx, int64_
 int b4r_scatter_add_rows(const float* src, const int64_t* idx, int64_t idx_add_per, int32_t per, int32_t n, int32_t H,
                          float* dst, int32_t dst_ld, const int64_t* skip_if_zero, b4r_stream_t stream);
 
-/* Masked-LM head of a train step without the [M, V] logits (hidden size 64, B4R_GEMM_BF16X3 arithmetic; what b4r_forward /
- * b4r_backward run under B4R_FLAG_FUSED_HEAD).  T [M,64] transform output, E [V,64] tied table, bias [V], y_true [M].
+/* Masked-LM head of a train step without the [M, V] logits (hidden size H = 64, 128 or 256, B4R_GEMM_BF16X3 arithmetic;
+ * what b4r_forward / b4r_backward run under B4R_FLAG_FUSED_HEAD).  T [M,H] transform output, E [V,H] tied table, bias [V],
+ * y_true [M].
  *   b4r_mlm_head_fused_fwd: row_scratch[4*M] (as b4r_softmax_ce leaves it; b4r_loss then reduces it into the state),
- *     lse[M] (+inf for ignored slots), labels[M] (int32, -1 for ignored slots) and dT [M,64] = d loss_sum / d T.
+ *     lse[M] (+inf for ignored slots), labels[M] (int32, -1 for ignored slots) and dT [M,H] = d loss_sum / d T.
  *     only_sweep != 0 runs the vocabulary sweep alone (partials in scratch) -- bench.py times that kernel.
- *   b4r_mlm_head_fused_bwd: dE [V,64] and dbias [V] (overwritten) from the forward's lse / labels.
- * scratch: b4r_mlm_head_fused_scratch_floats(M, V) floats, 16-byte aligned.  Replaces, for the train step only, the
+ *   b4r_mlm_head_fused_bwd: dE [V,H] and dbias [V] (overwritten) from the forward's lse / labels.
+ * scratch: b4r_mlm_head_fused_scratch_floats(M, V, H) floats, 16-byte aligned.  Replaces, for the train step only, the
  * tfm MaskedLM logits + trainer_utils.py:12-23 loss + their autograd (bert4rec_model.py:151-173). */
-int64_t b4r_mlm_head_fused_scratch_floats(int32_t M, int32_t V);
+int64_t b4r_mlm_head_fused_scratch_floats(int32_t M, int32_t V, int32_t H);
 int b4r_mlm_head_fused_fwd(const float* T, const float* E, const float* bias, const int64_t* y_true, int32_t M, int32_t V,
-                           float* scratch, float* dT, float* row_scratch, float* lse, int32_t* labels, int32_t only_sweep,
-                           b4r_stream_t stream);
+                           int32_t H, float* scratch, float* dT, float* row_scratch, float* lse, int32_t* labels,
+                           int32_t only_sweep, b4r_stream_t stream);
 int b4r_mlm_head_fused_bwd(const float* T, const float* E, const float* bias, const float* lse, const int32_t* labels,
-                          int32_t M, int32_t V, float* scratch, float* dE, float* dbias, b4r_stream_t stream);
+                           int32_t M, int32_t V, int32_t H, float* scratch, float* dE, float* dbias, b4r_stream_t stream);
 
 /* per-row softmax cross entropy over logits [M, ld] (V valid columns) + argmax metrics; row scalars then an ordered
  * single-workgroup reduction into the state.  want_grad: logits <- softmax - onehot for valid rows, 0 otherwise

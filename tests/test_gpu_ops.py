@@ -347,12 +347,13 @@ def test_rank_candidates_bit_exact_against_c_oracle(R, Cn, H, V):
     assert sc[0, 5] == sc[0, 9] and pos[0, 5] + 1 == pos[0, 9]
 
 
-@pytest.mark.parametrize("M,V", [(100, 301), (256, 3709), (32, 33), (1000, 64), (5, 4000)])
-def test_fused_mlm_head_matches_materialised_math(M, V):
+@pytest.mark.parametrize("M,V,H", [(100, 301, 64), (256, 3709, 64), (32, 33, 64), (1000, 64, 64), (5, 4000, 64),
+                                   (96, 1000, 128), (200, 301, 256), (64, 5000, 256)])
+def test_fused_mlm_head_matches_materialised_math(M, V, H):
     """b4r_mlm_head_fused_fwd / _bwd (train step without the [M,V] logits) against logits -> softmax CE -> autograd in
     fp64 (tfm MaskedLM head + trainer_utils.py:12-23,49-60): loss terms, metrics, dT, dE, dbias"""
     lib = _lib.load()
-    T_, E_, b_ = rnd(M, 64, seed=41, scale=1.5), rnd(V, 64, seed=42, scale=0.3), rnd(V, seed=43, scale=0.5)
+    T_, E_, b_ = rnd(M, H, seed=41, scale=1.5), rnd(V, H, seed=42, scale=0.3 * (64 / H) ** 0.5), rnd(V, seed=43, scale=0.5)
     g = torch.Generator().manual_seed(44)
     y = torch.randint(1, V, (M,), generator=g)
     y[::5] = 0                                           # ignored slots
@@ -361,12 +362,12 @@ def test_fused_mlm_head_matches_materialised_math(M, V):
     if M > 7:
         y[7] = int(logits[7].argmax())
     Td, Ed, bd, yd = T_.to(DEV), E_.to(DEV), b_.to(DEV), y.to(DEV)
-    scratch = torch.empty(lib.b4r_mlm_head_fused_scratch_floats(M, V), device=DEV)
-    dT = torch.full((M, 64), float("nan"), device=DEV)
+    scratch = torch.empty(lib.b4r_mlm_head_fused_scratch_floats(M, V, H), device=DEV)
+    dT = torch.full((M, H), float("nan"), device=DEV)
     rows = torch.full((4 * M,), float("nan"), device=DEV)
     lse = torch.empty(M, device=DEV)
     lab = torch.empty(M, dtype=torch.int32, device=DEV)
-    _lib.check(lib.b4r_mlm_head_fused_fwd(P(Td), P(Ed), P(bd), P(yd), M, V, P(scratch), P(dT), P(rows), P(lse), P(lab), 0, stream()))
+    _lib.check(lib.b4r_mlm_head_fused_fwd(P(Td), P(Ed), P(bd), P(yd), M, V, H, P(scratch), P(dT), P(rows), P(lse), P(lab), 0, stream()))
     Tr = T_.double().requires_grad_(True)
     Er, br = E_.double().requires_grad_(True), b_.double().requires_grad_(True)
     lg = Tr @ Er.T + br
@@ -381,9 +382,9 @@ def test_fused_mlm_head_matches_materialised_math(M, V):
     assert T.maxdiff(lse.cpu()[valid], torch.logsumexp(logits, -1)[valid]) < 2e-4 and bool(torch.isinf(lse.cpu()[~valid]).all())
     assert torch.equal(lab.cpu().long(), torch.where(valid, y, torch.full_like(y, -1)))
     assert T.maxdiff(dT, Tr.grad) < 1e-3 * float(Tr.grad.abs().max())
-    dE = torch.full((V, 64), float("nan"), device=DEV)
+    dE = torch.full((V, H), float("nan"), device=DEV)
     db = torch.full((V,), float("nan"), device=DEV)
-    _lib.check(lib.b4r_mlm_head_fused_bwd(P(Td), P(Ed), P(bd), P(lse), P(lab), M, V, P(scratch), P(dE), P(db), stream()))
+    _lib.check(lib.b4r_mlm_head_fused_bwd(P(Td), P(Ed), P(bd), P(lse), P(lab), M, V, H, P(scratch), P(dE), P(db), stream()))
     assert T.maxdiff(dE, Er.grad) < 1e-3 * float(Er.grad.abs().max())
     assert T.maxdiff(db, br.grad) < 1e-3 * float(br.grad.abs().max())
 

@@ -1,4 +1,6 @@
 // Keras MultiHeadAttention core (head_dim 32) on the exact-fp32 matrix cores, never materialising the [B,h,L,L] scores.
+// These kernels serve the B4R_GEMM_F32 mode; the default mode runs the split-precision kernels of b4r_attn_rx.hip, which
+// the C entry points at the bottom of this file dispatch to.
 //
 //   scores = q k^T + (1 - input_mask[b,key]) * -1e9 ; A = softmax(scores) ; A = dropout(A) ; ctx = A v
 //   (tfm SelfAttentionMask is key-padding only: bert4rec_encoder.py:134-135,216; q arrives pre-scaled by 1/sqrt(d))

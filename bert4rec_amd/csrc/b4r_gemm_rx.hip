@@ -1,6 +1,8 @@
-// Dense layers for K <= 64 (every projection whose reduction dimension is the hidden size of the 64-wide configurations:
-// QKV, attention output, FFN-in, the MLM transform and the tied vocabulary projection, and the input gradients that
-// reduce over H) on the bf16 matrix cores with a 3-term split ("bf16x3"):
+// Dense layers on the bf16 matrix cores with a 3-term split ("bf16x3"): rx_gemm_kn_kernel / rx_gemm_nk_kernel for K = 32
+// or 64 (every projection that reduces over the hidden size of the 64-wide configurations: QKV, attention output, FFN-in,
+// the MLM transform, the materialising vocabulary projection, and the input gradients that reduce over H),
+// rx_gemm_kloop_kernel for longer reductions (multiples of 64, optional split-K), rx_gemm_tn_kernel for the weight
+// gradients (both operands transposed: LDS-staged, see there).
 //
 //     x = hi + lo,  hi = bf16(x), lo = bf16(x - hi);      A.B ~= Ahi.Bhi + Ahi.Blo + Alo.Bhi   (fp32 accumulate)
 //

@@ -165,7 +165,7 @@ struct WsLayout {
       rstd1[B4R_MAX_LAYERS], x1[B4R_MAX_LAYERS], fpre[B4R_MAX_LAYERS], f[B4R_MAX_LAYERS], z2[B4R_MAX_LAYERS],
       mean2[B4R_MAX_LAYERS], rstd2[B4R_MAX_LAYERS], x2[B4R_MAX_LAYERS];
   int64_t gath, upre, u, meanm, rstdm, t, logits, rowsc, pooled, head_lse, head_ylab;
-  int64_t dx, da, db, dctx, dqkv, df, dt, dg;
+  int64_t dx, hot, da, db, dctx, dqkv, df, dt, dg;   // hot directly behind dx: one memset clears both
   int64_t scratch, scratch_floats;
 };
 
@@ -188,7 +188,7 @@ WsLayout make_ws_layout(const b4r_model_config& c, int B, int L, int P) {
   w.gath = take(M * H); w.upre = take(M * H); w.u = take(M * H); w.meanm = take(M); w.rstdm = take(M);
   w.t = take(M * H); w.logits = take(M * w.Vp); w.rowsc = take(4 * M); w.pooled = take((int64_t)B * H);
   w.head_lse = take(M); w.head_ylab = take(M);
-  w.dx = take(N * H); w.da = take(N * H); w.db = take(N * H); w.dctx = take(N * H);
+  w.dx = take(N * H); w.hot = take(b4r_scatter_hot_scratch_floats(3, (int)H)); w.da = take(N * H); w.db = take(N * H); w.dctx = take(N * H);
   w.dqkv = take(N * 3 * H); w.df = take(N * I); w.dt = take(M * H); w.dg = take(M * H);
   // scratch: every two-stage reduction of the backward pass keeps its partials until the single deferred reduce launch,
   // so the regions are summed (not max-ed); the two immediate reductions (split-K dT, position table) have their own
@@ -210,7 +210,6 @@ WsLayout make_ws_layout(const b4r_model_config& c, int B, int L, int P) {
     if (b4r_head_rx_hidden_ok((int)H)) add(b4r_head_rx_dE_scratch_floats((int)M, (int)V, (int)H));
   }
   add((int64_t)b4r_cdiv(B, 16) * L * H);  // position-table gradient partials
-  add(b4r_scatter_hot_scratch_floats(3, (int)H));   // per-workgroup sums of the special-token rows of the table gradient
   // the fused head's forward partials live at the start of the scratch region (consumed before the backward starts)
   if (M > 0 && b4r_head_rx_hidden_ok((int)H) && s < b4r_head_rx_fwd_scratch_floats((int)M, (int)V, (int)H))
     s = up4(b4r_head_rx_fwd_scratch_floats((int)M, (int)V, (int)H));
@@ -479,7 +478,7 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
   b4r_reduce_queue_begin(&queue);   // every ordered reduction below is summed by ONE launch at the end
 
   if (hipMemsetAsync(grads, 0, (size_t)pl.total * sizeof(float), s) != hipSuccess ||
-      hipMemsetAsync(ws + w.dx, 0, (size_t)N * H * sizeof(float), s) != hipSuccess) {
+      hipMemsetAsync(ws + w.dx, 0, (size_t)(w.da - w.dx) * sizeof(float), s) != hipSuccess) {   // dx and the hot-row slots
     b4r_set_error("b4r_backward: hipMemsetAsync failed");
     return B4R_E_HIP;
   }
@@ -579,7 +578,7 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
   B4rReduceQueue tail_queue;
   b4r_reduce_queue_begin(&tail_queue);   // the two small reductions below share one launch as well
   RC(b4r_scatter_add_rows_impl(ws + w.da, batch->input_word_ids, 0, 1, N, H, grads + pl.word_emb, H, nullptr, V, 3,
-                               take(b4r_scatter_hot_scratch_floats(3, H)), s));
+                               ws + w.hot, s));   // slots zeroed by the memset at the top
   RC(b4r_batch_colsum(ws + w.da, B, L, H, grads + pl.pos_emb, take((int64_t)b4r_cdiv(B, 16) * L * H), s));
   RC(b4r_reduce_queue_flush(s));
   B4R_CHECK_ARG(scratch_used <= w.scratch_floats, B4R_E_NOMEM, "b4r_backward: internal scratch overflow");

@@ -738,7 +738,7 @@ extern "C" int b4r_gather_rows(const float* src, int32_t src_ld, const int64_t* 
   return B4R_OK;
 }
 
-// hot_scratch (optional, with hot_rows > 0): b4r_scatter_hot_scratch_floats(hot_rows, H) floats
+// hot_scratch (optional, with hot_rows > 0): b4r_scatter_hot_scratch_floats(hot_rows, H) floats, ZEROED by the caller
 int64_t b4r_scatter_hot_scratch_floats(int hot_rows, int H) { return (int64_t)HOT_SLOTS * hot_rows * H; }
 
 int b4r_scatter_add_rows_impl(const float* src, const int64_t* idx, int64_t idx_add_per, int per, int n, int H,
@@ -748,10 +748,6 @@ int b4r_scatter_add_rows_impl(const float* src, const int64_t* idx, int64_t idx_
   const int cap = hot_rows > 0 ? 1024 : 8192;
   if (grid > cap) grid = cap;
   if (hot_rows <= 0) hot_scratch = nullptr;
-  if (hot_scratch && hipMemsetAsync(hot_scratch, 0, (size_t)HOT_SLOTS * hot_rows * H * sizeof(float), stream) != hipSuccess) {
-    b4r_set_error("b4r_scatter_add_rows: hipMemsetAsync failed");
-    return B4R_E_HIP;
-  }
   hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid), dim3(256), (size_t)hot_rows * H * sizeof(float), stream, src, idx,
                      idx_add_per, per, n, H, dst, dst_ld, skip_if_zero, dst_rows, hot_rows, hot_scratch);
   B4R_CHECK_LAUNCH("b4r_scatter_add_rows");

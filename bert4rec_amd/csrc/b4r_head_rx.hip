@@ -187,10 +187,12 @@ __global__ __launch_bounds__(256) void head_combine_kernel(const float* part, in
   const int m = min(idx / TPR, M - 1), c4 = idx % TPR;         // whole TPR-lane groups are in or out of range together
   if (idx / TPR >= M) return;
   float mx = -INFINITY;
+#pragma unroll 4
   for (int s = 0; s < slices; ++s) mx = fmaxf(mx, part[((int64_t)s * M + m) * PART_LD + H]);
   float sum = 0.f, best = -INFINITY;
   int bidx = 0x7fffffff;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
   for (int s = 0; s < slices; ++s) {                            // slices in increasing column order: lowest index wins ties
     const float* src = part + ((int64_t)s * M + m) * PART_LD;
     const float w = ex2(src[H] - mx);                           // the sweep's maxima are in log2 units

@@ -310,13 +310,7 @@ int key_tiles(int L) {
 }
 
 template <typename K>
-int set_lds(K kernel, size_t bytes) {
-  if (bytes > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) { b4r_set_error("attention: cannot raise the LDS limit to %zu: %s", bytes, hipGetErrorString(e)); return B4R_E_HIP; }
-  }
-  return B4R_OK;
-}
+int set_lds(K kernel, size_t bytes) { return b4r_raise_lds((const void*)kernel, bytes, "attention"); }
 
 int check_common(const char* who, const float* qkv, const int64_t* mask, int B, int L, int heads) {
   B4R_CHECK_ARG(qkv && mask, B4R_E_BADARG, "%s: null argument", who);

@@ -337,13 +337,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_rx_dkv_kernel(AttnRxP p) {
 }
 
 template <typename K>
-int set_lds(K kernel, size_t bytes) {
-  if (bytes > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) { b4r_set_error("attention: cannot raise the LDS limit to %zu: %s", bytes, hipGetErrorString(e)); return B4R_E_HIP; }
-  }
-  return B4R_OK;
-}
+int set_lds(K kernel, size_t bytes) { return b4r_raise_lds((const void*)kernel, bytes, "attention"); }
 
 }  // namespace
 

@@ -155,6 +155,23 @@ __device__ __forceinline__ f32x4 b4r_drop4(const DropCtx& c, f32x4 x, uint64_t i
   return x;
 }
 
+// raise a kernel's dynamic-LDS limit once per (kernel, size): hipFuncSetAttribute costs ~10 us of host time per call,
+// and the attention kernels (58 KB) would pay it at every launch
+#include <mutex>
+#include <unordered_map>
+static inline int b4r_raise_lds(const void* kernel, size_t bytes, const char* who) {
+  if (bytes <= 48 * 1024) return B4R_OK;
+  static std::mutex mu;
+  static std::unordered_map<const void*, size_t> raised;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = raised.find(kernel);
+  if (it != raised.end() && it->second >= bytes) return B4R_OK;
+  hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) { b4r_set_error("%s: cannot raise the LDS limit to %zu: %s", who, bytes, hipGetErrorString(e)); return B4R_E_HIP; }
+  raised[kernel] = bytes;
+  return B4R_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // split precision: x = hi + lo with hi = bf16(x), lo = bf16(x - hi).  Written on packed pairs: hipcc's own lowering of
 // convert(x - convert(hi)) converts every element a second time on its own (32 VALU instructions per 8 elements, 20 here)

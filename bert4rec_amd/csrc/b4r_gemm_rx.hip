@@ -404,9 +404,7 @@ void launch_kloop(const RxP& p, hipStream_t s) {
     hipLaunchKernelGGL((rx_gemm_kloop_kernel<B_NK, EPI, A_DROP, 2>), grid, dim3(256), lds, s, p);
   } else {
     const size_t lds = STAGE_FLOATS * sizeof(float) + (B_NK ? 2 * 2 * 4 * 32 * 36 * 4 : 0);
-    if (lds > 48 * 1024)
-      (void)hipFuncSetAttribute((const void*)rx_gemm_kloop_kernel<B_NK, EPI, A_DROP, 4>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)b4r_raise_lds((const void*)rx_gemm_kloop_kernel<B_NK, EPI, A_DROP, 4>, lds, "gemm");
     hipLaunchKernelGGL((rx_gemm_kloop_kernel<B_NK, EPI, A_DROP, 4>), grid, dim3(256), lds, s, p);
   }
 }

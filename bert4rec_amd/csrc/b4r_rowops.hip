@@ -1012,10 +1012,7 @@ extern "C" int b4r_sample_candidates(const float* logp, int32_t V, const int64_t
   B4R_CHECK_ARG(V > 0 && R > 0 && C > 0 && E >= 0 && C <= V, B4R_E_SHAPE, "b4r_sample_candidates: bad shape");
   const size_t lds = (size_t)V * sizeof(float);
   B4R_CHECK_ARG(lds <= 150 * 1024, B4R_E_SHAPE, "b4r_sample_candidates: vocabulary %d does not fit the 160 KB of LDS", V);
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)sample_candidates_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) { b4r_set_error("b4r_sample_candidates: cannot raise the LDS limit: %s", hipGetErrorString(e)); return B4R_E_HIP; }
-  }
+  { int rc = b4r_raise_lds((const void*)sample_candidates_kernel, lds, "b4r_sample_candidates"); if (rc) return rc; }
   hipLaunchKernelGGL(sample_candidates_kernel, dim3(R), dim3(256), lds, (hipStream_t)stream, logp, V, exclude, E, gt, C,
                      (uint32_t)seed, (uint32_t)(seed >> 32), cand);
   B4R_CHECK_LAUNCH("b4r_sample_candidates");

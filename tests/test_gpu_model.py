@@ -184,3 +184,30 @@ def test_gradient_of_unused_rows_is_zero_and_pooler_untouched():
     gpos = grads["position_embedding/embeddings"]
     assert float(gpos[10:].abs().max()) == 0.0 and float(gpos[:10].abs().max()) > 0.0
     assert "pooler_transform/kernel" not in grads
+
+
+def test_graph_replayed_steps_equal_eager_steps():
+    """Engine.train_step_graphed: the step-varying scalars live in the device state, so replaying a captured hipGraph is a
+    new train step each time (eager, capture + replay, replay, ... must follow the eager trajectory)."""
+    cfg_o, shp = CONFIGS["tiny"]
+    cfg_o = orc.OracleConfig(**{**cfg_o.__dict__, "output_dropout": 0.1, "attention_dropout": 0.1})
+    batch = orc.synthetic_batch(shp["B"], shp["L"], shp["P"], cfg_o.vocab_size, seed=8, ragged=True)
+    from bert4rec_amd.engine import make_adamw_config
+    hp = make_adamw_config(num_warmup_steps=2, num_train_steps=20)
+    runs = []
+    for graphed in (False, True):
+        eng, _ = build(cfg_o)
+        eng.set_seed(77)
+        cb, keep = eng.prepare_batch(batch)
+        losses = []
+        for _ in range(6):
+            (eng.train_step_graphed if graphed else eng.train_step)(hp, cb)
+            torch.cuda.synchronize()
+            st = eng.read_state()
+            losses.append((st["step"], st["loss_sum"], st["lr"]))
+        runs.append((losses, eng.params.cpu().clone()))
+    (l0, p0), (l1, p1) = runs
+    assert [s for s, _, _ in l1] == [1, 2, 3, 4, 5, 6] == [s for s, _, _ in l0]
+    for (s0, a, lra), (s1, b, lrb) in zip(l0, l1):
+        assert abs(a - b) <= 1e-4 * abs(a) and lra == lrb
+    assert float((p0 - p1).abs().max()) < 1e-6

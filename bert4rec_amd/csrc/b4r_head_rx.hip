@@ -72,18 +72,25 @@ __device__ __forceinline__ void feed_pair(const char* img, const FragAddr& fa, i
   }
 }
 
-// one chunk of `nrows` rows (row c0 onwards of a [*, 32*NKH] fp32 matrix) -> the chunk's images; rows >= valid are zero
-template <int NKH>
-__device__ __forceinline__ void stage_chunk(char* img, const float* src, int c0, int nrows, int valid) {
-  constexpr int H = 32 * NKH, TB = 2 * NKH * IMG_BYTES, CH = head_ch(NKH);
-  constexpr int NIT = (CH * 16 * 8 + 64 * WAVES - 1) / (64 * WAVES);   // float4 pieces per thread and 32-column group
+// one chunk of `nrows` rows (row c0 onwards of a [*, 32*NKH] fp32 matrix) -> the chunk's images; rows >= valid are zero.
+// Split in two so that the loads of chunk c+1 are in flight while chunk c is multiplied (a chunk is only 5 tile pairs of
+// work; waiting out the load latency at every chunk boundary was a quarter of the kernel).
+template <int NKH> struct ChunkRegs {
+  static constexpr int NIT = (head_ch(NKH) * 16 * 8 + 64 * WAVES - 1) / (64 * WAVES);   // float4 pieces per thread and 32-column group
   StagedRowsT<NIT> st[NKH / 2];
+};
+template <int NKH>
+__device__ __forceinline__ void chunk_fetch(ChunkRegs<NKH>& r, const float* src, int c0, int valid) {
+  constexpr int H = 32 * NKH;
 #pragma unroll
   for (int j = 0; j < NKH / 2; ++j)
-    stage_fetch<NIT>(st[j], src + (int64_t)c0 * H + 64 * j, H, src + (int64_t)c0 * H + 64 * j + 32, H, 0, valid);
-  __syncthreads();                                              // the previous chunk has been consumed
+    stage_fetch<ChunkRegs<NKH>::NIT>(r.st[j], src + (int64_t)c0 * H + 64 * j, H, src + (int64_t)c0 * H + 64 * j + 32, H, 0, valid);
+}
+template <int NKH>
+__device__ __forceinline__ void chunk_write(const ChunkRegs<NKH>& r, char* img, int nrows, int valid) {
+  constexpr int TB = 2 * NKH * IMG_BYTES;
 #pragma unroll
-  for (int j = 0; j < NKH / 2; ++j) stage_write<NIT, TB>(st[j], img + 4 * j * IMG_BYTES, nrows, valid);
+  for (int j = 0; j < NKH / 2; ++j) stage_write<ChunkRegs<NKH>::NIT, TB>(r.st[j], img + 4 * j * IMG_BYTES, nrows, valid);
 }
 
 // -----------------------------------------------------------------------------------------------------------
@@ -112,13 +119,21 @@ __global__ __launch_bounds__(64 * WAVES) void head_fwd_kernel(HeadP p) {
 #pragma unroll
   for (int kb = 0; kb < 2 * NKH; ++kb) acc[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  ChunkRegs<NKH> regs;
+  auto chunk_valid = [&](int c0) { return min(min(HEAD_CH * 16, v_end - c0), p.V - c0); };   // >= 1: chunks start below V
+  chunk_fetch<NKH>(regs, p.E, v_begin, chunk_valid(v_begin));
+  float bz = p.bias[min(v_begin + (int)threadIdx.x, p.V - 1)];
   for (int c0 = v_begin; c0 < v_end; c0 += HEAD_CH * 16) {
     const int nrows = min(HEAD_CH * 16, v_end - c0);            // multiple of 32
-    const int valid = min(nrows, p.V - c0);                     // >= 1: every chunk starts below V
-    const float bz = p.bias[min(c0 + (int)threadIdx.x, p.V - 1)];
-    stage_chunk<NKH>(img, p.E, c0, nrows, valid);
+    __syncthreads();                                            // the previous chunk has been consumed
+    chunk_write<NKH>(regs, img, nrows, chunk_valid(c0));
     if ((int)threadIdx.x < nrows) sBias[threadIdx.x] = (c0 + (int)threadIdx.x < p.V) ? bz * LOG2E : -INFINITY;
     __syncthreads();
+    const int cn = c0 + HEAD_CH * 16;
+    if (cn < v_end) {                                           // block-uniform: the next chunk travels during this one
+      chunk_fetch<NKH>(regs, p.E, cn, chunk_valid(cn));
+      bz = p.bias[min(cn + (int)threadIdx.x, p.V - 1)];
+    }
     for (int tp = 0; tp < nrows / 32; ++tp) {
       f32x4 x[2];
 #pragma unroll
@@ -251,19 +266,27 @@ __global__ __launch_bounds__(64 * WAVES) void head_dE_kernel(HeadP p) {
   f32x4 acc[2 * NKH];
 #pragma unroll
   for (int kb = 0; kb < 2 * NKH; ++kb) acc[kb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  ChunkRegs<NKH> regs;
+  auto chunk_valid = [&](int c0) { return min(min(HEAD_CH * 16, m_end - c0), p.M - c0); };
+  chunk_fetch<NKH>(regs, p.T, m_begin, chunk_valid(m_begin));
+  float lz = p.lse[min(m_begin + (int)threadIdx.x, p.M - 1)];
+  int yz = p.ylab[min(m_begin + (int)threadIdx.x, p.M - 1)];
   for (int c0 = m_begin; c0 < m_end; c0 += HEAD_CH * 16) {
     const int nrows = min(HEAD_CH * 16, m_end - c0);
-    const int valid = min(nrows, p.M - c0);
-    const int mr = min(c0 + (int)threadIdx.x, p.M - 1);
-    const float lz = p.lse[mr];
-    const int yz = p.ylab[mr];
-    stage_chunk<NKH>(img, p.T, c0, nrows, valid);
+    __syncthreads();                                            // the previous chunk has been consumed
+    chunk_write<NKH>(regs, img, nrows, chunk_valid(c0));
     if ((int)threadIdx.x < nrows) {
       const bool in = c0 + (int)threadIdx.x < p.M;
       sLse[threadIdx.x] = in ? lz * LOG2E : INFINITY;
       sY[threadIdx.x] = in ? yz : -1;
     }
     __syncthreads();
+    const int cn = c0 + HEAD_CH * 16;
+    if (cn < m_end) {                                           // block-uniform: the next chunk travels during this one
+      chunk_fetch<NKH>(regs, p.T, cn, chunk_valid(cn));
+      lz = p.lse[min(cn + (int)threadIdx.x, p.M - 1)];
+      yz = p.ylab[min(cn + (int)threadIdx.x, p.M - 1)];
+    }
     for (int tp = 0; tp < nrows / 32; ++tp) {
       f32x4 gv[2];
 #pragma unroll

@@ -39,6 +39,7 @@ int b4r_attn_bwd_streams(const float* qkv, const int64_t* input_mask, const floa
                          int32_t B, int32_t L, int32_t heads, float qscale, float* dqkv, const uint32_t* rng,
                          uint32_t drop_stream, float drop_rate, const uint32_t* keep_bits, hipStream_t stream,
                          hipStream_t stream_dkv);
+int b4r_zero2(float* a, int64_t na, float* b, int64_t nb, hipStream_t stream);
 int b4r_optimizer_fused(const b4r_adamw_config* hp, float* params, const float* grads, float* adam_m, float* adam_v, int64_t n,
                         int64_t n_decay, float* scratch, b4r_train_state* state, hipStream_t stream);
 
@@ -477,11 +478,7 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
   B4rReduceQueue queue;
   b4r_reduce_queue_begin(&queue);   // every ordered reduction below is summed by ONE launch at the end
 
-  if (hipMemsetAsync(grads, 0, (size_t)pl.total * sizeof(float), s) != hipSuccess ||
-      hipMemsetAsync(ws + w.dx, 0, (size_t)(w.da - w.dx) * sizeof(float), s) != hipSuccess) {   // dx and the hot-row slots
-    b4r_set_error("b4r_backward: hipMemsetAsync failed");
-    return B4R_E_HIP;
-  }
+  RC(b4r_zero2(grads, pl.total, ws + w.dx, w.da - w.dx, s));   // the gradient buffer; dx and the scatter's hot-row slots
 
   // ---- masked-LM head (logits buffer holds d loss_sum / d logits, pad columns zero) --------------------------------
   // s2: independent branches (see SideStream); it is ordered after the memsets here, joined before every reuse of a buffer

@@ -796,6 +796,27 @@ extern "C" int b4r_softmax_ce(float* logits, int32_t M, int32_t V, int32_t ld, c
   return B4R_OK;
 }
 
+// zero two float regions (16-byte aligned, sizes multiples of 4 floats) in one launch.  Used instead of hipMemsetAsync by
+// the backward pass: one launch instead of two, and an ordinary kernel node when the step is captured into a hipGraph
+// (memset nodes of a replayed graph were observed to leave the regions untouched from the second replay on).
+__global__ __launch_bounds__(256) void zero2_kernel(float* a, int64_t na4, float* b, int64_t nb4) {
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < na4 + nb4; i += (int64_t)gridDim.x * 256) {
+    if (i < na4) *reinterpret_cast<f32x4*>(a + 4 * i) = z;
+    else *reinterpret_cast<f32x4*>(b + 4 * (i - na4)) = z;
+  }
+}
+int b4r_zero2(float* a, int64_t na, float* b, int64_t nb, hipStream_t stream) {
+  B4R_CHECK_ARG(na % 4 == 0 && nb % 4 == 0 && b4r_aligned16(a) && b4r_aligned16(b), B4R_E_ALIGN, "zero2: regions must be 16-byte granular");
+  int64_t n4 = (na + nb) / 4;
+  int grid = (int)((n4 + 255) / 256);
+  if (grid > 2048) grid = 2048;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(zero2_kernel, dim3(grid), dim3(256), 0, stream, a, na / 4, b, nb / 4);
+  B4R_CHECK_LAUNCH("zero fill");
+  return B4R_OK;
+}
+
 int b4r_ce_finalize_launch(const float* row_scratch, int M, b4r_train_state* state, int overwrite, hipStream_t stream) {
   B4R_CHECK_ARG(row_scratch && state && M > 0, B4R_E_BADARG, "ce_finalize: bad argument");
   hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1024), 0, stream, row_scratch, M, state, overwrite);

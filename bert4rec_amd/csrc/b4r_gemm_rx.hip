@@ -50,6 +50,7 @@ struct RxP {
   int M, N, K;
   int n_store;                    // columns that may be written: N rounded up to 4 (<= ldc; pad columns are scratch)
   int n_splits, steps_per_split;  // n-steps (32 columns each) per workgroup
+  int n_items;                    // row blocks x column splits (the grid is this rounded up to 8, see xcd_logical_id)
   int k_chunks_per_split;         // K-loop kernel: chunks of 64 per blockIdx.z (all of them when the grid has one z)
   int64_t slab_stride;            // K-loop kernel with several z: partial products go to C + z * slab_stride
   float qscale; int qcols;
@@ -84,6 +85,18 @@ __device__ __forceinline__ f32x8 drop8(const DropCtx& c, const f32x8 x, uint64_t
   const f32x4 b = b4r_drop4(c, (f32x4){x[4], x[5], x[6], x[7]}, idx + 4);
   return (f32x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
+
+// Consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2).  Workgroups that share an operand (the
+// column splits of one row block, the output tiles of one row slice) are given consecutive LOGICAL ids, so the logical
+// id is chosen such that a run of consecutive logical ids sits on one XCD: logical = (id % 8) * ceil(n/8) + id / 8.
+// Ids whose logical id falls beyond n (n not a multiple of 8) return without work; the grid is rounded up to 8.
+// (At the ML-1M shapes the kernel times did not move -- the re-reads were already served by the shared MALL -- so this is
+// about L2 / fabric traffic, not speed.)
+__device__ __forceinline__ int xcd_logical_id(int id, int n) {
+  const int per = (n + 7) >> 3;
+  return (id & 7) * per + (id >> 3);
+}
+inline unsigned xcd_grid(int64_t n) { return (unsigned)(((n + 7) >> 3) << 3); }
 
 constexpr bool epi_has_bias(int e) {
   return e == B4R_EPI_BIAS || e == B4R_EPI_BIAS_QSCALE || e == B4R_EPI_BIAS_GELU || e == B4R_EPI_BIAS_DROP_RES ||
@@ -165,7 +178,9 @@ __global__ __launch_bounds__(256) void rx_gemm_kn_kernel(RxP p) {
   extern __shared__ __attribute__((aligned(16))) float s_lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int mblock = blockIdx.x / p.n_splits, split = blockIdx.x % p.n_splits;
+  const int lid = xcd_logical_id(blockIdx.x, p.n_items);
+  if (lid >= p.n_items) return;   // block-uniform, before any barrier
+  const int mblock = lid / p.n_splits, split = lid % p.n_splits;
   const int m0 = mblock * 128 + wave * 32;
   if (m0 >= p.M) return;  // wave-uniform; no barriers in this kernel
   const int total_steps = (p.N + 31) / 32;
@@ -218,7 +233,9 @@ __global__ __launch_bounds__(256) void rx_gemm_nk_kernel(RxP p) {
   constexpr int PLANE = 32 * BROW * 4;                // bytes per plane
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int mblock = blockIdx.x / p.n_splits, split = blockIdx.x % p.n_splits;
+  const int lid = xcd_logical_id(blockIdx.x, p.n_items);
+  if (lid >= p.n_items) return;   // block-uniform, before any barrier
+  const int mblock = lid / p.n_splits, split = lid % p.n_splits;
   const int m0 = mblock * 128 + wave * 32;
   const bool live = m0 < p.M;                         // wave-uniform; dead waves still take part in the barriers
   const int total_steps = (p.N + 31) / 32;
@@ -475,9 +492,11 @@ __global__ __launch_bounds__(256) void rx_gemm_tn_kernel(RxTnP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  const int64_t item = blockIdx.x;
-  const int z = (int)(item / ((int64_t)p.tiles_i * p.tiles_j));
-  const int t = (int)(item % ((int64_t)p.tiles_i * p.tiles_j));
+  const int n_items = p.tiles_i * p.tiles_j * p.S;
+  const int item = xcd_logical_id(blockIdx.x, n_items);   // the tiles of one row slice share its chunks of A and B
+  if (item >= n_items) return;                            // block-uniform, before any barrier
+  const int z = item / (p.tiles_i * p.tiles_j);
+  const int t = item % (p.tiles_i * p.tiles_j);
   const int ti = t / p.tiles_j, tj = t % p.tiles_j;
   const int i0 = ti * 64, j0 = tj * 64;
   const int r_begin = min(p.R, z * p.chunk), r_end = min(p.R, r_begin + p.chunk);
@@ -630,7 +649,8 @@ int b4r_gemm_rx_launch(const b4r_gemm_desc* d, hipStream_t stream) {
   if (splits < 1) splits = 1;
   p.steps_per_split = b4r_cdiv(total_steps, splits);
   p.n_splits = b4r_cdiv(total_steps, p.steps_per_split);
-  dim3 grid((unsigned)(mblocks * p.n_splits));
+  p.n_items = mblocks * p.n_splits;
+  dim3 grid(xcd_grid(p.n_items));
   int rc = d->b_is_nk ? dispatch_rx<true>(p, d->epilogue, a_drop, grid, stream)
                       : dispatch_rx<false>(p, d->epilogue, a_drop, grid, stream);
   if (rc != B4R_OK) return rc;
@@ -692,7 +712,7 @@ int b4r_gemm_rx_tn_launch(const b4r_gemm_tn_desc* d, float* scratch, hipStream_t
   p.drop = b4r_make_drop(d->rng, d->drop_stream, d->drop_rate, 1);
   const bool b_drop = d->b_dropout && p.drop.rng != nullptr;
   const int64_t items = (int64_t)p.tiles_i * p.tiles_j * S;
-  dim3 grid((unsigned)items);
+  dim3 grid(xcd_grid(items));
   constexpr size_t lds = (size_t)4 * TN_KS * 128;
   static bool lds_raised = false;
   if (lds > 48 * 1024 && !lds_raised) {

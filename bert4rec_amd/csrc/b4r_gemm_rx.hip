@@ -90,12 +90,14 @@ __device__ __forceinline__ f32x8 drop8(const DropCtx& c, const f32x8 x, uint64_t
 // column splits of one row block, the output tiles of one row slice) are given consecutive LOGICAL ids, so the logical
 // id is chosen such that a run of consecutive logical ids sits on one XCD: logical = (id % 8) * ceil(n/8) + id / 8.
 // Ids whose logical id falls beyond n (n not a multiple of 8) return without work; the grid is rounded up to 8.
-// (At the ML-1M shapes the kernel times did not move -- the re-reads were already served by the shared MALL -- so this is
-// about L2 / fabric traffic, not speed.)
+// (ML-1M step, same box: 0.922 ms with the mapping, 0.931 ms without (B4R_XCD=0); single kernels move by < 1 us -- the
+// re-reads were mostly served by the shared MALL already.)
 __device__ __forceinline__ int xcd_logical_id(int id, int n) {
+  if (n < 0) return id;   // mapping switched off (B4R_XCD=0): n is passed negated
   const int per = (n + 7) >> 3;
   return (id & 7) * per + (id >> 3);
 }
+inline bool xcd_on() { static const bool on = !(getenv("B4R_XCD") && atoi(getenv("B4R_XCD")) == 0); return on; }
 inline unsigned xcd_grid(int64_t n) { return (unsigned)(((n + 7) >> 3) << 3); }
 
 constexpr bool epi_has_bias(int e) {
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(256) void rx_gemm_kn_kernel(RxP p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int lid = xcd_logical_id(blockIdx.x, p.n_items);
-  if (lid >= p.n_items) return;   // block-uniform, before any barrier
+  if (lid >= abs(p.n_items)) return;   // block-uniform, before any barrier
   const int mblock = lid / p.n_splits, split = lid % p.n_splits;
   const int m0 = mblock * 128 + wave * 32;
   if (m0 >= p.M) return;  // wave-uniform; no barriers in this kernel
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(256) void rx_gemm_nk_kernel(RxP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int lid = xcd_logical_id(blockIdx.x, p.n_items);
-  if (lid >= p.n_items) return;   // block-uniform, before any barrier
+  if (lid >= abs(p.n_items)) return;   // block-uniform, before any barrier
   const int mblock = lid / p.n_splits, split = lid % p.n_splits;
   const int m0 = mblock * 128 + wave * 32;
   const bool live = m0 < p.M;                         // wave-uniform; dead waves still take part in the barriers
@@ -651,6 +653,7 @@ int b4r_gemm_rx_launch(const b4r_gemm_desc* d, hipStream_t stream) {
   p.n_splits = b4r_cdiv(total_steps, p.steps_per_split);
   p.n_items = mblocks * p.n_splits;
   dim3 grid(xcd_grid(p.n_items));
+  if (!xcd_on()) p.n_items = -p.n_items;
   int rc = d->b_is_nk ? dispatch_rx<true>(p, d->epilogue, a_drop, grid, stream)
                       : dispatch_rx<false>(p, d->epilogue, a_drop, grid, stream);
   if (rc != B4R_OK) return rc;

@@ -131,22 +131,34 @@ __device__ __forceinline__ f32x4 load_bias4(const RxP& p, int n0, int c4) {
   return bv;
 }
 
+// the lane's 4 x float4 of the residual / pre-activation operand R for the 32 x 32 tile at (m0, n0): requested by the
+// callers one step AHEAD (with the B tile), so its HBM latency is not paid inside the epilogue
+struct RTile { f32x4 v[4]; };
+template <int EPI>
+__device__ __forceinline__ RTile load_r_tile(const RxP& p, int m0, int n0, int lane) {
+  RTile t;
+  if (epi_has_r(EPI)) {
+    const int c4 = (lane & 7) * 4, rsub = lane >> 3;
+    const int col = min(n0 + c4, p.n_store - 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t.v[i] = *reinterpret_cast<const f32x4*>(p.R + (int64_t)(m0 + rsub + 8 * i) * p.ldr + col);
+  }
+  return t;
+}
+
 template <int EPI>
 __device__ __forceinline__ void epilogue_tile(const RxP& p, const DropCtx& dctx, const f32x16& acc, const f32x4 bv,
-                                              float* stage, int m0, int n0, int lane) {
+                                              const RTile& rt, float* stage, int m0, int n0, int lane) {
   const int r = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int reg = 0; reg < 16; ++reg) stage[((reg & 3) + 8 * (reg >> 2) + 4 * h) * ST_LD + r] = acc[reg];
   __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes have landed; no other wave touches the tile
   const int c4 = (lane & 7) * 4, rsub = lane >> 3;
   const int col = min(n0 + c4, p.n_store - 4);
-  f32x4 vin[4], rr[4];
+  f32x4 vin[4];
+  const f32x4 (&rr)[4] = rt.v;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int lrow = rsub + 8 * i;
-    vin[i] = *reinterpret_cast<const f32x4*>(&stage[lrow * ST_LD + (col - n0)]);
-    if (epi_has_r(EPI)) rr[i] = *reinterpret_cast<const f32x4*>(p.R + (int64_t)(m0 + lrow) * p.ldr + col);
-  }
+  for (int i = 0; i < 4; ++i) vin[i] = *reinterpret_cast<const f32x4*>(&stage[(rsub + 8 * i) * ST_LD + (col - n0)]);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = m0 + rsub + 8 * i;
@@ -204,6 +216,7 @@ __global__ __launch_bounds__(256) void rx_gemm_kn_kernel(RxP p) {
 #pragma unroll
   for (int kb = 0; kb < NKB; ++kb) braw[kb] = load_b_raw(s_begin * 32, kb);
   f32x4 bias_next = load_bias4<EPI>(p, s_begin * 32, c4);
+  RTile r_next = load_r_tile<EPI>(p, m0, s_begin * 32, lane);
 
   for (int s = s_begin; s < s_end; ++s) {
     const int n0 = s * 32;
@@ -211,17 +224,19 @@ __global__ __launch_bounds__(256) void rx_gemm_kn_kernel(RxP p) {
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) split8(braw[kb], bh[kb], bl[kb]);
     const f32x4 bv = bias_next;
+    const RTile rt = r_next;
     // unconditional look-ahead (the last step re-requests its own tile: cheaper than a branch, see header)
     const int n_next = min(n0 + 32, (s_end - 1) * 32);
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) braw[kb] = load_b_raw(n_next, kb);
     bias_next = load_bias4<EPI>(p, n_next, c4);
+    r_next = load_r_tile<EPI>(p, m0, n_next, lane);
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) acc = mfma3(ah[kb], al[kb], bh[kb], bl[kb], acc);
-    epilogue_tile<EPI>(p, dctx, acc, bv, stage, m0, n0, lane);
+    epilogue_tile<EPI>(p, dctx, acc, bv, rt, stage, m0, n0, lane);
   }
 }
 
@@ -278,6 +293,8 @@ __global__ __launch_bounds__(256) void rx_gemm_nk_kernel(RxP p) {
     stash_b(0);
   }
   f32x4 bv = load_bias4<EPI>(p, s_begin * 32, c4);
+  const int mr = min(m0, p.M - 32);                    // dead waves (m0 >= M) still issue the look-ahead: keep it in range
+  RTile rt = load_r_tile<EPI>(p, mr, s_begin * 32, lane);
   __syncthreads();
 
   for (int s = s_begin; s < s_end; ++s) {
@@ -285,6 +302,7 @@ __global__ __launch_bounds__(256) void rx_gemm_nk_kernel(RxP p) {
     const int n_next = min(n0 + 32, (s_end - 1) * 32);
     fetch_b(n_next);                                   // in flight under the MFMAs and older than this step's stores
     const f32x4 bias_next = load_bias4<EPI>(p, n_next, c4);
+    const RTile r_next = load_r_tile<EPI>(p, mr, n_next, lane);
     bf16x8 bh[NKB], bl[NKB];
     const char* src = bbuf + cur * (2 * PLANE) + r * (BROW * 4) + 16 * h;
 #pragma unroll
@@ -297,9 +315,10 @@ __global__ __launch_bounds__(256) void rx_gemm_nk_kernel(RxP p) {
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) acc = mfma3(ah[kb], al[kb], bh[kb], bl[kb], acc);
-    if (live) epilogue_tile<EPI>(p, dctx, acc, bv, stage, m0, n0, lane);
+    if (live) epilogue_tile<EPI>(p, dctx, acc, bv, rt, stage, m0, n0, lane);
     stash_b(cur ^ 1);                                  // the other buffer: nobody reads it during this step
     bv = bias_next;
+    rt = r_next;
     __syncthreads();
   }
 }
@@ -364,6 +383,10 @@ __global__ __launch_bounds__(256) void rx_gemm_kloop_kernel(RxP p) {
   for (int j = 0; j < NT; ++j)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+  // the residual tiles the epilogue will add are requested now: they arrive during the K loop
+  RTile rt[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) rt[j] = load_r_tile<EPI>(p, min(m0, p.M - 32), min(nb + 32 * j, p.N - 1), lane);
 
   fetch_a(c_begin);
   fetch_b(c_begin);
@@ -408,7 +431,8 @@ __global__ __launch_bounds__(256) void rx_gemm_kloop_kernel(RxP p) {
     q.C = p.C + (int64_t)blockIdx.z * p.slab_stride;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      if (nb + 32 * j < p.N) epilogue_tile<EPI>(q, dctx, acc[j], load_bias4<EPI>(p, nb + 32 * j, c4), stage, m0, nb + 32 * j, lane);
+      if (nb + 32 * j < p.N)
+        epilogue_tile<EPI>(q, dctx, acc[j], load_bias4<EPI>(p, nb + 32 * j, c4), rt[j], stage, m0, nb + 32 * j, lane);
     }
   }
 }

@@ -534,17 +534,19 @@ __global__ __launch_bounds__(256) void rx_gemm_tn_kernel(RxTnP p) {
   // ones (their products land in output elements that are never stored)
   const int c4 = tid & 15, srow = tid >> 4;
   const int ca = min(i0 + 4 * c4, p.a_lim - 4), cb = min(j0 + 4 * c4, p.b_lim - 4);
-  f32x4 ra[NLD], rb[NLD];
-  auto fetch = [&](int k0) {
+  struct Chunk { f32x4 a[NLD], b[NLD]; };
+  auto fetch = [&](Chunk& c, int k0) {
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
       const int row = min(k0 + srow + 16 * j, p.R - 1);
-      ra[j] = *reinterpret_cast<const f32x4*>(p.A + (int64_t)row * p.lda + ca);
-      rb[j] = *reinterpret_cast<const f32x4*>(p.B + (int64_t)row * p.ldb + cb);
+      c.a[j] = *reinterpret_cast<const f32x4*>(p.A + (int64_t)row * p.lda + ca);
+      c.b[j] = *reinterpret_cast<const f32x4*>(p.B + (int64_t)row * p.ldb + cb);
     }
   };
   f32x4 cs = {0.f, 0.f, 0.f, 0.f}, csa = {0.f, 0.f, 0.f, 0.f};
-  auto stash = [&](int k0) {
+  auto stash = [&](const Chunk& c, int k0) {
+    const f32x4 (&ra)[NLD] = c.a;
+    const f32x4 (&rb)[NLD] = c.b;
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
       const int lrow = srow + 16 * j, row = k0 + lrow;
@@ -584,15 +586,27 @@ __global__ __launch_bounds__(256) void rx_gemm_tn_kernel(RxTnP p) {
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  if (r_begin < r_end) fetch(r_begin);
-  for (int k0 = r_begin; k0 < r_end; k0 += KS) {
-    __syncthreads();                 // every wave is done with the previous chunk's images
-    stash(k0);
-    __syncthreads();
-    fetch(min(k0 + KS, p.R - 1));    // unconditional look-ahead (rows are clamped; unused after the last chunk)
+  // Two register sets alternate: the loads of chunk k+1 are issued at the TOP of iteration k (before the barrier, the
+  // conversion and the products of chunk k), so they have a whole iteration to arrive; one set of LDS images.
+  auto products = [&]() {
 #pragma unroll
     for (int kb = 0; kb < KS / 16; ++kb)
       acc = mfma3(tr8(0, tr_a, kb), tr8(1, tr_a, kb), tr8(2, tr_b, kb), tr8(3, tr_b, kb), acc);
+  };
+  Chunk c0, c1;
+  if (r_begin < r_end) fetch(c0, r_begin);
+  for (int k0 = r_begin; k0 < r_end; k0 += 2 * KS) {
+    fetch(c1, k0 + KS);              // unconditional look-ahead (rows are clamped; stash() zeroes what lies beyond r_end)
+    __syncthreads();                 // every wave is done with the previous chunk's images
+    stash(c0, k0);
+    __syncthreads();
+    products();
+    if (k0 + KS >= r_end) break;     // block-uniform
+    fetch(c0, k0 + 2 * KS);
+    __syncthreads();
+    stash(c1, k0 + KS);
+    __syncthreads();
+    products();
   }
 
   float* slab = p.slab + (int64_t)z * p.Mo * p.No;

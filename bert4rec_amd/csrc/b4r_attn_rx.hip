@@ -182,21 +182,23 @@ __global__ __launch_bounds__(64 * WAVES) void attn_rx_dq_kernel(AttnRxP p) {
   bf16x8 qh, ql, doh, dol;
   split8(qx, qh, ql);
   split8(dox, doh, dol);
-  __syncthreads();
-  if (q0 + 16 * wave >= L) return;
-
-  const FragAddr fa = frag_addr(lane);
+  // per-lane scalars of the sweep are requested before the barrier too (they used to cost a round trip after it)
   const int64_t bh = (int64_t)b * p.heads + hd;
-  const float Dq = sD[16 * wave + i];
-  const float lse = qlive ? p.lse_in[bh * L + q] : 0.f;
+  const float lse = p.lse_in[bh * L + qc];
   const DropCtx dctx = b4r_drop_ctx(p.drop);
   uint32_t w[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
   if (dctx.on) {
-    const uint32_t* wi = p.bits_in + ((bh * p.KT + (q0 >> 4) + wave) * 2) * 64 + lane;
+    const int qt = min((q0 >> 4) + wave, p.KT - 1);             // waves beyond L exit below; keep their address in range
+    const uint32_t* wi = p.bits_in + ((bh * p.KT + qt) * 2) * 64 + lane;
     w[0] = wi[0];
     w[1] = wi[64];
   }
   const float dscale = dctx.on ? dctx.scale : 1.0f;
+  __syncthreads();
+  if (q0 + 16 * wave >= L) return;
+
+  const FragAddr fa = frag_addr(lane);
+  const float Dq = sD[16 * wave + i];
 
   f32x4 dq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   for (int tp = 0; tp < KTE / 2; ++tp) {
@@ -264,12 +266,13 @@ __global__ __launch_bounds__(64 * WAVES) void attn_rx_dkv_kernel(AttnRxP p) {
   bf16x8 kh, kl, vh, vl;
   split8(kx, kh, kl);
   split8(vx, vh, vl);
+  const float kmask = (float)p.mask[row0 + kc];                // requested before the barrier
+  const DropCtx dctx = b4r_drop_ctx(p.drop);
   __syncthreads();
   if (k0 >= L) return;  // wave-uniform; no barrier below
 
   const FragAddr fa = frag_addr(lane);
-  const float add = klive ? (1.0f - (float)p.mask[row0 + key]) * -1e9f : -INFINITY;
-  const DropCtx dctx = b4r_drop_ctx(p.drop);
+  const float add = klive ? (1.0f - kmask) * -1e9f : -INFINITY;
   const float dscale = dctx.on ? dctx.scale : 1.0f;
   const int tk = k0 >> 4;
   // the forward lane that hashed (query 16t + 4g + r, this key) is lane (4g + r) + 16 * (i >> 2): 4 consecutive words

@@ -90,8 +90,8 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=2, help="timed oracle steps for cpu_baseline (0 disables)")
     ap.add_argument("--phases", action="store_true", help="also print per-phase timings to stderr")
     ap.add_argument("--no-dropout", action="store_true", help="diagnostic only: dropout 0 (NOT the headline configuration)")
-    ap.add_argument("--graph", action="store_true", help="single GPU: replay each batch's step from a captured hipGraph "
-                                                         "(same GPU time, ~7x less host time per step)")
+    ap.add_argument("--graph", action="store_true", help="replay each batch's step from captured hipGraphs (same GPU time, "
+                                                         "~7x less host time per step; N > 1: two graphs around the all-reduce)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -128,7 +128,7 @@ def main():
     def step(i):
         cb, _ = prepared[i % nb]
         if world > 1:
-            eng.dp_train_step(hp, cb)
+            (eng.dp_train_step_graphed if args.graph else eng.dp_train_step)(hp, cb)
         elif args.graph:
             eng.train_step_graphed(hp, cb)
         else:

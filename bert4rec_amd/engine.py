@@ -312,6 +312,36 @@ class Engine:
         graphs[key] = g
         g.replay()
 
+    def dp_train_step_graphed(self, hp: AdamWConfig, cb: Batch, group=None, max_graphs: int = 64) -> None:
+        """dp_train_step with the two local halves of the step replayed from captured hipGraphs and the all-reduce (RCCL
+        is not captured) between them; same first-eager / second-capture / then-replay protocol as train_step_graphed."""
+        from .distributed import allreduce_step
+        key = (cb.input_word_ids, cb.input_mask, cb.masked_lm_positions, cb.masked_lm_ids, cb.B, cb.L, cb.P,
+               bytes(memoryview(hp)))
+        graphs = self.__dict__.setdefault("_dp_graphs", {})
+        seen = self.__dict__.setdefault("_dp_graph_seen", set())
+        pair = graphs.get(key)
+        if pair is None:
+            if key not in seen or len(graphs) >= max_graphs:
+                seen.add(key)
+                self.dp_train_step(hp, cb, group)
+                return
+            self.ensure_training_buffers()
+            fused = self.fused_head_supported()
+            torch.cuda.synchronize(self.device)
+            g_pre, g_post = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_pre):
+                self.begin_step()
+                self.forward(cb, training=True, pooler=False, fused_head=fused)
+                self.loss(cb, want_grad=True, fused_head=fused)
+                self.backward(cb, training=True, fused_head=fused)
+            with torch.cuda.graph(g_post):
+                self.optimizer_step(hp, cb)
+            pair = graphs[key] = (g_pre, g_post)
+        pair[0].replay()
+        allreduce_step(self.grad_ext, self.state, self.n_params, group)
+        pair[1].replay()
+
     def dp_train_step(self, hp: AdamWConfig, cb: Batch, group=None) -> None:
         """Data-parallel train step: local forward/backward of the loss SUM, one all-reduce (RCCL over xGMI) of
         [grads | loss sums], then the clip + AdamW step on the reduced buffer (identical on every rank)."""

@@ -15,7 +15,7 @@ import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
 
-V, H, NL, NH, L, I, B, P, STEPS = 203, 64, 2, 2, 32, 128, 16, 6, 3
+V, H, NL, NH, L, I, B, P, STEPS, EPOCHS = 203, 64, 2, 2, 32, 128, 16, 6, 3, 3
 
 
 def _free_port():
@@ -36,7 +36,7 @@ def _batches():
     return [orc.synthetic_batch(B, L, P, V, seed=70 + i, ragged=True) for i in range(STEPS)]
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, graphed=False):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from bert4rec_amd.distributed import broadcast_parameters, shard_rows
@@ -46,35 +46,38 @@ def _worker(rank, world, port, out_path):
     broadcast_parameters(eng.params)
     hp = make_adamw_config(num_warmup_steps=2, num_train_steps=10)
     losses = []
-    for full in _batches():
-        sl = shard_rows(B, rank, world)
-        cb, keep = eng.prepare_batch({k: v[sl] for k, v in full.items()})
-        eng.dp_train_step(hp, cb)
-        torch.cuda.synchronize()
-        st = eng.read_state()
-        losses.append((st["loss_sum"], st["valid_count"], st["grad_norm"]))
+    sl = shard_rows(B, rank, world)
+    prepared = [eng.prepare_batch({k: v[sl] for k, v in full.items()}) for full in _batches()]   # kept alive: graphs hold pointers
+    for epoch in range(EPOCHS):      # graphed: epoch 0 runs eagerly, epoch 1 captures, epoch 2 replays
+        for cb, keep in prepared:
+            (eng.dp_train_step_graphed if graphed else eng.dp_train_step)(hp, cb)
+            torch.cuda.synchronize()
+            st = eng.read_state()
+            losses.append((st["loss_sum"], st["valid_count"], st["grad_norm"]))
     if rank == 0:
         torch.save({"params": eng.params.cpu(), "losses": losses}, out_path)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_dp_steps_equal_single_process_steps_on_the_whole_batch():
+@pytest.mark.parametrize("graphed", [False, True])
+def test_two_rank_dp_steps_equal_single_process_steps_on_the_whole_batch(graphed):
     from bert4rec_amd.engine import make_adamw_config
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "rank0.pt")
-        mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, _free_port(), out, graphed), nprocs=2, join=True)
         got = torch.load(out)
     eng = _engine()
     hp = make_adamw_config(num_warmup_steps=2, num_train_steps=10)
     want_losses = []
-    for full in _batches():
-        cb, keep = eng.prepare_batch(full)
-        eng.train_step(hp, cb)
-        torch.cuda.synchronize()
-        st = eng.read_state()
-        want_losses.append((st["loss_sum"], st["valid_count"], st["grad_norm"]))
+    prepared = [eng.prepare_batch(full) for full in _batches()]
+    for epoch in range(EPOCHS):
+        for cb, keep in prepared:
+            eng.train_step(hp, cb)
+            torch.cuda.synchronize()
+            st = eng.read_state()
+            want_losses.append((st["loss_sum"], st["valid_count"], st["grad_norm"]))
     for (ls, vc, gn), (wls, wvc, wgn) in zip(got["losses"], want_losses):
         assert vc == wvc and abs(ls - wls) < 1e-3 * abs(wls) and abs(gn - wgn) < 2e-3 * abs(wgn)
     a, b = got["params"].double(), eng.params.cpu().double()
-    assert float((a - b).abs().max()) < 2e-5, float((a - b).abs().max())   # 3 Adam steps of lr <= 1e-4
+    assert float((a - b).abs().max()) < 5e-5, float((a - b).abs().max())   # 9 Adam steps of lr <= 1e-4

@@ -691,7 +691,9 @@ int b4r_gemm_rx_launch(const b4r_gemm_desc* d, hipStream_t stream) {
   p.n_splits = b4r_cdiv(total_steps, p.steps_per_split);
   p.n_items = mblocks * p.n_splits;
   dim3 grid(xcd_grid(p.n_items));
-  if (!xcd_on()) p.n_items = -p.n_items;
+  // many column splits = a store-dominated product (the materialising vocabulary projection: 12 splits): there the
+  // mapping concentrates each XCD's writes and costs time (34 -> 40 us measured), so it is kept to the few-split products
+  if (!xcd_on() || p.n_splits > 4) p.n_items = -p.n_items;
   int rc = d->b_is_nk ? dispatch_rx<true>(p, d->epilogue, a_drop, grid, stream)
                       : dispatch_rx<false>(p, d->epilogue, a_drop, grid, stream);
   if (rc != B4R_OK) return rc;

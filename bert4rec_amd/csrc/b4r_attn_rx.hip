@@ -21,6 +21,20 @@
 
 namespace {
 
+// 1-D grid with XCD-aware logical ids (consecutive workgroup ids go round-robin over the 8 XCDs): the row blocks of one
+// (batch, head) stage the same K / V (or Q / dO) rows, so they get consecutive logical ids = one XCD's L2.
+struct WgCoord { int x, hd, b; bool live; };
+__device__ __forceinline__ WgCoord wg_coord(int nx, int heads, int B) {
+  const int n = nx * heads * B, per = (n + 7) >> 3;
+  const int lid = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+  WgCoord c;
+  c.live = lid < n;
+  const int l = c.live ? lid : 0;
+  c.x = l % nx; c.hd = (l / nx) % heads; c.b = l / (nx * heads);
+  return c;
+}
+inline dim3 wg_grid(int nx, int heads, int B) { return dim3((unsigned)((((int64_t)nx * heads * B + 7) >> 3) << 3)); }
+
 struct AttnRxP {
   const float* qkv; const int64_t* mask; const float* ctx; const float* lse_in; const float* dctx;
   float* ctx_out; float* lse_out; float* dqkv;
@@ -65,7 +79,9 @@ __global__ __launch_bounds__(64 * WAVES) void attn_rx_fwd_kernel(AttnRxP p) {
   char* img = smem_rx;                                    // images 0/1 = K hi/lo, 2/3 = V hi/lo
   float* sAdd = reinterpret_cast<float*>(img + KTE * TILE_BYTES);
 
-  const int b = blockIdx.z, hd = blockIdx.y, q0 = blockIdx.x * ROWS_WG;
+  const WgCoord wg = wg_coord((p.L + ROWS_WG - 1) / ROWS_WG, p.heads, p.B);
+  if (!wg.live) return;   // block-uniform, before any barrier
+  const int b = wg.b, hd = wg.hd, q0 = wg.x * ROWS_WG;
   const int L = p.L, H = p.H, ld3 = 3 * H;
   const int64_t row0 = (int64_t)b * L;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
@@ -162,7 +178,9 @@ __global__ __launch_bounds__(64 * WAVES) void attn_rx_dq_kernel(AttnRxP p) {
   float* sAdd = reinterpret_cast<float*>(img + KTE * TILE_BYTES);
   float* sD = sAdd + LPE;
 
-  const int b = blockIdx.z, hd = blockIdx.y, q0 = blockIdx.x * ROWS_WG;
+  const WgCoord wg = wg_coord((p.L + ROWS_WG - 1) / ROWS_WG, p.heads, p.B);
+  if (!wg.live) return;   // block-uniform, before any barrier
+  const int b = wg.b, hd = wg.hd, q0 = wg.x * ROWS_WG;
   const int L = p.L, H = p.H, ld3 = 3 * H;
   const int64_t row0 = (int64_t)b * L;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
@@ -245,13 +263,15 @@ __global__ __launch_bounds__(64 * WAVES) void attn_rx_dkv_kernel(AttnRxP p) {
   float* sLse = reinterpret_cast<float*>(img + KTE * TILE_BYTES);
   float* sD = sLse + LPE;
 
-  const int b = blockIdx.z, hd = blockIdx.y;
+  const WgCoord wg = wg_coord((p.L + ROWS_WG - 1) / ROWS_WG, p.heads, p.B);
+  if (!wg.live) return;   // block-uniform, before any barrier
+  const int b = wg.b, hd = wg.hd;
   const int L = p.L, H = p.H, ld3 = 3 * H;
   const int64_t row0 = (int64_t)b * L;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
   const int64_t bh = (int64_t)b * p.heads + hd;
 
-  const int k0 = (blockIdx.x * WAVES + wave) * 16;
+  const int k0 = (wg.x * WAVES + wave) * 16;
   const int key = k0 + i;
   const bool klive = key < L;
   const int kc = min(key, L - 1);
@@ -360,7 +380,7 @@ int b4r_attn_rx_fwd_launch(const float* qkv, const int64_t* mask, int B, int L, 
   p.KT = b4r_cdiv(L, 16);
   p.KTE = (KTt + 1) & ~1;
   const size_t sh = (size_t)4 * p.KTE * 16 * 64 + (size_t)p.KTE * 16 * sizeof(float);
-  dim3 grid(b4r_cdiv(L, ROWS_WG), heads, B);
+  const dim3 grid = wg_grid(b4r_cdiv(L, ROWS_WG), heads, B);
   int rc;
 #define FWD_CASE(KT_)                                                                                      \
   case KT_:                                                                                                \
@@ -387,7 +407,7 @@ int b4r_attn_rx_bwd_launch(const float* qkv, const int64_t* mask, const float* c
   p.KT = b4r_cdiv(L, 16);
   p.KTE = (p.KT + 1) & ~1;
   p.drop = drop;
-  dim3 grid(b4r_cdiv(L, ROWS_WG), heads, B);
+  const dim3 grid = wg_grid(b4r_cdiv(L, ROWS_WG), heads, B);
   const size_t planes = (size_t)4 * p.KTE * 16 * 64;
   const size_t sh_dq = planes + ((size_t)p.KTE * 16 + ROWS_WG) * sizeof(float);
   int rc = set_lds(attn_rx_dq_kernel, sh_dq);

@@ -317,20 +317,24 @@ __global__ __launch_bounds__(64 * WAVES) void head_dE_kernel(HeadP p) {
   }
 }
 
-int even_tiles(int rows, int slices) {
+// tiles per slice: even, and a whole number of LDS chunks when that costs at most one chunk (a slice of 24 tiles would run
+// chunks of 10, 10 and 4 tiles: three staging rounds for 2.4 chunks of work)
+int even_tiles(int rows, int slices, int chunk = 0) {
   const int tiles = b4r_cdiv(rows, 16);
   int per = b4r_cdiv(tiles, slices < 1 ? 1 : slices);
   per = (per + 1) & ~1;
-  return per < 2 ? 2 : per;
+  if (per < 2) per = 2;
+  if (chunk > 0 && per > chunk) per = b4r_cdiv(per, chunk) * chunk;
+  return per;
 }
 
 int fwd_slices_wanted(int M) {
-  static const int target = getenv("B4R_HEAD_FWD_WGS") ? atoi(getenv("B4R_HEAD_FWD_WGS")) : 768;
+  static const int target = getenv("B4R_HEAD_FWD_WGS") ? atoi(getenv("B4R_HEAD_FWD_WGS")) : 480;
   int s = b4r_cdiv(target, b4r_cdiv(M, ROWS_WG));
   return s < 1 ? 1 : (s > 16 ? 16 : s);
 }
 int dE_slices_wanted(int V) {
-  static const int target = getenv("B4R_HEAD_DE_WGS") ? atoi(getenv("B4R_HEAD_DE_WGS")) : 768;
+  static const int target = getenv("B4R_HEAD_DE_WGS") ? atoi(getenv("B4R_HEAD_DE_WGS")) : 512;
   int s = b4r_cdiv(target, b4r_cdiv(V, ROWS_WG));
   return s < 1 ? 1 : (s > 32 ? 32 : s);
 }
@@ -370,24 +374,24 @@ int launch_dE(const HeadP& p, int slices, hipStream_t stream) {
 bool b4r_head_rx_hidden_ok(int H) { return H == 64 || H == 128 || H == 256; }
 
 // number of V slices the forward uses / M slices the dE kernel uses, and the scratch they need (floats)
-int b4r_head_rx_fwd_slices(int M, int V) {
-  const int per = even_tiles(V, fwd_slices_wanted(M));
+int b4r_head_rx_fwd_slices(int M, int V, int H) {
+  const int per = even_tiles(V, fwd_slices_wanted(M), head_ch(H / 32));
   return b4r_cdiv(b4r_cdiv(V, 16), per);
 }
-int64_t b4r_head_rx_fwd_scratch_floats(int M, int V, int H) { return (int64_t)b4r_head_rx_fwd_slices(M, V) * M * (H + 8); }
-int b4r_head_rx_dE_slices(int M, int V) {
-  const int per = even_tiles(M, dE_slices_wanted(V));
+int64_t b4r_head_rx_fwd_scratch_floats(int M, int V, int H) { return (int64_t)b4r_head_rx_fwd_slices(M, V, H) * M * (H + 8); }
+int b4r_head_rx_dE_slices(int M, int V, int H) {
+  const int per = even_tiles(M, dE_slices_wanted(V), head_ch(H / 32));
   return b4r_cdiv(b4r_cdiv(M, 16), per);
 }
-int64_t b4r_head_rx_dE_scratch_floats(int M, int V, int H) { return (int64_t)b4r_head_rx_dE_slices(M, V) * ((int64_t)V * H + V); }
+int64_t b4r_head_rx_dE_scratch_floats(int M, int V, int H) { return (int64_t)b4r_head_rx_dE_slices(M, V, H) * ((int64_t)V * H + V); }
 
 int b4r_head_rx_fwd_launch2(const float* T, const float* E, const float* bias, const int64_t* y, int M, int V, int H,
                             float* scratch, float* dT, float* row_out, float* lse, int32_t* ylab, int only_sweep,
                             hipStream_t stream) {
   HeadP p{};
   p.T = T; p.E = E; p.bias = bias; p.y = y; p.part = scratch; p.M = M; p.V = V;
-  const int slices = b4r_head_rx_fwd_slices(M, V);
-  p.tiles_per_slice = even_tiles(V, fwd_slices_wanted(M));
+  const int slices = b4r_head_rx_fwd_slices(M, V, H);
+  p.tiles_per_slice = even_tiles(V, fwd_slices_wanted(M), head_ch(H / 32));
   switch (H) {
     case 64: return launch_fwd<2>(p, slices, dT, row_out, lse, ylab, only_sweep, stream);
     case 128: return launch_fwd<4>(p, slices, dT, row_out, lse, ylab, only_sweep, stream);
@@ -410,8 +414,8 @@ int b4r_head_rx_dE_launch(const float* T, const float* E, const float* bias, con
                           int H, float* scratch, float* dE, float* db, hipStream_t stream) {
   HeadP p{};
   p.T = T; p.E = E; p.bias = bias; p.lse = lse; p.ylab = ylab; p.M = M; p.V = V;
-  const int slices = b4r_head_rx_dE_slices(M, V);
-  p.tiles_per_slice = even_tiles(M, dE_slices_wanted(V));
+  const int slices = b4r_head_rx_dE_slices(M, V, H);
+  p.tiles_per_slice = even_tiles(M, dE_slices_wanted(V), head_ch(H / 32));
   p.slab = scratch;
   p.bslab = scratch + (int64_t)slices * V * H;
   int rc;

@@ -24,7 +24,6 @@ int b4r_scatter_add_rows_impl(const float* src, const int64_t* idx, int64_t idx_
                               float* hot_scratch, hipStream_t stream);
 int64_t b4r_scatter_hot_scratch_floats(int hot_rows, int H);
 int b4r_batch_colsum(const float* x, int B, int L, int H, float* dpos, float* scratch, hipStream_t stream);
-int b4r_mul_gelu_grad(float* du, const float* pre, int64_t n, hipStream_t stream);
 int b4r_gemm_f32_splitk(const b4r_gemm_desc* d, int splits, float* scratch, int k_pad_ok, hipStream_t stream);
 // b4r_head_rx.hip: masked-LM head of a train step without materialised logits (hidden size 64, bf16x3 mode)
 bool b4r_head_rx_hidden_ok(int H);

@@ -306,17 +306,6 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* src,
   }
 }
 
-// du[i] *= gelu'(pre[i])   (MLM transform backward)
-__global__ __launch_bounds__(256) void mul_gelu_grad_kernel(float* du, const float* pre, int64_t n4) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    f32x4 d = *reinterpret_cast<f32x4*>(du + 4 * i);
-    const f32x4 x = *reinterpret_cast<const f32x4*>(pre + 4 * i);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) d[e] *= b4r_gelu_grad(x[e]);
-    *reinterpret_cast<f32x4*>(du + 4 * i) = d;
-  }
-}
-
 // partial[s][l][c] = sum over b in slice s of x[(b*L + l)*H + c]
 __global__ __launch_bounds__(256) void batch_colsum_kernel(const float* x, int B, int L, int H, int bchunk, float* partial) {
   const int h4 = H / 4;
@@ -763,14 +752,6 @@ extern "C" int b4r_scatter_add_rows(const float* src, const int64_t* idx, int64_
   B4R_CHECK_ARG(n > 0 && H > 0 && H % 4 == 0 && per > 0 && dst_ld % 4 == 0, B4R_E_SHAPE, "b4r_scatter_add_rows: bad shape");
   return b4r_scatter_add_rows_impl(src, idx, idx_add_per, per, n, H, dst, dst_ld, skip_if_zero, (int64_t)1 << 62, 0, nullptr,
                                    (hipStream_t)stream);
-}
-
-int b4r_mul_gelu_grad(float* du, const float* pre, int64_t n, hipStream_t stream) {
-  int grid = (int)((n / 4 + 255) / 256);
-  if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(mul_gelu_grad_kernel, dim3(grid), dim3(256), 0, stream, du, pre, n / 4);
-  B4R_CHECK_LAUNCH("mul_gelu_grad");
-  return B4R_OK;
 }
 
 // dpos[l][c] = sum_b x[(b*L+l)*H + c]; scratch >= ceil(B/16)*L*H floats

@@ -437,6 +437,160 @@ __global__ __launch_bounds__(256) void rx_gemm_kloop_kernel(RxP p) {
   }
 }
 
+// ---- wide shapes (K >= 128 and N >= 128: every dense layer of the 128- and 256-wide configurations) ------------------
+// A classic LDS-tiled product: a workgroup owns a 128 x 128 output tile (4 waves as 2 x 2, 64 x 64 each = 2 x 2
+// accumulator tiles), K advances in chunks of 32.  Both operand chunks are fetched with full-line 16-byte loads (one chunk
+// ahead, in registers), converted ONCE per workgroup to bf16 hi / lo and stored as LDS images; fragments are 16-byte row
+// reads (A, and B when it is [N,K]) or transposed reads (B as [K,N]).  The K-loop kernel above re-reads its A strip from
+// L2 once per 128-column pass with fragment-shaped loads, which left the ML-20M shapes at ~15 % of the matrix-core peak.
+// A / [N,K]-B image: [16-row tile][hi, lo][16 rows x 64 B], 16-byte chunk index XORed with (-(row>>2))&3 (conflict-free
+// for the 32x32x16 row fragment: checked as in b4r_rx_tiles.h); [K,N]-B image: the weight-gradient kernel's layout.
+// [k rows][64 columns] bf16 image with 128-byte rows (weight-gradient kernel and the [K,N] operand here): the 32-byte
+// block index of a row is XORed with 2*bit1(row), see rx_gemm_tn_kernel
+__device__ __forceinline__ int tn_img_off(int row, int c4) {   // bytes; c4 = float4 index (0..15) within the 64 columns
+  return row * 128 + 32 * ((c4 >> 2) ^ (row & 2)) + 8 * (c4 & 3);
+}
+
+constexpr int WIDE_KC = 32;
+constexpr int WIDE_A_BYTES = 128 * 64 * 2;        // hi + lo images of 128 rows x 32 bf16
+constexpr int WIDE_LDS = 2 * WIDE_A_BYTES + STAGE_FLOATS * 4;
+
+__device__ __forceinline__ int wide_off(int row, int ch) {   // image 0 (hi); lo is 1024 bytes further
+  return (row >> 4) * 2048 + (row & 15) * 64 + 16 * (ch ^ ((0 - (row >> 2)) & 3));
+}
+
+template <bool B_NK, int EPI, bool A_DROP>
+__global__ __launch_bounds__(256) void rx_gemm_wide_kernel(RxP p) {
+  extern __shared__ __attribute__((aligned(16))) char s_w[];
+  char* sA = s_w;
+  char* sB = s_w + WIDE_A_BYTES;
+  float* stage = reinterpret_cast<float*>(s_w + 2 * WIDE_A_BYTES) + (threadIdx.x >> 6) * (32 * ST_LD);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  const int ntn = (p.N + 127) / 128;
+  const int lid = xcd_logical_id(blockIdx.x, p.n_items);   // the column tiles of one row block share its A chunks
+  if (lid >= abs(p.n_items)) return;
+  const int m0 = (lid / ntn) * 128, n0 = (lid % ntn) * 128;
+  const DropCtx dctx = b4r_drop_ctx(p.drop);
+  const int nchunks = p.K / WIDE_KC;
+
+  // staging maps.  A (and [N,K] B): piece f -> row f>>3, k = 4*(f&7).  [K,N] B: piece f -> k row f>>5, n = 4*(f&31).
+  f32x4 ra[4], rb[4];
+  auto fetch = [&](int c) {
+    const int k0 = c * WIDE_KC;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int f = tid + 256 * it;
+      const int row = f >> 3, c4 = f & 7;
+      ra[it] = *reinterpret_cast<const f32x4*>(p.A + (int64_t)min(m0 + row, p.M - 1) * p.lda + k0 + 4 * c4);
+      if (B_NK) {
+        rb[it] = *reinterpret_cast<const f32x4*>(p.B + (int64_t)min(n0 + row, p.N - 1) * p.ldb + k0 + 4 * c4);
+      } else {
+        const int krow = f >> 5, c4n = f & 31;
+        rb[it] = *reinterpret_cast<const f32x4*>(p.B + (int64_t)(k0 + krow) * p.ldb + min(n0 + 4 * c4n, p.n_store - 4));
+      }
+    }
+  };
+  auto stash = [&](int c) {
+    const int k0 = c * WIDE_KC;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int f = tid + 256 * it;
+      const int row = f >> 3, c4 = f & 7;
+      f32x4 va = ra[it];
+      if (A_DROP) va = b4r_drop4(dctx, va, (uint64_t)min(m0 + row, p.M - 1) * (uint64_t)p.K + (uint64_t)(k0 + 4 * c4));
+      bf16x4 hi, lo;
+      b4r_split4(va, hi, lo);
+      char* da = sA + wide_off(row, c4 >> 1) + 8 * (c4 & 1);
+      *reinterpret_cast<bf16x4*>(da) = hi;
+      *reinterpret_cast<bf16x4*>(da + 1024) = lo;
+      b4r_split4(rb[it], hi, lo);
+      if (B_NK) {
+        char* db = sB + wide_off(row, c4 >> 1) + 8 * (c4 & 1);
+        *reinterpret_cast<bf16x4*>(db) = hi;
+        *reinterpret_cast<bf16x4*>(db + 1024) = lo;
+      } else {
+        const int krow = f >> 5, c4n = f & 31;
+        char* db = sB + (c4n >> 4) * 8192 + tn_img_off(krow, c4n & 15);   // [64-column half][hi 4 KB | lo 4 KB]
+        *reinterpret_cast<bf16x4*>(db) = hi;
+        *reinterpret_cast<bf16x4*>(db + 4096) = lo;
+      }
+    }
+  };
+  // fragment addresses: kb = 16-wide k block of the chunk (0, 1)
+  int a_addr[2][2], b_addr[2][2];
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      a_addr[blk][kb] = wide_off(64 * wm + 32 * blk + r, 2 * kb + h);
+      b_addr[blk][kb] = wide_off(64 * wn + 32 * blk + r, 2 * kb + h);
+    }
+  const int qq = (lane & 15) >> 2, pp = lane & 3, gb = (lane >> 4) & 1;
+  typedef __attribute__((address_space(3))) s16x4* lds_ptr;
+  auto b_frag = [&](int cb, int kb, int plane) -> bf16x8 {
+    if (B_NK) return *reinterpret_cast<const bf16x8*>(sB + b_addr[cb][kb] + 1024 * plane);
+    const char* src = sB + wn * 8192 + plane * 4096 + tn_img_off(8 * h + qq, 4 * (2 * cb + gb) + pp) + kb * (16 * 128);
+    const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(src));
+    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(src + 4 * 128));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+  fetch(0);
+  for (int c = 0; c < nchunks; ++c) {
+    __syncthreads();                       // the previous chunk's images have been consumed
+    stash(c);
+    __syncthreads();
+    fetch(min(c + 1, nchunks - 1));        // unconditional look-ahead
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+        ah[blk] = *reinterpret_cast<const bf16x8*>(sA + a_addr[blk][kb]);
+        al[blk] = *reinterpret_cast<const bf16x8*>(sA + a_addr[blk][kb] + 1024);
+        bh[blk] = b_frag(blk, kb, 0);
+        bl[blk] = b_frag(blk, kb, 1);
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = mfma3(ah[a], al[a], bh[b], bl[b], acc[a][b]);
+    }
+  }
+  const int c4 = (lane & 7) * 4;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int ms = m0 + 64 * wm + 32 * a, ns = n0 + 64 * wn + 32 * b;
+      if (ms < p.M && ns < p.N)
+        epilogue_tile<EPI>(p, dctx, acc[a][b], load_bias4<EPI>(p, ns, c4), load_r_tile<EPI>(p, ms, ns, lane), stage, ms, ns, lane);
+    }
+}
+
+inline bool wide_shape(const RxP& p) {
+  static const bool on = !(getenv("B4R_WIDE") && atoi(getenv("B4R_WIDE")) == 0);
+  return on && p.K >= 128 && p.K % WIDE_KC == 0 && p.N >= 128 && p.slab_stride == 0;
+}
+
+template <bool B_NK, int EPI, bool A_DROP>
+void launch_wide(RxP p, hipStream_t s) {
+  p.n_items = b4r_cdiv(p.M, 128) * b4r_cdiv(p.N, 128);
+  const dim3 grid(xcd_grid(p.n_items));
+  if (!xcd_on()) p.n_items = -p.n_items;
+  (void)b4r_raise_lds((const void*)rx_gemm_wide_kernel<B_NK, EPI, A_DROP>, WIDE_LDS, "gemm");
+  hipLaunchKernelGGL((rx_gemm_wide_kernel<B_NK, EPI, A_DROP>), grid, dim3(256), WIDE_LDS, s, p);
+}
+
 template <bool B_NK, int EPI, bool A_DROP>
 void launch_kloop(const RxP& p, hipStream_t s) {
   const int nt = b4r_cdiv(p.N, 32);
@@ -454,6 +608,7 @@ void launch_kloop(const RxP& p, hipStream_t s) {
 
 template <bool B_NK, int EPI, bool A_DROP>
 void launch_rx2(const RxP& p, dim3 grid, hipStream_t s) {
+  if (wide_shape(p)) { launch_wide<B_NK, EPI, A_DROP>(p, s); return; }
   if (p.K > 64) { launch_kloop<B_NK, EPI, A_DROP>(p, s); return; }
   if (B_NK) {
     if (p.K == 64) hipLaunchKernelGGL((rx_gemm_nk_kernel<EPI, A_DROP, 4>), grid, dim3(256), NK_LDS_BYTES, s, p);
@@ -506,9 +661,6 @@ struct RxTnP {
   DropArgs drop;
 };
 
-__device__ __forceinline__ int tn_img_off(int row, int c4) {   // bytes; c4 = float4 index (0..15) within the 64 columns
-  return row * 128 + 32 * ((c4 >> 2) ^ (row & 2)) + 8 * (c4 & 3);
-}
 
 template <int KS, bool B_DROP>
 __global__ __launch_bounds__(256) void rx_gemm_tn_kernel(RxTnP p) {

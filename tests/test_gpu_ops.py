@@ -33,7 +33,8 @@ def gelu_grad(x):
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 70, 64), (128, 64, 32), (257, 192, 100), (64, 256, 256), (5, 3, 7), (512, 192, 64),
-                                   (96, 256, 64), (1024, 64, 64), (256, 64, 256), (128, 64, 192), (160, 128, 512), (64, 100, 128)])
+                                   (96, 256, 64), (1024, 64, 64), (256, 64, 256), (128, 64, 192), (160, 128, 512), (64, 100, 128),
+                                   (384, 320, 256), (96, 1024, 128), (288, 132, 160)])   # the last three: 128 x 128 LDS tiles
 def test_gemm_nn_epilogues(M, N, K):
     A, B, bias, R = rnd(M, K, seed=1), rnd(K, N, seed=2, scale=0.3), rnd(N, seed=3), rnd(M, N, seed=4)
     ref = A.double() @ B.double()
@@ -61,8 +62,9 @@ def test_gemm_nn_epilogues(M, N, K):
     assert T.maxdiff(c, torch.tanh(ref + bias.double())) < TOL * scale
 
 
-def test_gemm_dropout_epilogue_and_a_operand():
-    M, N, K, rate, seed, step, sid = 200, 64, 96, 0.2, 99, 7, 5
+@pytest.mark.parametrize("M,N,K", [(200, 64, 96), (224, 256, 128)])
+def test_gemm_dropout_epilogue_and_a_operand(M, N, K):
+    rate, seed, step, sid = 0.2, 99, 7, 5
     A, B, bias, R = rnd(M, K, seed=1), rnd(K, N, seed=2, scale=0.3), rnd(N, seed=3), rnd(M, N, seed=4)
     st = T.new_state(seed, step)
     keep = orc.dropout_keep_mask((M, N), rate, seed, step, sid).double()
@@ -79,7 +81,7 @@ def test_gemm_dropout_epilogue_and_a_operand():
 
 
 @pytest.mark.parametrize("M,N,K,ldc", [(256, 3709, 64, 3712), (130, 37, 16, 64), (96, 64, 192, 64), (512, 64, 256, 64),
-                                       (128, 128, 128, 128)])
+                                       (128, 128, 128, 128), (256, 384, 256, 384), (160, 1001, 128, 1004)])
 def test_gemm_nt_vocab_projection(M, N, K, ldc):
     """C = A.B^T with B [N,K]: the tied projection T.E^T + b (tfm MaskedLM) incl. the padded leading dimension."""
     A, B, bias = rnd(M, K, seed=5), rnd(N, K, seed=6, scale=0.05), rnd(N, seed=7, scale=0.1)

@@ -452,41 +452,49 @@ __device__ __forceinline__ int tn_img_off(int row, int c4) {   // bytes; c4 = fl
 }
 
 constexpr int WIDE_KC = 32;
-constexpr int WIDE_A_BYTES = 128 * 64 * 2;        // hi + lo images of 128 rows x 32 bf16
-constexpr int WIDE_LDS = 2 * WIDE_A_BYTES + STAGE_FLOATS * 4;
+constexpr int wide_lds(int TM, int TN) { return (TM + TN) * 64 * 2 + STAGE_FLOATS * 4; }   // hi + lo images of TM + TN rows of 32 bf16
 
 __device__ __forceinline__ int wide_off(int row, int ch) {   // image 0 (hi); lo is 1024 bytes further
   return (row >> 4) * 2048 + (row & 15) * 64 + 16 * (ch ^ ((0 - (row >> 2)) & 3));
 }
 
-template <bool B_NK, int EPI, bool A_DROP>
+// TM x TN = 128 x 128 (wide N) or 64 x 64 (N = 64 with a long K: the products that reduce over the FFN width or 3H);
+// the 4 waves always form a 2 x 2 grid of (TM/2) x (TN/2) quarters
+template <bool B_NK, int EPI, bool A_DROP, int TM, int TN>
 __global__ __launch_bounds__(256) void rx_gemm_wide_kernel(RxP p) {
   extern __shared__ __attribute__((aligned(16))) char s_w[];
+  constexpr int RB = TM / 64, CB = TN / 64;                 // 32-row / 32-column blocks per wave
+  constexpr int A_BYTES = TM * 64 * 2, B_BYTES = TN * 64 * 2;
+  constexpr int NA = TM * 8 / 256, NB = TN * 8 / 256;       // 16-byte pieces per thread and chunk
+  constexpr int KN_HALF = 32 * 128 * 2;                     // [K,N] image of one 64-column half: hi 4 KB | lo 4 KB
   char* sA = s_w;
-  char* sB = s_w + WIDE_A_BYTES;
-  float* stage = reinterpret_cast<float*>(s_w + 2 * WIDE_A_BYTES) + (threadIdx.x >> 6) * (32 * ST_LD);
+  char* sB = s_w + A_BYTES;
+  float* stage = reinterpret_cast<float*>(s_w + A_BYTES + B_BYTES) + (threadIdx.x >> 6) * (32 * ST_LD);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
-  const int ntn = (p.N + 127) / 128;
+  const int ntn = (p.N + TN - 1) / TN;
   const int lid = xcd_logical_id(blockIdx.x, p.n_items);   // the column tiles of one row block share its A chunks
   if (lid >= abs(p.n_items)) return;
-  const int m0 = (lid / ntn) * 128, n0 = (lid % ntn) * 128;
+  const int m0 = (lid / ntn) * TM, n0 = (lid % ntn) * TN;
   const DropCtx dctx = b4r_drop_ctx(p.drop);
   const int nchunks = p.K / WIDE_KC;
 
-  // staging maps.  A (and [N,K] B): piece f -> row f>>3, k = 4*(f&7).  [K,N] B: piece f -> k row f>>5, n = 4*(f&31).
-  f32x4 ra[4], rb[4];
+  // staging maps.  A (and [N,K] B): piece f -> row f>>3, k = 4*(f&7).  [K,N] B: piece f -> k row f / (TN/4), n = 4*(f % (TN/4)).
+  f32x4 ra[NA], rb[NB];
   auto fetch = [&](int c) {
     const int k0 = c * WIDE_KC;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < NA; ++it) {
       const int f = tid + 256 * it;
-      const int row = f >> 3, c4 = f & 7;
-      ra[it] = *reinterpret_cast<const f32x4*>(p.A + (int64_t)min(m0 + row, p.M - 1) * p.lda + k0 + 4 * c4);
+      ra[it] = *reinterpret_cast<const f32x4*>(p.A + (int64_t)min(m0 + (f >> 3), p.M - 1) * p.lda + k0 + 4 * (f & 7));
+    }
+#pragma unroll
+    for (int it = 0; it < NB; ++it) {
+      const int f = tid + 256 * it;
       if (B_NK) {
-        rb[it] = *reinterpret_cast<const f32x4*>(p.B + (int64_t)min(n0 + row, p.N - 1) * p.ldb + k0 + 4 * c4);
+        rb[it] = *reinterpret_cast<const f32x4*>(p.B + (int64_t)min(n0 + (f >> 3), p.N - 1) * p.ldb + k0 + 4 * (f & 7));
       } else {
-        const int krow = f >> 5, c4n = f & 31;
+        const int krow = f / (TN / 4), c4n = f % (TN / 4);
         rb[it] = *reinterpret_cast<const f32x4*>(p.B + (int64_t)(k0 + krow) * p.ldb + min(n0 + 4 * c4n, p.n_store - 4));
       }
     }
@@ -494,7 +502,7 @@ __global__ __launch_bounds__(256) void rx_gemm_wide_kernel(RxP p) {
   auto stash = [&](int c) {
     const int k0 = c * WIDE_KC;
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < NA; ++it) {
       const int f = tid + 256 * it;
       const int row = f >> 3, c4 = f & 7;
       f32x4 va = ra[it];
@@ -504,43 +512,52 @@ __global__ __launch_bounds__(256) void rx_gemm_wide_kernel(RxP p) {
       char* da = sA + wide_off(row, c4 >> 1) + 8 * (c4 & 1);
       *reinterpret_cast<bf16x4*>(da) = hi;
       *reinterpret_cast<bf16x4*>(da + 1024) = lo;
+    }
+#pragma unroll
+    for (int it = 0; it < NB; ++it) {
+      const int f = tid + 256 * it;
+      bf16x4 hi, lo;
       b4r_split4(rb[it], hi, lo);
       if (B_NK) {
+        const int row = f >> 3, c4 = f & 7;
         char* db = sB + wide_off(row, c4 >> 1) + 8 * (c4 & 1);
         *reinterpret_cast<bf16x4*>(db) = hi;
         *reinterpret_cast<bf16x4*>(db + 1024) = lo;
       } else {
-        const int krow = f >> 5, c4n = f & 31;
-        char* db = sB + (c4n >> 4) * 8192 + tn_img_off(krow, c4n & 15);   // [64-column half][hi 4 KB | lo 4 KB]
+        const int krow = f / (TN / 4), c4n = f % (TN / 4);
+        char* db = sB + (c4n >> 4) * KN_HALF + tn_img_off(krow, c4n & 15);
         *reinterpret_cast<bf16x4*>(db) = hi;
         *reinterpret_cast<bf16x4*>(db + 4096) = lo;
       }
     }
   };
   // fragment addresses: kb = 16-wide k block of the chunk (0, 1)
-  int a_addr[2][2], b_addr[2][2];
+  int a_addr[RB][2], b_addr[CB][2];
 #pragma unroll
-  for (int blk = 0; blk < 2; ++blk)
+  for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      a_addr[blk][kb] = wide_off(64 * wm + 32 * blk + r, 2 * kb + h);
-      b_addr[blk][kb] = wide_off(64 * wn + 32 * blk + r, 2 * kb + h);
-    }
+    for (int blk = 0; blk < RB; ++blk) a_addr[blk][kb] = wide_off((TM / 2) * wm + 32 * blk + r, 2 * kb + h);
+#pragma unroll
+    for (int blk = 0; blk < CB; ++blk) b_addr[blk][kb] = wide_off((TN / 2) * wn + 32 * blk + r, 2 * kb + h);
+  }
   const int qq = (lane & 15) >> 2, pp = lane & 3, gb = (lane >> 4) & 1;
   typedef __attribute__((address_space(3))) s16x4* lds_ptr;
   auto b_frag = [&](int cb, int kb, int plane) -> bf16x8 {
     if (B_NK) return *reinterpret_cast<const bf16x8*>(sB + b_addr[cb][kb] + 1024 * plane);
-    const char* src = sB + wn * 8192 + plane * 4096 + tn_img_off(8 * h + qq, 4 * (2 * cb + gb) + pp) + kb * (16 * 128);
+    // the wave's columns (TN/2)*wn + 32*cb ..: 64-column half and 16-column block inside it
+    const int col0 = (TN / 2) * wn + 32 * cb;
+    const char* src = sB + (col0 >> 6) * KN_HALF + plane * 4096 +
+                      tn_img_off(8 * h + qq, 4 * (((col0 & 63) >> 4) + gb) + pp) + kb * (16 * 128);
     const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(src));
     const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(src + 4 * 128));
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[RB][CB];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < RB; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < CB; ++b)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
@@ -552,43 +569,50 @@ __global__ __launch_bounds__(256) void rx_gemm_wide_kernel(RxP p) {
     fetch(min(c + 1, nchunks - 1));        // unconditional look-ahead
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      bf16x8 ah[2], al[2], bh[2], bl[2];
+      bf16x8 ah[RB], al[RB], bh[CB], bl[CB];
 #pragma unroll
-      for (int blk = 0; blk < 2; ++blk) {
+      for (int blk = 0; blk < RB; ++blk) {
         ah[blk] = *reinterpret_cast<const bf16x8*>(sA + a_addr[blk][kb]);
         al[blk] = *reinterpret_cast<const bf16x8*>(sA + a_addr[blk][kb] + 1024);
+      }
+#pragma unroll
+      for (int blk = 0; blk < CB; ++blk) {
         bh[blk] = b_frag(blk, kb, 0);
         bl[blk] = b_frag(blk, kb, 1);
       }
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < RB; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = mfma3(ah[a], al[a], bh[b], bl[b], acc[a][b]);
+        for (int b = 0; b < CB; ++b) acc[a][b] = mfma3(ah[a], al[a], bh[b], bl[b], acc[a][b]);
     }
   }
   const int c4 = (lane & 7) * 4;
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < RB; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int ms = m0 + 64 * wm + 32 * a, ns = n0 + 64 * wn + 32 * b;
+    for (int b = 0; b < CB; ++b) {
+      const int ms = m0 + (TM / 2) * wm + 32 * a, ns = n0 + (TN / 2) * wn + 32 * b;
       if (ms < p.M && ns < p.N)
         epilogue_tile<EPI>(p, dctx, acc[a][b], load_bias4<EPI>(p, ns, c4), load_r_tile<EPI>(p, ms, ns, lane), stage, ms, ns, lane);
     }
 }
 
-inline bool wide_shape(const RxP& p) {
-  static const bool on = !(getenv("B4R_WIDE") && atoi(getenv("B4R_WIDE")) == 0);
-  return on && p.K >= 128 && p.K % WIDE_KC == 0 && p.N >= 128 && p.slab_stride == 0;
+// 0: K-loop / register kernels; 128: 128 x 128 tiles; 64: 64 x 64 tiles
+inline int wide_tile(const RxP& p) {
+  static const int mode = getenv("B4R_WIDE") ? atoi(getenv("B4R_WIDE")) : 3;   // bit 0: 128-tiles, bit 1: 64-tiles
+  if (p.K < 128 || p.K % WIDE_KC != 0 || p.slab_stride != 0) return 0;
+  if (p.N >= 128) return (mode & 1) ? 128 : 0;
+  if (p.N == 64) return (mode & 2) ? 64 : 0;
+  return 0;
 }
 
-template <bool B_NK, int EPI, bool A_DROP>
+template <bool B_NK, int EPI, bool A_DROP, int T>
 void launch_wide(RxP p, hipStream_t s) {
-  p.n_items = b4r_cdiv(p.M, 128) * b4r_cdiv(p.N, 128);
+  p.n_items = b4r_cdiv(p.M, T) * b4r_cdiv(p.N, T);
   const dim3 grid(xcd_grid(p.n_items));
   if (!xcd_on()) p.n_items = -p.n_items;
-  (void)b4r_raise_lds((const void*)rx_gemm_wide_kernel<B_NK, EPI, A_DROP>, WIDE_LDS, "gemm");
-  hipLaunchKernelGGL((rx_gemm_wide_kernel<B_NK, EPI, A_DROP>), grid, dim3(256), WIDE_LDS, s, p);
+  (void)b4r_raise_lds((const void*)rx_gemm_wide_kernel<B_NK, EPI, A_DROP, T, T>, wide_lds(T, T), "gemm");
+  hipLaunchKernelGGL((rx_gemm_wide_kernel<B_NK, EPI, A_DROP, T, T>), grid, dim3(256), wide_lds(T, T), s, p);
 }
 
 template <bool B_NK, int EPI, bool A_DROP>
@@ -608,7 +632,9 @@ void launch_kloop(const RxP& p, hipStream_t s) {
 
 template <bool B_NK, int EPI, bool A_DROP>
 void launch_rx2(const RxP& p, dim3 grid, hipStream_t s) {
-  if (wide_shape(p)) { launch_wide<B_NK, EPI, A_DROP>(p, s); return; }
+  const int wt = wide_tile(p);
+  if (wt == 128) { launch_wide<B_NK, EPI, A_DROP, 128>(p, s); return; }
+  if (wt == 64) { launch_wide<B_NK, EPI, A_DROP, 64>(p, s); return; }
   if (p.K > 64) { launch_kloop<B_NK, EPI, A_DROP>(p, s); return; }
   if (B_NK) {
     if (p.K == 64) hipLaunchKernelGGL((rx_gemm_nk_kernel<EPI, A_DROP, 4>), grid, dim3(256), NK_LDS_BYTES, s, p);

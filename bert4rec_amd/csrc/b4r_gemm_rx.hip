@@ -597,10 +597,19 @@ __global__ __launch_bounds__(256) void rx_gemm_wide_kernel(RxP p) {
     }
 }
 
-// 0: K-loop / register kernels; 128: 128 x 128 tiles; 64: 64 x 64 tiles
+// 0: K-loop / register-operand kernels; 128: 128 x 128 tiles; 64: 64 x 64 tiles.  Measured on one box (ML-1M shapes, us):
+//   K >= 128: tiles always (FFN-out 22 -> 17.5, dX1 19 -> 16.5, dX 15 -> 12.5; ML-20M step 7.3 -> 5.9 ms)
+//   K = 64:   QKV 19.2 -> 16.3, attention-out 12.5 -> 8.9, FFN-in 28.6 -> 26, dctx 10.2 -> 8.1 with tiles; the two products
+//             with B as [N,K] and many columns stay on rx_gemm_nk_kernel (GELU' product 30 vs 31.5; vocabulary
+//             projection 32 vs 38.5: its one-tile-per-workgroup sweep with the A strip in registers writes faster)
+// B4R_WIDE bits switch the three groups off for experiments: 1 = 128-tiles, 2 = 64-tiles, 4 = K = 64 shapes.
+template <bool B_NK>
 inline int wide_tile(const RxP& p) {
-  static const int mode = getenv("B4R_WIDE") ? atoi(getenv("B4R_WIDE")) : 3;   // bit 0: 128-tiles, bit 1: 64-tiles
-  if (p.K < 128 || p.K % WIDE_KC != 0 || p.slab_stride != 0) return 0;
+  static const int mode = getenv("B4R_WIDE") ? atoi(getenv("B4R_WIDE")) : 7;
+  if (p.K % WIDE_KC != 0 || p.slab_stride != 0) return 0;
+  if (p.K < 128) {
+    if (!(mode & 4) || p.K != 64 || p.N > 256 || (B_NK && p.N > 128)) return 0;
+  }
   if (p.N >= 128) return (mode & 1) ? 128 : 0;
   if (p.N == 64) return (mode & 2) ? 64 : 0;
   return 0;
@@ -632,7 +641,7 @@ void launch_kloop(const RxP& p, hipStream_t s) {
 
 template <bool B_NK, int EPI, bool A_DROP>
 void launch_rx2(const RxP& p, dim3 grid, hipStream_t s) {
-  const int wt = wide_tile(p);
+  const int wt = wide_tile<B_NK>(p);
   if (wt == 128) { launch_wide<B_NK, EPI, A_DROP, 128>(p, s); return; }
   if (wt == 64) { launch_wide<B_NK, EPI, A_DROP, 64>(p, s); return; }
   if (p.K > 64) { launch_kloop<B_NK, EPI, A_DROP>(p, s); return; }

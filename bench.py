@@ -104,8 +104,14 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs the GPU (the product has no CPU path)"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # B4R_BENCH_FORCE_DIST=1: run the RCCL code path (init, broadcast, all-reduce, barriers) with one rank -- the only way to
+    # rehearse it on a one-GPU box
+    use_dist = world > 1 or os.environ.get("B4R_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=device)
 
     from bert4rec_amd import _lib
@@ -127,7 +133,7 @@ def main():
 
     def step(i):
         cb, _ = prepared[i % nb]
-        if world > 1:
+        if use_dist:
             (eng.dp_train_step_graphed if args.graph else eng.dp_train_step)(hp, cb)
         elif args.graph:
             eng.train_step_graphed(hp, cb)
@@ -137,18 +143,18 @@ def main():
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -274,7 +280,7 @@ def main():
                   "per_gpu": round(value / world, 1), "final_loss": round(loss, 5),
                   "roofline": roofline, "roofline_materialising": roofline_mat, "cpu_baseline": cpu}
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

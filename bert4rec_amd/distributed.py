@@ -8,6 +8,7 @@ of that gradient).  Backend: torch.distributed "nccl" = RCCL over xGMI on ROCm; 
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -37,7 +38,9 @@ def unpack_sums(grad_ext: torch.Tensor, state: torch.Tensor, n_params: int) -> N
 def allreduce_step(grad_ext: torch.Tensor, state: torch.Tensor, n_params: int,
                    group: Optional[dist.ProcessGroup] = None) -> None:
     """Sum gradients and loss/metric sums over the data-parallel group (in place)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    if dist.get_world_size(group) == 1 and os.environ.get("B4R_BENCH_FORCE_DIST") != "1":   # the override rehearses RCCL with one rank
         return
     pack_sums(grad_ext, state, n_params)
     dist.all_reduce(grad_ext, op=dist.ReduceOp.SUM, group=group)

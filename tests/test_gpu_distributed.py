@@ -81,3 +81,23 @@ def test_two_rank_dp_steps_equal_single_process_steps_on_the_whole_batch(graphed
         assert vc == wvc and abs(ls - wls) < 1e-3 * abs(wls) and abs(gn - wgn) < 2e-3 * abs(wgn)
     a, b = got["params"].double(), eng.params.cpu().double()
     assert float((a - b).abs().max()) < 5e-5, float((a - b).abs().max())   # 9 Adam steps of lr <= 1e-4
+
+
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "graphed"])
+def test_bench_runs_its_rccl_path_with_one_rank(graph):
+    """bench.py with the "nccl" (= RCCL) process group forced on for a single rank: init, parameter broadcast, the
+    [grads | sums] all-reduce between backward and the optimizer, barriers and the MAX reduction of the timing -- the
+    code the driver runs at N = 2, 4, 8, rehearsed on the one GPU this box has."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, B4R_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "3", "--cpu-steps", "0"]
+    if graph:
+        cmd.append("--graph")
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 1 and res["value"] > 0 and 0 < res["final_loss"] < 12

@@ -495,6 +495,11 @@ extern "C" int b4r_set_gemm_mode(int mode) {
 }
 extern "C" int b4r_get_gemm_mode(void) { return g_gemm_mode; }
 
+extern "C" int b4r_gemm_ln_supported(const b4r_gemm_desc* d) {
+  return (d != nullptr && d->epilogue == B4R_EPI_BIAS_DROP_RES_LN && g_gemm_mode == B4R_GEMM_BF16X3 && d->A && d->B && d->C &&
+          d->M > 0 && d->R && d->ldr >= d->N && b4r_gemm_rx_supported(d)) ? 1 : 0;
+}
+
 extern "C" int b4r_gemm_f32(const b4r_gemm_desc* d, b4r_stream_t stream) {
   B4R_CHECK_ARG(d != nullptr, B4R_E_BADARG, "b4r_gemm_f32: null descriptor");
   B4R_CHECK_ARG(d->A && d->B && d->C, B4R_E_BADARG, "b4r_gemm_f32: null operand");
@@ -503,12 +508,19 @@ extern "C" int b4r_gemm_f32(const b4r_gemm_desc* d, b4r_stream_t stream) {
                 "b4r_gemm_f32: leading dimension smaller than the row length");
   const int epi = d->epilogue;
   const bool needs_bias = epi == B4R_EPI_BIAS || epi == B4R_EPI_BIAS_QSCALE || epi == B4R_EPI_BIAS_GELU ||
-                          epi == B4R_EPI_BIAS_DROP_RES || epi == B4R_EPI_BIAS_TANH;
+                          epi == B4R_EPI_BIAS_DROP_RES || epi == B4R_EPI_BIAS_TANH || epi == B4R_EPI_BIAS_DROP_RES_LN;
   B4R_CHECK_ARG(!needs_bias || d->bias, B4R_E_BADARG, "b4r_gemm_f32: epilogue %d needs a bias", epi);
-  const bool needs_r = epi == B4R_EPI_BIAS_DROP_RES || epi == B4R_EPI_GELU_BWD || epi == B4R_EPI_ADD_RES;
+  const bool needs_r = epi == B4R_EPI_BIAS_DROP_RES || epi == B4R_EPI_GELU_BWD || epi == B4R_EPI_ADD_RES ||
+                       epi == B4R_EPI_BIAS_DROP_RES_LN;
   B4R_CHECK_ARG(!needs_r || (d->R && d->ldr >= d->N), B4R_E_BADARG, "b4r_gemm_f32: epilogue %d needs R", epi);
   B4R_CHECK_ARG(epi != B4R_EPI_BIAS_GELU || (d->C2 && d->ldc2 >= d->N), B4R_E_BADARG, "b4r_gemm_f32: BIAS_GELU needs C2");
-  B4R_CHECK_ARG(epi >= B4R_EPI_NONE && epi <= B4R_EPI_BIAS_TANH, B4R_E_BADARG, "b4r_gemm_f32: unknown epilogue %d", epi);
+  B4R_CHECK_ARG(epi >= B4R_EPI_NONE && epi <= B4R_EPI_BIAS_DROP_RES_LN, B4R_E_BADARG, "b4r_gemm_f32: unknown epilogue %d", epi);
+  if (epi == B4R_EPI_BIAS_DROP_RES_LN) {
+    B4R_CHECK_ARG(d->C2 && d->ln_gamma && d->ln_beta, B4R_E_BADARG, "b4r_gemm_f32: BIAS_DROP_RES_LN needs C2, ln_gamma, ln_beta");
+    B4R_CHECK_ARG(b4r_gemm_ln_supported(d), B4R_E_SHAPE,
+                  "b4r_gemm_f32: BIAS_DROP_RES_LN not available for M=%d N=%d K=%d in this mode (b4r_gemm_ln_supported)", d->M,
+                  d->N, d->K);
+  }
   if (g_gemm_mode == B4R_GEMM_BF16X3 && b4r_gemm_rx_supported(d)) return b4r_gemm_rx_launch(d, (hipStream_t)stream);
 
   GemmP p;

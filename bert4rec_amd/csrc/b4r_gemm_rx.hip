@@ -55,6 +55,8 @@ struct RxP {
   int64_t slab_stride;            // K-loop kernel with several z: partial products go to C + z * slab_stride
   float qscale; int qcols;
   DropArgs drop;
+  // B4R_EPI_BIAS_DROP_RES_LN: C2 = LayerNorm(C) * ln_gamma + ln_beta, row statistics of C
+  const float* ln_gamma; const float* ln_beta; float* ln_mean; float* ln_rstd; float ln_eps;
 };
 
 __device__ __forceinline__ void split8(const f32x8 x, bf16x8& hi, bf16x8& lo) { b4r_split8(x, hi, lo); }
@@ -102,9 +104,11 @@ inline unsigned xcd_grid(int64_t n) { return (unsigned)(((n + 7) >> 3) << 3); }
 
 constexpr bool epi_has_bias(int e) {
   return e == B4R_EPI_BIAS || e == B4R_EPI_BIAS_QSCALE || e == B4R_EPI_BIAS_GELU || e == B4R_EPI_BIAS_DROP_RES ||
-         e == B4R_EPI_BIAS_TANH;
+         e == B4R_EPI_BIAS_TANH || e == B4R_EPI_BIAS_DROP_RES_LN;
 }
-constexpr bool epi_has_r(int e) { return e == B4R_EPI_BIAS_DROP_RES || e == B4R_EPI_GELU_BWD || e == B4R_EPI_ADD_RES; }
+constexpr bool epi_has_r(int e) {
+  return e == B4R_EPI_BIAS_DROP_RES || e == B4R_EPI_GELU_BWD || e == B4R_EPI_ADD_RES || e == B4R_EPI_BIAS_DROP_RES_LN;
+}
 
 // the wave's 32 x K strip of A, split into hi/lo fragments (row must be valid: M % 32 == 0 and the wave is live)
 template <bool A_DROP, int NKB>
@@ -180,6 +184,73 @@ __device__ __forceinline__ void epilogue_tile(const RxP& p, const DropCtx& dctx,
     }
     *reinterpret_cast<f32x4*>(p.C + (int64_t)row * p.ldc + col) = o;
     if (EPI == B4R_EPI_BIAS_GELU) *reinterpret_cast<f32x4*>(p.C2 + (int64_t)row * p.ldc2 + col) = o2;
+  }
+}
+
+// B4R_EPI_BIAS_DROP_RES_LN in the 64 x 64 tile kernel with N = 64: the workgroup holds whole rows, wave (wm, wn) the 32 x 32
+// quarter at (32 wm, 32 wn).  z = R + dropout(acc + bias) -> C as in BIAS_DROP_RES; then the LayerNorm of b4r_ln_fwd on the
+// values still in registers: each wave reduces its 32 columns of a row to (mean, sum of squared deviations) over the 8
+// lanes that share the row, the two waves of a row exchange them through their (now idle) staging areas and merge them
+// (Chan et al.: M2 = M2a + M2b + (ma - mb)^2 n/2 with n = 32 per half), so the variance is a two-pass one like the stand-alone
+// kernel's.  `live` = the quarter's rows exist (M % 32 == 0, so a quarter is whole or absent); every wave takes the barrier.
+__device__ __forceinline__ void epilogue_tile_ln(const RxP& p, const DropCtx& dctx, const f32x16& acc, const f32x4 bv,
+                                                 const RTile& rt, float* stage, float* stage_other, int m0, int n0, int lane,
+                                                 bool live) {
+  const int r = lane & 31, h = lane >> 5;
+  const int c4 = (lane & 7) * 4, rsub = lane >> 3;
+  const int col = n0 + c4;
+  f32x4 z[4];
+  float mean_w[4], m2_w[4];
+  if (live) {
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) stage[((reg & 3) + 8 * (reg >> 2) + 4 * h) * ST_LD + r] = acc[reg];
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    f32x4 vin[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vin[i] = *reinterpret_cast<const f32x4*>(&stage[(rsub + 8 * i) * ST_LD + c4]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = m0 + rsub + 8 * i;
+      z[i] = rt.v[i] + b4r_drop4(dctx, vin[i] + bv, (uint64_t)row * (uint64_t)p.N + (uint64_t)col);
+      *reinterpret_cast<f32x4*>(p.C + (int64_t)row * p.ldc + col) = z[i];
+      float sw = (z[i][0] + z[i][1]) + (z[i][2] + z[i][3]);
+      sw += __shfl_xor(sw, 1, 64); sw += __shfl_xor(sw, 2, 64); sw += __shfl_xor(sw, 4, 64);
+      mean_w[i] = sw * (1.0f / 32.0f);
+      float q = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float dd = z[i][e] - mean_w[i]; q += dd * dd; }
+      q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+      m2_w[i] = q;
+    }
+    // the tile reads above are complete for the whole wave (the shuffles consumed them): reuse the first 64 floats
+    if ((lane & 7) == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<float2*>(&stage[2 * (rsub + 8 * i)]) = make_float2(mean_w[i], m2_w[i]);
+    }
+  }
+  __syncthreads();
+  if (!live) return;
+  const f32x4 g = *reinterpret_cast<const f32x4*>(p.ln_gamma + col);
+  const f32x4 b = *reinterpret_cast<const f32x4*>(p.ln_beta + col);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = m0 + rsub + 8 * i;
+    const float2 o = *reinterpret_cast<const float2*>(&stage_other[2 * (rsub + 8 * i)]);
+    const float dm = mean_w[i] - o.x;
+    const float mean = 0.5f * (mean_w[i] + o.x);
+    const float var = (m2_w[i] + o.y + dm * dm * 16.0f) * (1.0f / 64.0f);
+    const float rstd = rsqrtf(var + p.ln_eps);
+    f32x4 y;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float inv = rstd * g[e];
+      y[e] = z[i][e] * inv + (b[e] - mean * inv);
+    }
+    *reinterpret_cast<f32x4*>(p.C2 + (int64_t)row * p.ldc2 + col) = y;
+    if (n0 == 0 && (lane & 7) == 0) {
+      if (p.ln_mean) p.ln_mean[row] = mean;
+      if (p.ln_rstd) p.ln_rstd[row] = rstd;
+    }
   }
 }
 
@@ -587,14 +658,24 @@ __global__ __launch_bounds__(256) void rx_gemm_wide_kernel(RxP p) {
     }
   }
   const int c4 = (lane & 7) * 4;
+  if constexpr (EPI == B4R_EPI_BIAS_DROP_RES_LN) {
+    static_assert(TM == 64 && TN == 64, "the LayerNorm epilogue needs whole rows in one workgroup");
+    const int ms = m0 + 32 * wm, ns = 32 * wn;   // N == 64: n0 == 0
+    const bool live = ms < p.M;
+    RTile rt;
+    if (live) rt = load_r_tile<EPI>(p, ms, ns, lane);
+    float* stage_other = reinterpret_cast<float*>(s_w + A_BYTES + B_BYTES) + (wave ^ 1) * (32 * ST_LD);
+    epilogue_tile_ln(p, dctx, acc[0][0], load_bias4<EPI>(p, ns, c4), rt, stage, stage_other, ms, ns, lane, live);
+  } else {
 #pragma unroll
-  for (int a = 0; a < RB; ++a)
+    for (int a = 0; a < RB; ++a)
 #pragma unroll
-    for (int b = 0; b < CB; ++b) {
-      const int ms = m0 + (TM / 2) * wm + 32 * a, ns = n0 + (TN / 2) * wn + 32 * b;
-      if (ms < p.M && ns < p.N)
-        epilogue_tile<EPI>(p, dctx, acc[a][b], load_bias4<EPI>(p, ns, c4), load_r_tile<EPI>(p, ms, ns, lane), stage, ms, ns, lane);
-    }
+      for (int b = 0; b < CB; ++b) {
+        const int ms = m0 + (TM / 2) * wm + 32 * a, ns = n0 + (TN / 2) * wn + 32 * b;
+        if (ms < p.M && ns < p.N)
+          epilogue_tile<EPI>(p, dctx, acc[a][b], load_bias4<EPI>(p, ns, c4), load_r_tile<EPI>(p, ms, ns, lane), stage, ms, ns, lane);
+      }
+  }
 }
 
 // 0: K-loop / register-operand kernels; 128: 128 x 128 tiles; 64: 64 x 64 tiles.  Measured on one box (ML-1M shapes, us):
@@ -662,6 +743,10 @@ void launch_rx(const RxP& p, bool a_drop, dim3 grid, hipStream_t s) {
 
 template <bool B_NK>
 int dispatch_rx(const RxP& p, int epi, bool a_drop, dim3 grid, hipStream_t s) {
+  if (epi == B4R_EPI_BIAS_DROP_RES_LN) {   // b4r_gemm_ln_supported: N == 64, B as [K,N], no operand dropout
+    launch_wide<false, B4R_EPI_BIAS_DROP_RES_LN, false, 64>(p, s);
+    return B4R_OK;
+  }
   switch (epi) {
     case B4R_EPI_NONE: launch_rx<B_NK, B4R_EPI_NONE>(p, a_drop, grid, s); break;
     case B4R_EPI_BIAS: launch_rx<B_NK, B4R_EPI_BIAS>(p, a_drop, grid, s); break;
@@ -851,6 +936,10 @@ bool b4r_gemm_rx_supported(const b4r_gemm_desc* d) {
   const int epi = d->epilogue;
   if (epi_has_r(epi) && (!vec_ok(d->R, d->ldr) || ns > d->ldr)) return false;
   if (epi == B4R_EPI_BIAS_GELU && (!vec_ok(d->C2, d->ldc2) || ns > d->ldc2)) return false;
+  if (epi == B4R_EPI_BIAS_DROP_RES_LN) {
+    if (d->N != 64 || d->K < 64 || d->K % WIDE_KC != 0 || d->b_is_nk || d->a_dropout) return false;
+    if (!vec_ok(d->C2, d->ldc2) || d->ldc2 < 64 || !vec_ok(d->ln_gamma, 4) || !vec_ok(d->ln_beta, 4)) return false;
+  }
   return true;
 }
 
@@ -862,6 +951,7 @@ int b4r_gemm_rx_launch(const b4r_gemm_desc* d, hipStream_t stream) {
   p.M = d->M; p.N = d->N; p.K = d->K;
   p.n_store = up4i(d->N);
   p.qscale = d->qscale; p.qcols = d->qcols;
+  p.ln_gamma = d->ln_gamma; p.ln_beta = d->ln_beta; p.ln_mean = d->ln_mean; p.ln_rstd = d->ln_rstd; p.ln_eps = d->ln_eps;
   p.drop = b4r_make_drop(d->rng, d->drop_stream, d->drop_rate, 1);
   p.k_chunks_per_split = d->K / 64 > 0 ? d->K / 64 : 1; p.slab_stride = 0;
   const bool a_drop = d->a_dropout && p.drop.rng != nullptr;

@@ -245,6 +245,23 @@ int gemm(const float* A, int lda, const float* Bm, int ldb, float* C, int ldc, i
   return b4r_gemm_f32(&d, (b4r_stream_t)s);
 }
 
+// dense + bias + dropout + residual (-> z) + LayerNorm (-> y, mean, rstd): one launch where b4r_gemm_ln_supported (hidden
+// size 64 in the bf16x3 mode), else the product with B4R_EPI_BIAS_DROP_RES followed by b4r_ln_fwd.  B4R_FUSE_LN=0: always two.
+int dense_res_ln(const float* A, int lda, const float* W, float* z, float* y, float* mean, float* rstd, int M, int H, int K,
+                 const float* bias, const float* R, const float* gamma, const float* beta, float eps, const uint32_t* rng,
+                 uint32_t stream_id, float rate, hipStream_t s) {
+  static const bool fuse = !(getenv("B4R_FUSE_LN") && atoi(getenv("B4R_FUSE_LN")) == 0);
+  b4r_gemm_desc d{};
+  d.A = A; d.lda = lda; d.B = W; d.ldb = H; d.C = z; d.ldc = H; d.M = M; d.N = H; d.K = K;
+  d.epilogue = B4R_EPI_BIAS_DROP_RES_LN; d.bias = bias; d.C2 = y; d.ldc2 = H; d.R = R; d.ldr = H; d.qscale = 1.f;
+  d.rng = rng; d.drop_stream = stream_id; d.drop_rate = rate; d.c_pad_scratch = 1;
+  d.ln_gamma = gamma; d.ln_beta = beta; d.ln_mean = mean; d.ln_rstd = rstd; d.ln_eps = eps;
+  if (fuse && b4r_gemm_ln_supported(&d)) return b4r_gemm_f32(&d, (b4r_stream_t)s);
+  d.epilogue = B4R_EPI_BIAS_DROP_RES; d.C2 = nullptr; d.ldc2 = 0;
+  RC(b4r_gemm_f32(&d, (b4r_stream_t)s));
+  return b4r_ln_fwd(z, M, H, gamma, beta, eps, y, mean, rstd, (b4r_stream_t)s);
+}
+
 // ---- a second stream for the branches of the backward pass that nothing downstream waits for -------------------------
 // (weight-gradient products, the dE sweep of the fused head, dK/dV next to dQ).  The idea: every kernel of this workload
 // leaves part of the chip idle at its start and tail, a concurrent independent kernel could fill those holes.  MEASURED
@@ -400,16 +417,14 @@ extern "C" int b4r_forward(const b4r_model_config* cfg, const b4r_batch* batch, 
             nullptr, 0, nullptr, 0, qscale, H, nullptr, 0, 0.f, 0, s));
     RC(b4r_attn_fwd(ws + w.qkv[i], batch->input_mask, B, L, cfg->num_heads, ws + w.ctx[i], ws + w.lse[i], rng,
                     B4R_STREAM_ATTN_PROBS(i), adp, reinterpret_cast<uint32_t*>(ws + w.keep[i]), stream));
-    RC(gemm(ws + w.ctx[i], H, params + pl.wo[i], H, ws + w.z1[i], H, N, H, H, 0, B4R_EPI_BIAS_DROP_RES, params + pl.bo[i],
-            nullptr, 0, x, H, 1.f, 0, rng, B4R_STREAM_ATTN_OUT(i), od, 0, s));
-    RC(b4r_ln_fwd(ws + w.z1[i], N, H, params + pl.ln1_g[i], params + pl.ln1_b[i], cfg->ln_eps, ws + w.x1[i], ws + w.mean1[i],
-                  ws + w.rstd1[i], stream));
+    RC(dense_res_ln(ws + w.ctx[i], H, params + pl.wo[i], ws + w.z1[i], ws + w.x1[i], ws + w.mean1[i], ws + w.rstd1[i], N, H, H,
+                    params + pl.bo[i], x, params + pl.ln1_g[i], params + pl.ln1_b[i], cfg->ln_eps, rng, B4R_STREAM_ATTN_OUT(i),
+                    od, s));
     RC(gemm(ws + w.x1[i], H, params + pl.w1[i], I, ws + w.f[i], I, N, I, H, 0, B4R_EPI_BIAS_GELU, params + pl.b1[i],
             ws + w.fpre[i], I, nullptr, 0, 1.f, 0, nullptr, 0, 0.f, 0, s));
-    RC(gemm(ws + w.f[i], I, params + pl.w2[i], H, ws + w.z2[i], H, N, H, I, 0, B4R_EPI_BIAS_DROP_RES, params + pl.b2[i],
-            nullptr, 0, ws + w.x1[i], H, 1.f, 0, rng, B4R_STREAM_FFN_OUT(i), od, 0, s));
-    RC(b4r_ln_fwd(ws + w.z2[i], N, H, params + pl.ln2_g[i], params + pl.ln2_b[i], cfg->ln_eps, ws + w.x2[i], ws + w.mean2[i],
-                  ws + w.rstd2[i], stream));
+    RC(dense_res_ln(ws + w.f[i], I, params + pl.w2[i], ws + w.z2[i], ws + w.x2[i], ws + w.mean2[i], ws + w.rstd2[i], N, H, I,
+                    params + pl.b2[i], ws + w.x1[i], params + pl.ln2_g[i], params + pl.ln2_b[i], cfg->ln_eps, rng,
+                    B4R_STREAM_FFN_OUT(i), od, s));
     x = ws + w.x2[i];
   }
   if ((flags & B4R_FLAG_POOLER) && pooler) {

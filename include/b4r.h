@@ -210,7 +210,11 @@ enum {
   B4R_EPI_BIAS_DROP_RES = 4, /* C = R + dropout(acc + bias)                               */
   B4R_EPI_GELU_BWD = 5,      /* C = acc * gelu'(R)                                        */
   B4R_EPI_ADD_RES = 6,       /* C = acc + R                                               */
-  B4R_EPI_BIAS_TANH = 7      /* C = tanh(acc + bias)                     (pooler, bert4rec_encoder.py:149-153) */
+  B4R_EPI_BIAS_TANH = 7,     /* C = tanh(acc + bias)                     (pooler, bert4rec_encoder.py:149-153) */
+  /* C = R + dropout(acc + bias) ; C2 = LayerNorm(C) * ln_gamma + ln_beta ; ln_mean / ln_rstd [M] = row statistics of C:
+   * the dense + dropout + residual + LayerNorm tail of both halves of a Keras TransformerEncoderBlock in one launch.
+   * Only where a workgroup holds whole rows: N == 64 (see b4r_gemm_ln_supported); otherwise B4R_E_SHAPE */
+  B4R_EPI_BIAS_DROP_RES_LN = 8
 };
 typedef struct b4r_gemm_desc {
   const float* A; int32_t lda;   /* [M,K] row-major                                       */
@@ -228,6 +232,8 @@ typedef struct b4r_gemm_desc {
   const uint32_t* rng; uint32_t drop_stream; float drop_rate; int32_t a_dropout;
   /* 1: columns [N, roundup(N,4)) of C / C2 (inside ldc) are scratch the kernel may overwrite, and of R may be read */
   int32_t c_pad_scratch;
+  /* B4R_EPI_BIAS_DROP_RES_LN only (zero otherwise): scale / offset [N], optional statistics outputs [M], epsilon */
+  const float* ln_gamma; const float* ln_beta; float* ln_mean; float* ln_rstd; float ln_eps;
 } b4r_gemm_desc;
 /* Arithmetic of the dense layers (process-wide switch; default B4R_GEMM_BF16X3):
  *   B4R_GEMM_F32     exact fp32 matrix cores (v_mfma_f32_32x32x2_f32), LDS-tiled
@@ -241,6 +247,10 @@ int b4r_get_gemm_mode(void);
 /* dense layers of the encoder / MLM head (Keras Dense / EinsumDense / MultiHeadAttention projections) on the exact
  * fp32 matrix cores (v_mfma_f32_32x32x2_f32) */
 int b4r_gemm_f32(const b4r_gemm_desc* d, b4r_stream_t stream);
+/* 1 when b4r_gemm_f32 accepts this descriptor with B4R_EPI_BIAS_DROP_RES_LN (B4R_GEMM_BF16X3 mode, N == 64, K a multiple
+ * of 64, B as [K,N], no operand dropout, 16-byte aligned operands), else 0: callers then issue
+ * B4R_EPI_BIAS_DROP_RES followed by b4r_ln_fwd */
+int b4r_gemm_ln_supported(const b4r_gemm_desc* d);
 
 /* out[Mo,No] = A[R,Mo]^T . B[R,No]  (weight gradients), optional colsum[No] = sum_r B[r,:] (bias gradients).
  * Deterministic split over R: partial slabs in `scratch` then an ordered reduce.  b_dropout as above (index r*No+c). */

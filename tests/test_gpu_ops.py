@@ -80,6 +80,48 @@ def test_gemm_dropout_epilogue_and_a_operand(M, N, K):
     assert T.maxdiff(c, ref) < 1e-4
 
 
+@pytest.mark.parametrize("M,K,rate", [(224, 64, 0.2), (96, 256, 0.0), (512, 256, 0.2), (32, 128, 0.1)])
+def test_gemm_residual_layernorm_epilogue(M, K, rate):
+    """B4R_EPI_BIAS_DROP_RES_LN (hidden size 64): z = R + dropout(A.B + bias) and LayerNorm(z) with its row statistics from
+    one launch == the two-launch sequence's results (transformer block tails, Keras TransformerEncoderBlock)."""
+    N, seed, step, sid, eps = 64, 31, 3, 9, 1e-12
+    lib = _lib.load()
+    A, B, bias, R = rnd(M, K, seed=1), rnd(K, N, seed=2, scale=0.3), rnd(N, seed=3), rnd(M, N, seed=4)
+    g, b = 1.0 + rnd(N, seed=5, scale=0.2), rnd(N, seed=6, scale=0.2)
+    st = T.new_state(seed, step)
+    keep = orc.dropout_keep_mask((M, N), rate, seed, step, sid).double() if rate > 0 else torch.ones(M, N, dtype=torch.float64)
+    z_ref = (A.double() @ B.double() + bias.double()) * keep / (1 - rate) + R.double()
+    mean_ref = z_ref.mean(1)
+    var_ref = z_ref.var(1, unbiased=False)
+    y_ref = (z_ref - mean_ref[:, None]) / torch.sqrt(var_ref[:, None] + eps) * g.double() + b.double()
+    dev = [t.to(DEV) for t in (A, B, bias, R, g, b)]
+    z = torch.full((M, N), float("nan"), device=DEV)
+    y = torch.full((M, N), float("nan"), device=DEV)
+    mean = torch.full((M,), float("nan"), device=DEV)
+    rstd = torch.full((M,), float("nan"), device=DEV)
+    d = _lib.GemmDesc()
+    d.A, d.lda, d.B, d.ldb, d.C, d.ldc = T.P(dev[0]), K, T.P(dev[1]), N, T.P(z), N
+    d.M, d.N, d.K, d.b_is_nk, d.epilogue = M, N, K, 0, _lib.EPI_BIAS_DROP_RES_LN
+    d.bias, d.C2, d.ldc2, d.R, d.ldr, d.qscale = T.P(dev[2]), T.P(y), N, T.P(dev[3]), N, 1.0
+    d.rng, d.drop_stream, d.drop_rate = (T.P(st) if rate > 0 else None), sid, rate
+    d.ln_gamma, d.ln_beta, d.ln_mean, d.ln_rstd, d.ln_eps = T.P(dev[4]), T.P(dev[5]), T.P(mean), T.P(rstd), eps
+    if lib.b4r_get_gemm_mode() != 1:   # exact-fp32 mode: no fused tail, and the request is refused
+        assert lib.b4r_gemm_ln_supported(C.byref(d)) == 0
+        assert lib.b4r_gemm_f32(C.byref(d), T.stream()) == -2   # B4R_E_SHAPE
+        return
+    assert lib.b4r_gemm_ln_supported(C.byref(d)) == 1
+    _lib.check(lib.b4r_gemm_f32(C.byref(d), T.stream()), "b4r_gemm_f32")
+    scale = float(z_ref.abs().max())                      # sums of K products of O(0.3): |z| reaches ~25 at K = 256
+    assert T.maxdiff(z, z_ref) < 1e-5 * max(scale, 4.0)
+    assert T.maxdiff(y, y_ref) < 5e-5                     # normalised values are O(1)
+    assert T.maxdiff(mean, mean_ref) < 1e-5
+    assert float(((rstd.cpu().double() * torch.sqrt(var_ref + eps)) - 1).abs().max()) < 1e-5
+    # shapes the fused tail does not take are refused, not silently computed another way
+    d.N = d.ldc = d.ldc2 = d.ldr = 128
+    assert lib.b4r_gemm_ln_supported(C.byref(d)) == 0
+    assert lib.b4r_gemm_f32(C.byref(d), T.stream()) == -2   # B4R_E_SHAPE
+
+
 @pytest.mark.parametrize("M,N,K,ldc", [(256, 3709, 64, 3712), (130, 37, 16, 64), (96, 64, 192, 64), (512, 64, 256, 64),
                                        (128, 128, 128, 128), (256, 384, 256, 384), (160, 1001, 128, 1004)])
 def test_gemm_nt_vocab_projection(M, N, K, ldc):

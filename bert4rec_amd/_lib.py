@@ -39,7 +39,8 @@ class GemmDesc(C.Structure):
                 ("R", C.c_void_p), ("ldr", C.c_int32), ("qscale", C.c_float), ("qcols", C.c_int32),
                 ("rng", C.c_void_p), ("drop_stream", C.c_uint32), ("drop_rate", C.c_float), ("a_dropout", C.c_int32),
                 ("c_pad_scratch", C.c_int32), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_mean", C.c_void_p),
-                ("ln_rstd", C.c_void_p), ("ln_eps", C.c_float)]
+                ("ln_rstd", C.c_void_p), ("ln_eps", C.c_float), ("ln_z", C.c_void_p), ("ln_ldz", C.c_int32),
+                ("ln_dgamma", C.c_void_p), ("ln_dbeta", C.c_void_p)]
 
 
 class GemmTnDesc(C.Structure):
@@ -55,7 +56,7 @@ ST_SEED, ST_STEP_LO, ST_STEP = 0, 1, 2  # step is int64 at words 2..3
 ST_LOSS_SUM, ST_VALID, ST_CORRECT_MASKED, ST_CORRECT_ALL, ST_SLOTS_ALL, ST_SQNORM, ST_GRAD_NORM, ST_LR = range(4, 12)
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_QSCALE, EPI_BIAS_GELU, EPI_BIAS_DROP_RES, EPI_GELU_BWD, EPI_ADD_RES, EPI_BIAS_TANH = range(8)
-EPI_BIAS_DROP_RES_LN = 8
+EPI_BIAS_DROP_RES_LN, EPI_ADD_RES_LN_BWD = 8, 9
 FLAG_TRAINING, FLAG_POOLER, FLAG_FUSED_HEAD = 1, 2, 4
 LOSS_FUSED_HEAD = 2
 GEMM_F32, GEMM_BF16X3 = 0, 1
@@ -92,6 +93,7 @@ PROTOTYPES = {
     "b4r_get_gemm_mode": (C.c_int, []),
     "b4r_gemm_f32": (C.c_int, [C.POINTER(GemmDesc), _P]),
     "b4r_gemm_ln_supported": (C.c_int, [C.POINTER(GemmDesc)]),
+    "b4r_gemm_ln_bwd_partial_floats": (_I64, [_I32]),
     "b4r_gemm_tn_scratch_floats": (_I64, [_I32, _I32, _I32]),
     "b4r_gemm_tn_f32": (C.c_int, [C.POINTER(GemmTnDesc), _P, _P]),
     "b4r_attn_fwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P, _P, _U32, _F, _P, _P]),

@@ -495,8 +495,9 @@ extern "C" int b4r_set_gemm_mode(int mode) {
 }
 extern "C" int b4r_get_gemm_mode(void) { return g_gemm_mode; }
 
+extern "C" int64_t b4r_gemm_ln_bwd_partial_floats(int32_t M) { return (int64_t)b4r_cdiv(M > 0 ? M : 1, 64) * 128; }
 extern "C" int b4r_gemm_ln_supported(const b4r_gemm_desc* d) {
-  return (d != nullptr && d->epilogue == B4R_EPI_BIAS_DROP_RES_LN && g_gemm_mode == B4R_GEMM_BF16X3 && d->A && d->B && d->C &&
+  return (d != nullptr && (d->epilogue == B4R_EPI_BIAS_DROP_RES_LN || d->epilogue == B4R_EPI_ADD_RES_LN_BWD) && g_gemm_mode == B4R_GEMM_BF16X3 && d->A && d->B && d->C &&
           d->M > 0 && d->R && d->ldr >= d->N && b4r_gemm_rx_supported(d)) ? 1 : 0;
 }
 
@@ -511,10 +512,22 @@ extern "C" int b4r_gemm_f32(const b4r_gemm_desc* d, b4r_stream_t stream) {
                           epi == B4R_EPI_BIAS_DROP_RES || epi == B4R_EPI_BIAS_TANH || epi == B4R_EPI_BIAS_DROP_RES_LN;
   B4R_CHECK_ARG(!needs_bias || d->bias, B4R_E_BADARG, "b4r_gemm_f32: epilogue %d needs a bias", epi);
   const bool needs_r = epi == B4R_EPI_BIAS_DROP_RES || epi == B4R_EPI_GELU_BWD || epi == B4R_EPI_ADD_RES ||
-                       epi == B4R_EPI_BIAS_DROP_RES_LN;
+                       epi == B4R_EPI_BIAS_DROP_RES_LN || epi == B4R_EPI_ADD_RES_LN_BWD;
   B4R_CHECK_ARG(!needs_r || (d->R && d->ldr >= d->N), B4R_E_BADARG, "b4r_gemm_f32: epilogue %d needs R", epi);
   B4R_CHECK_ARG(epi != B4R_EPI_BIAS_GELU || (d->C2 && d->ldc2 >= d->N), B4R_E_BADARG, "b4r_gemm_f32: BIAS_GELU needs C2");
-  B4R_CHECK_ARG(epi >= B4R_EPI_NONE && epi <= B4R_EPI_BIAS_DROP_RES_LN, B4R_E_BADARG, "b4r_gemm_f32: unknown epilogue %d", epi);
+  B4R_CHECK_ARG(epi >= B4R_EPI_NONE && epi <= B4R_EPI_ADD_RES_LN_BWD, B4R_E_BADARG, "b4r_gemm_f32: unknown epilogue %d", epi);
+  if (epi == B4R_EPI_ADD_RES_LN_BWD) {
+    B4R_CHECK_ARG(d->C2 && d->ln_gamma && d->ln_z && d->ln_mean && d->ln_rstd && d->ln_dgamma, B4R_E_BADARG,
+                  "b4r_gemm_f32: ADD_RES_LN_BWD needs C2 (partials), ln_gamma, ln_z, ln_mean, ln_rstd, ln_dgamma");
+    B4R_CHECK_ARG(d->ln_dbeta == d->ln_dgamma + 64, B4R_E_BADARG, "b4r_gemm_f32: ADD_RES_LN_BWD: ln_dbeta must be ln_dgamma + 64");
+    B4R_CHECK_ARG(b4r_gemm_ln_supported(d), B4R_E_SHAPE,
+                  "b4r_gemm_f32: ADD_RES_LN_BWD not available for M=%d N=%d K=%d in this mode (b4r_gemm_ln_supported)", d->M,
+                  d->N, d->K);
+    int rc = b4r_gemm_rx_launch(d, (hipStream_t)stream);
+    if (rc) return rc;
+    return b4r_launch_slab_reduce_full(d->C2, b4r_cdiv(d->M, 64), 1, 128, d->ln_dgamma, 128, 0, nullptr, nullptr, nullptr, nullptr,
+                                       (hipStream_t)stream);
+  }
   if (epi == B4R_EPI_BIAS_DROP_RES_LN) {
     B4R_CHECK_ARG(d->C2 && d->ln_gamma && d->ln_beta, B4R_E_BADARG, "b4r_gemm_f32: BIAS_DROP_RES_LN needs C2, ln_gamma, ln_beta");
     B4R_CHECK_ARG(b4r_gemm_ln_supported(d), B4R_E_SHAPE,

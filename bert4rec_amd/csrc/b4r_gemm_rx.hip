@@ -57,6 +57,8 @@ struct RxP {
   DropArgs drop;
   // B4R_EPI_BIAS_DROP_RES_LN: C2 = LayerNorm(C) * ln_gamma + ln_beta, row statistics of C
   const float* ln_gamma; const float* ln_beta; float* ln_mean; float* ln_rstd; float ln_eps;
+  // B4R_EPI_ADD_RES_LN_BWD: the normalisation's input [M,64] (ln_mean / ln_rstd / ln_gamma are inputs here, C2 = partials)
+  const float* ln_z; int ln_ldz;
 };
 
 __device__ __forceinline__ void split8(const f32x8 x, bf16x8& hi, bf16x8& lo) { b4r_split8(x, hi, lo); }
@@ -107,7 +109,8 @@ constexpr bool epi_has_bias(int e) {
          e == B4R_EPI_BIAS_TANH || e == B4R_EPI_BIAS_DROP_RES_LN;
 }
 constexpr bool epi_has_r(int e) {
-  return e == B4R_EPI_BIAS_DROP_RES || e == B4R_EPI_GELU_BWD || e == B4R_EPI_ADD_RES || e == B4R_EPI_BIAS_DROP_RES_LN;
+  return e == B4R_EPI_BIAS_DROP_RES || e == B4R_EPI_GELU_BWD || e == B4R_EPI_ADD_RES || e == B4R_EPI_BIAS_DROP_RES_LN ||
+         e == B4R_EPI_ADD_RES_LN_BWD;
 }
 
 // the wave's 32 x K strip of A, split into hi/lo fragments (row must be valid: M % 32 == 0 and the wave is live)
@@ -251,6 +254,96 @@ __device__ __forceinline__ void epilogue_tile_ln(const RxP& p, const DropCtx& dc
       if (p.ln_mean) p.ln_mean[row] = mean;
       if (p.ln_rstd) p.ln_rstd[row] = rstd;
     }
+  }
+}
+
+// B4R_EPI_ADD_RES_LN_BWD, same geometry: dy = acc + R never leaves the registers; the LayerNorm backward of b4r_ln_bwd
+//   g = dy gamma ; xhat = (z - mean) rstd ; dz = rstd (g - mean_c(g) - xhat mean_c(g xhat))  -> C
+// needs two row sums over the 64 columns (8-lane shuffles, then one exchange between the two waves of a row) and yields the
+// column sums of dy xhat / dy over the tile's 64 rows (shuffles over the 8 row groups of a wave, then wave (0, wn) adds wave
+// (1, wn)'s): partial[lid][2][64], summed over the workgroups in slab order by the caller's deferred reduction.  Both
+// exchanges go through the waves' idle staging areas and share ONE barrier (the column sums do not depend on the row sums).
+__device__ __forceinline__ void epilogue_tile_ln_bwd(const RxP& p, const f32x16& acc, const RTile& rt, float* stage,
+                                                     const float* stage_row_other, const float* stage_col_other, int lid,
+                                                     int m0, int n0, int lane, int wm, bool live) {
+  const int r = lane & 31, h = lane >> 5;
+  const int c4 = (lane & 7) * 4, rsub = lane >> 3;
+  const int col = n0 + c4;
+  f32x4 g[4], xh[4];
+  float rstd[4], s1w[4], s2w[4];
+  f32x4 dgp = {0.f, 0.f, 0.f, 0.f}, dbp = {0.f, 0.f, 0.f, 0.f};
+  if (live) {
+    f32x4 zz[4];
+    float mean[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = m0 + rsub + 8 * i;
+      zz[i] = *reinterpret_cast<const f32x4*>(p.ln_z + (int64_t)row * p.ln_ldz + col);
+      mean[i] = p.ln_mean[row];
+      rstd[i] = p.ln_rstd[row];
+    }
+    const f32x4 gam = *reinterpret_cast<const f32x4*>(p.ln_gamma + col);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) stage[((reg & 3) + 8 * (reg >> 2) + 4 * h) * ST_LD + r] = acc[reg];
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    f32x4 vin[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vin[i] = *reinterpret_cast<const f32x4*>(&stage[(rsub + 8 * i) * ST_LD + c4]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const f32x4 dy = vin[i] + rt.v[i];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float xe = (zz[i][e] - mean[i]) * rstd[i];
+        const float ge = dy[e] * gam[e];
+        xh[i][e] = xe; g[i][e] = ge;
+        s1 += ge; s2 += ge * xe;
+        dgp[e] += dy[e] * xe;
+        dbp[e] += dy[e];
+      }
+      s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64); s1 += __shfl_xor(s1, 4, 64);
+      s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64); s2 += __shfl_xor(s2, 4, 64);
+      s1w[i] = s1; s2w[i] = s2;
+    }
+#pragma unroll
+    for (int o = 8; o <= 32; o <<= 1) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        dgp[e] += __shfl_xor(dgp[e], o, 64);
+        dbp[e] += __shfl_xor(dbp[e], o, 64);
+      }
+    }
+    // the tile has been read by the whole wave (the shuffles above consumed it): floats [0,64) row sums, [64,128) column sums
+    if ((lane & 7) == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<float2*>(&stage[2 * (rsub + 8 * i)]) = make_float2(s1w[i], s2w[i]);
+    }
+    if (rsub == 0) {
+      *reinterpret_cast<f32x4*>(&stage[64 + c4]) = dgp;
+      *reinterpret_cast<f32x4*>(&stage[96 + c4]) = dbp;
+    }
+  } else {
+    stage[64 + lane] = 0.f;   // an absent lower quarter adds nothing to the column sums
+  }
+  __syncthreads();
+  if (!live) return;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = m0 + rsub + 8 * i;
+    const float2 o = *reinterpret_cast<const float2*>(&stage_row_other[2 * (rsub + 8 * i)]);
+    const float c1 = (s1w[i] + o.x) * (1.0f / 64.0f), c2 = (s2w[i] + o.y) * (1.0f / 64.0f);
+    f32x4 dz;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dz[e] = rstd[i] * (g[i][e] - c1 - xh[i][e] * c2);
+    *reinterpret_cast<f32x4*>(p.C + (int64_t)row * p.ldc + col) = dz;
+  }
+  if (wm == 0 && rsub == 0) {
+    const f32x4 og = *reinterpret_cast<const f32x4*>(&stage_col_other[64 + c4]);
+    const f32x4 ob = *reinterpret_cast<const f32x4*>(&stage_col_other[96 + c4]);
+    float* dst = p.C2 + (int64_t)lid * 128 + col;
+    *reinterpret_cast<f32x4*>(dst) = dgp + og;
+    *reinterpret_cast<f32x4*>(dst + 64) = dbp + ob;
   }
 }
 
@@ -666,6 +759,15 @@ __global__ __launch_bounds__(256) void rx_gemm_wide_kernel(RxP p) {
     if (live) rt = load_r_tile<EPI>(p, ms, ns, lane);
     float* stage_other = reinterpret_cast<float*>(s_w + A_BYTES + B_BYTES) + (wave ^ 1) * (32 * ST_LD);
     epilogue_tile_ln(p, dctx, acc[0][0], load_bias4<EPI>(p, ns, c4), rt, stage, stage_other, ms, ns, lane, live);
+  } else if constexpr (EPI == B4R_EPI_ADD_RES_LN_BWD) {
+    static_assert(TM == 64 && TN == 64, "the LayerNorm epilogue needs whole rows in one workgroup");
+    const int ms = m0 + 32 * wm, ns = 32 * wn;
+    const bool live = ms < p.M;
+    RTile rt;
+    if (live) rt = load_r_tile<EPI>(p, ms, ns, lane);
+    const float* stage0 = reinterpret_cast<const float*>(s_w + A_BYTES + B_BYTES);
+    epilogue_tile_ln_bwd(p, acc[0][0], rt, stage, stage0 + (wave ^ 1) * (32 * ST_LD), stage0 + (wave ^ 2) * (32 * ST_LD), lid, ms,
+                         ns, lane, wm, live);
   } else {
 #pragma unroll
     for (int a = 0; a < RB; ++a)
@@ -745,6 +847,10 @@ template <bool B_NK>
 int dispatch_rx(const RxP& p, int epi, bool a_drop, dim3 grid, hipStream_t s) {
   if (epi == B4R_EPI_BIAS_DROP_RES_LN) {   // b4r_gemm_ln_supported: N == 64, B as [K,N], no operand dropout
     launch_wide<false, B4R_EPI_BIAS_DROP_RES_LN, false, 64>(p, s);
+    return B4R_OK;
+  }
+  if (epi == B4R_EPI_ADD_RES_LN_BWD) {     // N == 64, B as [N,K]
+    launch_wide<true, B4R_EPI_ADD_RES_LN_BWD, false, 64>(p, s);
     return B4R_OK;
   }
   switch (epi) {
@@ -940,6 +1046,12 @@ bool b4r_gemm_rx_supported(const b4r_gemm_desc* d) {
     if (d->N != 64 || d->K < 64 || d->K % WIDE_KC != 0 || d->b_is_nk || d->a_dropout) return false;
     if (!vec_ok(d->C2, d->ldc2) || d->ldc2 < 64 || !vec_ok(d->ln_gamma, 4) || !vec_ok(d->ln_beta, 4)) return false;
   }
+  if (epi == B4R_EPI_ADD_RES_LN_BWD) {
+    if (d->N != 64 || d->K < 64 || d->K % WIDE_KC != 0 || !d->b_is_nk || d->a_dropout) return false;
+    if (!vec_ok(d->C2, 4) || !vec_ok(d->ln_gamma, 4) || !vec_ok(d->ln_z, d->ln_ldz) || d->ln_ldz < 64 || !d->ln_mean ||
+        !d->ln_rstd)
+      return false;
+  }
   return true;
 }
 
@@ -952,6 +1064,7 @@ int b4r_gemm_rx_launch(const b4r_gemm_desc* d, hipStream_t stream) {
   p.n_store = up4i(d->N);
   p.qscale = d->qscale; p.qcols = d->qcols;
   p.ln_gamma = d->ln_gamma; p.ln_beta = d->ln_beta; p.ln_mean = d->ln_mean; p.ln_rstd = d->ln_rstd; p.ln_eps = d->ln_eps;
+  p.ln_z = d->ln_z; p.ln_ldz = d->ln_ldz;
   p.drop = b4r_make_drop(d->rng, d->drop_stream, d->drop_rate, 1);
   p.k_chunks_per_split = d->K / 64 > 0 ? d->K / 64 : 1; p.slab_stride = 0;
   const bool a_drop = d->a_dropout && p.drop.rng != nullptr;

@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 
+#include <algorithm>
 #include "b4r_common.h"
 
 // ---- internal launchers defined in the other translation units --------------------------------------------------
@@ -199,7 +200,7 @@ WsLayout make_ws_layout(const b4r_model_config& c, int B, int L, int P) {
     add(b4r_gemm_tn_scratch_floats((int)N, (int)H, (int)H));
     add(b4r_gemm_tn_scratch_floats((int)N, (int)H, (int)I));
     add(b4r_gemm_tn_scratch_floats((int)N, (int)I, (int)H));
-    add(2 * b4r_ln_bwd_scratch_floats((int)N, (int)H));
+    add(2 * std::max(b4r_ln_bwd_scratch_floats((int)N, (int)H), b4r_gemm_ln_bwd_partial_floats((int)N)));
   }
   add(b4r_ln_bwd_scratch_floats((int)N, (int)H));
   if (M > 0) {
@@ -260,6 +261,24 @@ int dense_res_ln(const float* A, int lda, const float* W, float* z, float* y, fl
   d.epilogue = B4R_EPI_BIAS_DROP_RES; d.C2 = nullptr; d.ldc2 = 0;
   RC(b4r_gemm_f32(&d, (b4r_stream_t)s));
   return b4r_ln_fwd(z, M, H, gamma, beta, eps, y, mean, rstd, (b4r_stream_t)s);
+}
+
+// input-gradient product + residual gradient + the LayerNorm backward in front of it:  dz = LN'(A.W^T + R)  (W as [N=H, K]).
+// One launch where b4r_gemm_ln_supported, else B4R_EPI_ADD_RES into `dz` followed by b4r_ln_bwd in place.
+int dgrad_ln_bwd(const float* A, int lda, const float* W, int K, const float* R, float* dz, int M, int H, const float* z,
+                 const float* mean, const float* rstd, const float* gamma, float* dgamma, float* dbeta, float* scratch,
+                 hipStream_t s) {
+  static const bool fuse = !(getenv("B4R_FUSE_LN") && atoi(getenv("B4R_FUSE_LN")) == 0);
+  b4r_gemm_desc d{};
+  d.A = A; d.lda = lda; d.B = W; d.ldb = K; d.C = dz; d.ldc = H; d.M = M; d.N = H; d.K = K; d.b_is_nk = 1;
+  d.epilogue = B4R_EPI_ADD_RES_LN_BWD; d.R = R; d.ldr = H; d.qscale = 1.f; d.c_pad_scratch = 1;
+  d.C2 = scratch; d.ln_gamma = gamma; d.ln_mean = const_cast<float*>(mean); d.ln_rstd = const_cast<float*>(rstd);
+  d.ln_z = z; d.ln_ldz = H; d.ln_dgamma = dgamma; d.ln_dbeta = dbeta;
+  if (fuse && dbeta == dgamma + 64 && b4r_gemm_ln_supported(&d)) return b4r_gemm_f32(&d, (b4r_stream_t)s);
+  d.epilogue = B4R_EPI_ADD_RES; d.C2 = nullptr;
+  RC(b4r_gemm_f32(&d, (b4r_stream_t)s));
+  return b4r_ln_bwd_launch(dz, z, mean, rstd, gamma, M, H, dz, dgamma, dbeta, scratch, nullptr, nullptr, nullptr, 1, 1,
+                           b4r_make_drop(nullptr, 0, 0.f, 0), s, nullptr);
 }
 
 // ---- a second stream for the branches of the backward pass that nothing downstream waits for -------------------------
@@ -538,27 +557,26 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
   RC(b4r_scatter_add_rows_impl(ws + w.dg, batch->masked_lm_positions, L, P, M, H, ws + w.dx, H, batch->masked_lm_ids, N, 0, nullptr, s));
 
   // ---- encoder layers, last to first ---------------------------------------------------------------------------------
+  const int64_t ln_scratch = std::max(b4r_ln_bwd_scratch_floats(N, H), b4r_gemm_ln_bwd_partial_floats(N));
   for (int i = cfg->num_layers - 1; i >= 0; --i) {
     const float* x_in = (i == 0) ? ws + w.x0 : ws + w.x2[i - 1];
     RC(order_after(s_tn, s));   // the branches of the previous layer still read da / df / db / dqkv, which this layer rewrites
-    // output LayerNorm
-    RC(b4r_ln_bwd_launch(ws + w.dx, ws + w.z2[i], ws + w.mean2[i], ws + w.rstd2[i], params + pl.ln2_g[i], N, H, ws + w.da,
-                         grads + pl.ln2_g[i], grads + pl.ln2_b[i], take(b4r_ln_bwd_scratch_floats(N, H)), nullptr, nullptr, nullptr, 1, 1, nodrop, s));
+    // output LayerNorm (for every layer but the last its backward rode on the QKV input-gradient product of layer i + 1)
+    if (i == cfg->num_layers - 1)
+      RC(b4r_ln_bwd_launch(ws + w.dx, ws + w.z2[i], ws + w.mean2[i], ws + w.rstd2[i], params + pl.ln2_g[i], N, H, ws + w.da,
+                           grads + pl.ln2_g[i], grads + pl.ln2_b[i], take(ln_scratch), nullptr, nullptr, nullptr, 1, 1, nodrop, s));
     // FFN: dFpre = (dropmask(dz2) . W2^T) * gelu'(fpre)
     RC(gemm(ws + w.da, H, params + pl.w2[i], H, ws + w.df, I, N, I, H, 1, B4R_EPI_GELU_BWD, nullptr, nullptr, 0, ws + w.fpre[i],
             I, 1.f, 0, rng, B4R_STREAM_FFN_OUT(i), od, 1, s));
     RC(order_after(s, s_tn));
     RC(gemm_tn(ws + w.f[i], I, ws + w.da, H, grads + pl.w2[i], H, N, I, H, grads + pl.b2[i], nullptr, rng, B4R_STREAM_FFN_OUT(i),
                od, 1, take(b4r_gemm_tn_scratch_floats(N, I, H)), s_tn));
-    // dX1 = dFpre . W1^T + dz2
-    RC(gemm(ws + w.df, I, params + pl.w1[i], I, ws + w.db, H, N, H, I, 1, B4R_EPI_ADD_RES, nullptr, nullptr, 0, ws + w.da, H, 1.f,
-            0, nullptr, 0, 0.f, 0, s));
+    // dz1 = attention LayerNorm backward of dX1 = dFpre . W1^T + dz2
+    RC(dgrad_ln_bwd(ws + w.df, I, params + pl.w1[i], I, ws + w.da, ws + w.db, N, H, ws + w.z1[i], ws + w.mean1[i], ws + w.rstd1[i],
+                    params + pl.ln1_g[i], grads + pl.ln1_g[i], grads + pl.ln1_b[i], take(ln_scratch), s));
     RC(order_after(s, s_tn));
     RC(gemm_tn(ws + w.x1[i], H, ws + w.df, I, grads + pl.w1[i], I, N, H, I, grads + pl.b1[i], nullptr, nullptr, 0, 0.f, 0,
                take(b4r_gemm_tn_scratch_floats(N, H, I)), s_tn));
-    // attention LayerNorm
-    RC(b4r_ln_bwd_launch(ws + w.db, ws + w.z1[i], ws + w.mean1[i], ws + w.rstd1[i], params + pl.ln1_g[i], N, H, ws + w.db,
-                         grads + pl.ln1_g[i], grads + pl.ln1_b[i], take(b4r_ln_bwd_scratch_floats(N, H)), nullptr, nullptr, nullptr, 1, 1, nodrop, s));
     // attention output projection
     RC(gemm(ws + w.db, H, params + pl.wo[i], H, ws + w.dctx, H, N, H, H, 1, B4R_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 1.f, 0,
             rng, B4R_STREAM_ATTN_OUT(i), od, 1, s));
@@ -571,9 +589,15 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
                             qscale, ws + w.dqkv, rng, B4R_STREAM_ATTN_PROBS(i), adp,
                             reinterpret_cast<const uint32_t*>(ws + w.keep[i]), s, s_kv));
     RC(order_after(s_kv, s));
-    // QKV projection: dX_in = dqkv . Wqkv^T + dz1
-    RC(gemm(ws + w.dqkv, 3 * H, params + pl.wqkv[i], 3 * H, ws + w.dx, H, N, H, 3 * H, 1, B4R_EPI_ADD_RES, nullptr, nullptr, 0,
-            ws + w.db, H, 1.f, 0, nullptr, 0, 0.f, 0, s));
+    // QKV projection: dX_in = dqkv . Wqkv^T + dz1, and for i > 0 straight on to layer i-1's output LayerNorm backward (-> da)
+    if (i > 0) RC(order_after(s_tn, s));   // this layer's side branches still read da, which the fused product rewrites
+    if (i > 0)
+      RC(dgrad_ln_bwd(ws + w.dqkv, 3 * H, params + pl.wqkv[i], 3 * H, ws + w.db, ws + w.da, N, H, ws + w.z2[i - 1],
+                      ws + w.mean2[i - 1], ws + w.rstd2[i - 1], params + pl.ln2_g[i - 1], grads + pl.ln2_g[i - 1],
+                      grads + pl.ln2_b[i - 1], take(ln_scratch), s));
+    else
+      RC(gemm(ws + w.dqkv, 3 * H, params + pl.wqkv[i], 3 * H, ws + w.dx, H, N, H, 3 * H, 1, B4R_EPI_ADD_RES, nullptr, nullptr, 0,
+              ws + w.db, H, 1.f, 0, nullptr, 0, 0.f, 0, s));
     RC(order_after(s, s_tn));
     RC(gemm_tn(x_in, H, ws + w.dqkv, 3 * H, grads + pl.wqkv[i], 3 * H, N, H, 3 * H, grads + pl.bqkv[i], nullptr, nullptr, 0, 0.f,
                0, take(b4r_gemm_tn_scratch_floats(N, H, 3 * H)), s_tn));

@@ -214,7 +214,13 @@ enum {
   /* C = R + dropout(acc + bias) ; C2 = LayerNorm(C) * ln_gamma + ln_beta ; ln_mean / ln_rstd [M] = row statistics of C:
    * the dense + dropout + residual + LayerNorm tail of both halves of a Keras TransformerEncoderBlock in one launch.
    * Only where a workgroup holds whole rows: N == 64 (see b4r_gemm_ln_supported); otherwise B4R_E_SHAPE */
-  B4R_EPI_BIAS_DROP_RES_LN = 8
+  B4R_EPI_BIAS_DROP_RES_LN = 8,
+  /* dy = acc + R (not stored) ; C = LayerNorm backward of dy through the normalisation that produced ln_mean / ln_rstd
+   * from its input ln_z with scale ln_gamma:  C = rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma, xhat = (z - mean) rstd;
+   * ln_dgamma [64] = sum_rows dy xhat and ln_dbeta [64] = sum_rows dy via the partials C2
+   * (b4r_gemm_ln_bwd_partial_floats(M) floats) and an ordered reduction.  The input-gradient product in front of a
+   * LayerNorm backward + that backward in one launch.  N == 64, B as [N,K] only (b4r_gemm_ln_supported) */
+  B4R_EPI_ADD_RES_LN_BWD = 9
 };
 typedef struct b4r_gemm_desc {
   const float* A; int32_t lda;   /* [M,K] row-major                                       */
@@ -234,6 +240,10 @@ typedef struct b4r_gemm_desc {
   int32_t c_pad_scratch;
   /* B4R_EPI_BIAS_DROP_RES_LN only (zero otherwise): scale / offset [N], optional statistics outputs [M], epsilon */
   const float* ln_gamma; const float* ln_beta; float* ln_mean; float* ln_rstd; float ln_eps;
+  /* B4R_EPI_ADD_RES_LN_BWD only: ln_gamma, ln_mean, ln_rstd are INPUTS (what the forward wrote), ln_z [M, ln_ldz] the
+   * normalisation's input, C2 the partials scratch, ln_dgamma / ln_dbeta the outputs (ln_dbeta == ln_dgamma + 64: the pair
+   * is one strip, as in the flat gradient buffer) */
+  const float* ln_z; int32_t ln_ldz; float* ln_dgamma; float* ln_dbeta;
 } b4r_gemm_desc;
 /* Arithmetic of the dense layers (process-wide switch; default B4R_GEMM_BF16X3):
  *   B4R_GEMM_F32     exact fp32 matrix cores (v_mfma_f32_32x32x2_f32), LDS-tiled
@@ -247,10 +257,11 @@ int b4r_get_gemm_mode(void);
 /* dense layers of the encoder / MLM head (Keras Dense / EinsumDense / MultiHeadAttention projections) on the exact
  * fp32 matrix cores (v_mfma_f32_32x32x2_f32) */
 int b4r_gemm_f32(const b4r_gemm_desc* d, b4r_stream_t stream);
-/* 1 when b4r_gemm_f32 accepts this descriptor with B4R_EPI_BIAS_DROP_RES_LN (B4R_GEMM_BF16X3 mode, N == 64, K a multiple
- * of 64, B as [K,N], no operand dropout, 16-byte aligned operands), else 0: callers then issue
- * B4R_EPI_BIAS_DROP_RES followed by b4r_ln_fwd */
+/* 1 when b4r_gemm_f32 accepts this descriptor with B4R_EPI_BIAS_DROP_RES_LN or B4R_EPI_ADD_RES_LN_BWD (B4R_GEMM_BF16X3
+ * mode, N == 64, K a multiple of 64, B as [K,N] for the former and [N,K] for the latter, no operand dropout, 16-byte
+ * aligned operands), else 0: callers then issue B4R_EPI_BIAS_DROP_RES + b4r_ln_fwd, or B4R_EPI_ADD_RES + b4r_ln_bwd */
 int b4r_gemm_ln_supported(const b4r_gemm_desc* d);
+int64_t b4r_gemm_ln_bwd_partial_floats(int32_t M);
 
 /* out[Mo,No] = A[R,Mo]^T . B[R,No]  (weight gradients), optional colsum[No] = sum_r B[r,:] (bias gradients).
  * Deterministic split over R: partial slabs in `scratch` then an ordered reduce.  b_dropout as above (index r*No+c). */

@@ -122,6 +122,47 @@ def test_gemm_residual_layernorm_epilogue(M, K, rate):
     assert lib.b4r_gemm_f32(C.byref(d), T.stream()) == -2   # B4R_E_SHAPE
 
 
+@pytest.mark.parametrize("M,K", [(224, 192), (96, 256), (512, 64), (32, 128)])
+def test_gemm_layernorm_backward_epilogue(M, K):
+    """B4R_EPI_ADD_RES_LN_BWD (hidden size 64): dz = LayerNorm'(A.B^T + R) with dgamma / dbeta from one launch == the
+    input-gradient product followed by the stand-alone LayerNorm backward (torch autograd of the same normalisation)."""
+    N, eps = 64, 1e-12
+    lib = _lib.load()
+    A, B, R = rnd(M, K, seed=1, scale=0.3), rnd(N, K, seed=2, scale=0.3), rnd(M, N, seed=4)
+    z = rnd(M, N, seed=7, scale=2.0) + 0.5
+    g = 1.0 + rnd(N, seed=5, scale=0.2)
+    zd = z.double().requires_grad_(True)
+    gd = g.double().requires_grad_(True)
+    bd = torch.zeros(N, dtype=torch.float64, requires_grad=True)
+    y = torch.nn.functional.layer_norm(zd, (N,), gd, bd, eps)
+    dy = A.double() @ B.double().t() + R.double()
+    y.backward(dy)
+    mean = z.double().mean(1)
+    rstd = 1.0 / torch.sqrt(z.double().var(1, unbiased=False) + eps)
+    dev = [t.to(DEV) for t in (A, B, R, z, g, mean.float(), rstd.float())]
+    dz = torch.full((M, N), float("nan"), device=DEV)
+    dgb = torch.full((2 * N,), float("nan"), device=DEV)
+    scratch = torch.full((lib.b4r_gemm_ln_bwd_partial_floats(M),), float("nan"), device=DEV)
+    d = _lib.GemmDesc()
+    d.A, d.lda, d.B, d.ldb, d.C, d.ldc = T.P(dev[0]), K, T.P(dev[1]), K, T.P(dz), N
+    d.M, d.N, d.K, d.b_is_nk, d.epilogue = M, N, K, 1, _lib.EPI_ADD_RES_LN_BWD
+    d.R, d.ldr, d.qscale, d.C2 = T.P(dev[2]), N, 1.0, T.P(scratch)
+    d.ln_z, d.ln_ldz, d.ln_gamma, d.ln_mean, d.ln_rstd = T.P(dev[3]), N, T.P(dev[4]), T.P(dev[5]), T.P(dev[6])
+    d.ln_dgamma, d.ln_dbeta = dgb.data_ptr(), dgb.data_ptr() + 4 * N
+    if lib.b4r_get_gemm_mode() != 1:
+        assert lib.b4r_gemm_ln_supported(C.byref(d)) == 0
+        assert lib.b4r_gemm_f32(C.byref(d), T.stream()) == -2   # B4R_E_SHAPE
+        return
+    assert lib.b4r_gemm_ln_supported(C.byref(d)) == 1
+    _lib.check(lib.b4r_gemm_f32(C.byref(d), T.stream()), "b4r_gemm_f32")
+    assert T.maxdiff(dz, zd.grad) < 5e-5 * max(1.0, float(zd.grad.abs().max()))
+    scale = max(1.0, float(gd.grad.abs().max()), float(bd.grad.abs().max()))
+    assert T.maxdiff(dgb[:N], gd.grad) < 2e-5 * scale * math.sqrt(M)
+    assert T.maxdiff(dgb[N:], bd.grad) < 2e-5 * scale * math.sqrt(M)
+    d.ln_dbeta = dgb.data_ptr()   # not the strip layout
+    assert lib.b4r_gemm_f32(C.byref(d), T.stream()) == -1   # B4R_E_BADARG
+
+
 @pytest.mark.parametrize("M,N,K,ldc", [(256, 3709, 64, 3712), (130, 37, 16, 64), (96, 64, 192, 64), (512, 64, 256, 64),
                                        (128, 128, 128, 128), (256, 384, 256, 384), (160, 1001, 128, 1004)])
 def test_gemm_nt_vocab_projection(M, N, K, ldc):

@@ -148,22 +148,29 @@ __global__ __launch_bounds__(64 * WAVES) void head_fwd_kernel(HeadP p) {
         for (int jj = 6; jj >= 0; --jj) j = (x[jj >> 2][jj & 3] == pl8) ? jj : j;
         bidx = c0 + 16 * (2 * tp + (j >> 2)) + 4 * g + (j & 3);   // columns grow with the pair: earlier maxima win ties
       }
-      float pm = fmaxf(pl8, __shfl_xor(pl8, 16, 64));
-      pm = fmaxf(pm, __shfl_xor(pm, 32, 64));
-      const float mnew = fmaxf(mx, pm);                         // finite: the first pair of a slice holds real columns
-      if (__builtin_amdgcn_ballot_w64(mnew != mx) != 0) {       // wave-uniform; the running maxima settle after a few tiles
+      // The reference `mx` of the running sums only has to be COMMON to the four lanes of a row and close enough to the
+      // row maximum that 2^(x - mx) cannot overflow; it need not be the maximum.  So it is moved (to the row maximum so
+      // far: two cross-lane exchanges, one rescale) only when some logit of the wave exceeds its row's reference by more
+      // than 2^SLACK -- at the first pair of a slice (mx = -inf) and then almost never -- and the common path is one
+      // compare and a wave-uniform branch.  The terms stay below 2^SLACK, their sum below 2^SLACK V: no overflow, and the
+      // relative precision of a floating-point sum does not depend on the reference.
+      constexpr float SLACK = 8.0f;
+      if (__builtin_amdgcn_ballot_w64(pl8 > mx + SLACK) != 0) {
+        float pm = fmaxf(pl8, __shfl_xor(pl8, 16, 64));
+        pm = fmaxf(pm, __shfl_xor(pm, 32, 64));
+        const float mnew = fmaxf(mx, pm);                       // finite: the first pair of a slice holds real columns
         const float alpha = (mx == mnew) ? 1.0f : ex2(mx - mnew);
         sum *= alpha;
 #pragma unroll
         for (int kb = 0; kb < 2 * NKH; ++kb) acc[kb] = acc[kb] * alpha;
+        mx = mnew;
       }
-      mx = mnew;
       f32x4 pr[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = ex2(x[u][r] - mnew);
+          const float e = ex2(x[u][r] - mx);
           pr[u][r] = e;
           sum += e;
         }

@@ -8,7 +8,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libb4r_hip.so")
+# B4R_LIB_PATH: another build of the same HIP library (kernel experiments: A/B of two builds inside one GPU session)
+LIB_PATH = os.environ.get("B4R_LIB_PATH") or os.path.join(_HERE, "libb4r_hip.so")
 
 
 class B4RError(RuntimeError):
@@ -40,7 +41,8 @@ class GemmDesc(C.Structure):
                 ("rng", C.c_void_p), ("drop_stream", C.c_uint32), ("drop_rate", C.c_float), ("a_dropout", C.c_int32),
                 ("c_pad_scratch", C.c_int32), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_mean", C.c_void_p),
                 ("ln_rstd", C.c_void_p), ("ln_eps", C.c_float), ("ln_z", C.c_void_p), ("ln_ldz", C.c_int32),
-                ("ln_dgamma", C.c_void_p), ("ln_dbeta", C.c_void_p)]
+                ("ln_dgamma", C.c_void_p), ("ln_dbeta", C.c_void_p), ("ln_ids", C.c_void_p), ("ln_table", C.c_void_p),
+                ("ln_pos", C.c_void_p), ("ln_L", C.c_int32), ("ln_V", C.c_int32)]
 
 
 class GemmTnDesc(C.Structure):

@@ -517,8 +517,10 @@ extern "C" int b4r_gemm_f32(const b4r_gemm_desc* d, b4r_stream_t stream) {
   B4R_CHECK_ARG(epi != B4R_EPI_BIAS_GELU || (d->C2 && d->ldc2 >= d->N), B4R_E_BADARG, "b4r_gemm_f32: BIAS_GELU needs C2");
   B4R_CHECK_ARG(epi >= B4R_EPI_NONE && epi <= B4R_EPI_ADD_RES_LN_BWD, B4R_E_BADARG, "b4r_gemm_f32: unknown epilogue %d", epi);
   if (epi == B4R_EPI_ADD_RES_LN_BWD) {
-    B4R_CHECK_ARG(d->C2 && d->ln_gamma && d->ln_z && d->ln_mean && d->ln_rstd && d->ln_dgamma, B4R_E_BADARG,
-                  "b4r_gemm_f32: ADD_RES_LN_BWD needs C2 (partials), ln_gamma, ln_z, ln_mean, ln_rstd, ln_dgamma");
+    B4R_CHECK_ARG(d->C2 && d->ln_gamma && (d->ln_z || d->ln_ids) && d->ln_mean && d->ln_rstd && d->ln_dgamma, B4R_E_BADARG,
+                  "b4r_gemm_f32: ADD_RES_LN_BWD needs C2 (partials), ln_gamma, ln_z (or ln_ids), ln_mean, ln_rstd, ln_dgamma");
+    B4R_CHECK_ARG(!d->ln_ids || (d->ln_table && d->ln_pos && d->ln_L > 0 && d->ln_V > 0), B4R_E_BADARG,
+                  "b4r_gemm_f32: ADD_RES_LN_BWD with ln_ids needs ln_table, ln_pos, ln_L, ln_V");
     B4R_CHECK_ARG(d->ln_dbeta == d->ln_dgamma + 64, B4R_E_BADARG, "b4r_gemm_f32: ADD_RES_LN_BWD: ln_dbeta must be ln_dgamma + 64");
     B4R_CHECK_ARG(b4r_gemm_ln_supported(d), B4R_E_SHAPE,
                   "b4r_gemm_f32: ADD_RES_LN_BWD not available for M=%d N=%d K=%d in this mode (b4r_gemm_ln_supported)", d->M,

@@ -59,6 +59,9 @@ struct RxP {
   const float* ln_gamma; const float* ln_beta; float* ln_mean; float* ln_rstd; float ln_eps;
   // B4R_EPI_ADD_RES_LN_BWD: the normalisation's input [M,64] (ln_mean / ln_rstd / ln_gamma are inputs here, C2 = partials)
   const float* ln_z; int ln_ldz;
+  // ... of the embedding stage (ln_ids != nullptr): z = ln_table[id] + ln_pos[row % ln_L] is recomputed, dy first goes back
+  // through the embedding dropout (`drop`, element index row * 64 + col)
+  const int64_t* ln_ids; const float* ln_table; const float* ln_pos; int ln_L, ln_V;
 };
 
 __device__ __forceinline__ void split8(const f32x8 x, bf16x8& hi, bf16x8& lo) { b4r_split8(x, hi, lo); }
@@ -104,13 +107,14 @@ __device__ __forceinline__ int xcd_logical_id(int id, int n) {
 inline bool xcd_on() { static const bool on = !(getenv("B4R_XCD") && atoi(getenv("B4R_XCD")) == 0); return on; }
 inline unsigned xcd_grid(int64_t n) { return (unsigned)(((n + 7) >> 3) << 3); }
 
+constexpr int EPI_ADD_RES_LN_BWD_EMBED = 10;   // internal: B4R_EPI_ADD_RES_LN_BWD with ln_ids set
 constexpr bool epi_has_bias(int e) {
   return e == B4R_EPI_BIAS || e == B4R_EPI_BIAS_QSCALE || e == B4R_EPI_BIAS_GELU || e == B4R_EPI_BIAS_DROP_RES ||
          e == B4R_EPI_BIAS_TANH || e == B4R_EPI_BIAS_DROP_RES_LN;
 }
 constexpr bool epi_has_r(int e) {
   return e == B4R_EPI_BIAS_DROP_RES || e == B4R_EPI_GELU_BWD || e == B4R_EPI_ADD_RES || e == B4R_EPI_BIAS_DROP_RES_LN ||
-         e == B4R_EPI_ADD_RES_LN_BWD;
+         e == B4R_EPI_ADD_RES_LN_BWD || e == EPI_ADD_RES_LN_BWD_EMBED;
 }
 
 // the wave's 32 x K strip of A, split into hi/lo fragments (row must be valid: M % 32 == 0 and the wave is live)
@@ -263,7 +267,8 @@ __device__ __forceinline__ void epilogue_tile_ln(const RxP& p, const DropCtx& dc
 // column sums of dy xhat / dy over the tile's 64 rows (shuffles over the 8 row groups of a wave, then wave (0, wn) adds wave
 // (1, wn)'s): partial[lid][2][64], summed over the workgroups in slab order by the caller's deferred reduction.  Both
 // exchanges go through the waves' idle staging areas and share ONE barrier (the column sums do not depend on the row sums).
-__device__ __forceinline__ void epilogue_tile_ln_bwd(const RxP& p, const f32x16& acc, const RTile& rt, float* stage,
+template <bool EMBED>
+__device__ __forceinline__ void epilogue_tile_ln_bwd(const RxP& p, const DropCtx& dctx, const f32x16& acc, const RTile& rt, float* stage,
                                                      const float* stage_row_other, const float* stage_col_other, int lid,
                                                      int m0, int n0, int lane, int wm, bool live) {
   const int r = lane & 31, h = lane >> 5;
@@ -278,7 +283,14 @@ __device__ __forceinline__ void epilogue_tile_ln_bwd(const RxP& p, const f32x16&
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = m0 + rsub + 8 * i;
-      zz[i] = *reinterpret_cast<const f32x4*>(p.ln_z + (int64_t)row * p.ln_ldz + col);
+      if (EMBED) {
+        int64_t id = p.ln_ids[row];
+        if (id < 0 || id >= p.ln_V) id = 0;   // as the forward: out-of-range ids read the PAD row
+        zz[i] = *reinterpret_cast<const f32x4*>(p.ln_table + id * 64 + col) +
+                *reinterpret_cast<const f32x4*>(p.ln_pos + (int64_t)(row % p.ln_L) * 64 + col);
+      } else {
+        zz[i] = *reinterpret_cast<const f32x4*>(p.ln_z + (int64_t)row * p.ln_ldz + col);
+      }
       mean[i] = p.ln_mean[row];
       rstd[i] = p.ln_rstd[row];
     }
@@ -291,7 +303,8 @@ __device__ __forceinline__ void epilogue_tile_ln_bwd(const RxP& p, const f32x16&
     for (int i = 0; i < 4; ++i) vin[i] = *reinterpret_cast<const f32x4*>(&stage[(rsub + 8 * i) * ST_LD + c4]);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const f32x4 dy = vin[i] + rt.v[i];
+      f32x4 dy = vin[i] + rt.v[i];
+      if (EMBED) dy = b4r_drop4(dctx, dy, (uint64_t)(m0 + rsub + 8 * i) * 64u + (uint64_t)col);
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -616,6 +629,13 @@ __device__ __forceinline__ int tn_img_off(int row, int c4) {   // bytes; c4 = fl
 }
 
 constexpr int WIDE_KC = 32;
+// chunks requested ahead of the one in the matrix cores.  MEASURED (same box): 2 is 1-3 % faster per product when the kernel
+// runs back to back on its own (operands warm in the 256 MB last-level cache) but 1.3 % SLOWER over the train step (0.859 vs
+// 0.847 ms), where every product reads what the kernel before it just wrote; so 1, and -DB4R_WIDE_DEPTH=2 for experiments
+#ifndef B4R_WIDE_DEPTH
+#define B4R_WIDE_DEPTH 1
+#endif
+constexpr int WIDE_DEPTH = B4R_WIDE_DEPTH;
 constexpr int wide_lds(int TM, int TN) { return (TM + TN) * 64 * 2 + STAGE_FLOATS * 4; }   // hi + lo images of TM + TN rows of 32 bf16
 
 __device__ __forceinline__ int wide_off(int row, int ch) {   // image 0 (hi); lo is 1024 bytes further
@@ -644,32 +664,32 @@ __global__ __launch_bounds__(256) void rx_gemm_wide_kernel(RxP p) {
   const int nchunks = p.K / WIDE_KC;
 
   // staging maps.  A (and [N,K] B): piece f -> row f>>3, k = 4*(f&7).  [K,N] B: piece f -> k row f / (TN/4), n = 4*(f % (TN/4)).
-  f32x4 ra[NA], rb[NB];
-  auto fetch = [&](int c) {
+  struct Regs { f32x4 ra[NA], rb[NB]; };
+  auto fetch = [&](Regs& q, int c) {
     const int k0 = c * WIDE_KC;
 #pragma unroll
     for (int it = 0; it < NA; ++it) {
       const int f = tid + 256 * it;
-      ra[it] = *reinterpret_cast<const f32x4*>(p.A + (int64_t)min(m0 + (f >> 3), p.M - 1) * p.lda + k0 + 4 * (f & 7));
+      q.ra[it] = *reinterpret_cast<const f32x4*>(p.A + (int64_t)min(m0 + (f >> 3), p.M - 1) * p.lda + k0 + 4 * (f & 7));
     }
 #pragma unroll
     for (int it = 0; it < NB; ++it) {
       const int f = tid + 256 * it;
       if (B_NK) {
-        rb[it] = *reinterpret_cast<const f32x4*>(p.B + (int64_t)min(n0 + (f >> 3), p.N - 1) * p.ldb + k0 + 4 * (f & 7));
+        q.rb[it] = *reinterpret_cast<const f32x4*>(p.B + (int64_t)min(n0 + (f >> 3), p.N - 1) * p.ldb + k0 + 4 * (f & 7));
       } else {
         const int krow = f / (TN / 4), c4n = f % (TN / 4);
-        rb[it] = *reinterpret_cast<const f32x4*>(p.B + (int64_t)(k0 + krow) * p.ldb + min(n0 + 4 * c4n, p.n_store - 4));
+        q.rb[it] = *reinterpret_cast<const f32x4*>(p.B + (int64_t)(k0 + krow) * p.ldb + min(n0 + 4 * c4n, p.n_store - 4));
       }
     }
   };
-  auto stash = [&](int c) {
+  auto stash = [&](const Regs& q, int c) {
     const int k0 = c * WIDE_KC;
 #pragma unroll
     for (int it = 0; it < NA; ++it) {
       const int f = tid + 256 * it;
       const int row = f >> 3, c4 = f & 7;
-      f32x4 va = ra[it];
+      f32x4 va = q.ra[it];
       if (A_DROP) va = b4r_drop4(dctx, va, (uint64_t)min(m0 + row, p.M - 1) * (uint64_t)p.K + (uint64_t)(k0 + 4 * c4));
       bf16x4 hi, lo;
       b4r_split4(va, hi, lo);
@@ -681,7 +701,7 @@ __global__ __launch_bounds__(256) void rx_gemm_wide_kernel(RxP p) {
     for (int it = 0; it < NB; ++it) {
       const int f = tid + 256 * it;
       bf16x4 hi, lo;
-      b4r_split4(rb[it], hi, lo);
+      b4r_split4(q.rb[it], hi, lo);
       if (B_NK) {
         const int row = f >> 3, c4 = f & 7;
         char* db = sB + wide_off(row, c4 >> 1) + 8 * (c4 & 1);
@@ -725,12 +745,12 @@ __global__ __launch_bounds__(256) void rx_gemm_wide_kernel(RxP p) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
 
-  fetch(0);
-  for (int c = 0; c < nchunks; ++c) {
+  // WIDE_DEPTH chunks travel ahead of the one being multiplied (with 2 the register sets q0 / q1 alternate)
+  auto step = [&](Regs& q, int c) {
     __syncthreads();                       // the previous chunk's images have been consumed
-    stash(c);
+    stash(q, c);
     __syncthreads();
-    fetch(min(c + 1, nchunks - 1));        // unconditional look-ahead
+    fetch(q, min(c + WIDE_DEPTH, nchunks - 1));   // unconditional look-ahead (the last chunks are re-requested, never used)
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       bf16x8 ah[RB], al[RB], bh[CB], bl[CB];
@@ -749,6 +769,16 @@ __global__ __launch_bounds__(256) void rx_gemm_wide_kernel(RxP p) {
 #pragma unroll
         for (int b = 0; b < CB; ++b) acc[a][b] = mfma3(ah[a], al[a], bh[b], bl[b], acc[a][b]);
     }
+  };
+  Regs q0, q1;
+  fetch(q0, 0);
+  if (WIDE_DEPTH == 2) {
+    fetch(q1, min(1, nchunks - 1));
+    int c = 0;
+    for (; c + 1 < nchunks; c += 2) { step(q0, c); step(q1, c + 1); }
+    if (c < nchunks) step(q0, c);
+  } else {
+    for (int c = 0; c < nchunks; ++c) step(q0, c);
   }
   const int c4 = (lane & 7) * 4;
   if constexpr (EPI == B4R_EPI_BIAS_DROP_RES_LN) {
@@ -759,15 +789,15 @@ __global__ __launch_bounds__(256) void rx_gemm_wide_kernel(RxP p) {
     if (live) rt = load_r_tile<EPI>(p, ms, ns, lane);
     float* stage_other = reinterpret_cast<float*>(s_w + A_BYTES + B_BYTES) + (wave ^ 1) * (32 * ST_LD);
     epilogue_tile_ln(p, dctx, acc[0][0], load_bias4<EPI>(p, ns, c4), rt, stage, stage_other, ms, ns, lane, live);
-  } else if constexpr (EPI == B4R_EPI_ADD_RES_LN_BWD) {
+  } else if constexpr (EPI == B4R_EPI_ADD_RES_LN_BWD || EPI == EPI_ADD_RES_LN_BWD_EMBED) {
     static_assert(TM == 64 && TN == 64, "the LayerNorm epilogue needs whole rows in one workgroup");
     const int ms = m0 + 32 * wm, ns = 32 * wn;
     const bool live = ms < p.M;
     RTile rt;
     if (live) rt = load_r_tile<EPI>(p, ms, ns, lane);
     const float* stage0 = reinterpret_cast<const float*>(s_w + A_BYTES + B_BYTES);
-    epilogue_tile_ln_bwd(p, acc[0][0], rt, stage, stage0 + (wave ^ 1) * (32 * ST_LD), stage0 + (wave ^ 2) * (32 * ST_LD), lid, ms,
-                         ns, lane, wm, live);
+    epilogue_tile_ln_bwd<EPI == EPI_ADD_RES_LN_BWD_EMBED>(p, dctx, acc[0][0], rt, stage, stage0 + (wave ^ 1) * (32 * ST_LD),
+                                                          stage0 + (wave ^ 2) * (32 * ST_LD), lid, ms, ns, lane, wm, live);
   } else {
 #pragma unroll
     for (int a = 0; a < RB; ++a)
@@ -850,7 +880,8 @@ int dispatch_rx(const RxP& p, int epi, bool a_drop, dim3 grid, hipStream_t s) {
     return B4R_OK;
   }
   if (epi == B4R_EPI_ADD_RES_LN_BWD) {     // N == 64, B as [N,K]
-    launch_wide<true, B4R_EPI_ADD_RES_LN_BWD, false, 64>(p, s);
+    if (p.ln_ids) launch_wide<true, EPI_ADD_RES_LN_BWD_EMBED, false, 64>(p, s);
+    else launch_wide<true, B4R_EPI_ADD_RES_LN_BWD, false, 64>(p, s);
     return B4R_OK;
   }
   switch (epi) {
@@ -1048,9 +1079,12 @@ bool b4r_gemm_rx_supported(const b4r_gemm_desc* d) {
   }
   if (epi == B4R_EPI_ADD_RES_LN_BWD) {
     if (d->N != 64 || d->K < 64 || d->K % WIDE_KC != 0 || !d->b_is_nk || d->a_dropout) return false;
-    if (!vec_ok(d->C2, 4) || !vec_ok(d->ln_gamma, 4) || !vec_ok(d->ln_z, d->ln_ldz) || d->ln_ldz < 64 || !d->ln_mean ||
-        !d->ln_rstd)
+    if (!vec_ok(d->C2, 4) || !vec_ok(d->ln_gamma, 4) || !d->ln_mean || !d->ln_rstd) return false;
+    if (d->ln_ids) {
+      if (!vec_ok(d->ln_table, 4) || !vec_ok(d->ln_pos, 4) || d->ln_L < 1 || d->ln_V < 1) return false;
+    } else if (!vec_ok(d->ln_z, d->ln_ldz) || d->ln_ldz < 64) {
       return false;
+    }
   }
   return true;
 }
@@ -1065,6 +1099,7 @@ int b4r_gemm_rx_launch(const b4r_gemm_desc* d, hipStream_t stream) {
   p.qscale = d->qscale; p.qcols = d->qcols;
   p.ln_gamma = d->ln_gamma; p.ln_beta = d->ln_beta; p.ln_mean = d->ln_mean; p.ln_rstd = d->ln_rstd; p.ln_eps = d->ln_eps;
   p.ln_z = d->ln_z; p.ln_ldz = d->ln_ldz;
+  p.ln_ids = d->ln_ids; p.ln_table = d->ln_table; p.ln_pos = d->ln_pos; p.ln_L = d->ln_L; p.ln_V = d->ln_V;
   p.drop = b4r_make_drop(d->rng, d->drop_stream, d->drop_rate, 1);
   p.k_chunks_per_split = d->K / 64 > 0 ? d->K / 64 : 1; p.slab_stride = 0;
   const bool a_drop = d->a_dropout && p.drop.rng != nullptr;

@@ -202,7 +202,7 @@ WsLayout make_ws_layout(const b4r_model_config& c, int B, int L, int P) {
     add(b4r_gemm_tn_scratch_floats((int)N, (int)I, (int)H));
     add(2 * std::max(b4r_ln_bwd_scratch_floats((int)N, (int)H), b4r_gemm_ln_bwd_partial_floats((int)N)));
   }
-  add(b4r_ln_bwd_scratch_floats((int)N, (int)H));
+  add(std::max(b4r_ln_bwd_scratch_floats((int)N, (int)H), b4r_gemm_ln_bwd_partial_floats((int)N)));
   if (M > 0) {
     add(b4r_gemm_tn_scratch_floats((int)M, (int)V, (int)H));
     add(b4r_gemm_tn_scratch_floats((int)M, (int)H, (int)H));
@@ -265,20 +265,24 @@ int dense_res_ln(const float* A, int lda, const float* W, float* z, float* y, fl
 
 // input-gradient product + residual gradient + the LayerNorm backward in front of it:  dz = LN'(A.W^T + R)  (W as [N=H, K]).
 // One launch where b4r_gemm_ln_supported, else B4R_EPI_ADD_RES into `dz` followed by b4r_ln_bwd in place.
+// With `ids` the LayerNorm is the embedding stage's (input recomputed from the tables, dy first through the dropout `drop`).
 int dgrad_ln_bwd(const float* A, int lda, const float* W, int K, const float* R, float* dz, int M, int H, const float* z,
                  const float* mean, const float* rstd, const float* gamma, float* dgamma, float* dbeta, float* scratch,
-                 hipStream_t s) {
+                 hipStream_t s, const int64_t* ids = nullptr, const float* table = nullptr, const float* pos_table = nullptr,
+                 int L = 1, int V = 1, const uint32_t* rng = nullptr, uint32_t drop_stream = 0, float drop_rate = 0.f) {
   static const bool fuse = !(getenv("B4R_FUSE_LN") && atoi(getenv("B4R_FUSE_LN")) == 0);
   b4r_gemm_desc d{};
   d.A = A; d.lda = lda; d.B = W; d.ldb = K; d.C = dz; d.ldc = H; d.M = M; d.N = H; d.K = K; d.b_is_nk = 1;
   d.epilogue = B4R_EPI_ADD_RES_LN_BWD; d.R = R; d.ldr = H; d.qscale = 1.f; d.c_pad_scratch = 1;
   d.C2 = scratch; d.ln_gamma = gamma; d.ln_mean = const_cast<float*>(mean); d.ln_rstd = const_cast<float*>(rstd);
   d.ln_z = z; d.ln_ldz = H; d.ln_dgamma = dgamma; d.ln_dbeta = dbeta;
+  d.ln_ids = ids; d.ln_table = table; d.ln_pos = pos_table; d.ln_L = L; d.ln_V = V;
+  d.rng = rng; d.drop_stream = drop_stream; d.drop_rate = drop_rate;
   if (fuse && dbeta == dgamma + 64 && b4r_gemm_ln_supported(&d)) return b4r_gemm_f32(&d, (b4r_stream_t)s);
-  d.epilogue = B4R_EPI_ADD_RES; d.C2 = nullptr;
+  d.epilogue = B4R_EPI_ADD_RES; d.C2 = nullptr; d.rng = nullptr; d.drop_rate = 0.f;
   RC(b4r_gemm_f32(&d, (b4r_stream_t)s));
-  return b4r_ln_bwd_launch(dz, z, mean, rstd, gamma, M, H, dz, dgamma, dbeta, scratch, nullptr, nullptr, nullptr, 1, 1,
-                           b4r_make_drop(nullptr, 0, 0.f, 0), s, nullptr);
+  return b4r_ln_bwd_launch(dz, z, mean, rstd, gamma, M, H, dz, dgamma, dbeta, scratch, ids, table, pos_table, L, V,
+                           b4r_make_drop(rng, drop_stream, drop_rate, 1), s, nullptr);
 }
 
 // ---- a second stream for the branches of the backward pass that nothing downstream waits for -------------------------
@@ -595,17 +599,16 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
       RC(dgrad_ln_bwd(ws + w.dqkv, 3 * H, params + pl.wqkv[i], 3 * H, ws + w.db, ws + w.da, N, H, ws + w.z2[i - 1],
                       ws + w.mean2[i - 1], ws + w.rstd2[i - 1], params + pl.ln2_g[i - 1], grads + pl.ln2_g[i - 1],
                       grads + pl.ln2_b[i - 1], take(ln_scratch), s));
-    else
-      RC(gemm(ws + w.dqkv, 3 * H, params + pl.wqkv[i], 3 * H, ws + w.dx, H, N, H, 3 * H, 1, B4R_EPI_ADD_RES, nullptr, nullptr, 0,
-              ws + w.db, H, 1.f, 0, nullptr, 0, 0.f, 0, s));
+    else   // ... and for layer 0 on to the embedding stage: dropout -> LayerNorm of (item row + position row)
+      RC(dgrad_ln_bwd(ws + w.dqkv, 3 * H, params + pl.wqkv[i], 3 * H, ws + w.db, ws + w.da, N, H, nullptr, ws + w.mean0, ws + w.rstd0,
+                      params + pl.emb_ln_g, grads + pl.emb_ln_g, grads + pl.emb_ln_b, take(ln_scratch), s, batch->input_word_ids,
+                      params + pl.word_emb, params + pl.pos_emb, L, V, rng, B4R_STREAM_EMB, od));
     RC(order_after(s, s_tn));
     RC(gemm_tn(x_in, H, ws + w.dqkv, 3 * H, grads + pl.wqkv[i], 3 * H, N, H, 3 * H, grads + pl.bqkv[i], nullptr, nullptr, 0, 0.f,
                0, take(b4r_gemm_tn_scratch_floats(N, H, 3 * H)), s_tn));
   }
-  // ---- embedding stage: dropout -> LayerNorm -> (word table scatter-add, position table batch sum) ---------------------
-  RC(b4r_ln_bwd_launch(ws + w.dx, nullptr, ws + w.mean0, ws + w.rstd0, params + pl.emb_ln_g, N, H, ws + w.da, grads + pl.emb_ln_g,
-                       grads + pl.emb_ln_b, take(b4r_ln_bwd_scratch_floats(N, H)), batch->input_word_ids, params + pl.word_emb, params + pl.pos_emb, L, V,
-                       b4r_make_drop(rng, B4R_STREAM_EMB, od, 1), s));
+  // ---- embedding stage: its dropout -> LayerNorm backward ran with layer 0's QKV product (da = d(item row + position row));
+  // what remains: word table scatter-add, position table batch sum
   // all queued ordered reductions (weight / bias / LayerNorm gradients) in one launch; the item-table gradient must be
   // complete before the embedding rows are scatter-added on top of it
   RC(order_after(s2, s));

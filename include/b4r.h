@@ -244,6 +244,11 @@ typedef struct b4r_gemm_desc {
    * normalisation's input, C2 the partials scratch, ln_dgamma / ln_dbeta the outputs (ln_dbeta == ln_dgamma + 64: the pair
    * is one strip, as in the flat gradient buffer) */
   const float* ln_z; int32_t ln_ldz; float* ln_dgamma; float* ln_dbeta;
+  /* ... and for the embedding stage (ln_ids != NULL; ln_z unused): the normalisation's input is recomputed as
+   * ln_table[ln_ids[row]] + ln_pos[row % ln_L] (ids outside [0, ln_V) read row 0) and dy first goes back through the
+   * dropout that followed the LayerNorm (rng / drop_stream / drop_rate, element index row*64+col)
+   * (bert4rec_encoder.py:186-199: embeddings -> LayerNorm -> dropout) */
+  const int64_t* ln_ids; const float* ln_table; const float* ln_pos; int32_t ln_L, ln_V;
 } b4r_gemm_desc;
 /* Arithmetic of the dense layers (process-wide switch; default B4R_GEMM_BF16X3):
  *   B4R_GEMM_F32     exact fp32 matrix cores (v_mfma_f32_32x32x2_f32), LDS-tiled

@@ -122,20 +122,30 @@ def test_gemm_residual_layernorm_epilogue(M, K, rate):
     assert lib.b4r_gemm_f32(C.byref(d), T.stream()) == -2   # B4R_E_SHAPE
 
 
-@pytest.mark.parametrize("M,K", [(224, 192), (96, 256), (512, 64), (32, 128)])
-def test_gemm_layernorm_backward_epilogue(M, K):
+@pytest.mark.parametrize("M,K,embed", [(224, 192, False), (96, 256, False), (512, 64, False), (32, 128, False),
+                                       (224, 192, True), (96, 64, True)])
+def test_gemm_layernorm_backward_epilogue(M, K, embed):
     """B4R_EPI_ADD_RES_LN_BWD (hidden size 64): dz = LayerNorm'(A.B^T + R) with dgamma / dbeta from one launch == the
     input-gradient product followed by the stand-alone LayerNorm backward (torch autograd of the same normalisation)."""
     N, eps = 64, 1e-12
     lib = _lib.load()
     A, B, R = rnd(M, K, seed=1, scale=0.3), rnd(N, K, seed=2, scale=0.3), rnd(M, N, seed=4)
     z = rnd(M, N, seed=7, scale=2.0) + 0.5
+    L, V, rate, seed, step, sid = 25, 50, 0.2, 11, 2, 0
+    st = T.new_state(seed, step)
+    if embed:   # the embedding stage: z = table[id] + pos[row % L] (ids outside [0, V) read row 0), dy through the dropout first
+        table, pos = rnd(V, N, seed=8), rnd(L, N, seed=9)
+        ids = torch.randint(-2, V + 2, (M,), generator=torch.Generator().manual_seed(3))
+        safe = torch.where((ids < 0) | (ids >= V), torch.zeros_like(ids), ids)
+        z = table[safe] + pos[torch.arange(M) % L]
     g = 1.0 + rnd(N, seed=5, scale=0.2)
     zd = z.double().requires_grad_(True)
     gd = g.double().requires_grad_(True)
     bd = torch.zeros(N, dtype=torch.float64, requires_grad=True)
     y = torch.nn.functional.layer_norm(zd, (N,), gd, bd, eps)
     dy = A.double() @ B.double().t() + R.double()
+    if embed:
+        dy = dy * orc.dropout_keep_mask((M, N), rate, seed, step, sid).double() / (1 - rate)
     y.backward(dy)
     mean = z.double().mean(1)
     rstd = 1.0 / torch.sqrt(z.double().var(1, unbiased=False) + eps)
@@ -149,6 +159,10 @@ def test_gemm_layernorm_backward_epilogue(M, K):
     d.R, d.ldr, d.qscale, d.C2 = T.P(dev[2]), N, 1.0, T.P(scratch)
     d.ln_z, d.ln_ldz, d.ln_gamma, d.ln_mean, d.ln_rstd = T.P(dev[3]), N, T.P(dev[4]), T.P(dev[5]), T.P(dev[6])
     d.ln_dgamma, d.ln_dbeta = dgb.data_ptr(), dgb.data_ptr() + 4 * N
+    if embed:
+        dev_e = [table.to(DEV), pos.to(DEV), ids.to(DEV)]
+        d.ln_z, d.ln_table, d.ln_pos, d.ln_ids, d.ln_L, d.ln_V = None, T.P(dev_e[0]), T.P(dev_e[1]), T.P(dev_e[2]), L, V
+        d.rng, d.drop_stream, d.drop_rate = T.P(st), sid, rate
     if lib.b4r_get_gemm_mode() != 1:
         assert lib.b4r_gemm_ln_supported(C.byref(d)) == 0
         assert lib.b4r_gemm_f32(C.byref(d), T.stream()) == -2   # B4R_E_SHAPE

@@ -124,6 +124,11 @@ def load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise B4RError(f"{LIB_PATH} is missing: build it first (python -c 'import __graft_entry__ as g; g.build()' "
                        f"or bert4rec_amd/build.py). bert4rec_amd has no CPU fallback.")
+    # The library and torch must share ONE HIP runtime in the process (device pointers, streams and events cross the
+    # boundary).  torch ships its own libamdhip64 and registers it under the same soname the library links against, so torch
+    # has to be imported first: the loader then resolves the library's dependency to the copy torch already loaded.  Loading
+    # the library first pulls in /opt/rocm's copy next to torch's, and its launches fail with "no ROCm-capable device".
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

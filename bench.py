@@ -220,7 +220,8 @@ def main():
             roofline = {"kernel": "head_fwd_kernel (masked-LM head: logit tiles -> online softmax -> p.E, bf16x3)",
                         "bound": "mfma", "achieved": round(tf, 1), "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(tf / BF16_PEAK_TFLOPS, 4), "traffic": None, "algorithmic_flops": alg_flops,
-                        "executed_mfma_flops": 3 * alg_flops, "avg_launch_us": round(h_us, 2)}
+                        "executed_mfma_flops": 3 * alg_flops, "frac_executed": round(3 * tf / BF16_PEAK_TFLOPS, 4),
+                        "avg_launch_us": round(h_us, 2)}
             tr = profiled_traffic("head_fwd_kernel") if args.config == "ml1m" else None
             if tr:
                 roofline["traffic"], roofline["traffic_source"] = tr["bytes"], tr["source"]

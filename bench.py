@@ -102,8 +102,10 @@ def main():
             raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs the GPU (the product has no CPU path)"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU; when the launcher isolates each rank's card (HIP_VISIBLE_DEVICES per rank) the only visible index is 0
+    dev_index = local_rank if local_rank < torch.cuda.device_count() else 0
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     # B4R_BENCH_FORCE_DIST=1: run the RCCL code path (init, broadcast, all-reduce, barriers) with one rank -- the only way to
     # rehearse it on a one-GPU box
     use_dist = world > 1 or os.environ.get("B4R_BENCH_FORCE_DIST") == "1"

@@ -33,7 +33,8 @@ import torch.distributed as dist
 CONFIGS = {
     # name: (vocab, hidden, layers, heads, inner, L, P, B, out_drop, att_drop, mask rate)
     "ml1m": (3709, 64, 2, 2, 256, 200, 40, 256, 0.2, 0.2, 0.2),
-    "ml20m": (26732, 256, 2, 8, 1024, 200, 40, 256, 0.1, 0.1, 0.2),
+    "ml20m": (26732, 256, 2, 8, 1024, 200, 40, 256, 0.1, 0.1, 0.2),      # layers as in ml-20m_256.json
+    "ml20m_4l": (26732, 256, 4, 8, 1024, 200, 40, 256, 0.1, 0.1, 0.2),   # BASELINE.json configs[3]: the 4-layer variant
     "steam": (13047, 64, 2, 2, 256, 50, 20, 256, 0.1, 0.1, 0.4),
 }
 

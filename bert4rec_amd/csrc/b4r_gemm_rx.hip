@@ -629,13 +629,16 @@ __device__ __forceinline__ int tn_img_off(int row, int c4) {   // bytes; c4 = fl
 }
 
 constexpr int WIDE_KC = 32;
-// chunks requested ahead of the one in the matrix cores.  MEASURED (same box): 2 is 1-3 % faster per product when the kernel
-// runs back to back on its own (operands warm in the 256 MB last-level cache) but 1.3 % SLOWER over the train step (0.859 vs
-// 0.847 ms), where every product reads what the kernel before it just wrote; so 1, and -DB4R_WIDE_DEPTH=2 for experiments
-#ifndef B4R_WIDE_DEPTH
-#define B4R_WIDE_DEPTH 1
-#endif
-constexpr int WIDE_DEPTH = B4R_WIDE_DEPTH;
+// WIDE_DEPTH = chunks requested ahead of the one in the matrix cores (template parameter of the kernel).  MEASURED: at the
+// ML-1M shapes (K <= 256) two are 1-3 % faster per product when the kernel runs back to back on its own (operands warm in the
+// 256 MB last-level cache) but 1.3 % SLOWER over the train step (0.859 vs 0.847 ms), where every product reads what the kernel
+// before it just wrote; at the ML-20M shapes (K up to 1024: 32 chunks) two win 1.9 % of the step (5.76 -> 5.66 ms).  So: two for
+// the 128 x 128 tiles with K >= B4R_WIDE_DEPTH2_K (256: 5.89 -> 5.79 ms on another box; 512: 5.84), one otherwise (no ML-1M
+// product has such a shape).
+inline int wide_depth2_k() {
+  static const int k = getenv("B4R_WIDE_DEPTH2_K") ? atoi(getenv("B4R_WIDE_DEPTH2_K")) : 256;
+  return k;
+}
 constexpr int wide_lds(int TM, int TN) { return (TM + TN) * 64 * 2 + STAGE_FLOATS * 4; }   // hi + lo images of TM + TN rows of 32 bf16
 
 __device__ __forceinline__ int wide_off(int row, int ch) {   // image 0 (hi); lo is 1024 bytes further
@@ -644,7 +647,7 @@ __device__ __forceinline__ int wide_off(int row, int ch) {   // image 0 (hi); lo
 
 // TM x TN = 128 x 128 (wide N) or 64 x 64 (N = 64 with a long K: the products that reduce over the FFN width or 3H);
 // the 4 waves always form a 2 x 2 grid of (TM/2) x (TN/2) quarters
-template <bool B_NK, int EPI, bool A_DROP, int TM, int TN>
+template <bool B_NK, int EPI, bool A_DROP, int TM, int TN, int WIDE_DEPTH = 1>
 __global__ __launch_bounds__(256) void rx_gemm_wide_kernel(RxP p) {
   extern __shared__ __attribute__((aligned(16))) char s_w[];
   constexpr int RB = TM / 64, CB = TN / 64;                 // 32-row / 32-column blocks per wave
@@ -833,8 +836,15 @@ void launch_wide(RxP p, hipStream_t s) {
   p.n_items = b4r_cdiv(p.M, T) * b4r_cdiv(p.N, T);
   const dim3 grid(xcd_grid(p.n_items));
   if (!xcd_on()) p.n_items = -p.n_items;
-  (void)b4r_raise_lds((const void*)rx_gemm_wide_kernel<B_NK, EPI, A_DROP, T, T>, wide_lds(T, T), "gemm");
-  hipLaunchKernelGGL((rx_gemm_wide_kernel<B_NK, EPI, A_DROP, T, T>), grid, dim3(256), wide_lds(T, T), s, p);
+  if constexpr (T == 128) {
+    if (p.K >= wide_depth2_k()) {
+      (void)b4r_raise_lds((const void*)rx_gemm_wide_kernel<B_NK, EPI, A_DROP, T, T, 2>, wide_lds(T, T), "gemm");
+      hipLaunchKernelGGL((rx_gemm_wide_kernel<B_NK, EPI, A_DROP, T, T, 2>), grid, dim3(256), wide_lds(T, T), s, p);
+      return;
+    }
+  }
+  (void)b4r_raise_lds((const void*)rx_gemm_wide_kernel<B_NK, EPI, A_DROP, T, T, 1>, wide_lds(T, T), "gemm");
+  hipLaunchKernelGGL((rx_gemm_wide_kernel<B_NK, EPI, A_DROP, T, T, 1>), grid, dim3(256), wide_lds(T, T), s, p);
 }
 
 template <bool B_NK, int EPI, bool A_DROP>

@@ -200,3 +200,60 @@ def test_evaluator_device_sampling_matches_host_sampling_in_distribution():
     # an untrained model ranks the ground truth anywhere among 101: both estimates of HR@10 sit near 10/101, within noise
     for k in ("HR@10", "NDCG@10", "MAP"):
         assert abs(rd[k] - rh[k]) < 0.06, (k, rd[k], rh[k])
+
+
+def test_ndcg_after_training_matches_the_oracle_trained_the_same_way():
+    """BASELINE.json north_star: NDCG@10 within +-0.002 of the reference.  The oracle stands in for the TF2 path:
+    both sides start from the same weights, take the same AdamW steps on the same masked batches of a Zipf-popularity log
+    (dropout off -- TF's dropout stream is not reproducible) and are evaluated leave-one-out against the same 100 negatives
+    per user (bert4rec_evaluator.py:60-120)."""
+    from bert4rec_amd.engine import make_adamw_config
+    dl = make_loader()
+    train, val, test = dl.prepare_training()
+    V = dl.tokenizer.get_vocab_size()
+    model = make_model(V, dropout=0.0)
+    cfg_o, params = oracle_of(model)
+    hp_o = orc.AdamWConfig(init_lr=2e-3, num_warmup_steps=5, num_train_steps=400)
+    hp = make_adamw_config(hp_o.init_lr, hp_o.num_train_steps, hp_o.num_warmup_steps, hp_o.end_lr, hp_o.weight_decay_rate,
+                           hp_o.beta_1, hp_o.beta_2, hp_o.epsilon, hp_o.gradient_clip_norm)
+    tb = dataloaders.make_batches(train, batch_size=64, seed=1)
+    m, v = orc.zeros_like_params(params), orc.zeros_like_params(params)
+    eng = model.engine
+    eng.set_step(0)
+    step = 0
+    for _ in range(4):                      # epochs over the cached batches, like trainer.train
+        for b in tb.batches:
+            b = {k: torch.as_tensor(t).cpu() for k, t in b.items()}
+            orc.train_step(params, m, v, b, cfg_o, hp_o, step=step, training=False)
+            cb, keep = eng.prepare_batch(b)
+            eng.train_step(hp, cb)
+            step += 1
+    torch.cuda.synchronize()
+    got_w = model.get_weights()
+    drift = max(float((got_w[n].cpu() - p.reshape(got_w[n].shape)).abs().max()) for n, p in params.items() if orc.is_trainable(n))
+    assert drift < 1e-4, drift              # the two trajectories stay together over all steps
+
+    ev = evaluation.get(sampler=dataloaders.samplers.get("random", vocab=list(range(V)), sample_size=100))
+    om = orc.EvalMetrics()
+    rng = np.random.default_rng(7)
+    n_users = 0
+    for b in dataloaders.make_batches(test, batch_size=64, seed=1).batches:
+        b = {k: torch.as_tensor(t).cpu() for k, t in b.items()}
+        gt = b["masked_lm_ids"][:, 0].numpy()
+        cands = []
+        for r in range(len(gt)):
+            seen = set(b["labels"][r].tolist()) | {int(gt[r])}
+            pool = [i for i in range(3, V) if i not in seen]
+            cands.append(rng.permutation(pool)[:100].tolist() + [int(gt[r])])
+        cands = np.array(cands, dtype=np.int64)
+        ev.evaluate_batch(model, b, candidates=cands, ground_truth=gt)
+        logits = orc.model_forward(params, b, cfg_o)["mlm_logits"][:, 0].numpy()
+        ranking, _ = orc.rank_candidates(np.take_along_axis(logits, cands, axis=1), cands)
+        for rnk in orc.rank_of_ground_truth(ranking, gt).tolist():
+            om.update(int(rnk))
+        n_users += len(gt)
+    got, want = ev.get_metrics_results(), om.results()
+    assert got["Valid Ranks"] == n_users == len(test)
+    for k in ("NDCG@10", "HR@10", "NDCG@5", "MAP"):
+        assert abs(got[k] - want[k]) <= 0.002, (k, got[k], want[k])
+    assert want["NDCG@10"] > 0.07           # the 4 epochs learned something: chance level is 0.045 with 100 negatives

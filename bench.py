@@ -63,21 +63,29 @@ def profiled_traffic(kernel_prefix):
     return None
 
 
-def synthetic_batch(B, L, P, V, rate, seed):
-    """S-full rows of SURVEY.md §8(d): every row has length L, n = min(P, max(1, int(L*rate))) masked positions."""
+def synthetic_batch(B, L, P, V, rate, seed, ragged=False):
+    """S-full rows of SURVEY.md §8(d): every row has length L, n = min(P, max(1, int(L*rate))) masked positions.
+    ragged (S-ragged, the realism check): row lengths ~ U{5..L}, right-padded with 0, same masking rule per row."""
     rng = np.random.default_rng(seed)
     ids = rng.integers(3, V, size=(B, L)).astype(np.int64)
-    n = min(P, max(1, int(L * rate)))
+    mask = np.ones((B, L), np.int64)
     pos = np.zeros((B, P), np.int64)
     mids = np.zeros((B, P), np.int64)
+    if ragged:
+        for b in range(B):
+            nb = int(rng.integers(5, L + 1))
+            ids[b, nb:] = 0
+            mask[b, nb:] = 0
     inp = ids.copy()
     for b in range(B):
-        p = np.sort(rng.choice(L, size=n, replace=False))
+        nb = int(mask[b].sum())
+        n = min(P, max(1, int(nb * rate)))
+        p = np.sort(rng.choice(nb, size=n, replace=False))
         pos[b, :n] = p
         mids[b, :n] = ids[b, p]
         inp[b, p] = 1  # [MASK]
     w = (mids != 0).astype(np.int64)
-    return {"input_word_ids": torch.from_numpy(inp), "input_mask": torch.ones(B, L, dtype=torch.int64),
+    return {"input_word_ids": torch.from_numpy(inp), "input_mask": torch.from_numpy(mask),
             "labels": torch.from_numpy(ids), "masked_lm_positions": torch.from_numpy(pos),
             "masked_lm_ids": torch.from_numpy(mids), "masked_lm_weights": torch.from_numpy(w)}
 
@@ -90,6 +98,8 @@ def main():
     ap.add_argument("--config", default="ml1m", choices=list(CONFIGS))
     ap.add_argument("--cpu-steps", type=int, default=2, help="timed oracle steps for cpu_baseline (0 disables)")
     ap.add_argument("--phases", action="store_true", help="also print per-phase timings to stderr")
+    ap.add_argument("--ragged", action="store_true", help="diagnostic only: S-ragged rows (lengths U{5..L}); reports the padding "
+                                                          "penalty, NOT the headline configuration")
     ap.add_argument("--no-dropout", action="store_true", help="diagnostic only: dropout 0 (NOT the headline configuration)")
     ap.add_argument("--graph", action="store_true", help="replay each batch's step from captured hipGraphs (same GPU time, "
                                                          "~7x less host time per step; N > 1: two graphs around the all-reduce)")
@@ -130,7 +140,7 @@ def main():
     broadcast_parameters(eng.params)
     hp = make_adamw_config()
     nb = 4
-    batches = [synthetic_batch(B, L, P, V, rate, seed=1000 * rank + i) for i in range(nb)]
+    batches = [synthetic_batch(B, L, P, V, rate, seed=1000 * rank + i, ragged=args.ragged) for i in range(nb)]
     prepared = [eng.prepare_batch(b) for b in batches]
     valid_per_step = float(sum(int((b["masked_lm_ids"] != 0).sum()) for b in batches)) / nb
 
@@ -279,7 +289,7 @@ def main():
                   "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                   "config": {"workload": f"{args.config}: full train step, B={B}/GPU L={L} P={P} H={H} layers={NL} heads={NH} "
                                          f"inner={I} V={V} dropout {od}/{ad}, full-vocab masked-LM head, {int(valid_per_step)} "
-                                         f"masked positions/GPU/step",
+                                         f"masked positions/GPU/step" + (" (S-ragged rows: lengths U{5..L})" if args.ragged else ""),
                              "global_batch": B * world, "seq_len": L, "parallelism": f"dp{world}"},
                   "per_gpu": round(value / world, 1), "final_loss": round(loss, 5),
                   "roofline": roofline, "roofline_materialising": roofline_mat, "cpu_baseline": cpu}

@@ -119,11 +119,15 @@ __global__ __launch_bounds__(64 * WAVES) void attn_rx_fwd_kernel(AttnRxP p) {
   float sum = 0.f;
   // (score - max) first: with Keras' -1e9 mask a fully masked row has scores and max of magnitude 1e9, and folding log2(e)
   // into separately rounded terms would lose the exact cancellation (same in the backward kernels)
+  f32x4 sum4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < KT; ++t) {
+    const f32x4 d = (acc[t] - m) * 1.4426950408889634f;   // packed subtract / multiply; e^x = 2^(x log2 e) as __expf does
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { const float e = __expf(acc[t][r] - m); acc[t][r] = e; sum += e; }
+    for (int r = 0; r < 4; ++r) acc[t][r] = __builtin_amdgcn_exp2f(d[r]);
+    sum4 += acc[t];
   }
+  sum = (sum4[0] + sum4[1]) + (sum4[2] + sum4[3]);
   sum += __shfl_xor(sum, 16, 64);
   sum += __shfl_xor(sum, 32, 64);
   const float inv = 1.0f / sum;
@@ -136,10 +140,11 @@ __global__ __launch_bounds__(64 * WAVES) void attn_rx_fwd_kernel(AttnRxP p) {
     uint32_t w[2] = {0u, 0u};
 #pragma unroll
     for (int t = 0; t < KT; ++t) {
-      const uint32_t k4 = b4r_keep4(dctx, dbase + (uint64_t)(16 * t + 4 * g));   // one hash for the lane's 4 keys
+      const B4rKeep4 k4 = b4r_keep4p(dctx, dbase + (uint64_t)(16 * t + 4 * g));   // one hash for the lane's 4 keys
+      const f32x4 ps = acc[t] * (inv * dctx.scale);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) acc[t][s] = ((k4 >> s) & 1u) ? acc[t][s] * (inv * dctx.scale) : 0.f;
-      w[t >> 3] |= k4 << (4 * (t & 7));
+      for (int s = 0; s < 4; ++s) acc[t][s] = k4.k[s] ? ps[s] : 0.f;
+      w[t >> 3] |= k4.bits() << (4 * (t & 7));
     }
     uint32_t* wo = p.bits_out + ((bh * p.KT + (q0 >> 4) + wave) * 2) * 64 + lane;
     wo[0] = w[0];

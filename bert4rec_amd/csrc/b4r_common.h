@@ -118,13 +118,22 @@ __device__ __forceinline__ void b4r_group_hash(const DropCtx& c, uint64_t g, uin
   h2 = h;
 }
 
-// bit e of the result = keep(idx4 + e); idx4 must be a multiple of 4
-__device__ __forceinline__ uint32_t b4r_keep4(const DropCtx& c, uint64_t idx4) {
+// the four keep decisions of a group as predicates (lane masks): selecting on them directly costs one v_cndmask per element,
+// testing the packed bits again costs an and + compare more
+struct B4rKeep4 {
+  bool k[4];
+  __device__ __forceinline__ uint32_t bits() const { return (k[0] ? 1u : 0u) | (k[1] ? 2u : 0u) | (k[2] ? 4u : 0u) | (k[3] ? 8u : 0u); }
+};
+__device__ __forceinline__ B4rKeep4 b4r_keep4p(const DropCtx& c, uint64_t idx4) {
   uint32_t h1, h2;
   b4r_group_hash(c, idx4 >> 2, h1, h2);
-  return ((h1 & 0xFFFFu) >= c.thr ? 1u : 0u) | ((h1 >> 16) >= c.thr ? 2u : 0u) |
-         ((h2 & 0xFFFFu) >= c.thr ? 4u : 0u) | ((h2 >> 16) >= c.thr ? 8u : 0u);
+  B4rKeep4 r;
+  r.k[0] = (h1 & 0xFFFFu) >= c.thr; r.k[1] = (h1 >> 16) >= c.thr;
+  r.k[2] = (h2 & 0xFFFFu) >= c.thr; r.k[3] = (h2 >> 16) >= c.thr;
+  return r;
 }
+// bit e of the result = keep(idx4 + e); idx4 must be a multiple of 4
+__device__ __forceinline__ uint32_t b4r_keep4(const DropCtx& c, uint64_t idx4) { return b4r_keep4p(c, idx4).bits(); }
 
 __device__ __forceinline__ bool b4r_keep(const DropCtx& c, uint64_t idx) {
   uint32_t h1, h2;
@@ -145,9 +154,10 @@ __device__ __forceinline__ float b4r_drop(const DropCtx& c, float x, uint64_t id
 __device__ __forceinline__ f32x4 b4r_drop4(const DropCtx& c, f32x4 x, uint64_t idx) {
   if (!c.on) return x;
   if ((idx & 3) == 0) {
-    const uint32_t k = b4r_keep4(c, idx);
+    const B4rKeep4 k = b4r_keep4p(c, idx);
+    const f32x4 xs = x * c.scale;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) x[e] = ((k >> e) & 1u) ? x[e] * c.scale : 0.0f;
+    for (int e = 0; e < 4; ++e) x[e] = k.k[e] ? xs[e] : 0.0f;
   } else {
 #pragma unroll
     for (int e = 0; e < 4; ++e) x[e] = b4r_keep(c, idx + e) ? x[e] * c.scale : 0.0f;

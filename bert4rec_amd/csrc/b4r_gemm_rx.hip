@@ -963,27 +963,22 @@ __global__ __launch_bounds__(256) void rx_gemm_tn_kernel(RxTnP p) {
     }
   };
   f32x4 cs = {0.f, 0.f, 0.f, 0.f}, csa = {0.f, 0.f, 0.f, 0.f};
-  // whole chunks (all but the last of a slice) skip the per-row zeroing, and the column sums are only kept by the workgroups
-  // that own them: both tests are block-uniform, the conversion below is the kernel's VALU budget (2 waves per SIMD)
   auto stash = [&](const Chunk& c, int k0) {
     const f32x4 (&ra)[NLD] = c.a;
     const f32x4 (&rb)[NLD] = c.b;
-    const bool whole = k0 + KS <= r_end;
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
       const int lrow = srow + 16 * j, row = k0 + lrow;
+      const bool live = row < r_end;
       f32x4 va = ra[j], vb = rb[j];
-      if (!whole) {
-        const bool live = row < r_end;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          va[e] = live ? va[e] : 0.f;
-          vb[e] = live ? vb[e] : 0.f;
-        }
+      for (int e = 0; e < 4; ++e) {
+        va[e] = live ? va[e] : 0.f;
+        vb[e] = live ? vb[e] : 0.f;
       }
       if (B_DROP) vb = b4r_drop4(dctx, vb, (uint64_t)row * (uint64_t)p.No + (uint64_t)cb);
-      if (do_cs) cs += vb;
-      if (do_csa) csa += va;
+      cs += vb;
+      csa += va;
       const int off = tn_img_off(lrow, c4);
       bf16x4 ah, al, bh, bl;
       b4r_split4(va, ah, al);

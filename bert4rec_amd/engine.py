@@ -81,6 +81,11 @@ def keras_shape(name: str, info: ParamInfo, cfg: ModelConfig) -> Tuple[int, ...]
     return (info.rows, info.cols)
 
 
+# hipGraph captures only contain this library's launches on the capturing thread; "thread_local" keeps runtime calls made by
+# other threads of the process during the capture (the RCCL watchdog polls events) from invalidating it
+_CAPTURE_MODE = "thread_local"
+
+
 class Engine:
     """One replica of the model on one GPU."""
 
@@ -307,7 +312,7 @@ class Engine:
             return
         torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
             self.train_step(hp, cb)        # capture only enqueues: the step itself runs at the replay below
         graphs[key] = g
         g.replay()
@@ -330,12 +335,12 @@ class Engine:
             fused = self.fused_head_supported()
             torch.cuda.synchronize(self.device)
             g_pre, g_post = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_pre):
+            with torch.cuda.graph(g_pre, capture_error_mode=_CAPTURE_MODE):
                 self.begin_step()
                 self.forward(cb, training=True, pooler=False, fused_head=fused)
                 self.loss(cb, want_grad=True, fused_head=fused)
                 self.backward(cb, training=True, fused_head=fused)
-            with torch.cuda.graph(g_post):
+            with torch.cuda.graph(g_post, capture_error_mode=_CAPTURE_MODE):
                 self.optimizer_step(hp, cb)
             pair = graphs[key] = (g_pre, g_post)
         pair[0].replay()

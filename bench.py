@@ -120,6 +120,11 @@ def main():
     # B4R_BENCH_FORCE_DIST=1: run the RCCL code path (init, broadcast, all-reduce, barriers) with one rank -- the only way to
     # rehearse it on a one-GPU box
     use_dist = world > 1 or os.environ.get("B4R_BENCH_FORCE_DIST") == "1"
+    # RCCL prints a version banner on stdout when its first communicator is created: until the warm-up is over, stdout (fd 1) is
+    # pointed at stderr so that the one JSON line stays the only thing on stdout
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -159,6 +164,9 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)

@@ -49,7 +49,8 @@ class GemmTnDesc(C.Structure):
     _fields_ = [("A", C.c_void_p), ("lda", C.c_int32), ("B", C.c_void_p), ("ldb", C.c_int32), ("out", C.c_void_p),
                 ("ldo", C.c_int32), ("R", C.c_int32), ("Mo", C.c_int32), ("No", C.c_int32), ("colsum", C.c_void_p),
                 ("colsum_a", C.c_void_p), ("rng", C.c_void_p), ("drop_stream", C.c_uint32), ("drop_rate", C.c_float),
-                ("b_dropout", C.c_int32), ("accumulate", C.c_int32)]
+                ("b_dropout", C.c_int32), ("accumulate", C.c_int32), ("dgrad_w", C.c_void_p), ("dgrad_ldw", C.c_int32),
+                ("dgrad_out", C.c_void_p), ("dgrad_ldo", C.c_int32)]
 
 
 # b4r_train_state: 16 x 32-bit words; word indices of the float fields
@@ -98,6 +99,7 @@ PROTOTYPES = {
     "b4r_gemm_ln_bwd_partial_floats": (_I64, [_I32]),
     "b4r_gemm_tn_scratch_floats": (_I64, [_I32, _I32, _I32]),
     "b4r_gemm_tn_f32": (C.c_int, [C.POINTER(GemmTnDesc), _P, _P]),
+    "b4r_gemm_tn_dgrad_supported": (C.c_int, [C.POINTER(GemmTnDesc)]),
     "b4r_attn_fwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P, _P, _U32, _F, _P, _P]),
     "b4r_attn_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _F, _P, _P, _U32, _F, _P, _P]),
     "b4r_attn_keep_words": (C.c_int64, [_I32, _I32, _I32]),

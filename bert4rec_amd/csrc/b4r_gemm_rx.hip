@@ -926,10 +926,12 @@ struct RxTnP {
   int a_lim, b_lim;                // first column that may not be fetched (Mo / No rounded up to 4), <= ld
   int tiles_i, tiles_j, S, chunk;  // chunk: rows per slice
   DropArgs drop;
+  // DGRAD (Mo = No = 64, one output tile): dX[R, 64] = dropout(B) . W^T with W [64, ldw] the weight whose gradient `out` is
+  const float* W; float* dX; int ldw, lddx;
 };
 
 
-template <int KS, bool B_DROP>
+template <int KS, bool B_DROP, bool DGRAD>
 __global__ __launch_bounds__(256) void rx_gemm_tn_kernel(RxTnP p) {
   constexpr int NLD = KS / 16;                       // float4 per thread per operand per chunk
   constexpr int PLANE = KS * 128;                    // bytes per image
@@ -1005,6 +1007,29 @@ __global__ __launch_bounds__(256) void rx_gemm_tn_kernel(RxTnP p) {
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  // DGRAD: the input gradient of the same layer from the same staged chunk.  The (dropped) B image is row-major, so its rows
+  // are MFMA A fragments by plain 16-byte reads (8 consecutive k of a row sit in one 32-byte block of the image); the B
+  // operand W[j][k] is held as register fragments for the wave's 32 columns j.  Quarter (wm, wn) = rows 32 wm.., columns 32 wn..
+  bf16x8 wh[KS / 16], wl[KS / 16];
+  if (DGRAD) {
+#pragma unroll
+    for (int kb = 0; kb < KS / 16; ++kb) split8(load8_contig(p.W + (int64_t)(32 * wn + r) * p.ldw + 16 * kb + 8 * h), wh[kb], wl[kb]);
+  }
+  auto dgrad = [&](int k0) {
+    f32x16 dx;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dx[i] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < KS / 16; ++kb) {
+      const char* src = s_tn + 2 * PLANE + tn_img_off(32 * wm + r, 4 * kb + 2 * h);
+      dx = mfma3(*reinterpret_cast<const bf16x8*>(src), *reinterpret_cast<const bf16x8*>(src + PLANE), wh[kb], wl[kb], dx);
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = k0 + 32 * wm + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      if (row < r_end) p.dX[(int64_t)row * p.lddx + 32 * wn + r] = dx[reg];
+    }
+  };
   // Two register sets alternate: the loads of chunk k+1 are issued at the TOP of iteration k (before the barrier, the
   // conversion and the products of chunk k), so they have a whole iteration to arrive; one set of LDS images.
   auto products = [&]() {
@@ -1020,12 +1045,14 @@ __global__ __launch_bounds__(256) void rx_gemm_tn_kernel(RxTnP p) {
     stash(c0, k0);
     __syncthreads();
     products();
+    if (DGRAD) dgrad(k0);
     if (k0 + KS >= r_end) break;     // block-uniform
     fetch(c0, k0 + 2 * KS);
     __syncthreads();
     stash(c1, k0 + KS);
     __syncthreads();
     products();
+    if (DGRAD) dgrad(k0 + KS);
   }
 
   float* slab = p.slab + (int64_t)z * p.Mo * p.No;
@@ -1054,13 +1081,18 @@ __global__ __launch_bounds__(256) void rx_gemm_tn_kernel(RxTnP p) {
 
 constexpr int TN_KS = 64;   // measured on the ML-1M shapes: 32 -> 1.185, 64 -> 1.173, 128 -> 1.197 ms/step
 
+inline int tn_single_tile_cap() {
+  static const int c = getenv("B4R_TN_CAP1") ? atoi(getenv("B4R_TN_CAP1")) : 512;
+  return c;
+}
 int rx_tn_split(int R, int Mo, int No) {
   static const int wg_target = getenv("B4R_TN_TARGET") ? atoi(getenv("B4R_TN_TARGET")) : 512;
   const int tiles = b4r_cdiv(Mo, 64) * b4r_cdiv(No, 64);
   int S = b4r_cdiv(wg_target, tiles);
   const int max_s = b4r_cdiv(R, 2 * TN_KS);  // at least two chunks per workgroup
   if (S > max_s) S = max_s;
-  if (S > 256) S = 256;
+  const int cap = tiles == 1 ? tn_single_tile_cap() : 256;   // one 64 x 64 output tile: the slices are the only parallelism
+  if (S > cap) S = cap;
   if (S < 1) S = 1;
   return S;
 }
@@ -1189,17 +1221,24 @@ int b4r_gemm_rx_tn_launch(const b4r_gemm_tn_desc* d, float* scratch, hipStream_t
   p.colsum_a_slab = d->colsum_a ? scratch + (int64_t)S * d->Mo * d->No + (int64_t)S * d->No : nullptr;
   p.drop = b4r_make_drop(d->rng, d->drop_stream, d->drop_rate, 1);
   const bool b_drop = d->b_dropout && p.drop.rng != nullptr;
+  const bool dgrad = d->dgrad_out != nullptr;   // b4r_gemm_tn_f32 has checked the shape contract (Mo = No = 64)
+  p.W = d->dgrad_w; p.ldw = d->dgrad_ldw; p.dX = d->dgrad_out; p.lddx = d->dgrad_ldo;
   const int64_t items = (int64_t)p.tiles_i * p.tiles_j * S;
   dim3 grid(xcd_grid(items));
   constexpr size_t lds = (size_t)4 * TN_KS * 128;
   static bool lds_raised = false;
   if (lds > 48 * 1024 && !lds_raised) {
-    hipFuncSetAttribute((const void*)rx_gemm_tn_kernel<TN_KS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute((const void*)rx_gemm_tn_kernel<TN_KS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)rx_gemm_tn_kernel<TN_KS, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)rx_gemm_tn_kernel<TN_KS, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)rx_gemm_tn_kernel<TN_KS, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)rx_gemm_tn_kernel<TN_KS, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     lds_raised = true;
   }
-  if (b_drop) hipLaunchKernelGGL((rx_gemm_tn_kernel<TN_KS, true>), grid, dim3(256), lds, stream, p);
-  else hipLaunchKernelGGL((rx_gemm_tn_kernel<TN_KS, false>), grid, dim3(256), lds, stream, p);
+  if (dgrad) {
+    if (b_drop) hipLaunchKernelGGL((rx_gemm_tn_kernel<TN_KS, true, true>), grid, dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL((rx_gemm_tn_kernel<TN_KS, false, true>), grid, dim3(256), lds, stream, p);
+  } else if (b_drop) hipLaunchKernelGGL((rx_gemm_tn_kernel<TN_KS, true, false>), grid, dim3(256), lds, stream, p);
+  else hipLaunchKernelGGL((rx_gemm_tn_kernel<TN_KS, false, false>), grid, dim3(256), lds, stream, p);
   B4R_CHECK_LAUNCH("b4r_gemm_tn_f32 (bf16x3)");
   return b4r_launch_slab_reduce_full(p.slab, S, d->Mo, d->No, d->out, d->ldo, d->accumulate, p.colsum_slab, d->colsum,
                                      p.colsum_a_slab, d->colsum_a, stream);

@@ -581,12 +581,24 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
     RC(order_after(s, s_tn));
     RC(gemm_tn(ws + w.x1[i], H, ws + w.df, I, grads + pl.w1[i], I, N, H, I, grads + pl.b1[i], nullptr, nullptr, 0, 0.f, 0,
                take(b4r_gemm_tn_scratch_floats(N, H, I)), s_tn));
-    // attention output projection
-    RC(gemm(ws + w.db, H, params + pl.wo[i], H, ws + w.dctx, H, N, H, H, 1, B4R_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 1.f, 0,
-            rng, B4R_STREAM_ATTN_OUT(i), od, 1, s));
-    RC(order_after(s, s_tn));
-    RC(gemm_tn(ws + w.ctx[i], H, ws + w.db, H, grads + pl.wo[i], H, N, H, H, grads + pl.bo[i], nullptr, rng,
-               B4R_STREAM_ATTN_OUT(i), od, 1, take(b4r_gemm_tn_scratch_floats(N, H, H)), s_tn));
+    // attention output projection: dctx = dropmask(dz1) . Wo^T and dWo = ctx^T . dropmask(dz1) (+ bias gradient) read dz1
+    // once where the pair kernel applies (hidden size 64), else as two products
+    {
+      b4r_gemm_tn_desc d{};
+      d.A = ws + w.ctx[i]; d.lda = H; d.B = ws + w.db; d.ldb = H; d.out = grads + pl.wo[i]; d.ldo = H; d.R = N; d.Mo = H; d.No = H;
+      d.colsum = grads + pl.bo[i]; d.rng = rng; d.drop_stream = B4R_STREAM_ATTN_OUT(i); d.drop_rate = od; d.b_dropout = 1;
+      d.dgrad_w = params + pl.wo[i]; d.dgrad_ldw = H; d.dgrad_out = ws + w.dctx; d.dgrad_ldo = H;
+      static const bool pair = !(getenv("B4R_PAIR") && atoi(getenv("B4R_PAIR")) == 0);
+      if (pair && b4r_gemm_tn_dgrad_supported(&d)) {
+        RC(b4r_gemm_tn_f32(&d, take(b4r_gemm_tn_scratch_floats(N, H, H)), (b4r_stream_t)s));
+      } else {
+        RC(gemm(ws + w.db, H, params + pl.wo[i], H, ws + w.dctx, H, N, H, H, 1, B4R_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 1.f,
+                0, rng, B4R_STREAM_ATTN_OUT(i), od, 1, s));
+        RC(order_after(s, s_tn));
+        RC(gemm_tn(ws + w.ctx[i], H, ws + w.db, H, grads + pl.wo[i], H, N, H, H, grads + pl.bo[i], nullptr, rng,
+                   B4R_STREAM_ATTN_OUT(i), od, 1, take(b4r_gemm_tn_scratch_floats(N, H, H)), s_tn));
+      }
+    }
     // attention core: dQ on the main stream, dK/dV on the other (both need dctx; the QKV product below needs both)
     RC(order_after(s, s_kv));
     RC(b4r_attn_bwd_streams(ws + w.qkv[i], batch->input_mask, ws + w.ctx[i], ws + w.lse[i], ws + w.dctx, B, L, cfg->num_heads,

@@ -279,9 +279,15 @@ typedef struct b4r_gemm_tn_desc {
   float* colsum_a; /* [Mo] = sum_r A[r,:] or NULL                              */
   const uint32_t* rng; uint32_t drop_stream; float drop_rate; int32_t b_dropout;
   int32_t accumulate; /* 1: out += result (out must hold defined values) */
+  /* optional (dgrad_out != NULL; zero otherwise): the input gradient of the same dense layer from the same pass over B,
+   *   dgrad_out[R, Mo] = dropout(B) . dgrad_w^T   with dgrad_w [Mo, dgrad_ldw >= No] the forward weight whose gradient `out` is
+   * (y = x.W: dW = x^T.dy and dx = dy.W^T read dy once).  Only Mo = No = 64 in the B4R_GEMM_BF16X3 mode
+   * (b4r_gemm_tn_dgrad_supported), otherwise B4R_E_SHAPE: callers then issue b4r_gemm_f32 with a_dropout for dx */
+  const float* dgrad_w; int32_t dgrad_ldw; float* dgrad_out; int32_t dgrad_ldo;
 } b4r_gemm_tn_desc;
 int64_t b4r_gemm_tn_scratch_floats(int32_t R, int32_t Mo, int32_t No);
 int b4r_gemm_tn_f32(const b4r_gemm_tn_desc* d, float* scratch, b4r_stream_t stream);
+int b4r_gemm_tn_dgrad_supported(const b4r_gemm_tn_desc* d);
 
 /* Keras MultiHeadAttention core for one layer, head_dim 32: ctx = dropout(softmax(q k^T + (1-mask)*-1e9)) v
  * qkv [B*L, 3H] (q pre-scaled by 1/sqrt(d)), ctx [B*L, H], lse [B, heads, L]; input_mask int64 [B,L]. */

@@ -552,11 +552,23 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
   RC(b4r_ln_bwd_launch(ws + w.dt, ws + w.u, ws + w.meanm, ws + w.rstdm, params + pl.lnm_g, M, H, ws + w.dt, grads + pl.lnm_g,
                        grads + pl.lnm_b, take(b4r_ln_bwd_scratch_floats(M, H)), nullptr, nullptr, nullptr, 1, 1, nodrop, s,
                        ws + w.upre));   // ... and straight through the GELU of the transform's dense layer
-  RC(order_after(s, s_tn));
-  RC(gemm_tn(ws + w.gath, H, ws + w.dt, H, grads + pl.wd, H, M, H, H, grads + pl.bd, nullptr, nullptr, 0, 0.f, 0,
-             take(b4r_gemm_tn_scratch_floats(M, H, H)), s_tn));
-  RC(gemm(ws + w.dt, H, params + pl.wd, H, ws + w.dg, H, M, H, H, 1, B4R_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 1.f, 0,
-          nullptr, 0, 0.f, 0, s));
+  {   // dense layer of the transform: dWd = gath^T . du (+ bias gradient) and dgath = du . Wd^T, one pass over du where the pair
+      // kernel applies (hidden size 64)
+    b4r_gemm_tn_desc d{};
+    d.A = ws + w.gath; d.lda = H; d.B = ws + w.dt; d.ldb = H; d.out = grads + pl.wd; d.ldo = H; d.R = M; d.Mo = H; d.No = H;
+    d.colsum = grads + pl.bd;
+    d.dgrad_w = params + pl.wd; d.dgrad_ldw = H; d.dgrad_out = ws + w.dg; d.dgrad_ldo = H;
+    static const bool pair = !(getenv("B4R_PAIR") && atoi(getenv("B4R_PAIR")) == 0);
+    if (pair && b4r_gemm_tn_dgrad_supported(&d)) {
+      RC(b4r_gemm_tn_f32(&d, take(b4r_gemm_tn_scratch_floats(M, H, H)), (b4r_stream_t)s));
+    } else {
+      RC(order_after(s, s_tn));
+      RC(gemm_tn(ws + w.gath, H, ws + w.dt, H, grads + pl.wd, H, M, H, H, grads + pl.bd, nullptr, nullptr, 0, 0.f, 0,
+                 take(b4r_gemm_tn_scratch_floats(M, H, H)), s_tn));
+      RC(gemm(ws + w.dt, H, params + pl.wd, H, ws + w.dg, H, M, H, H, 1, B4R_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 1.f, 0,
+              nullptr, 0, 0.f, 0, s));
+    }
+  }
   // scatter into d sequence_output (slots with y_true == 0 carry exactly zero gradient and are skipped)
   RC(b4r_scatter_add_rows_impl(ws + w.dg, batch->masked_lm_positions, L, P, M, H, ws + w.dx, H, batch->masked_lm_ids, N, 0, nullptr, s));
 

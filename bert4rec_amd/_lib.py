@@ -50,7 +50,7 @@ class GemmTnDesc(C.Structure):
                 ("ldo", C.c_int32), ("R", C.c_int32), ("Mo", C.c_int32), ("No", C.c_int32), ("colsum", C.c_void_p),
                 ("colsum_a", C.c_void_p), ("rng", C.c_void_p), ("drop_stream", C.c_uint32), ("drop_rate", C.c_float),
                 ("b_dropout", C.c_int32), ("accumulate", C.c_int32), ("dgrad_w", C.c_void_p), ("dgrad_ldw", C.c_int32),
-                ("dgrad_out", C.c_void_p), ("dgrad_ldo", C.c_int32)]
+                ("dgrad_out", C.c_void_p), ("dgrad_ldo", C.c_int32), ("dgrad_gelu_pre", C.c_void_p), ("dgrad_ldg", C.c_int32)]
 
 
 # b4r_train_state: 16 x 32-bit words; word indices of the float fields

@@ -604,9 +604,9 @@ extern "C" int64_t b4r_gemm_tn_scratch_floats(int32_t R, int32_t Mo, int32_t No)
 }
 
 extern "C" int b4r_gemm_tn_dgrad_supported(const b4r_gemm_tn_desc* d) {
-  return (d != nullptr && g_gemm_mode == B4R_GEMM_BF16X3 && d->Mo == 64 && d->No == 64 && d->R > 0 && d->A && d->B &&
-          d->dgrad_w && d->dgrad_out && d->dgrad_ldw >= 64 && d->dgrad_ldw % 4 == 0 && b4r_aligned16(d->dgrad_w) &&
-          d->dgrad_ldo >= 64 && b4r_gemm_rx_tn_supported(d)) ? 1 : 0;
+  return (d != nullptr && g_gemm_mode == B4R_GEMM_BF16X3 && d->Mo >= 64 && d->Mo % 64 == 0 && d->No == 64 && d->R > 0 && d->A &&
+          d->B && d->dgrad_w && d->dgrad_out && d->dgrad_ldw >= 64 && d->dgrad_ldw % 4 == 0 && b4r_aligned16(d->dgrad_w) &&
+          d->dgrad_ldo >= d->Mo && (d->dgrad_gelu_pre == nullptr || d->dgrad_ldg >= d->Mo) && b4r_gemm_rx_tn_supported(d)) ? 1 : 0;
 }
 
 extern "C" int b4r_gemm_tn_f32(const b4r_gemm_tn_desc* d, float* scratch, b4r_stream_t stream) {
@@ -617,7 +617,7 @@ extern "C" int b4r_gemm_tn_f32(const b4r_gemm_tn_desc* d, float* scratch, b4r_st
   if (d->dgrad_out != nullptr) {
     B4R_CHECK_ARG(d->dgrad_w != nullptr, B4R_E_BADARG, "b4r_gemm_tn_f32: dgrad_out needs dgrad_w");
     B4R_CHECK_ARG(b4r_gemm_tn_dgrad_supported(d), B4R_E_SHAPE,
-                  "b4r_gemm_tn_f32: the fused input gradient needs Mo = No = 64, aligned operands and the bf16x3 mode "
+                  "b4r_gemm_tn_f32: the fused input gradient needs No = 64, Mo %% 64 == 0, aligned operands and the bf16x3 mode "
                   "(b4r_gemm_tn_dgrad_supported)");
   }
   if (g_gemm_mode == B4R_GEMM_BF16X3 && b4r_gemm_rx_tn_supported(d)) return b4r_gemm_rx_tn_launch(d, scratch, (hipStream_t)stream);

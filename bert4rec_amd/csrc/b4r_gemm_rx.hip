@@ -926,12 +926,13 @@ struct RxTnP {
   int a_lim, b_lim;                // first column that may not be fetched (Mo / No rounded up to 4), <= ld
   int tiles_i, tiles_j, S, chunk;  // chunk: rows per slice
   DropArgs drop;
-  // DGRAD (Mo = No = 64, one output tile): dX[R, 64] = dropout(B) . W^T with W [64, ldw] the weight whose gradient `out` is
-  const float* W; float* dX; int ldw, lddx;
+  // DGRAD (No = 64, Mo a multiple of 64): dX[R, Mo] = dropout(B) . W^T with W [Mo, ldw] the weight whose gradient `out` is; the
+  // workgroup of output tile ti forms columns 64 ti .. of dX.  DGRAD == 2: dX is further multiplied by gelu'(G) (G [R, ldg])
+  const float* W; float* dX; const float* G; int ldw, lddx, ldg;
 };
 
 
-template <int KS, bool B_DROP, bool DGRAD>
+template <int KS, bool B_DROP, int DGRAD>
 __global__ __launch_bounds__(256) void rx_gemm_tn_kernel(RxTnP p) {
   constexpr int NLD = KS / 16;                       // float4 per thread per operand per chunk
   constexpr int PLANE = KS * 128;                    // bytes per image
@@ -1013,12 +1014,20 @@ __global__ __launch_bounds__(256) void rx_gemm_tn_kernel(RxTnP p) {
   bf16x8 wh[KS / 16], wl[KS / 16];
   if (DGRAD) {
 #pragma unroll
-    for (int kb = 0; kb < KS / 16; ++kb) split8(load8_contig(p.W + (int64_t)(32 * wn + r) * p.ldw + 16 * kb + 8 * h), wh[kb], wl[kb]);
+    for (int kb = 0; kb < KS / 16; ++kb)
+      split8(load8_contig(p.W + (int64_t)(i0 + 32 * wn + r) * p.ldw + 16 * kb + 8 * h), wh[kb], wl[kb]);
   }
   auto dgrad = [&](int k0) {
-    f32x16 dx;
+    f32x16 dx, gp;
 #pragma unroll
     for (int i = 0; i < 16; ++i) dx[i] = 0.f;
+    if (DGRAD == 2) {   // the pre-activations travel while the products run (rows clamped, stores guarded)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = min(k0 + 32 * wm + (reg & 3) + 8 * (reg >> 2) + 4 * h, p.R - 1);
+        gp[reg] = p.G[(int64_t)row * p.ldg + i0 + 32 * wn + r];
+      }
+    }
 #pragma unroll
     for (int kb = 0; kb < KS / 16; ++kb) {
       const char* src = s_tn + 2 * PLANE + tn_img_off(32 * wm + r, 4 * kb + 2 * h);
@@ -1027,7 +1036,9 @@ __global__ __launch_bounds__(256) void rx_gemm_tn_kernel(RxTnP p) {
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
       const int row = k0 + 32 * wm + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-      if (row < r_end) p.dX[(int64_t)row * p.lddx + 32 * wn + r] = dx[reg];
+      float v = dx[reg];
+      if (DGRAD == 2) v *= b4r_gelu_grad_fast(gp[reg]);
+      if (row < r_end) p.dX[(int64_t)row * p.lddx + i0 + 32 * wn + r] = v;
     }
   };
   // Two register sets alternate: the loads of chunk k+1 are issued at the TOP of iteration k (before the barrier, the
@@ -1221,24 +1232,27 @@ int b4r_gemm_rx_tn_launch(const b4r_gemm_tn_desc* d, float* scratch, hipStream_t
   p.colsum_a_slab = d->colsum_a ? scratch + (int64_t)S * d->Mo * d->No + (int64_t)S * d->No : nullptr;
   p.drop = b4r_make_drop(d->rng, d->drop_stream, d->drop_rate, 1);
   const bool b_drop = d->b_dropout && p.drop.rng != nullptr;
-  const bool dgrad = d->dgrad_out != nullptr;   // b4r_gemm_tn_f32 has checked the shape contract (Mo = No = 64)
-  p.W = d->dgrad_w; p.ldw = d->dgrad_ldw; p.dX = d->dgrad_out; p.lddx = d->dgrad_ldo;
+  const int dgrad = d->dgrad_out == nullptr ? 0 : (d->dgrad_gelu_pre ? 2 : 1);   // b4r_gemm_tn_f32 has checked the shape contract
+  p.W = d->dgrad_w; p.ldw = d->dgrad_ldw; p.dX = d->dgrad_out; p.lddx = d->dgrad_ldo; p.G = d->dgrad_gelu_pre; p.ldg = d->dgrad_ldg;
   const int64_t items = (int64_t)p.tiles_i * p.tiles_j * S;
   dim3 grid(xcd_grid(items));
   constexpr size_t lds = (size_t)4 * TN_KS * 128;
   static bool lds_raised = false;
   if (lds > 48 * 1024 && !lds_raised) {
-    (void)hipFuncSetAttribute((const void*)rx_gemm_tn_kernel<TN_KS, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)rx_gemm_tn_kernel<TN_KS, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)rx_gemm_tn_kernel<TN_KS, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)rx_gemm_tn_kernel<TN_KS, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)rx_gemm_tn_kernel<TN_KS, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)rx_gemm_tn_kernel<TN_KS, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)rx_gemm_tn_kernel<TN_KS, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)rx_gemm_tn_kernel<TN_KS, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)rx_gemm_tn_kernel<TN_KS, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)rx_gemm_tn_kernel<TN_KS, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     lds_raised = true;
   }
-  if (dgrad) {
-    if (b_drop) hipLaunchKernelGGL((rx_gemm_tn_kernel<TN_KS, true, true>), grid, dim3(256), lds, stream, p);
-    else hipLaunchKernelGGL((rx_gemm_tn_kernel<TN_KS, false, true>), grid, dim3(256), lds, stream, p);
-  } else if (b_drop) hipLaunchKernelGGL((rx_gemm_tn_kernel<TN_KS, true, false>), grid, dim3(256), lds, stream, p);
-  else hipLaunchKernelGGL((rx_gemm_tn_kernel<TN_KS, false, false>), grid, dim3(256), lds, stream, p);
+#define B4R_TN_LAUNCH(BD, DG) hipLaunchKernelGGL((rx_gemm_tn_kernel<TN_KS, BD, DG>), grid, dim3(256), lds, stream, p)
+  if (dgrad == 2) { if (b_drop) B4R_TN_LAUNCH(true, 2); else B4R_TN_LAUNCH(false, 2); }
+  else if (dgrad == 1) { if (b_drop) B4R_TN_LAUNCH(true, 1); else B4R_TN_LAUNCH(false, 1); }
+  else if (b_drop) B4R_TN_LAUNCH(true, 0);
+  else B4R_TN_LAUNCH(false, 0);
+#undef B4R_TN_LAUNCH
   B4R_CHECK_LAUNCH("b4r_gemm_tn_f32 (bf16x3)");
   return b4r_launch_slab_reduce_full(p.slab, S, d->Mo, d->No, d->out, d->ldo, d->accumulate, p.colsum_slab, d->colsum,
                                      p.colsum_a_slab, d->colsum_a, stream);

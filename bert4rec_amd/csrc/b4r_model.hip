@@ -285,6 +285,13 @@ int dgrad_ln_bwd(const float* A, int lda, const float* W, int K, const float* R,
                            b4r_make_drop(rng, drop_stream, drop_rate, 1), s, nullptr);
 }
 
+// pair kernels (input gradient inside the weight-gradient kernel, b4r_gemm_tn_desc.dgrad_*): B4R_PAIR bit 0 = the 64 x 64 layers
+// (attention output, masked-LM transform), bit 1 = the FFN output layer with its GELU' tail
+int pair_level() {
+  static const int lv = getenv("B4R_PAIR") ? atoi(getenv("B4R_PAIR")) : 3;
+  return lv;
+}
+
 // ---- a second stream for the branches of the backward pass that nothing downstream waits for -------------------------
 // (weight-gradient products, the dE sweep of the fused head, dK/dV next to dQ).  The idea: every kernel of this workload
 // leaves part of the chip idle at its start and tail, a concurrent independent kernel could fill those holes.  MEASURED
@@ -558,8 +565,7 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
     d.A = ws + w.gath; d.lda = H; d.B = ws + w.dt; d.ldb = H; d.out = grads + pl.wd; d.ldo = H; d.R = M; d.Mo = H; d.No = H;
     d.colsum = grads + pl.bd;
     d.dgrad_w = params + pl.wd; d.dgrad_ldw = H; d.dgrad_out = ws + w.dg; d.dgrad_ldo = H;
-    static const bool pair = !(getenv("B4R_PAIR") && atoi(getenv("B4R_PAIR")) == 0);
-    if (pair && b4r_gemm_tn_dgrad_supported(&d)) {
+    if ((pair_level() & 1) && b4r_gemm_tn_dgrad_supported(&d)) {
       RC(b4r_gemm_tn_f32(&d, take(b4r_gemm_tn_scratch_floats(M, H, H)), (b4r_stream_t)s));
     } else {
       RC(order_after(s, s_tn));
@@ -581,12 +587,24 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
     if (i == cfg->num_layers - 1)
       RC(b4r_ln_bwd_launch(ws + w.dx, ws + w.z2[i], ws + w.mean2[i], ws + w.rstd2[i], params + pl.ln2_g[i], N, H, ws + w.da,
                            grads + pl.ln2_g[i], grads + pl.ln2_b[i], take(ln_scratch), nullptr, nullptr, nullptr, 1, 1, nodrop, s));
-    // FFN: dFpre = (dropmask(dz2) . W2^T) * gelu'(fpre)
-    RC(gemm(ws + w.da, H, params + pl.w2[i], H, ws + w.df, I, N, I, H, 1, B4R_EPI_GELU_BWD, nullptr, nullptr, 0, ws + w.fpre[i],
-            I, 1.f, 0, rng, B4R_STREAM_FFN_OUT(i), od, 1, s));
-    RC(order_after(s, s_tn));
-    RC(gemm_tn(ws + w.f[i], I, ws + w.da, H, grads + pl.w2[i], H, N, I, H, grads + pl.b2[i], nullptr, rng, B4R_STREAM_FFN_OUT(i),
-               od, 1, take(b4r_gemm_tn_scratch_floats(N, I, H)), s_tn));
+    // FFN: dFpre = (dropmask(dz2) . W2^T) * gelu'(fpre) and dW2 = f^T . dropmask(dz2) (+ bias gradient): one pass over dz2
+    // where the pair kernel applies (B4R_PAIR bit 1), else two products
+    {
+      b4r_gemm_tn_desc d{};
+      d.A = ws + w.f[i]; d.lda = I; d.B = ws + w.da; d.ldb = H; d.out = grads + pl.w2[i]; d.ldo = H; d.R = N; d.Mo = I; d.No = H;
+      d.colsum = grads + pl.b2[i]; d.rng = rng; d.drop_stream = B4R_STREAM_FFN_OUT(i); d.drop_rate = od; d.b_dropout = 1;
+      d.dgrad_w = params + pl.w2[i]; d.dgrad_ldw = H; d.dgrad_out = ws + w.df; d.dgrad_ldo = I;
+      d.dgrad_gelu_pre = ws + w.fpre[i]; d.dgrad_ldg = I;
+      if ((pair_level() & 2) && b4r_gemm_tn_dgrad_supported(&d)) {
+        RC(b4r_gemm_tn_f32(&d, take(b4r_gemm_tn_scratch_floats(N, I, H)), (b4r_stream_t)s));
+      } else {
+        RC(gemm(ws + w.da, H, params + pl.w2[i], H, ws + w.df, I, N, I, H, 1, B4R_EPI_GELU_BWD, nullptr, nullptr, 0, ws + w.fpre[i],
+                I, 1.f, 0, rng, B4R_STREAM_FFN_OUT(i), od, 1, s));
+        RC(order_after(s, s_tn));
+        RC(gemm_tn(ws + w.f[i], I, ws + w.da, H, grads + pl.w2[i], H, N, I, H, grads + pl.b2[i], nullptr, rng,
+                   B4R_STREAM_FFN_OUT(i), od, 1, take(b4r_gemm_tn_scratch_floats(N, I, H)), s_tn));
+      }
+    }
     // dz1 = attention LayerNorm backward of dX1 = dFpre . W1^T + dz2
     RC(dgrad_ln_bwd(ws + w.df, I, params + pl.w1[i], I, ws + w.da, ws + w.db, N, H, ws + w.z1[i], ws + w.mean1[i], ws + w.rstd1[i],
                     params + pl.ln1_g[i], grads + pl.ln1_g[i], grads + pl.ln1_b[i], take(ln_scratch), s));
@@ -600,8 +618,7 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
       d.A = ws + w.ctx[i]; d.lda = H; d.B = ws + w.db; d.ldb = H; d.out = grads + pl.wo[i]; d.ldo = H; d.R = N; d.Mo = H; d.No = H;
       d.colsum = grads + pl.bo[i]; d.rng = rng; d.drop_stream = B4R_STREAM_ATTN_OUT(i); d.drop_rate = od; d.b_dropout = 1;
       d.dgrad_w = params + pl.wo[i]; d.dgrad_ldw = H; d.dgrad_out = ws + w.dctx; d.dgrad_ldo = H;
-      static const bool pair = !(getenv("B4R_PAIR") && atoi(getenv("B4R_PAIR")) == 0);
-      if (pair && b4r_gemm_tn_dgrad_supported(&d)) {
+      if ((pair_level() & 1) && b4r_gemm_tn_dgrad_supported(&d)) {
         RC(b4r_gemm_tn_f32(&d, take(b4r_gemm_tn_scratch_floats(N, H, H)), (b4r_stream_t)s));
       } else {
         RC(gemm(ws + w.db, H, params + pl.wo[i], H, ws + w.dctx, H, N, H, H, 1, B4R_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 1.f,

@@ -281,9 +281,11 @@ typedef struct b4r_gemm_tn_desc {
   int32_t accumulate; /* 1: out += result (out must hold defined values) */
   /* optional (dgrad_out != NULL; zero otherwise): the input gradient of the same dense layer from the same pass over B,
    *   dgrad_out[R, Mo] = dropout(B) . dgrad_w^T   with dgrad_w [Mo, dgrad_ldw >= No] the forward weight whose gradient `out` is
-   * (y = x.W: dW = x^T.dy and dx = dy.W^T read dy once).  Only Mo = No = 64 in the B4R_GEMM_BF16X3 mode
+   * (y = x.W: dW = x^T.dy and dx = dy.W^T read dy once), optionally times gelu'(dgrad_gelu_pre [R, dgrad_ldg >= Mo]) -- the
+   * layer's input was gelu(pre).  Only No = 64 and Mo a multiple of 64 in the B4R_GEMM_BF16X3 mode
    * (b4r_gemm_tn_dgrad_supported), otherwise B4R_E_SHAPE: callers then issue b4r_gemm_f32 with a_dropout for dx */
   const float* dgrad_w; int32_t dgrad_ldw; float* dgrad_out; int32_t dgrad_ldo;
+  const float* dgrad_gelu_pre; int32_t dgrad_ldg;
 } b4r_gemm_tn_desc;
 int64_t b4r_gemm_tn_scratch_floats(int32_t R, int32_t Mo, int32_t No);
 int b4r_gemm_tn_f32(const b4r_gemm_tn_desc* d, float* scratch, b4r_stream_t stream);

@@ -216,6 +216,37 @@ def test_gemm_tn_weight_gradient(R, Mo, No):
     assert torch.equal(out, out2) and torch.equal(cs, cs2)
 
 
+@pytest.mark.parametrize("R,Mo,rate", [(1000, 256, 0.2), (300, 128, 0.0)])
+def test_gemm_tn_with_fused_input_gradient_and_gelu_tail(R, Mo, rate):
+    """the FFN output layer's pair: dW2 = f^T.drop(dz) and dFpre = (drop(dz).W2^T) * gelu'(fpre) from one pass over dz."""
+    No = 64
+    seed, step, sid = 8, 3, 7
+    lib = _lib.load()
+    A, B, W, G = rnd(R, Mo, seed=1), rnd(R, No, seed=2), rnd(Mo, No, seed=3, scale=0.3), rnd(R, Mo, seed=4, scale=1.5)
+    st = T.new_state(seed, step)
+    keep = orc.dropout_keep_mask((R, No), rate, seed, step, sid).double() if rate > 0 else torch.ones(R, No, dtype=torch.float64)
+    Bd = B.double() * keep / (1 - rate)
+    dev = [t.to(DEV) for t in (A, B, W, G)]
+    out = torch.full((Mo, No), float("nan"), device=DEV)
+    cs = torch.full((No,), float("nan"), device=DEV)
+    dx = torch.full((R, Mo), float("nan"), device=DEV)
+    scratch = torch.empty(lib.b4r_gemm_tn_scratch_floats(R, Mo, No), device=DEV)
+    d = _lib.GemmTnDesc()
+    d.A, d.lda, d.B, d.ldb, d.out, d.ldo = T.P(dev[0]), Mo, T.P(dev[1]), No, T.P(out), No
+    d.R, d.Mo, d.No, d.colsum = R, Mo, No, T.P(cs)
+    d.rng, d.drop_stream, d.drop_rate, d.b_dropout = (T.P(st) if rate > 0 else None), sid, rate, 1
+    d.dgrad_w, d.dgrad_ldw, d.dgrad_out, d.dgrad_ldo = T.P(dev[2]), No, T.P(dx), Mo
+    d.dgrad_gelu_pre, d.dgrad_ldg = T.P(dev[3]), Mo
+    if lib.b4r_get_gemm_mode() != 1:
+        assert lib.b4r_gemm_tn_dgrad_supported(C.byref(d)) == 0
+        return
+    assert lib.b4r_gemm_tn_dgrad_supported(C.byref(d)) == 1
+    _lib.check(lib.b4r_gemm_tn_f32(C.byref(d), T.P(scratch), T.stream()), "b4r_gemm_tn_f32")
+    assert T.maxdiff(out, A.double().t() @ Bd) < 2e-5 * math.sqrt(R) * 4
+    assert T.maxdiff(cs, Bd.sum(0)) < 2e-5 * math.sqrt(R) * 4
+    assert T.maxdiff(dx, (Bd @ W.double().t()) * gelu_grad(G.double())) < 2e-4   # A&S erf in gelu' (1.5e-7) x |dx| up to ~10
+
+
 @pytest.mark.parametrize("R,rate", [(1000, 0.2), (4096, 0.0), (200, 0.1), (70, 0.2)])
 def test_gemm_tn_with_fused_input_gradient(R, rate):
     """b4r_gemm_tn_f32 with dgrad_out: dW = A^T.drop(B) (+ column sums) AND dX = drop(B).W^T from one pass over B (the pair

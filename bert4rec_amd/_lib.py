@@ -42,7 +42,7 @@ class GemmDesc(C.Structure):
                 ("c_pad_scratch", C.c_int32), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_mean", C.c_void_p),
                 ("ln_rstd", C.c_void_p), ("ln_eps", C.c_float), ("ln_z", C.c_void_p), ("ln_ldz", C.c_int32),
                 ("ln_dgamma", C.c_void_p), ("ln_dbeta", C.c_void_p), ("ln_ids", C.c_void_p), ("ln_table", C.c_void_p),
-                ("ln_pos", C.c_void_p), ("ln_L", C.c_int32), ("ln_V", C.c_int32)]
+                ("ln_pos", C.c_void_p), ("ln_L", C.c_int32), ("ln_V", C.c_int32), ("C3", C.c_void_p), ("ldc3", C.c_int32)]
 
 
 class GemmTnDesc(C.Structure):
@@ -59,7 +59,7 @@ ST_SEED, ST_STEP_LO, ST_STEP = 0, 1, 2  # step is int64 at words 2..3
 ST_LOSS_SUM, ST_VALID, ST_CORRECT_MASKED, ST_CORRECT_ALL, ST_SLOTS_ALL, ST_SQNORM, ST_GRAD_NORM, ST_LR = range(4, 12)
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_QSCALE, EPI_BIAS_GELU, EPI_BIAS_DROP_RES, EPI_GELU_BWD, EPI_ADD_RES, EPI_BIAS_TANH = range(8)
-EPI_BIAS_DROP_RES_LN, EPI_ADD_RES_LN_BWD = 8, 9
+EPI_BIAS_DROP_RES_LN, EPI_ADD_RES_LN_BWD, EPI_BIAS_GELU_LN = 8, 9, 10
 FLAG_TRAINING, FLAG_POOLER, FLAG_FUSED_HEAD = 1, 2, 4
 LOSS_FUSED_HEAD = 2
 GEMM_F32, GEMM_BF16X3 = 0, 1

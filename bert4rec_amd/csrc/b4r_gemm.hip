@@ -497,8 +497,10 @@ extern "C" int b4r_get_gemm_mode(void) { return g_gemm_mode; }
 
 extern "C" int64_t b4r_gemm_ln_bwd_partial_floats(int32_t M) { return (int64_t)b4r_cdiv(M > 0 ? M : 1, 64) * 128; }
 extern "C" int b4r_gemm_ln_supported(const b4r_gemm_desc* d) {
-  return (d != nullptr && (d->epilogue == B4R_EPI_BIAS_DROP_RES_LN || d->epilogue == B4R_EPI_ADD_RES_LN_BWD) && g_gemm_mode == B4R_GEMM_BF16X3 && d->A && d->B && d->C &&
-          d->M > 0 && d->R && d->ldr >= d->N && b4r_gemm_rx_supported(d)) ? 1 : 0;
+  if (d == nullptr || g_gemm_mode != B4R_GEMM_BF16X3 || !d->A || !d->B || !d->C || d->M <= 0) return 0;
+  if (d->epilogue == B4R_EPI_BIAS_GELU_LN) return b4r_gemm_rx_supported(d) ? 1 : 0;
+  return ((d->epilogue == B4R_EPI_BIAS_DROP_RES_LN || d->epilogue == B4R_EPI_ADD_RES_LN_BWD) && d->R && d->ldr >= d->N &&
+          b4r_gemm_rx_supported(d)) ? 1 : 0;
 }
 
 extern "C" int b4r_gemm_f32(const b4r_gemm_desc* d, b4r_stream_t stream) {
@@ -509,13 +511,20 @@ extern "C" int b4r_gemm_f32(const b4r_gemm_desc* d, b4r_stream_t stream) {
                 "b4r_gemm_f32: leading dimension smaller than the row length");
   const int epi = d->epilogue;
   const bool needs_bias = epi == B4R_EPI_BIAS || epi == B4R_EPI_BIAS_QSCALE || epi == B4R_EPI_BIAS_GELU ||
-                          epi == B4R_EPI_BIAS_DROP_RES || epi == B4R_EPI_BIAS_TANH || epi == B4R_EPI_BIAS_DROP_RES_LN;
+                          epi == B4R_EPI_BIAS_DROP_RES || epi == B4R_EPI_BIAS_TANH || epi == B4R_EPI_BIAS_DROP_RES_LN ||
+                          epi == B4R_EPI_BIAS_GELU_LN;
   B4R_CHECK_ARG(!needs_bias || d->bias, B4R_E_BADARG, "b4r_gemm_f32: epilogue %d needs a bias", epi);
   const bool needs_r = epi == B4R_EPI_BIAS_DROP_RES || epi == B4R_EPI_GELU_BWD || epi == B4R_EPI_ADD_RES ||
                        epi == B4R_EPI_BIAS_DROP_RES_LN || epi == B4R_EPI_ADD_RES_LN_BWD;
   B4R_CHECK_ARG(!needs_r || (d->R && d->ldr >= d->N), B4R_E_BADARG, "b4r_gemm_f32: epilogue %d needs R", epi);
   B4R_CHECK_ARG(epi != B4R_EPI_BIAS_GELU || (d->C2 && d->ldc2 >= d->N), B4R_E_BADARG, "b4r_gemm_f32: BIAS_GELU needs C2");
-  B4R_CHECK_ARG(epi >= B4R_EPI_NONE && epi <= B4R_EPI_ADD_RES_LN_BWD, B4R_E_BADARG, "b4r_gemm_f32: unknown epilogue %d", epi);
+  B4R_CHECK_ARG(epi >= B4R_EPI_NONE && epi <= B4R_EPI_BIAS_GELU_LN, B4R_E_BADARG, "b4r_gemm_f32: unknown epilogue %d", epi);
+  if (epi == B4R_EPI_BIAS_GELU_LN) {
+    B4R_CHECK_ARG(d->C2 && d->C3 && d->ln_gamma && d->ln_beta, B4R_E_BADARG, "b4r_gemm_f32: BIAS_GELU_LN needs C2, C3, ln_gamma, ln_beta");
+    B4R_CHECK_ARG(b4r_gemm_ln_supported(d), B4R_E_SHAPE,
+                  "b4r_gemm_f32: BIAS_GELU_LN not available for M=%d N=%d K=%d in this mode (b4r_gemm_ln_supported)", d->M, d->N,
+                  d->K);
+  }
   if (epi == B4R_EPI_ADD_RES_LN_BWD) {
     B4R_CHECK_ARG(d->C2 && d->ln_gamma && (d->ln_z || d->ln_ids) && d->ln_mean && d->ln_rstd && d->ln_dgamma, B4R_E_BADARG,
                   "b4r_gemm_f32: ADD_RES_LN_BWD needs C2 (partials), ln_gamma, ln_z (or ln_ids), ln_mean, ln_rstd, ln_dgamma");

@@ -62,6 +62,7 @@ struct RxP {
   // ... of the embedding stage (ln_ids != nullptr): z = ln_table[id] + ln_pos[row % ln_L] is recomputed, dy first goes back
   // through the embedding dropout (`drop`, element index row * 64 + col)
   const int64_t* ln_ids; const float* ln_table; const float* ln_pos; int ln_L, ln_V;
+  float* C3; int ldc3;   // B4R_EPI_BIAS_GELU_LN: the pre-activation
 };
 
 __device__ __forceinline__ void split8(const f32x8 x, bf16x8& hi, bf16x8& lo) { b4r_split8(x, hi, lo); }
@@ -107,10 +108,10 @@ __device__ __forceinline__ int xcd_logical_id(int id, int n) {
 inline bool xcd_on() { static const bool on = !(getenv("B4R_XCD") && atoi(getenv("B4R_XCD")) == 0); return on; }
 inline unsigned xcd_grid(int64_t n) { return (unsigned)(((n + 7) >> 3) << 3); }
 
-constexpr int EPI_ADD_RES_LN_BWD_EMBED = 10;   // internal: B4R_EPI_ADD_RES_LN_BWD with ln_ids set
+constexpr int EPI_ADD_RES_LN_BWD_EMBED = 11;   // internal: B4R_EPI_ADD_RES_LN_BWD with ln_ids set
 constexpr bool epi_has_bias(int e) {
   return e == B4R_EPI_BIAS || e == B4R_EPI_BIAS_QSCALE || e == B4R_EPI_BIAS_GELU || e == B4R_EPI_BIAS_DROP_RES ||
-         e == B4R_EPI_BIAS_TANH || e == B4R_EPI_BIAS_DROP_RES_LN;
+         e == B4R_EPI_BIAS_TANH || e == B4R_EPI_BIAS_DROP_RES_LN || e == B4R_EPI_BIAS_GELU_LN;
 }
 constexpr bool epi_has_r(int e) {
   return e == B4R_EPI_BIAS_DROP_RES || e == B4R_EPI_GELU_BWD || e == B4R_EPI_ADD_RES || e == B4R_EPI_BIAS_DROP_RES_LN ||
@@ -200,6 +201,8 @@ __device__ __forceinline__ void epilogue_tile(const RxP& p, const DropCtx& dctx,
 // lanes that share the row, the two waves of a row exchange them through their (now idle) staging areas and merge them
 // (Chan et al.: M2 = M2a + M2b + (ma - mb)^2 n/2 with n = 32 per half), so the variance is a two-pass one like the stand-alone
 // kernel's.  `live` = the quarter's rows exist (M % 32 == 0, so a quarter is whole or absent); every wave takes the barrier.
+// GELU: B4R_EPI_BIAS_GELU_LN instead -- z = gelu(acc + bias) (-> C), the pre-activation goes to C3, no residual / dropout
+template <bool GELU>
 __device__ __forceinline__ void epilogue_tile_ln(const RxP& p, const DropCtx& dctx, const f32x16& acc, const f32x4 bv,
                                                  const RTile& rt, float* stage, float* stage_other, int m0, int n0, int lane,
                                                  bool live) {
@@ -218,7 +221,14 @@ __device__ __forceinline__ void epilogue_tile_ln(const RxP& p, const DropCtx& dc
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = m0 + rsub + 8 * i;
-      z[i] = rt.v[i] + b4r_drop4(dctx, vin[i] + bv, (uint64_t)row * (uint64_t)p.N + (uint64_t)col);
+      if (GELU) {
+        const f32x4 pre = vin[i] + bv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) z[i][e] = b4r_gelu_fast(pre[e]);
+        *reinterpret_cast<f32x4*>(p.C3 + (int64_t)row * p.ldc3 + col) = pre;
+      } else {
+        z[i] = rt.v[i] + b4r_drop4(dctx, vin[i] + bv, (uint64_t)row * (uint64_t)p.N + (uint64_t)col);
+      }
       *reinterpret_cast<f32x4*>(p.C + (int64_t)row * p.ldc + col) = z[i];
       float sw = (z[i][0] + z[i][1]) + (z[i][2] + z[i][3]);
       sw += __shfl_xor(sw, 1, 64); sw += __shfl_xor(sw, 2, 64); sw += __shfl_xor(sw, 4, 64);
@@ -784,14 +794,15 @@ __global__ __launch_bounds__(256) void rx_gemm_wide_kernel(RxP p) {
     for (int c = 0; c < nchunks; ++c) step(q0, c);
   }
   const int c4 = (lane & 7) * 4;
-  if constexpr (EPI == B4R_EPI_BIAS_DROP_RES_LN) {
+  if constexpr (EPI == B4R_EPI_BIAS_DROP_RES_LN || EPI == B4R_EPI_BIAS_GELU_LN) {
     static_assert(TM == 64 && TN == 64, "the LayerNorm epilogue needs whole rows in one workgroup");
     const int ms = m0 + 32 * wm, ns = 32 * wn;   // N == 64: n0 == 0
     const bool live = ms < p.M;
     RTile rt;
     if (live) rt = load_r_tile<EPI>(p, ms, ns, lane);
     float* stage_other = reinterpret_cast<float*>(s_w + A_BYTES + B_BYTES) + (wave ^ 1) * (32 * ST_LD);
-    epilogue_tile_ln(p, dctx, acc[0][0], load_bias4<EPI>(p, ns, c4), rt, stage, stage_other, ms, ns, lane, live);
+    epilogue_tile_ln<EPI == B4R_EPI_BIAS_GELU_LN>(p, dctx, acc[0][0], load_bias4<EPI>(p, ns, c4), rt, stage, stage_other, ms, ns,
+                                                  lane, live);
   } else if constexpr (EPI == B4R_EPI_ADD_RES_LN_BWD || EPI == EPI_ADD_RES_LN_BWD_EMBED) {
     static_assert(TM == 64 && TN == 64, "the LayerNorm epilogue needs whole rows in one workgroup");
     const int ms = m0 + 32 * wm, ns = 32 * wn;
@@ -887,6 +898,10 @@ template <bool B_NK>
 int dispatch_rx(const RxP& p, int epi, bool a_drop, dim3 grid, hipStream_t s) {
   if (epi == B4R_EPI_BIAS_DROP_RES_LN) {   // b4r_gemm_ln_supported: N == 64, B as [K,N], no operand dropout
     launch_wide<false, B4R_EPI_BIAS_DROP_RES_LN, false, 64>(p, s);
+    return B4R_OK;
+  }
+  if (epi == B4R_EPI_BIAS_GELU_LN) {
+    launch_wide<false, B4R_EPI_BIAS_GELU_LN, false, 64>(p, s);
     return B4R_OK;
   }
   if (epi == B4R_EPI_ADD_RES_LN_BWD) {     // N == 64, B as [N,K]
@@ -1126,9 +1141,10 @@ bool b4r_gemm_rx_supported(const b4r_gemm_desc* d) {
   const int epi = d->epilogue;
   if (epi_has_r(epi) && (!vec_ok(d->R, d->ldr) || ns > d->ldr)) return false;
   if (epi == B4R_EPI_BIAS_GELU && (!vec_ok(d->C2, d->ldc2) || ns > d->ldc2)) return false;
-  if (epi == B4R_EPI_BIAS_DROP_RES_LN) {
+  if (epi == B4R_EPI_BIAS_DROP_RES_LN || epi == B4R_EPI_BIAS_GELU_LN) {
     if (d->N != 64 || d->K < 64 || d->K % WIDE_KC != 0 || d->b_is_nk || d->a_dropout) return false;
     if (!vec_ok(d->C2, d->ldc2) || d->ldc2 < 64 || !vec_ok(d->ln_gamma, 4) || !vec_ok(d->ln_beta, 4)) return false;
+    if (epi == B4R_EPI_BIAS_GELU_LN && (!vec_ok(d->C3, d->ldc3) || d->ldc3 < 64)) return false;
   }
   if (epi == B4R_EPI_ADD_RES_LN_BWD) {
     if (d->N != 64 || d->K < 64 || d->K % WIDE_KC != 0 || !d->b_is_nk || d->a_dropout) return false;
@@ -1153,6 +1169,7 @@ int b4r_gemm_rx_launch(const b4r_gemm_desc* d, hipStream_t stream) {
   p.ln_gamma = d->ln_gamma; p.ln_beta = d->ln_beta; p.ln_mean = d->ln_mean; p.ln_rstd = d->ln_rstd; p.ln_eps = d->ln_eps;
   p.ln_z = d->ln_z; p.ln_ldz = d->ln_ldz;
   p.ln_ids = d->ln_ids; p.ln_table = d->ln_table; p.ln_pos = d->ln_pos; p.ln_L = d->ln_L; p.ln_V = d->ln_V;
+  p.C3 = d->C3; p.ldc3 = d->ldc3;
   p.drop = b4r_make_drop(d->rng, d->drop_stream, d->drop_rate, 1);
   p.k_chunks_per_split = d->K / 64 > 0 ? d->K / 64 : 1; p.slab_stride = 0;
   const bool a_drop = d->a_dropout && p.drop.rng != nullptr;

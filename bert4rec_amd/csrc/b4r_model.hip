@@ -465,9 +465,23 @@ extern "C" int b4r_forward(const b4r_model_config* cfg, const b4r_batch* batch, 
   if (P > 0) {
     // tfm MaskedLM: gather -> dense(gelu) -> LayerNorm -> . E^T + bias
     RC(b4r_gather_rows(x, H, batch->masked_lm_positions, L, P, M, H, ws + w.gath, stream));
-    RC(gemm(ws + w.gath, H, params + pl.wd, H, ws + w.u, H, M, H, H, 0, B4R_EPI_BIAS_GELU, params + pl.bd, ws + w.upre, H,
-            nullptr, 0, 1.f, 0, nullptr, 0, 0.f, 0, s));
-    RC(b4r_ln_fwd(ws + w.u, M, H, params + pl.lnm_g, params + pl.lnm_b, cfg->ln_eps, ws + w.t, ws + w.meanm, ws + w.rstdm, stream));
+    {   // dense(gelu) + LayerNorm: one launch where the LayerNorm tail applies (hidden size 64), else two
+      static const bool fuse = !(getenv("B4R_FUSE_LN") && atoi(getenv("B4R_FUSE_LN")) == 0);
+      b4r_gemm_desc d{};
+      d.A = ws + w.gath; d.lda = H; d.B = params + pl.wd; d.ldb = H; d.C = ws + w.u; d.ldc = H; d.M = M; d.N = H; d.K = H;
+      d.epilogue = B4R_EPI_BIAS_GELU_LN; d.bias = params + pl.bd; d.C2 = ws + w.t; d.ldc2 = H; d.C3 = ws + w.upre; d.ldc3 = H;
+      d.qscale = 1.f; d.c_pad_scratch = 1;
+      d.ln_gamma = params + pl.lnm_g; d.ln_beta = params + pl.lnm_b; d.ln_mean = ws + w.meanm; d.ln_rstd = ws + w.rstdm;
+      d.ln_eps = cfg->ln_eps;
+      if (fuse && b4r_gemm_ln_supported(&d)) {
+        RC(b4r_gemm_f32(&d, (b4r_stream_t)s));
+      } else {
+        RC(gemm(ws + w.gath, H, params + pl.wd, H, ws + w.u, H, M, H, H, 0, B4R_EPI_BIAS_GELU, params + pl.bd, ws + w.upre, H,
+                nullptr, 0, 1.f, 0, nullptr, 0, 0.f, 0, s));
+        RC(b4r_ln_fwd(ws + w.u, M, H, params + pl.lnm_g, params + pl.lnm_b, cfg->ln_eps, ws + w.t, ws + w.meanm, ws + w.rstdm,
+                      stream));
+      }
+    }
     if (flags & B4R_FLAG_FUSED_HEAD) {
       // no [M,V] tensor: loss rows, log-sum-exp and d loss_sum / d T straight from T, E and the bias
       B4R_CHECK_ARG(b4r_fused_head_supported(cfg), B4R_E_BADARG, "b4r_forward: B4R_FLAG_FUSED_HEAD needs hidden size 64 / 128 / 256 and the bf16x3 mode");

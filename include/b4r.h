@@ -220,7 +220,10 @@ enum {
    * ln_dgamma [64] = sum_rows dy xhat and ln_dbeta [64] = sum_rows dy via the partials C2
    * (b4r_gemm_ln_bwd_partial_floats(M) floats) and an ordered reduction.  The input-gradient product in front of a
    * LayerNorm backward + that backward in one launch.  N == 64, B as [N,K] only (b4r_gemm_ln_supported) */
-  B4R_EPI_ADD_RES_LN_BWD = 9
+  B4R_EPI_ADD_RES_LN_BWD = 9,
+  /* C3 = acc + bias ; C = gelu_erf(C3) ; C2 = LayerNorm(C) * ln_gamma + ln_beta ; ln_mean / ln_rstd: the dense(gelu) ->
+   * LayerNorm transform of tfm MaskedLM in one launch.  N == 64 only (b4r_gemm_ln_supported) */
+  B4R_EPI_BIAS_GELU_LN = 10
 };
 typedef struct b4r_gemm_desc {
   const float* A; int32_t lda;   /* [M,K] row-major                                       */
@@ -249,6 +252,7 @@ typedef struct b4r_gemm_desc {
    * dropout that followed the LayerNorm (rng / drop_stream / drop_rate, element index row*64+col)
    * (bert4rec_encoder.py:186-199: embeddings -> LayerNorm -> dropout) */
   const int64_t* ln_ids; const float* ln_table; const float* ln_pos; int32_t ln_L, ln_V;
+  float* C3; int32_t ldc3;       /* B4R_EPI_BIAS_GELU_LN: the pre-activation [M, N] */
 } b4r_gemm_desc;
 /* Arithmetic of the dense layers (process-wide switch; default B4R_GEMM_BF16X3):
  *   B4R_GEMM_F32     exact fp32 matrix cores (v_mfma_f32_32x32x2_f32), LDS-tiled
@@ -262,7 +266,7 @@ int b4r_get_gemm_mode(void);
 /* dense layers of the encoder / MLM head (Keras Dense / EinsumDense / MultiHeadAttention projections) on the exact
  * fp32 matrix cores (v_mfma_f32_32x32x2_f32) */
 int b4r_gemm_f32(const b4r_gemm_desc* d, b4r_stream_t stream);
-/* 1 when b4r_gemm_f32 accepts this descriptor with B4R_EPI_BIAS_DROP_RES_LN or B4R_EPI_ADD_RES_LN_BWD (B4R_GEMM_BF16X3
+/* 1 when b4r_gemm_f32 accepts this descriptor with B4R_EPI_BIAS_DROP_RES_LN, B4R_EPI_BIAS_GELU_LN or B4R_EPI_ADD_RES_LN_BWD (B4R_GEMM_BF16X3
  * mode, N == 64, K a multiple of 64, B as [K,N] for the former and [N,K] for the latter, no operand dropout, 16-byte
  * aligned operands), else 0: callers then issue B4R_EPI_BIAS_DROP_RES + b4r_ln_fwd, or B4R_EPI_ADD_RES + b4r_ln_bwd */
 int b4r_gemm_ln_supported(const b4r_gemm_desc* d);

@@ -122,6 +122,37 @@ def test_gemm_residual_layernorm_epilogue(M, K, rate):
     assert lib.b4r_gemm_f32(C.byref(d), T.stream()) == -2   # B4R_E_SHAPE
 
 
+@pytest.mark.parametrize("M,K", [(224, 64), (96, 128)])
+def test_gemm_gelu_layernorm_epilogue(M, K):
+    """B4R_EPI_BIAS_GELU_LN (hidden size 64): the dense(gelu) -> LayerNorm transform of tfm MaskedLM from one launch."""
+    N, eps = 64, 1e-12
+    lib = _lib.load()
+    A, B, bias = rnd(M, K, seed=1), rnd(K, N, seed=2, scale=0.2), rnd(N, seed=3)
+    g, b = 1.0 + rnd(N, seed=5, scale=0.2), rnd(N, seed=6, scale=0.2)
+    pre_ref = A.double() @ B.double() + bias.double()
+    u_ref = gelu(pre_ref)
+    mean_ref, var_ref = u_ref.mean(1), u_ref.var(1, unbiased=False)
+    t_ref = (u_ref - mean_ref[:, None]) / torch.sqrt(var_ref[:, None] + eps) * g.double() + b.double()
+    dev = [t.to(DEV) for t in (A, B, bias, g, b)]
+    u, t, pre = (torch.full((M, N), float("nan"), device=DEV) for _ in range(3))
+    mean, rstd = torch.full((M,), float("nan"), device=DEV), torch.full((M,), float("nan"), device=DEV)
+    d = _lib.GemmDesc()
+    d.A, d.lda, d.B, d.ldb, d.C, d.ldc = T.P(dev[0]), K, T.P(dev[1]), N, T.P(u), N
+    d.M, d.N, d.K, d.b_is_nk, d.epilogue, d.bias, d.qscale = M, N, K, 0, _lib.EPI_BIAS_GELU_LN, T.P(dev[2]), 1.0
+    d.C2, d.ldc2, d.C3, d.ldc3 = T.P(t), N, T.P(pre), N
+    d.ln_gamma, d.ln_beta, d.ln_mean, d.ln_rstd, d.ln_eps = T.P(dev[3]), T.P(dev[4]), T.P(mean), T.P(rstd), eps
+    if lib.b4r_get_gemm_mode() != 1:
+        assert lib.b4r_gemm_ln_supported(C.byref(d)) == 0
+        assert lib.b4r_gemm_f32(C.byref(d), T.stream()) == -2   # B4R_E_SHAPE
+        return
+    assert lib.b4r_gemm_ln_supported(C.byref(d)) == 1
+    _lib.check(lib.b4r_gemm_f32(C.byref(d), T.stream()), "b4r_gemm_f32")
+    assert T.maxdiff(pre, pre_ref) < 5e-5
+    assert T.maxdiff(u, u_ref) < 5e-5
+    assert T.maxdiff(t, t_ref) < 2e-4      # the LayerNorm divides by the small spread of gelu outputs
+    assert T.maxdiff(mean, mean_ref) < 1e-5
+
+
 @pytest.mark.parametrize("M,K,embed", [(224, 192, False), (96, 256, False), (512, 64, False), (32, 128, False),
                                        (224, 192, True), (96, 64, True)])
 def test_gemm_layernorm_backward_epilogue(M, K, embed):

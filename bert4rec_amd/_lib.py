@@ -42,7 +42,9 @@ class GemmDesc(C.Structure):
                 ("c_pad_scratch", C.c_int32), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_mean", C.c_void_p),
                 ("ln_rstd", C.c_void_p), ("ln_eps", C.c_float), ("ln_z", C.c_void_p), ("ln_ldz", C.c_int32),
                 ("ln_dgamma", C.c_void_p), ("ln_dbeta", C.c_void_p), ("ln_ids", C.c_void_p), ("ln_table", C.c_void_p),
-                ("ln_pos", C.c_void_p), ("ln_L", C.c_int32), ("ln_V", C.c_int32), ("C3", C.c_void_p), ("ldc3", C.c_int32)]
+                ("ln_pos", C.c_void_p), ("ln_L", C.c_int32), ("ln_V", C.c_int32), ("C3", C.c_void_p), ("ldc3", C.c_int32),
+                ("a_gather_idx", C.c_void_p), ("a_gather_add_per", C.c_int64), ("a_gather_per", C.c_int32), ("a_copy", C.c_void_p),
+                ("a_copy_ld", C.c_int32)]
 
 
 class GemmTnDesc(C.Structure):

@@ -519,6 +519,11 @@ extern "C" int b4r_gemm_f32(const b4r_gemm_desc* d, b4r_stream_t stream) {
   B4R_CHECK_ARG(!needs_r || (d->R && d->ldr >= d->N), B4R_E_BADARG, "b4r_gemm_f32: epilogue %d needs R", epi);
   B4R_CHECK_ARG(epi != B4R_EPI_BIAS_GELU || (d->C2 && d->ldc2 >= d->N), B4R_E_BADARG, "b4r_gemm_f32: BIAS_GELU needs C2");
   B4R_CHECK_ARG(epi >= B4R_EPI_NONE && epi <= B4R_EPI_BIAS_GELU_LN, B4R_E_BADARG, "b4r_gemm_f32: unknown epilogue %d", epi);
+  B4R_CHECK_ARG(d->a_gather_idx == nullptr || (epi == B4R_EPI_BIAS_GELU_LN && d->a_gather_add_per > 0 && d->a_gather_per > 0),
+                B4R_E_BADARG, "b4r_gemm_f32: a_gather_idx only with B4R_EPI_BIAS_GELU_LN (and a_gather_add_per, a_gather_per > 0)");
+  B4R_CHECK_ARG(d->a_copy == nullptr || (d->a_gather_idx != nullptr && d->a_copy_ld >= d->K && d->a_copy_ld % 4 == 0 &&
+                                         b4r_aligned16(d->a_copy)),
+                B4R_E_BADARG, "b4r_gemm_f32: a_copy needs a_gather_idx, a_copy_ld >= K (multiple of 4) and 16-byte alignment");
   if (epi == B4R_EPI_BIAS_GELU_LN) {
     B4R_CHECK_ARG(d->C2 && d->C3 && d->ln_gamma && d->ln_beta, B4R_E_BADARG, "b4r_gemm_f32: BIAS_GELU_LN needs C2, C3, ln_gamma, ln_beta");
     B4R_CHECK_ARG(b4r_gemm_ln_supported(d), B4R_E_SHAPE,

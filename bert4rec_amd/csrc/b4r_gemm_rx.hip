@@ -63,6 +63,10 @@ struct RxP {
   // through the embedding dropout (`drop`, element index row * 64 + col)
   const int64_t* ln_ids; const float* ln_table; const float* ln_pos; int ln_L, ln_V;
   float* C3; int ldc3;   // B4R_EPI_BIAS_GELU_LN: the pre-activation
+  // gathered A rows (tile kernel, B4R_EPI_BIAS_GELU_LN only): row m of the product reads row
+  // clamp(a_idx[m], 0, a_add_per - 1) + (m / a_per) * a_add_per of A, as b4r_gather_rows does; a_copy [M, a_copy_ld] (optional)
+  // receives the gathered rows (the weight-gradient product of the backward pass reads them again)
+  const int64_t* a_idx; int64_t a_add_per; int a_per; float* a_copy; int a_copy_ld;
 };
 
 __device__ __forceinline__ void split8(const f32x8 x, bf16x8& hi, bf16x8& lo) { b4r_split8(x, hi, lo); }
@@ -683,7 +687,16 @@ __global__ __launch_bounds__(256) void rx_gemm_wide_kernel(RxP p) {
 #pragma unroll
     for (int it = 0; it < NA; ++it) {
       const int f = tid + 256 * it;
-      q.ra[it] = *reinterpret_cast<const f32x4*>(p.A + (int64_t)min(m0 + (f >> 3), p.M - 1) * p.lda + k0 + 4 * (f & 7));
+      const int m = min(m0 + (f >> 3), p.M - 1);
+      int64_t src = m;
+      if (p.a_idx) {   // block-uniform
+        int64_t pos = p.a_idx[m];
+        pos = pos < 0 ? 0 : (pos >= p.a_add_per ? p.a_add_per - 1 : pos);
+        src = pos + (int64_t)(m / p.a_per) * p.a_add_per;
+      }
+      q.ra[it] = *reinterpret_cast<const f32x4*>(p.A + src * p.lda + k0 + 4 * (f & 7));
+      if (p.a_copy && n0 == 0 && m0 + (f >> 3) < p.M)
+        *reinterpret_cast<f32x4*>(p.a_copy + (int64_t)m * p.a_copy_ld + k0 + 4 * (f & 7)) = q.ra[it];
     }
 #pragma unroll
     for (int it = 0; it < NB; ++it) {
@@ -1170,6 +1183,8 @@ int b4r_gemm_rx_launch(const b4r_gemm_desc* d, hipStream_t stream) {
   p.ln_z = d->ln_z; p.ln_ldz = d->ln_ldz;
   p.ln_ids = d->ln_ids; p.ln_table = d->ln_table; p.ln_pos = d->ln_pos; p.ln_L = d->ln_L; p.ln_V = d->ln_V;
   p.C3 = d->C3; p.ldc3 = d->ldc3;
+  p.a_idx = d->a_gather_idx; p.a_add_per = d->a_gather_add_per; p.a_per = d->a_gather_per > 0 ? d->a_gather_per : 1;
+  p.a_copy = d->a_copy; p.a_copy_ld = d->a_copy_ld;
   p.drop = b4r_make_drop(d->rng, d->drop_stream, d->drop_rate, 1);
   p.k_chunks_per_split = d->K / 64 > 0 ? d->K / 64 : 1; p.slab_stride = 0;
   const bool a_drop = d->a_dropout && p.drop.rng != nullptr;

@@ -464,11 +464,12 @@ extern "C" int b4r_forward(const b4r_model_config* cfg, const b4r_batch* batch, 
   }
   if (P > 0) {
     // tfm MaskedLM: gather -> dense(gelu) -> LayerNorm -> . E^T + bias
-    RC(b4r_gather_rows(x, H, batch->masked_lm_positions, L, P, M, H, ws + w.gath, stream));
-    {   // dense(gelu) + LayerNorm: one launch where the LayerNorm tail applies (hidden size 64), else two
+    {   // gather + dense(gelu) + LayerNorm: one launch where the LayerNorm tail applies (hidden size 64), else three
       static const bool fuse = !(getenv("B4R_FUSE_LN") && atoi(getenv("B4R_FUSE_LN")) == 0);
       b4r_gemm_desc d{};
-      d.A = ws + w.gath; d.lda = H; d.B = params + pl.wd; d.ldb = H; d.C = ws + w.u; d.ldc = H; d.M = M; d.N = H; d.K = H;
+      d.A = x; d.lda = H; d.B = params + pl.wd; d.ldb = H; d.C = ws + w.u; d.ldc = H; d.M = M; d.N = H; d.K = H;
+      d.a_gather_idx = batch->masked_lm_positions; d.a_gather_add_per = L; d.a_gather_per = P;
+      d.a_copy = ws + w.gath; d.a_copy_ld = H;   // the gathered rows: A operand of the transform's weight gradient
       d.epilogue = B4R_EPI_BIAS_GELU_LN; d.bias = params + pl.bd; d.C2 = ws + w.t; d.ldc2 = H; d.C3 = ws + w.upre; d.ldc3 = H;
       d.qscale = 1.f; d.c_pad_scratch = 1;
       d.ln_gamma = params + pl.lnm_g; d.ln_beta = params + pl.lnm_b; d.ln_mean = ws + w.meanm; d.ln_rstd = ws + w.rstdm;
@@ -476,6 +477,7 @@ extern "C" int b4r_forward(const b4r_model_config* cfg, const b4r_batch* batch, 
       if (fuse && b4r_gemm_ln_supported(&d)) {
         RC(b4r_gemm_f32(&d, (b4r_stream_t)s));
       } else {
+        RC(b4r_gather_rows(x, H, batch->masked_lm_positions, L, P, M, H, ws + w.gath, stream));
         RC(gemm(ws + w.gath, H, params + pl.wd, H, ws + w.u, H, M, H, H, 0, B4R_EPI_BIAS_GELU, params + pl.bd, ws + w.upre, H,
                 nullptr, 0, 1.f, 0, nullptr, 0, 0.f, 0, s));
         RC(b4r_ln_fwd(ws + w.u, M, H, params + pl.lnm_g, params + pl.lnm_b, cfg->ln_eps, ws + w.t, ws + w.meanm, ws + w.rstdm,

@@ -253,6 +253,10 @@ typedef struct b4r_gemm_desc {
    * (bert4rec_encoder.py:186-199: embeddings -> LayerNorm -> dropout) */
   const int64_t* ln_ids; const float* ln_table; const float* ln_pos; int32_t ln_L, ln_V;
   float* C3; int32_t ldc3;       /* B4R_EPI_BIAS_GELU_LN: the pre-activation [M, N] */
+  /* B4R_EPI_BIAS_GELU_LN only (NULL otherwise): gathered A rows, with the semantics of b4r_gather_rows -- row m of the product
+   * reads row clamp(a_gather_idx[m], 0, a_gather_add_per - 1) + (m / a_gather_per) * a_gather_add_per of A (tfm MaskedLM gathers
+   * the masked positions of every sequence, bert4rec_model.py:143); a_copy [M, a_copy_ld >= K] (optional) receives the gathered rows */
+  const int64_t* a_gather_idx; int64_t a_gather_add_per; int32_t a_gather_per; float* a_copy; int32_t a_copy_ld;
 } b4r_gemm_desc;
 /* Arithmetic of the dense layers (process-wide switch; default B4R_GEMM_BF16X3):
  *   B4R_GEMM_F32     exact fp32 matrix cores (v_mfma_f32_32x32x2_f32), LDS-tiled

@@ -122,12 +122,18 @@ def test_gemm_residual_layernorm_epilogue(M, K, rate):
     assert lib.b4r_gemm_f32(C.byref(d), T.stream()) == -2   # B4R_E_SHAPE
 
 
-@pytest.mark.parametrize("M,K", [(224, 64), (96, 128)])
-def test_gemm_gelu_layernorm_epilogue(M, K):
-    """B4R_EPI_BIAS_GELU_LN (hidden size 64): the dense(gelu) -> LayerNorm transform of tfm MaskedLM from one launch."""
+@pytest.mark.parametrize("M,K,gather", [(224, 64, False), (96, 128, False), (224, 64, True)])
+def test_gemm_gelu_layernorm_epilogue(M, K, gather):
+    """B4R_EPI_BIAS_GELU_LN (hidden size 64): the dense(gelu) -> LayerNorm transform of tfm MaskedLM from one launch,
+    optionally on rows gathered like b4r_gather_rows does (P positions per sequence of length L, clamped into the sequence)."""
     N, eps = 64, 1e-12
     lib = _lib.load()
     A, B, bias = rnd(M, K, seed=1), rnd(K, N, seed=2, scale=0.2), rnd(N, seed=3)
+    src, idx, per, L = None, None, 7, 20
+    if gather:
+        src = rnd((M // per) * L, K, seed=11)
+        idx = torch.randint(-1, L + 1, (M,), generator=torch.Generator().manual_seed(5))   # -1 and L are clamped
+        A = src[idx.clamp(0, L - 1) + (torch.arange(M) // per) * L]
     g, b = 1.0 + rnd(N, seed=5, scale=0.2), rnd(N, seed=6, scale=0.2)
     pre_ref = A.double() @ B.double() + bias.double()
     u_ref = gelu(pre_ref)
@@ -141,12 +147,20 @@ def test_gemm_gelu_layernorm_epilogue(M, K):
     d.M, d.N, d.K, d.b_is_nk, d.epilogue, d.bias, d.qscale = M, N, K, 0, _lib.EPI_BIAS_GELU_LN, T.P(dev[2]), 1.0
     d.C2, d.ldc2, d.C3, d.ldc3 = T.P(t), N, T.P(pre), N
     d.ln_gamma, d.ln_beta, d.ln_mean, d.ln_rstd, d.ln_eps = T.P(dev[3]), T.P(dev[4]), T.P(mean), T.P(rstd), eps
+    copy = torch.full((M, K), float("nan"), device=DEV)
+    if gather:
+        src_d, idx_d = src.to(DEV), idx.to(DEV)
+        d.A, d.a_gather_idx, d.a_gather_add_per, d.a_gather_per, d.a_copy, d.a_copy_ld = T.P(src_d), T.P(idx_d), L, per, T.P(copy), K
     if lib.b4r_get_gemm_mode() != 1:
         assert lib.b4r_gemm_ln_supported(C.byref(d)) == 0
         assert lib.b4r_gemm_f32(C.byref(d), T.stream()) == -2   # B4R_E_SHAPE
         return
     assert lib.b4r_gemm_ln_supported(C.byref(d)) == 1
     _lib.check(lib.b4r_gemm_f32(C.byref(d), T.stream()), "b4r_gemm_f32")
+    if gather:
+        assert torch.equal(copy.cpu(), A)          # the gathered rows, bit for bit
+        d.epilogue = _lib.EPI_BIAS_GELU            # gathering is only offered with this epilogue: refused elsewhere
+        assert lib.b4r_gemm_f32(C.byref(d), T.stream()) == -1
     assert T.maxdiff(pre, pre_ref) < 5e-5
     assert T.maxdiff(u, u_ref) < 5e-5
     assert T.maxdiff(t, t_ref) < 2e-4      # the LayerNorm divides by the small spread of gelu outputs

@@ -55,6 +55,15 @@ class GemmTnDesc(C.Structure):
                 ("dgrad_out", C.c_void_p), ("dgrad_ldo", C.c_int32), ("dgrad_gelu_pre", C.c_void_p), ("dgrad_ldg", C.c_int32)]
 
 
+class FfnDesc(C.Structure):
+    _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("I", C.c_int32), ("x1", C.c_void_p), ("W1", C.c_void_p), ("b1", C.c_void_p),
+                ("W2", C.c_void_p), ("b2", C.c_void_p), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float),
+                ("rng", C.c_void_p), ("drop_stream", C.c_uint32), ("drop_rate", C.c_float), ("z2", C.c_void_p), ("x2", C.c_void_p),
+                ("mean2", C.c_void_p), ("rstd2", C.c_void_p), ("dz2", C.c_void_p), ("z1", C.c_void_p), ("mean1", C.c_void_p),
+                ("rstd1", C.c_void_p), ("ln1_gamma", C.c_void_p), ("dz1", C.c_void_p), ("dW1", C.c_void_p), ("db1", C.c_void_p),
+                ("dW2", C.c_void_p), ("db2", C.c_void_p), ("dln1_gamma", C.c_void_p), ("scratch", C.c_void_p)]
+
+
 # b4r_train_state: 16 x 32-bit words; word indices of the float fields
 STATE_WORDS = 16
 ST_SEED, ST_STEP_LO, ST_STEP = 0, 1, 2  # step is int64 at words 2..3
@@ -105,6 +114,10 @@ PROTOTYPES = {
     "b4r_attn_fwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P, _P, _U32, _F, _P, _P]),
     "b4r_attn_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _F, _P, _P, _U32, _F, _P, _P]),
     "b4r_attn_keep_words": (C.c_int64, [_I32, _I32, _I32]),
+    "b4r_ffn_block_supported": (_I32, [_I32, _I32]),
+    "b4r_ffn_block_bwd_scratch_floats": (_I64, [_I32]),
+    "b4r_ffn_block_fwd": (C.c_int, [C.POINTER(FfnDesc), _P]),
+    "b4r_ffn_block_bwd": (C.c_int, [C.POINTER(FfnDesc), _P]),
     "b4r_gather_rows": (C.c_int, [_P, _I32, _P, _I64, _I32, _I32, _I32, _P, _P]),
     "b4r_scatter_add_rows": (C.c_int, [_P, _P, _I64, _I32, _I32, _I32, _P, _I32, _P, _P]),
     "b4r_mlm_head_fused_scratch_floats": (C.c_int64, [_I32, _I32, _I32]),

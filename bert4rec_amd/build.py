@@ -7,7 +7,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["b4r_gemm.hip", "b4r_gemm_rx.hip", "b4r_rowops.hip", "b4r_attn.hip", "b4r_attn_rx.hip", "b4r_head_rx.hip", "b4r_model.hip"]
+SOURCES = ["b4r_gemm.hip", "b4r_gemm_rx.hip", "b4r_rowops.hip", "b4r_attn.hip", "b4r_attn_rx.hip", "b4r_head_rx.hip", "b4r_ffn_rx.hip", "b4r_model.hip"]
 OUT = os.path.join(HERE, "libb4r_hip.so")
 
 
@@ -20,7 +20,7 @@ def _newer(target: str, deps) -> bool:
 
 def build_library(force: bool = False, verbose: bool = True) -> str:
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "b4r_common.h"), os.path.join(os.path.dirname(HERE), "include", "b4r.h")]
+    deps = srcs + [os.path.join(CSRC, "b4r_common.h"), os.path.join(CSRC, "b4r_rx_tiles.h"), os.path.join(os.path.dirname(HERE), "include", "b4r.h")]
     if not force and _newer(OUT, deps):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

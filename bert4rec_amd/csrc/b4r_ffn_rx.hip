@@ -1,0 +1,547 @@
+// Feed-forward half of a Keras TransformerEncoderBlock (post-LN) as THREE kernels that keep the [N, inner] intermediate on
+// the chip (hidden size 64, inner size 256, split-precision bf16x3 arithmetic of b4r_rx_tiles.h):
+//
+//   forward   x2 = LN(x1 + dropout(gelu(x1.W1 + b1).W2 + b2))                     ffn_fwd_kernel
+//   backward  dz1 = LN1'( (dropmask(dz2).W2^T * gelu'(x1.W1 + b1)).W1^T + dz2 )    ffn_bwd_dx_kernel   (recomputes the pre-activation)
+//             dW2 = gelu(..)^T.dropmask(dz2), dW1 = x1^T.dFpre, db1, db2           ffn_bwd_dw_kernel   (recomputes it again)
+//
+// Reference: tfm TransformerEncoderBlock as constructed at bert4rec/models/components/networks/bert4rec_encoder.py:136-147 and
+// called at :220-222 (intermediate dense + erf-GELU, output dense, output dropout, residual, output_layer_norm).
+//
+// Why three kernels and not the five launches of round 1 (FFN-in, FFN-out + LN | pair kernel, dX1 + LN', dW1): the
+// [N, 256] pre-activation / activation / their gradients were written and re-read through HBM seven times per layer
+// (~565 MB of the layer's ~1.3 GB); here they only ever exist as accumulator tiles.  The price is recomputing x1.W1 in
+// both backward kernels (2 x 1.7 GFLOP at ML-1M), which the matrix pipe has to spare.
+//
+// Orientation.  v_mfma_f32_16x16x32_bf16 leaves D[4g + r][i] in register r of lane (i = lane & 15, g = lane >> 4).  A product
+// whose result feeds the NEXT product as its B operand (k on (g, j), column on i) must therefore be computed so that the
+// index the next product sums over lands on D's rows:
+//   * forward / dx:  everything transposed, tokens on i.  fpre^T = W1^T.x1^T puts the inner index on D's rows, so
+//     G^T = W2^T.f^T (forward) and dx1^T = W1.dfpre^T (backward) take the activation tiles straight from the accumulators,
+//     two 16-row tiles per 32-deep instruction: k-slot (g, j) = row 4g + j of the first tile for j < 4, of the second for
+//     j >= 4 (the attention kernels' convention).  A wave owns 16 tokens end to end: no barrier, no LDS traffic for
+//     activations, the LayerNorm statistics are two 4-lane shuffles.
+//   * dw:  tokens are the summation index, so fpre / dF are computed un-transposed (tokens on D's rows, the wave's 16
+//     inner columns on i) and feed dW2^T = dG^T.f and dW1 = x1^T.dFpre as B operands; a wave owns 16 inner columns (its
+//     slices of W1 / W2 live in registers), the 16 waves of a workgroup share 32-token chunks of x1 / dropmask(dz2) staged
+//     as images.
+// Weights live in LDS as natural-order bf16 hi / lo images cut in 16 x 32 sub-tiles (b4r_rx_tiles.h's swizzle); one image
+// serves both fragment shapes: transposed (ds_read_b64_tr_b16: W^T as the A operand) and "split row" (two 8-byte pieces of a
+// row at columns 4g and 16 + 4g: W as the A operand in the k-slot order above).
+#include "b4r_rx_tiles.h"
+
+namespace {
+
+constexpr int FW = 16;        // waves per workgroup (1024 threads, one workgroup per CU: 129 KB of weight images)
+constexpr int SUB = 1024;     // bytes of one 16 x 32 bf16 sub-tile
+constexpr int HID = 64, INNER = 256;
+constexpr int W_IMG = HID * INNER * 4;   // hi + lo image of one weight matrix: 64 KB
+// unroll factors of the inner-dimension loops: what hipcc allocates without spilling into the loop at 128 VGPRs (16 waves)
+#ifndef FFN_FWD_UNROLL
+#define FFN_FWD_UNROLL 4
+#endif
+#ifndef FFN_DX_UNROLL
+#define FFN_DX_UNROLL 1
+#endif
+
+__device__ __forceinline__ int sub_off(int r16, int ch) { return r16 * 64 + 16 * (ch ^ ((0 - (r16 >> 2)) & 3)); }
+// hi sub-tile (row tile rt, column block cb) of an image with ncb column blocks; the lo sub-tile follows it
+__device__ __forceinline__ int sub_base(int rt, int cb, int ncb) { return ((rt * ncb + cb) * 2) * SUB; }
+
+struct LaneK {
+  int tr[2];   // transposed fragment of column half db: rows 4g .. 4g+3, column 16 db + i
+  int sr[2];   // split-row fragment: row i, columns 4g .. 4g+3 and 16 + 4g .. 16 + 4g + 3
+  int row;     // row fragment: row i, columns 8g .. 8g+7
+};
+__device__ __forceinline__ LaneK lane_consts(int lane) {
+  const int i = lane & 15, g = lane >> 4, qq = i >> 2, pp = i & 3;
+  LaneK k;
+#pragma unroll
+  for (int db = 0; db < 2; ++db) k.tr[db] = sub_off(4 * g + qq, 2 * db + (pp >> 1)) + 8 * (pp & 1);
+  k.sr[0] = sub_off(i, g >> 1) + 8 * (g & 1);
+  k.sr[1] = sub_off(i, 2 + (g >> 1)) + 8 * (g & 1);
+  k.row = sub_off(i, g);
+  return k;
+}
+
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+__device__ __forceinline__ bf16x8 tr_pair(const char* a, const char* b) {
+  const s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)a);
+  const s16x4 y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)b);
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+__device__ __forceinline__ bf16x8 sr_pair(const char* a, const char* b) {
+  const s16x4 x = *reinterpret_cast<const s16x4*>(a);
+  const s16x4 y = *reinterpret_cast<const s16x4*>(b);
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+__device__ __forceinline__ bf16x8 row_at(const char* a) { return *reinterpret_cast<const bf16x8*>(a); }
+
+// W [R][C] fp32 row-major -> natural hi / lo image (R % 16 == 0, C % 32 == 0), all threads of the workgroup
+__device__ __forceinline__ void stage_weight(char* img, const float* W, int R, int C) {
+  const int c4n = C >> 2, ncb = C >> 5, nf4 = R * c4n;
+  for (int f = threadIdx.x; f < nf4; f += 64 * FW) {
+    const int r = f / c4n, c = 4 * (f - r * c4n);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(W + (int64_t)r * C + c);
+    bf16x4 h, l;
+    b4r_split4(v, h, l);
+    const int cc = c & 31;
+    char* dst = img + sub_base(r >> 4, c >> 5, ncb) + sub_off(r & 15, cc >> 3) + 8 * ((cc >> 2) & 1);
+    *reinterpret_cast<bf16x4*>(dst) = h;
+    *reinterpret_cast<bf16x4*>(dst + SUB) = l;
+  }
+}
+
+// gelu(x) and gelu'(x) from one erf / exp evaluation (b4r_erf_as)
+__device__ __forceinline__ void gelu_both(float x, float& gl, float& gr) {
+  float e;
+  const float er = b4r_erf_as(x * 0.70710678118654752440f, e);
+  const float cdf = 0.5f * (1.0f + er);
+  gl = x * cdf;
+  gr = fmaf(x * 0.39894228040143267794f, e, cdf);
+}
+
+struct FfnP {
+  const float* x1; const float* W1; const float* b1; const float* W2; const float* b2;
+  const float* g2; const float* be2;
+  float* z2; float* x2; float* mean2; float* rstd2;
+  const float* dz2; const float* z1; const float* mean1; const float* rstd1; const float* g1;
+  float* dz1; float* ln_part;
+  float* slab_w1; float* slab_b1; float* slab_w2; float* slab_b2;
+  int N; float eps;
+  DropArgs drop;
+};
+
+__device__ __forceinline__ float sum4(const f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+__device__ __forceinline__ float quad_sum(float s) {   // over the four lanes i, i+16, i+32, i+48 that share a token
+  s += __shfl_xor(s, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  return s;
+}
+
+// fpre^T tile `a` (inner rows 32 kt + 16 a .. +15, the wave's 16 tokens on the columns), accumulator preset to the bias
+__device__ __forceinline__ f32x4 fpre_tile(const char* w1img, const float* sb1, const LaneK& lk, int kt, int a, int g,
+                                           const bf16x8 (&xh)[2], const bf16x8 (&xl)[2]) {
+  f32x4 c = *reinterpret_cast<const f32x4*>(&sb1[32 * kt + 16 * a + 4 * g]);
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const char* t0 = w1img + sub_base(2 * ks, kt, 8) + lk.tr[a];
+    const char* t1 = t0 + 8 * 2 * SUB;
+    c = mfma3(tr_pair(t0, t1), tr_pair(t0 + SUB, t1 + SUB), xh[ks], xl[ks], c);
+  }
+  return c;
+}
+
+// -----------------------------------------------------------------------------------------------------------
+// forward.  LDS: [W1 image 64 KB | W2 image 64 KB | b1]
+// -----------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * FW) void ffn_fwd_kernel(FfnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_ffn[];
+  char* w1img = smem_ffn;
+  char* w2img = smem_ffn + W_IMG;
+  float* sb1 = reinterpret_cast<float*>(smem_ffn + 2 * W_IMG);
+  stage_weight(w1img, p.W1, HID, INNER);
+  stage_weight(w2img, p.W2, INNER, HID);
+  if (threadIdx.x < INNER) sb1[threadIdx.x] = p.b1[threadIdx.x];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+  const LaneK lk = lane_consts(lane);
+  const DropCtx dctx = b4r_drop_ctx(p.drop);
+  const int ntiles = (p.N + 15) >> 4;
+  for (int t = blockIdx.x + gridDim.x * wave; t < ntiles; t += gridDim.x * FW) {   // wave-uniform: EXEC stays full
+    const int tok = 16 * t + i, tokc = min(tok, p.N - 1);
+    f32x4 xr[4];
+#pragma unroll
+    for (int hb = 0; hb < 4; ++hb) xr[hb] = *reinterpret_cast<const f32x4*>(p.x1 + (int64_t)tokc * HID + 16 * hb + 4 * g);
+    bf16x8 xh[2], xl[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) split8(cat(xr[2 * ks], xr[2 * ks + 1]), xh[ks], xl[ks]);
+    f32x4 acc[4];
+#pragma unroll
+    for (int hb = 0; hb < 4; ++hb) acc[hb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll FFN_FWD_UNROLL
+    for (int kt = 0; kt < INNER / 32; ++kt) {
+      f32x4 f[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const f32x4 c = fpre_tile(w1img, sb1, lk, kt, a, g, xh, xl);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) f[a][r] = b4r_gelu_fast(c[r]);
+      }
+      bf16x8 fh, fl;
+      split8(cat(f[0], f[1]), fh, fl);
+#pragma unroll
+      for (int hb = 0; hb < 4; ++hb) {   // G^T[16 hb + ..][token] += W2^T[.., inner of the pair] . f^T
+        const char* t0 = w2img + sub_base(2 * kt, hb >> 1, 2) + lk.tr[hb & 1];
+        const char* t1 = t0 + 2 * 2 * SUB;
+        acc[hb] = mfma3(tr_pair(t0, t1), tr_pair(t0 + SUB, t1 + SUB), fh, fl, acc[hb]);
+      }
+    }
+    // bias + dropout + residual + LayerNorm: lane (i, g) holds columns 16 hb + 4g .. +3 of token i
+    f32x4 z[4];
+    float s = 0.f;
+#pragma unroll
+    for (int hb = 0; hb < 4; ++hb) {
+      const f32x4 y = acc[hb] + *reinterpret_cast<const f32x4*>(p.b2 + 16 * hb + 4 * g);
+      z[hb] = xr[hb] + b4r_drop4(dctx, y, (uint64_t)tok * HID + (uint64_t)(16 * hb + 4 * g));
+      s += sum4(z[hb]);
+    }
+    const float mean = quad_sum(s) * (1.0f / HID);
+    float q = 0.f;
+#pragma unroll
+    for (int hb = 0; hb < 4; ++hb) {
+      const f32x4 d = z[hb] - mean;
+      q += sum4(d * d);
+    }
+    const float rstd = rsqrtf(quad_sum(q) * (1.0f / HID) + p.eps);
+    if (tok < p.N) {
+#pragma unroll
+      for (int hb = 0; hb < 4; ++hb) {
+        const int64_t o = (int64_t)tok * HID + 16 * hb + 4 * g;
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(p.g2 + 16 * hb + 4 * g);
+        const f32x4 be = *reinterpret_cast<const f32x4*>(p.be2 + 16 * hb + 4 * g);
+        f32x4 y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float inv = rstd * gm[e];
+          y[e] = z[hb][e] * inv + (be[e] - mean * inv);
+        }
+        if (p.z2) *reinterpret_cast<f32x4*>(p.z2 + o) = z[hb];
+        *reinterpret_cast<f32x4*>(p.x2 + o) = y;
+      }
+      if (g == 0) {
+        if (p.mean2) p.mean2[tok] = mean;
+        if (p.rstd2) p.rstd2[tok] = rstd;
+      }
+    }
+  }
+}
+
+// -----------------------------------------------------------------------------------------------------------
+// backward, input gradient + the attention LayerNorm's backward.  LDS: [W1 image | W2 image | b1 | LayerNorm partials]
+// -----------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64 * FW) void ffn_bwd_dx_kernel(FfnP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_ffn[];
+  char* w1img = smem_ffn;
+  char* w2img = smem_ffn + W_IMG;
+  float* sb1 = reinterpret_cast<float*>(smem_ffn + 2 * W_IMG);
+  float* sred = sb1 + INNER;   // [FW][128]
+  stage_weight(w1img, p.W1, HID, INNER);
+  stage_weight(w2img, p.W2, INNER, HID);
+  if (threadIdx.x < INNER) sb1[threadIdx.x] = p.b1[threadIdx.x];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+  const LaneK lk = lane_consts(lane);
+  const DropCtx dctx = b4r_drop_ctx(p.drop);
+  const int ntiles = (p.N + 15) >> 4;
+  f32x4 dgam[4], dbet[4];   // this lane's share of sum_tokens dx1 * xhat / dx1 (columns 16 hb + 4g .. +3)
+#pragma unroll
+  for (int hb = 0; hb < 4; ++hb) { dgam[hb] = (f32x4){0.f, 0.f, 0.f, 0.f}; dbet[hb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+  for (int t = blockIdx.x + gridDim.x * wave; t < ntiles; t += gridDim.x * FW) {
+    const int tok = 16 * t + i, tokc = min(tok, p.N - 1);
+    const int64_t rowo = (int64_t)tokc * HID + 4 * g;
+    bf16x8 xh[2], xl[2], gh[2], gl[2];
+    {
+      f32x4 xr[4], dg[4];
+#pragma unroll
+      for (int hb = 0; hb < 4; ++hb) {
+        xr[hb] = *reinterpret_cast<const f32x4*>(p.x1 + rowo + 16 * hb);
+        dg[hb] = *reinterpret_cast<const f32x4*>(p.dz2 + rowo + 16 * hb);
+      }
+#pragma unroll
+      for (int hb = 0; hb < 4; ++hb) dg[hb] = b4r_drop4(dctx, dg[hb], (uint64_t)tok * HID + (uint64_t)(16 * hb + 4 * g));
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        split8(cat(xr[2 * ks], xr[2 * ks + 1]), xh[ks], xl[ks]);
+        split8(cat(dg[2 * ks], dg[2 * ks + 1]), gh[ks], gl[ks]);
+      }
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int hb = 0; hb < 4; ++hb) acc[hb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll FFN_DX_UNROLL
+    for (int kt = 0; kt < INNER / 32; ++kt) {
+      f32x4 dfp[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const f32x4 c = fpre_tile(w1img, sb1, lk, kt, a, g, xh, xl);
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};   // dF^T[inner][token] = W2[inner][:] . dG^T
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const char* s0 = w2img + sub_base(2 * kt + a, ks, 2);
+          d = mfma3(sr_pair(s0 + lk.sr[0], s0 + lk.sr[1]), sr_pair(s0 + SUB + lk.sr[0], s0 + SUB + lk.sr[1]), gh[ks], gl[ks], d);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dfp[a][r] = d[r] * b4r_gelu_grad_fast(c[r]);
+      }
+      bf16x8 ph, pl;
+      split8(cat(dfp[0], dfp[1]), ph, pl);
+#pragma unroll
+      for (int hb = 0; hb < 4; ++hb) {   // dx1^T[16 hb + ..][token] += W1[.., inner of the pair] . dFpre^T
+        const char* s0 = w1img + sub_base(hb, kt, 8);
+        acc[hb] = mfma3(sr_pair(s0 + lk.sr[0], s0 + lk.sr[1]), sr_pair(s0 + SUB + lk.sr[0], s0 + SUB + lk.sr[1]), ph, pl, acc[hb]);
+      }
+    }
+    // dx1 = acc + dz2 (the residual branch), then back through x1 = LN(z1)
+    const float mean = p.mean1[tokc], rstd = p.rstd1[tokc];
+    const bool live = tok < p.N;
+    f32x4 ge[4], xhat[4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int hb = 0; hb < 4; ++hb) {
+      const f32x4 dx = acc[hb] + *reinterpret_cast<const f32x4*>(p.dz2 + rowo + 16 * hb);
+      const f32x4 zz = *reinterpret_cast<const f32x4*>(p.z1 + rowo + 16 * hb);
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(p.g1 + 16 * hb + 4 * g);
+      xhat[hb] = (zz - mean) * rstd;
+      ge[hb] = dx * gm;
+      s1 += sum4(ge[hb]);
+      s2 += sum4(ge[hb] * xhat[hb]);
+      if (live) { dgam[hb] += dx * xhat[hb]; dbet[hb] += dx; }
+    }
+    const float c1 = quad_sum(s1) * (1.0f / HID), c2 = quad_sum(s2) * (1.0f / HID);
+    if (live) {
+#pragma unroll
+      for (int hb = 0; hb < 4; ++hb) {
+        f32x4 dz;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dz[e] = rstd * (ge[hb][e] - c1 - xhat[hb][e] * c2);
+        *reinterpret_cast<f32x4*>(p.dz1 + (int64_t)tok * HID + 16 * hb + 4 * g) = dz;
+      }
+    }
+  }
+  // LayerNorm gamma / beta partial sums: over the 16 tokens of a lane group (fixed butterfly), then over the waves in order
+#pragma unroll
+  for (int hb = 0; hb < 4; ++hb) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a = dgam[hb][e], b = dbet[hb][e];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+      if (i == 0) { sred[wave * 128 + 16 * hb + 4 * g + e] = a; sred[wave * 128 + 64 + 16 * hb + 4 * g + e] = b; }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    float r = 0.f;
+#pragma unroll
+    for (int w = 0; w < FW; ++w) r += sred[w * 128 + threadIdx.x];
+    p.ln_part[(int64_t)blockIdx.x * 128 + threadIdx.x] = r;
+  }
+}
+
+// -----------------------------------------------------------------------------------------------------------
+// backward, weight gradients.  Wave w owns inner columns 16 w .. 16 w + 15; the workgroup walks 32-token chunks.
+// LDS: 2 stages x [x1 image 8 KB | dropmask(dz2) image 8 KB]
+// -----------------------------------------------------------------------------------------------------------
+constexpr int CH_TOK = 32;
+constexpr int CH_IMG = CH_TOK * HID * 4;   // hi + lo image of one [32, 64] chunk: 8 KB
+
+__global__ __launch_bounds__(64 * FW) void ffn_bwd_dw_kernel(FfnP p) {
+  __shared__ __attribute__((aligned(16))) char smem_dw[4 * CH_IMG];
+  const int lane = threadIdx.x & 63, ib = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+  const LaneK lk = lane_consts(lane);
+  const DropCtx dctx = b4r_drop_ctx(p.drop);
+
+  // the wave's weight slices as B operands (k = hidden index in natural order 32 ks + 8g + j, column = inner 16 ib + i)
+  bf16x8 w1h[2], w1l[2], w2h[2], w2l[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    f32x8 a;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = p.W1[(int64_t)(32 * ks + 8 * g + j) * INNER + 16 * ib + i];
+    split8(a, w1h[ks], w1l[ks]);
+    split8(load8(p.W2 + (int64_t)(16 * ib + i) * HID + 32 * ks + 8 * g), w2h[ks], w2l[ks]);
+  }
+  const float b1v = p.b1[16 * ib + i];
+
+  // staging role of this thread: threads 0..511 carry x1, 512..1023 carry dz2; one float4 of the chunk each
+  const int sid = threadIdx.x & 511, stok = sid >> 4, sc4 = sid & 15;
+  const bool is_dz = threadIdx.x >= 512;
+  const float* ssrc = is_dz ? p.dz2 : p.x1;
+  const int soff = (is_dz ? CH_IMG : 0) + sub_base(stok >> 4, sc4 >> 3, 2) + sub_off(stok & 15, (sc4 & 7) >> 1) + 8 * (sc4 & 1);
+  const int nchunks = (p.N + CH_TOK - 1) / CH_TOK;
+  f32x4 sv;
+  f32x4 db2 = {0.f, 0.f, 0.f, 0.f};
+  auto fetch = [&](int c) {
+    const int tok = min(CH_TOK * c + stok, p.N - 1);
+    sv = *reinterpret_cast<const f32x4*>(ssrc + (int64_t)tok * HID + 4 * sc4);
+  };
+  auto put = [&](int c, int stage) {
+    const int tok = CH_TOK * c + stok;
+    f32x4 v = sv;
+    if (is_dz) v = b4r_drop4(dctx, v, (uint64_t)tok * HID + (uint64_t)(4 * sc4));
+    if (tok >= p.N) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (is_dz) db2 += v;
+    bf16x4 h, l;
+    b4r_split4(v, h, l);
+    char* dst = smem_dw + stage * 2 * CH_IMG + soff;
+    *reinterpret_cast<bf16x4*>(dst) = h;
+    *reinterpret_cast<bf16x4*>(dst + SUB) = l;
+  };
+
+  f32x4 dw1[4], dw2[4];
+#pragma unroll
+  for (int hb = 0; hb < 4; ++hb) { dw1[hb] = (f32x4){0.f, 0.f, 0.f, 0.f}; dw2[hb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  float db1 = 0.f;
+
+  int c = blockIdx.x;
+  if (c < nchunks) { fetch(c); put(c, 0); }
+  __syncthreads();
+  for (int it = 0; c < nchunks; c += gridDim.x, ++it) {
+    const int cn = c + gridDim.x;
+    if (cn < nchunks) fetch(cn);   // in flight while this chunk is multiplied
+    const char* ximg = smem_dw + (it & 1) * 2 * CH_IMG;
+    const char* gimg = ximg + CH_IMG;
+    f32x4 f[2], dfp[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      f32x4 pre = {b1v, b1v, b1v, b1v}, d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const char* xa = ximg + sub_base(tt, ks, 2) + lk.row;
+        const char* ga = gimg + sub_base(tt, ks, 2) + lk.row;
+        pre = mfma3(row_at(xa), row_at(xa + SUB), w1h[ks], w1l[ks], pre);   // fpre[token][inner] = x1.W1 + b1
+        d = mfma3(row_at(ga), row_at(ga + SUB), w2h[ks], w2l[ks], d);       // dF[token][inner] = dG.W2^T
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float gl_, gr_;
+        gelu_both(pre[r], gl_, gr_);
+        f[tt][r] = gl_;
+        dfp[tt][r] = d[r] * gr_;
+      }
+      db1 += sum4(dfp[tt]);
+    }
+    bf16x8 fh, fl, ph, pl;
+    split8(cat(f[0], f[1]), fh, fl);
+    split8(cat(dfp[0], dfp[1]), ph, pl);
+#pragma unroll
+    for (int hb = 0; hb < 4; ++hb) {
+      const char* g0 = gimg + sub_base(0, hb >> 1, 2) + lk.tr[hb & 1];
+      const char* x0 = ximg + sub_base(0, hb >> 1, 2) + lk.tr[hb & 1];
+      const int nt = 2 * 2 * SUB;   // the chunk's second 16-token tile
+      dw2[hb] = mfma3(tr_pair(g0, g0 + nt), tr_pair(g0 + SUB, g0 + SUB + nt), fh, fl, dw2[hb]);   // dW2^T[h][inner] += dG^T.f
+      dw1[hb] = mfma3(tr_pair(x0, x0 + nt), tr_pair(x0 + SUB, x0 + SUB + nt), ph, pl, dw1[hb]);   // dW1[h][inner] += x1^T.dFpre
+    }
+    if (cn < nchunks) put(cn, (it + 1) & 1);
+    __syncthreads();
+  }
+
+  // partial results of this workgroup -> slabs (summed over the workgroups in slab order by the deferred reduction)
+  const int64_t wg = blockIdx.x;
+  float* sw1 = p.slab_w1 + wg * (HID * INNER);
+  float* sw2 = p.slab_w2 + wg * (HID * INNER);
+#pragma unroll
+  for (int hb = 0; hb < 4; ++hb) {
+    *reinterpret_cast<f32x4*>(sw2 + (int64_t)(16 * ib + i) * HID + 16 * hb + 4 * g) = dw2[hb];   // dW2 [inner][h]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sw1[(int64_t)(16 * hb + 4 * g + r) * INNER + 16 * ib + i] = dw1[hb][r];   // dW1 [h][inner]
+  }
+  db1 = quad_sum(db1);
+  if (g == 0) p.slab_b1[wg * INNER + 16 * ib + i] = db1;
+  // db2[h] = sum over tokens of dropmask(dz2): per-thread sums over chunks, then over the 32 token slots of the staging layout
+  float* red = reinterpret_cast<float*>(smem_dw);   // [32][64]; the loop's last barrier has passed
+  if (is_dz) *reinterpret_cast<f32x4*>(&red[stok * HID + 4 * sc4]) = db2;
+  __syncthreads();
+  if (threadIdx.x < HID) {
+    float r = 0.f;
+#pragma unroll
+    for (int s = 0; s < CH_TOK; ++s) r += red[s * HID + threadIdx.x];
+    p.slab_b2[wg * HID + threadIdx.x] = r;
+  }
+}
+
+int ffn_grid(int units) {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (cus <= 0 || cus > 256) cus = 256;   // the scratch layout assumes at most 256 partial slabs
+  }
+  return units < cus ? units : cus;
+}
+
+constexpr size_t FWD_LDS = 2 * W_IMG + INNER * sizeof(float);
+constexpr size_t DX_LDS = FWD_LDS + FW * 128 * sizeof(float);
+
+FfnP make_p(const b4r_ffn_desc* d) {
+  FfnP p{};
+  p.x1 = d->x1; p.W1 = d->W1; p.b1 = d->b1; p.W2 = d->W2; p.b2 = d->b2; p.g2 = d->ln_gamma; p.be2 = d->ln_beta;
+  p.z2 = d->z2; p.x2 = d->x2; p.mean2 = d->mean2; p.rstd2 = d->rstd2;
+  p.dz2 = d->dz2; p.z1 = d->z1; p.mean1 = d->mean1; p.rstd1 = d->rstd1; p.g1 = d->ln1_gamma; p.dz1 = d->dz1;
+  p.N = d->N; p.eps = d->ln_eps;
+  p.drop = b4r_make_drop(d->rng, d->drop_stream, d->drop_rate, d->rng != nullptr);
+  return p;
+}
+
+bool al16(const void* q) { return q == nullptr || b4r_aligned16(q); }
+
+}  // namespace
+
+extern "C" int32_t b4r_ffn_block_supported(int32_t hidden_size, int32_t inner_dim) {
+  return (hidden_size == HID && inner_dim == INNER && b4r_get_gemm_mode() == B4R_GEMM_BF16X3) ? 1 : 0;
+}
+
+// per workgroup: dW1 + dW2 slabs, db1 + db2 strips, 128 LayerNorm partials
+extern "C" int64_t b4r_ffn_block_bwd_scratch_floats(int32_t N) {
+  const int64_t slabs = 256;   // an upper bound of the grid (one workgroup per CU)
+  (void)N;
+  return slabs * (2 * HID * INNER + INNER + HID + 128);
+}
+
+extern "C" int b4r_ffn_block_fwd(const b4r_ffn_desc* d, b4r_stream_t stream) {
+  B4R_CHECK_ARG(d != nullptr, B4R_E_BADARG, "b4r_ffn_block_fwd: null descriptor");
+  B4R_CHECK_ARG(b4r_ffn_block_supported(d->H, d->I), B4R_E_SHAPE,
+                "b4r_ffn_block_fwd: needs hidden size 64, inner size 256 and the bf16x3 mode (H=%d I=%d)", d->H, d->I);
+  B4R_CHECK_ARG(d->N > 0 && d->x1 && d->W1 && d->b1 && d->W2 && d->b2 && d->ln_gamma && d->ln_beta && d->x2, B4R_E_BADARG,
+                "b4r_ffn_block_fwd: null argument");
+  B4R_CHECK_ARG(al16(d->x1) && al16(d->W1) && al16(d->W2) && al16(d->b2) && al16(d->ln_gamma) && al16(d->ln_beta) && al16(d->z2) &&
+                    al16(d->x2),
+                B4R_E_ALIGN, "b4r_ffn_block_fwd: operands must be 16-byte aligned");
+  const FfnP p = make_p(d);
+  int rc = b4r_raise_lds((const void*)ffn_fwd_kernel, FWD_LDS, "b4r_ffn_block_fwd");
+  if (rc) return rc;
+  hipLaunchKernelGGL(ffn_fwd_kernel, dim3(ffn_grid(b4r_cdiv(d->N, 16))), dim3(64 * FW), FWD_LDS, (hipStream_t)stream, p);
+  B4R_CHECK_LAUNCH("b4r_ffn_block_fwd");
+  return B4R_OK;
+}
+
+int b4r_launch_slab_reduce_full(const float* slab, int S, int Mo, int No, float* out, int ldo, int accumulate,
+                                const float* cslab, float* colsum, const float* caslab, float* colsum_a, hipStream_t stream);
+
+extern "C" int b4r_ffn_block_bwd(const b4r_ffn_desc* d, b4r_stream_t stream) {
+  B4R_CHECK_ARG(d != nullptr, B4R_E_BADARG, "b4r_ffn_block_bwd: null descriptor");
+  B4R_CHECK_ARG(b4r_ffn_block_supported(d->H, d->I), B4R_E_SHAPE,
+                "b4r_ffn_block_bwd: needs hidden size 64, inner size 256 and the bf16x3 mode (H=%d I=%d)", d->H, d->I);
+  B4R_CHECK_ARG(d->N > 0 && d->x1 && d->W1 && d->b1 && d->W2 && d->dz2 && d->z1 && d->mean1 && d->rstd1 && d->ln1_gamma && d->dz1 &&
+                    d->dW1 && d->db1 && d->dW2 && d->db2 && d->dln1_gamma && d->scratch,
+                B4R_E_BADARG, "b4r_ffn_block_bwd: null argument");
+  B4R_CHECK_ARG(al16(d->x1) && al16(d->W1) && al16(d->W2) && al16(d->dz2) && al16(d->z1) && al16(d->ln1_gamma) && al16(d->dz1) &&
+                    al16(d->scratch),
+                B4R_E_ALIGN, "b4r_ffn_block_bwd: operands must be 16-byte aligned");
+  FfnP p = make_p(d);
+  hipStream_t s = (hipStream_t)stream;
+  const int gdx = ffn_grid(b4r_cdiv(d->N, 16)), gdw = ffn_grid(b4r_cdiv(d->N, CH_TOK));
+  float* sc = d->scratch;
+  p.slab_w1 = sc; sc += (int64_t)gdw * HID * INNER;
+  p.slab_w2 = sc; sc += (int64_t)gdw * HID * INNER;
+  p.slab_b1 = sc; sc += (int64_t)gdw * INNER;
+  p.slab_b2 = sc; sc += (int64_t)gdw * HID;
+  p.ln_part = sc;
+  int rc = b4r_raise_lds((const void*)ffn_bwd_dx_kernel, DX_LDS, "b4r_ffn_block_bwd");
+  if (rc) return rc;
+  hipLaunchKernelGGL(ffn_bwd_dx_kernel, dim3(gdx), dim3(64 * FW), DX_LDS, s, p);
+  B4R_CHECK_LAUNCH("b4r_ffn_block_bwd (dx)");
+  hipLaunchKernelGGL(ffn_bwd_dw_kernel, dim3(gdw), dim3(64 * FW), 0, s, p);
+  B4R_CHECK_LAUNCH("b4r_ffn_block_bwd (dw)");
+  // ordered sums over the workgroups (queued when the caller collects its reductions into one launch)
+  rc = b4r_launch_slab_reduce_full(p.slab_w1, gdw, HID, INNER, d->dW1, INNER, 0, p.slab_b1, d->db1, nullptr, nullptr, s);
+  if (rc) return rc;
+  rc = b4r_launch_slab_reduce_full(p.slab_w2, gdw, INNER, HID, d->dW2, HID, 0, p.slab_b2, d->db2, nullptr, nullptr, s);
+  if (rc) return rc;
+  return b4r_launch_slab_reduce_full(p.ln_part, gdx, 1, 128, d->dln1_gamma, 128, 0, nullptr, nullptr, nullptr, nullptr, s);
+}

@@ -201,6 +201,7 @@ WsLayout make_ws_layout(const b4r_model_config& c, int B, int L, int P) {
     add(b4r_gemm_tn_scratch_floats((int)N, (int)H, (int)I));
     add(b4r_gemm_tn_scratch_floats((int)N, (int)I, (int)H));
     add(2 * std::max(b4r_ln_bwd_scratch_floats((int)N, (int)H), b4r_gemm_ln_bwd_partial_floats((int)N)));
+    if (H == 64 && I == 256) add(b4r_ffn_block_bwd_scratch_floats((int)N));   // partial slabs of the fused feed-forward backward
   }
   add(std::max(b4r_ln_bwd_scratch_floats((int)N, (int)H), b4r_gemm_ln_bwd_partial_floats((int)N)));
   if (M > 0) {
@@ -283,6 +284,13 @@ int dgrad_ln_bwd(const float* A, int lda, const float* W, int K, const float* R,
   RC(b4r_gemm_f32(&d, (b4r_stream_t)s));
   return b4r_ln_bwd_launch(dz, z, mean, rstd, gamma, M, H, dz, dgamma, dbeta, scratch, ids, table, pos_table, L, V,
                            b4r_make_drop(rng, drop_stream, drop_rate, 1), s, nullptr);
+}
+
+// the feed-forward half of a layer as one launch forward / two backward (b4r_ffn_rx.hip); B4R_FFN_FUSED=0: the separate
+// dense launches of round 1 (kept for A/B timing and for shapes / modes the fused block does not cover)
+bool ffn_fused(const b4r_model_config* c) {
+  static const bool on = !(getenv("B4R_FFN_FUSED") && atoi(getenv("B4R_FFN_FUSED")) == 0);
+  return on && b4r_ffn_block_supported(c->hidden_size, c->inner_dim) != 0;
 }
 
 // pair kernels (input gradient inside the weight-gradient kernel, b4r_gemm_tn_desc.dgrad_*): B4R_PAIR bit 0 = the 64 x 64 layers
@@ -450,11 +458,21 @@ extern "C" int b4r_forward(const b4r_model_config* cfg, const b4r_batch* batch, 
     RC(dense_res_ln(ws + w.ctx[i], H, params + pl.wo[i], ws + w.z1[i], ws + w.x1[i], ws + w.mean1[i], ws + w.rstd1[i], N, H, H,
                     params + pl.bo[i], x, params + pl.ln1_g[i], params + pl.ln1_b[i], cfg->ln_eps, rng, B4R_STREAM_ATTN_OUT(i),
                     od, s));
+    if (ffn_fused(cfg)) {
+      b4r_ffn_desc fd{};
+      fd.N = N; fd.H = H; fd.I = I; fd.x1 = ws + w.x1[i];
+      fd.W1 = params + pl.w1[i]; fd.b1 = params + pl.b1[i]; fd.W2 = params + pl.w2[i]; fd.b2 = params + pl.b2[i];
+      fd.ln_gamma = params + pl.ln2_g[i]; fd.ln_beta = params + pl.ln2_b[i]; fd.ln_eps = cfg->ln_eps;
+      fd.rng = od > 0.f ? rng : nullptr; fd.drop_stream = B4R_STREAM_FFN_OUT(i); fd.drop_rate = od;
+      fd.z2 = ws + w.z2[i]; fd.x2 = ws + w.x2[i]; fd.mean2 = ws + w.mean2[i]; fd.rstd2 = ws + w.rstd2[i];
+      RC(b4r_ffn_block_fwd(&fd, stream));
+    } else {
     RC(gemm(ws + w.x1[i], H, params + pl.w1[i], I, ws + w.f[i], I, N, I, H, 0, B4R_EPI_BIAS_GELU, params + pl.b1[i],
             ws + w.fpre[i], I, nullptr, 0, 1.f, 0, nullptr, 0, 0.f, 0, s));
     RC(dense_res_ln(ws + w.f[i], I, params + pl.w2[i], ws + w.z2[i], ws + w.x2[i], ws + w.mean2[i], ws + w.rstd2[i], N, H, I,
                     params + pl.b2[i], ws + w.x1[i], params + pl.ln2_g[i], params + pl.ln2_b[i], cfg->ln_eps, rng,
                     B4R_STREAM_FFN_OUT(i), od, s));
+    }
     x = ws + w.x2[i];
   }
   if ((flags & B4R_FLAG_POOLER) && pooler) {
@@ -603,6 +621,20 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
     if (i == cfg->num_layers - 1)
       RC(b4r_ln_bwd_launch(ws + w.dx, ws + w.z2[i], ws + w.mean2[i], ws + w.rstd2[i], params + pl.ln2_g[i], N, H, ws + w.da,
                            grads + pl.ln2_g[i], grads + pl.ln2_b[i], take(ln_scratch), nullptr, nullptr, nullptr, 1, 1, nodrop, s));
+    if (ffn_fused(cfg)) {
+      // feed-forward block: dz1 (-> db), dW1 / db1 / dW2 / db2 and the attention LayerNorm's gamma / beta gradients from dz2 (da);
+      // the [N, inner] pre-activation is recomputed from x1 inside the two kernels
+      b4r_ffn_desc fd{};
+      fd.N = N; fd.H = H; fd.I = I; fd.x1 = ws + w.x1[i];
+      fd.W1 = params + pl.w1[i]; fd.b1 = params + pl.b1[i]; fd.W2 = params + pl.w2[i]; fd.b2 = params + pl.b2[i];
+      fd.rng = od > 0.f ? rng : nullptr; fd.drop_stream = B4R_STREAM_FFN_OUT(i); fd.drop_rate = od;
+      fd.dz2 = ws + w.da; fd.z1 = ws + w.z1[i]; fd.mean1 = ws + w.mean1[i]; fd.rstd1 = ws + w.rstd1[i];
+      fd.ln1_gamma = params + pl.ln1_g[i]; fd.dz1 = ws + w.db;
+      fd.dW1 = grads + pl.w1[i]; fd.db1 = grads + pl.b1[i]; fd.dW2 = grads + pl.w2[i]; fd.db2 = grads + pl.b2[i];
+      fd.dln1_gamma = grads + pl.ln1_g[i];
+      fd.scratch = take(b4r_ffn_block_bwd_scratch_floats(N));
+      RC(b4r_ffn_block_bwd(&fd, stream));
+    } else {
     // FFN: dFpre = (dropmask(dz2) . W2^T) * gelu'(fpre) and dW2 = f^T . dropmask(dz2) (+ bias gradient): one pass over dz2
     // where the pair kernel applies (B4R_PAIR bit 1), else two products
     {
@@ -627,6 +659,7 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
     RC(order_after(s, s_tn));
     RC(gemm_tn(ws + w.x1[i], H, ws + w.df, I, grads + pl.w1[i], I, N, H, I, grads + pl.b1[i], nullptr, nullptr, 0, 0.f, 0,
                take(b4r_gemm_tn_scratch_floats(N, H, I)), s_tn));
+    }
     // attention output projection: dctx = dropmask(dz1) . Wo^T and dWo = ctx^T . dropmask(dz1) (+ bias gradient) read dz1
     // once where the pair kernel applies (hidden size 64), else as two products
     {

@@ -314,6 +314,37 @@ int b4r_attn_bwd(const float* qkv, const int64_t* input_mask, const float* ctx, 
  * backward of one step must run in the same mode. */
 int64_t b4r_attn_keep_words(int32_t B, int32_t L, int32_t heads);
 
+/* ---- fused encoder-layer halves (hidden size 64, B4R_GEMM_BF16X3) ------------------------------------------------------
+ * One Keras TransformerEncoderBlock call (bert4rec_encoder.py:136-147 constructs it, :220-222 calls it once per layer) is
+ * two blocks here, each one launch forward: the attention block (b4r_attn_block_*) and the feed-forward block below.  The
+ * feed-forward block keeps the [N, inner] intermediate on the chip in both directions:
+ *   fwd:  z2 = x1 + dropout(gelu_erf(x1.W1 + b1).W2 + b2) ; x2 = LayerNorm(z2) * ln_gamma + ln_beta ; mean2 / rstd2 [N]
+ *   bwd:  from dz2 = d loss / d z2:  dW1, db1, dW2, db2 and dz1 = LayerNorm'(dx1) through the LayerNorm that produced
+ *         x1 = LN(z1) (statistics mean1 / rstd1, scale ln1_gamma), dx1 = (dropmask(dz2).W2^T * gelu'(x1.W1 + b1)).W1^T + dz2,
+ *         plus that LayerNorm's dgamma / dbeta (dln1_gamma[0..63], then dbeta at dln1_gamma + 64, as in the flat gradient buffer).
+ *         The pre-activation is recomputed from x1, nothing of size [N, inner] is stored by the forward.
+ * Dropout: element index row*64 + col of site drop_stream (rng == NULL: off).  Gradient outputs are overwritten (deterministic
+ * ordered sums over per-workgroup partials in `scratch`, b4r_ffn_block_bwd_scratch_floats floats, 16-byte aligned).
+ * b4r_ffn_block_supported: hidden 64, inner 256, bf16x3 mode; other shapes get B4R_E_SHAPE (callers then use b4r_gemm_f32). */
+typedef struct b4r_ffn_desc {
+  int32_t N, H, I;
+  const float* x1;                                  /* [N,H] block input */
+  const float* W1; const float* b1;                 /* [H,I], [I]  intermediate/kernel, bias */
+  const float* W2; const float* b2;                 /* [I,H], [H]  output/kernel, bias */
+  const float* ln_gamma; const float* ln_beta; float ln_eps;   /* output_layer_norm (forward only) */
+  const uint32_t* rng; uint32_t drop_stream; float drop_rate;
+  float* z2; float* x2; float* mean2; float* rstd2; /* forward outputs (z2 / mean2 / rstd2 may be NULL) */
+  const float* dz2;                                 /* backward input [N,H] */
+  const float* z1; const float* mean1; const float* rstd1; const float* ln1_gamma;
+  float* dz1;                                       /* [N,H] */
+  float* dW1; float* db1; float* dW2; float* db2; float* dln1_gamma;
+  float* scratch;
+} b4r_ffn_desc;
+int32_t b4r_ffn_block_supported(int32_t hidden_size, int32_t inner_dim);
+int64_t b4r_ffn_block_bwd_scratch_floats(int32_t N);
+int b4r_ffn_block_fwd(const b4r_ffn_desc* d, b4r_stream_t stream);
+int b4r_ffn_block_bwd(const b4r_ffn_desc* d, b4r_stream_t stream);
+
 /* rows gather / scatter-add:  dst[i,:] = src[idx[i],:]   /   dst[idx[i],:] += src[i,:] (fp32 atomics) */
 int b4r_gather_rows(const float* src, int32_t src_ld, const int64_t* idx, int64_t idx_add_per, int32_t per,
                     int32_t n, int32_t H, float* dst, b4r_stream_t stream);

@@ -1,33 +1,36 @@
-"""mirrors bert4rec/dataloaders/samplers/popular_sampler.py:53-71 (the `sample_size` most frequent items)."""
-from .base_sampler import BaseSampler
+"""The n most frequent items that are not banned (bert4rec/dataloaders/samplers/popular_sampler.py:53-71).  Deterministic:
+the source is ranked by frequency once (dataloader_utils.rank_items_by_popularity) and every sample is a prefix of that
+ranking after the banned items are dropped."""
+from __future__ import annotations
+
 from .. import dataloader_utils
+from .base_sampler import BaseSampler
 
 
 class PopularSampler(BaseSampler):
     def __init__(self, source: list = None, vocab: list = None, sample_size: int = None):
         super().__init__(source, vocab, sample_size)
-        if self.source is not None:
+        self._ranked = self.source is not None   # self.source then holds the popularity ranking, not the raw log
+        if self._ranked:
             self.source = dataloader_utils.rank_items_by_popularity(self.source)
 
     def is_fully_prepared(self) -> bool:
         return self.source is not None and self.sample_size is not None
 
-    def _get_parameters(self, source=None, vocab=None, sample_size=None):
-        source, vocab, sample_size = super()._get_parameters(source, vocab, sample_size)
+    def _get_parameters(self, source: list = None, vocab: list = None, sample_size: int = None):
+        source, vocab, n = super()._get_parameters(source, vocab, sample_size)
         if source is None:
-            raise ValueError("The source argument has to be provided to the popular sampler but None was given.")
-        return source, vocab, sample_size
+            self._pick("source", None, required=True)
+        return source, vocab, n
 
-    def sample(self, sample_size=None, source=None, vocab=None, without=None) -> list:
-        source, vocab, sample_size = self._get_parameters(source, vocab, sample_size)
-        _source = source.copy()
-        if without is not None:
-            wo = set(without)
-            _source = [i for i in _source if i not in wo]
-        if self.source is None:
-            _source = dataloader_utils.rank_items_by_popularity(_source)
-        return _source[:sample_size]
+    def sample(self, sample_size: int = None, source: list = None, vocab: list = None, without: list = None) -> list:
+        source, _, n = self._get_parameters(source, vocab, sample_size)
+        banned = self._banned(without)
+        ranking = [item for item in source if item not in banned]
+        if not self._ranked:                      # raw log handed in at call time: rank what is left of it
+            ranking = dataloader_utils.rank_items_by_popularity(ranking)
+        return ranking[:n]
 
     def set_source(self, source: list):
-        super().set_source(source)
-        self.source = dataloader_utils.rank_items_by_popularity(self.source)
+        self.source = dataloader_utils.rank_items_by_popularity(list(source))
+        self._ranked = True

@@ -55,6 +55,15 @@ class GemmTnDesc(C.Structure):
                 ("dgrad_out", C.c_void_p), ("dgrad_ldo", C.c_int32), ("dgrad_gelu_pre", C.c_void_p), ("dgrad_ldg", C.c_int32)]
 
 
+class AttnBlockDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("heads", C.c_int32), ("x", C.c_void_p),
+                ("input_mask", C.c_void_p), ("Wqkv", C.c_void_p), ("bqkv", C.c_void_p), ("Wo", C.c_void_p), ("bo", C.c_void_p),
+                ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float), ("rng", C.c_void_p),
+                ("probs_stream", C.c_uint32), ("probs_rate", C.c_float), ("out_stream", C.c_uint32), ("out_rate", C.c_float),
+                ("qkv", C.c_void_p), ("ctx", C.c_void_p), ("lse", C.c_void_p), ("keep_bits", C.c_void_p), ("z1", C.c_void_p),
+                ("x1", C.c_void_p), ("mean1", C.c_void_p), ("rstd1", C.c_void_p)]
+
+
 class FfnDesc(C.Structure):
     _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("I", C.c_int32), ("x1", C.c_void_p), ("W1", C.c_void_p), ("b1", C.c_void_p),
                 ("W2", C.c_void_p), ("b2", C.c_void_p), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float),
@@ -114,6 +123,8 @@ PROTOTYPES = {
     "b4r_attn_fwd": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P, _P, _U32, _F, _P, _P]),
     "b4r_attn_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _F, _P, _P, _U32, _F, _P, _P]),
     "b4r_attn_keep_words": (C.c_int64, [_I32, _I32, _I32]),
+    "b4r_attn_block_supported": (_I32, [_I32, _I32, _I32]),
+    "b4r_attn_block_fwd": (C.c_int, [C.POINTER(AttnBlockDesc), _P]),
     "b4r_ffn_block_supported": (_I32, [_I32, _I32]),
     "b4r_ffn_block_bwd_scratch_floats": (_I64, [_I32]),
     "b4r_ffn_block_fwd": (C.c_int, [C.POINTER(FfnDesc), _P]),

@@ -26,8 +26,12 @@
 //     slices of W1 / W2 live in registers), the 16 waves of a workgroup share 32-token chunks of x1 / dropmask(dz2) staged
 //     as images.
 // Weights live in LDS as natural-order bf16 hi / lo images cut in 16 x 32 sub-tiles (b4r_rx_tiles.h's swizzle); one image
-// serves both fragment shapes: transposed (ds_read_b64_tr_b16: W^T as the A operand) and "split row" (two 8-byte pieces of a
-// row at columns 4g and 16 + 4g: W as the A operand in the k-slot order above).
+// serves both fragment shapes: transposed (ds_read_b64_tr_b16: W^T as the A operand) and row (ds_read_b128: W as the A
+// operand).  So that the row reads stay 16-byte reads, the two fpre^T tiles of a 32-wide inner block interleave its columns
+// in groups of four (tile a holds inner columns 8p + 4a + e, p, e < 4, on its rows 4p + e): stacked as a B operand, k-slot
+// (g, j) is then inner column 8g + j -- the natural order a row fragment delivers.  (An earlier layout with contiguous
+// tiles needed two 8-byte reads per fragment; hipcc fused the hi / lo pair into ds_read2st64_b64, which banks modulo 32 and
+// ran the input-gradient kernel at 72 % LDS bank-conflict cycles.)
 #include "b4r_rx_tiles.h"
 
 namespace {
@@ -43,24 +47,37 @@ constexpr int W_IMG = HID * INNER * 4;   // hi + lo image of one weight matrix: 
 #ifndef FFN_DX_UNROLL
 #define FFN_DX_UNROLL 1
 #endif
+// timing experiments only (tools/build_variant.sh): 1 = no weight staging, 2 = no GELU arithmetic, 4 = no output stores
+#ifndef FFN_EXP
+#define FFN_EXP 0
+#endif
 
 __device__ __forceinline__ int sub_off(int r16, int ch) { return r16 * 64 + 16 * (ch ^ ((0 - (r16 >> 2)) & 3)); }
 // hi sub-tile (row tile rt, column block cb) of an image with ncb column blocks; the lo sub-tile follows it
 __device__ __forceinline__ int sub_base(int rt, int cb, int ncb) { return ((rt * ncb + cb) * 2) * SUB; }
 
 struct LaneK {
-  int tr[2];   // transposed fragment of column half db: rows 4g .. 4g+3, column 16 db + i
-  int sr[2];   // split-row fragment: row i, columns 4g .. 4g+3 and 16 + 4g .. 16 + 4g + 3
-  int row;     // row fragment: row i, columns 8g .. 8g+7
+  int tr[2];      // transposed fragment, rows = two stacked 16-row tiles (dw kernel): rows 4g .. 4g+3, column 16 db + i
+  int trk[2][2];  // transposed fragment whose rows are a 32-deep k block in natural order: [db][s] = rows 8g + 4s .. +3 of the
+                  // block (row tile g >> 1 of the pair: + (g >> 1) * row-tile stride, added by the caller), column 16 db + i
+  int trw[2][2];  // the same rows, columns interleaved: [a][s] = rows 8g + 4s .., column 8p + 4a + e for lane i = 4p + e
+  int row;        // row fragment: row i, columns 8g .. 8g+7
+  int hi_tile;    // g >> 1: which row tile of a 32-row pair the lane's k rows are in
 };
 __device__ __forceinline__ LaneK lane_consts(int lane) {
   const int i = lane & 15, g = lane >> 4, qq = i >> 2, pp = i & 3;
   LaneK k;
 #pragma unroll
-  for (int db = 0; db < 2; ++db) k.tr[db] = sub_off(4 * g + qq, 2 * db + (pp >> 1)) + 8 * (pp & 1);
-  k.sr[0] = sub_off(i, g >> 1) + 8 * (g & 1);
-  k.sr[1] = sub_off(i, 2 + (g >> 1)) + 8 * (g & 1);
+  for (int db = 0; db < 2; ++db) {
+    k.tr[db] = sub_off(4 * g + qq, 2 * db + (pp >> 1)) + 8 * (pp & 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      k.trk[db][s] = sub_off(8 * (g & 1) + 4 * s + qq, 2 * db + (pp >> 1)) + 8 * (pp & 1);
+      k.trw[db][s] = sub_off(8 * (g & 1) + 4 * s + qq, pp) + 8 * db;
+    }
+  }
   k.row = sub_off(i, g);
+  k.hi_tile = g >> 1;
   return k;
 }
 
@@ -68,11 +85,6 @@ typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
 __device__ __forceinline__ bf16x8 tr_pair(const char* a, const char* b) {
   const s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)a);
   const s16x4 y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)b);
-  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7));
-}
-__device__ __forceinline__ bf16x8 sr_pair(const char* a, const char* b) {
-  const s16x4 x = *reinterpret_cast<const s16x4*>(a);
-  const s16x4 y = *reinterpret_cast<const s16x4*>(b);
   return __builtin_bit_cast(bf16x8, __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 __device__ __forceinline__ bf16x8 row_at(const char* a) { return *reinterpret_cast<const bf16x8*>(a); }
@@ -119,17 +131,23 @@ __device__ __forceinline__ float quad_sum(float s) {   // over the four lanes i,
   return s;
 }
 
-// fpre^T tile `a` (inner rows 32 kt + 16 a .. +15, the wave's 16 tokens on the columns), accumulator preset to the bias
-__device__ __forceinline__ f32x4 fpre_tile(const char* w1img, const float* sb1, const LaneK& lk, int kt, int a, int g,
+// fpre^T tile `a` of inner block kt (rows 4p + e = inner columns 32 kt + 8p + 4a + e, the wave's 16 tokens on the columns),
+// accumulator preset to the bias `c` (sb1[32 kt + 8g + 4a ..], read by the caller an iteration ahead: a wait on it would
+// otherwise drain every LDS read in flight in front of each product); xh / xl: the tokens' x1 rows as B operands, k-slot (g, j) = hidden column 32 ks + 8g + j
+__device__ __forceinline__ f32x4 fpre_tile(const char* w1img, f32x4 c, const LaneK& lk, int kt, int a,
                                            const bf16x8 (&xh)[2], const bf16x8 (&xl)[2]) {
-  f32x4 c = *reinterpret_cast<const f32x4*>(&sb1[32 * kt + 16 * a + 4 * g]);
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
-    const char* t0 = w1img + sub_base(2 * ks, kt, 8) + lk.tr[a];
-    const char* t1 = t0 + 8 * 2 * SUB;
-    c = mfma3(tr_pair(t0, t1), tr_pair(t0 + SUB, t1 + SUB), xh[ks], xl[ks], c);
+    const char* t = w1img + sub_base(2 * ks + lk.hi_tile, kt, 8);
+    c = mfma3(tr_pair(t + lk.trw[a][0], t + lk.trw[a][1]), tr_pair(t + SUB + lk.trw[a][0], t + SUB + lk.trw[a][1]), xh[ks], xl[ks], c);
   }
   return c;
+}
+
+// the wave's 16 rows of a [N, 64] matrix as B operands of products that sum over the hidden index
+__device__ __forceinline__ void load_rows(const float* src, int tokc, int g, f32x8 (&v)[2]) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) v[ks] = load8(src + (int64_t)tokc * HID + 32 * ks + 8 * g);
 }
 
 // -----------------------------------------------------------------------------------------------------------
@@ -140,8 +158,10 @@ __global__ __launch_bounds__(64 * FW) void ffn_fwd_kernel(FfnP p) {
   char* w1img = smem_ffn;
   char* w2img = smem_ffn + W_IMG;
   float* sb1 = reinterpret_cast<float*>(smem_ffn + 2 * W_IMG);
+  if (!(FFN_EXP & 1)) {
   stage_weight(w1img, p.W1, HID, INNER);
   stage_weight(w2img, p.W2, INNER, HID);
+  }
   if (threadIdx.x < INNER) sb1[threadIdx.x] = p.b1[threadIdx.x];
   __syncthreads();
 
@@ -151,31 +171,38 @@ __global__ __launch_bounds__(64 * FW) void ffn_fwd_kernel(FfnP p) {
   const int ntiles = (p.N + 15) >> 4;
   for (int t = blockIdx.x + gridDim.x * wave; t < ntiles; t += gridDim.x * FW) {   // wave-uniform: EXEC stays full
     const int tok = 16 * t + i, tokc = min(tok, p.N - 1);
-    f32x4 xr[4];
-#pragma unroll
-    for (int hb = 0; hb < 4; ++hb) xr[hb] = *reinterpret_cast<const f32x4*>(p.x1 + (int64_t)tokc * HID + 16 * hb + 4 * g);
     bf16x8 xh[2], xl[2];
+    {
+      f32x8 xv[2];
+      load_rows(p.x1, tokc, g, xv);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) split8(cat(xr[2 * ks], xr[2 * ks + 1]), xh[ks], xl[ks]);
+      for (int ks = 0; ks < 2; ++ks) split8(xv[ks], xh[ks], xl[ks]);
+    }
     f32x4 acc[4];
 #pragma unroll
     for (int hb = 0; hb < 4; ++hb) acc[hb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x8 bnext = load8(&sb1[8 * g]);
 #pragma unroll FFN_FWD_UNROLL
     for (int kt = 0; kt < INNER / 32; ++kt) {
+      const f32x8 bias = bnext;
+      bnext = load8(&sb1[32 * min(kt + 1, INNER / 32 - 1) + 8 * g]);
       f32x4 f[2];
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
-        const f32x4 c = fpre_tile(w1img, sb1, lk, kt, a, g, xh, xl);
+        const f32x4 c = fpre_tile(w1img, a ? (f32x4){bias[4], bias[5], bias[6], bias[7]} : (f32x4){bias[0], bias[1], bias[2], bias[3]},
+                                  lk, kt, a, xh, xl);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) f[a][r] = b4r_gelu_fast(c[r]);
+        for (int r = 0; r < 4; ++r) f[a][r] = (FFN_EXP & 2) ? c[r] : b4r_gelu_fast(c[r]);
       }
       bf16x8 fh, fl;
-      split8(cat(f[0], f[1]), fh, fl);
+      split8(cat(f[0], f[1]), fh, fl);   // k-slot (g, j) = inner column 32 kt + 8g + j
+      const char* t = w2img + sub_base(2 * kt + lk.hi_tile, 0, 2);
 #pragma unroll
-      for (int hb = 0; hb < 4; ++hb) {   // G^T[16 hb + ..][token] += W2^T[.., inner of the pair] . f^T
-        const char* t0 = w2img + sub_base(2 * kt, hb >> 1, 2) + lk.tr[hb & 1];
-        const char* t1 = t0 + 2 * 2 * SUB;
-        acc[hb] = mfma3(tr_pair(t0, t1), tr_pair(t0 + SUB, t1 + SUB), fh, fl, acc[hb]);
+      for (int hb = 0; hb < 4; ++hb) {   // G^T[16 hb + ..][token] += W2^T[.., inner block kt] . f^T
+        const char* th = t + (hb >> 1) * 2 * SUB;
+        const int db = hb & 1;
+        acc[hb] = mfma3(tr_pair(th + lk.trk[db][0], th + lk.trk[db][1]), tr_pair(th + SUB + lk.trk[db][0], th + SUB + lk.trk[db][1]),
+                        fh, fl, acc[hb]);
       }
     }
     // bias + dropout + residual + LayerNorm: lane (i, g) holds columns 16 hb + 4g .. +3 of token i
@@ -184,7 +211,8 @@ __global__ __launch_bounds__(64 * FW) void ffn_fwd_kernel(FfnP p) {
 #pragma unroll
     for (int hb = 0; hb < 4; ++hb) {
       const f32x4 y = acc[hb] + *reinterpret_cast<const f32x4*>(p.b2 + 16 * hb + 4 * g);
-      z[hb] = xr[hb] + b4r_drop4(dctx, y, (uint64_t)tok * HID + (uint64_t)(16 * hb + 4 * g));
+      const f32x4 res = *reinterpret_cast<const f32x4*>(p.x1 + (int64_t)tokc * HID + 16 * hb + 4 * g);
+      z[hb] = res + b4r_drop4(dctx, y, (uint64_t)tok * HID + (uint64_t)(16 * hb + 4 * g));
       s += sum4(z[hb]);
     }
     const float mean = quad_sum(s) * (1.0f / HID);
@@ -195,7 +223,7 @@ __global__ __launch_bounds__(64 * FW) void ffn_fwd_kernel(FfnP p) {
       q += sum4(d * d);
     }
     const float rstd = rsqrtf(quad_sum(q) * (1.0f / HID) + p.eps);
-    if (tok < p.N) {
+    if (tok < p.N && (!(FFN_EXP & 4) || rstd == 12345.f)) {
 #pragma unroll
       for (int hb = 0; hb < 4; ++hb) {
         const int64_t o = (int64_t)tok * HID + 16 * hb + 4 * g;
@@ -245,44 +273,52 @@ __global__ __launch_bounds__(64 * FW) void ffn_bwd_dx_kernel(FfnP p) {
     const int64_t rowo = (int64_t)tokc * HID + 4 * g;
     bf16x8 xh[2], xl[2], gh[2], gl[2];
     {
-      f32x4 xr[4], dg[4];
-#pragma unroll
-      for (int hb = 0; hb < 4; ++hb) {
-        xr[hb] = *reinterpret_cast<const f32x4*>(p.x1 + rowo + 16 * hb);
-        dg[hb] = *reinterpret_cast<const f32x4*>(p.dz2 + rowo + 16 * hb);
-      }
-#pragma unroll
-      for (int hb = 0; hb < 4; ++hb) dg[hb] = b4r_drop4(dctx, dg[hb], (uint64_t)tok * HID + (uint64_t)(16 * hb + 4 * g));
+      f32x8 xv[2], dg[2];
+      load_rows(p.x1, tokc, g, xv);
+      load_rows(p.dz2, tokc, g, dg);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        split8(cat(xr[2 * ks], xr[2 * ks + 1]), xh[ks], xl[ks]);
-        split8(cat(dg[2 * ks], dg[2 * ks + 1]), gh[ks], gl[ks]);
+        if (dctx.on) {
+          const uint64_t e0 = (uint64_t)tok * HID + (uint64_t)(32 * ks + 8 * g);
+          const f32x4 lo4 = b4r_drop4(dctx, (f32x4){dg[ks][0], dg[ks][1], dg[ks][2], dg[ks][3]}, e0);
+          const f32x4 hi4 = b4r_drop4(dctx, (f32x4){dg[ks][4], dg[ks][5], dg[ks][6], dg[ks][7]}, e0 + 4);
+          dg[ks] = cat(lo4, hi4);
+        }
+        split8(xv[ks], xh[ks], xl[ks]);
+        split8(dg[ks], gh[ks], gl[ks]);
       }
     }
     f32x4 acc[4];
 #pragma unroll
     for (int hb = 0; hb < 4; ++hb) acc[hb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x8 bnext = load8(&sb1[8 * g]);
 #pragma unroll FFN_DX_UNROLL
     for (int kt = 0; kt < INNER / 32; ++kt) {
+      const f32x8 bias = bnext;
+      bnext = load8(&sb1[32 * min(kt + 1, INNER / 32 - 1) + 8 * g]);
       f32x4 dfp[2];
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
-        const f32x4 c = fpre_tile(w1img, sb1, lk, kt, a, g, xh, xl);
-        f32x4 d = {0.f, 0.f, 0.f, 0.f};   // dF^T[inner][token] = W2[inner][:] . dG^T
+        const f32x4 c = fpre_tile(w1img, a ? (f32x4){bias[4], bias[5], bias[6], bias[7]} : (f32x4){bias[0], bias[1], bias[2], bias[3]},
+                                  lk, kt, a, xh, xl);
+        // dF^T[inner][token] = W2[inner][:] . dG^T for the same inner columns as the fpre tile: row i = 4p + e of the
+        // operand is row 8p + 4a + e of the 32-row block of W2
+        const int wrow = 8 * (i >> 2) + 4 * a + (i & 3);
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          const char* s0 = w2img + sub_base(2 * kt + a, ks, 2);
-          d = mfma3(sr_pair(s0 + lk.sr[0], s0 + lk.sr[1]), sr_pair(s0 + SUB + lk.sr[0], s0 + SUB + lk.sr[1]), gh[ks], gl[ks], d);
+          const char* s0 = w2img + sub_base(2 * kt + (wrow >> 4), ks, 2) + sub_off(wrow & 15, g);
+          d = mfma3(row_at(s0), row_at(s0 + SUB), gh[ks], gl[ks], d);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) dfp[a][r] = d[r] * b4r_gelu_grad_fast(c[r]);
       }
       bf16x8 ph, pl;
-      split8(cat(dfp[0], dfp[1]), ph, pl);
+      split8(cat(dfp[0], dfp[1]), ph, pl);   // k-slot (g, j) = inner column 32 kt + 8g + j
 #pragma unroll
-      for (int hb = 0; hb < 4; ++hb) {   // dx1^T[16 hb + ..][token] += W1[.., inner of the pair] . dFpre^T
-        const char* s0 = w1img + sub_base(hb, kt, 8);
-        acc[hb] = mfma3(sr_pair(s0 + lk.sr[0], s0 + lk.sr[1]), sr_pair(s0 + SUB + lk.sr[0], s0 + SUB + lk.sr[1]), ph, pl, acc[hb]);
+      for (int hb = 0; hb < 4; ++hb) {   // dx1^T[16 hb + ..][token] += W1[.., inner block kt] . dFpre^T
+        const char* s0 = w1img + sub_base(hb, kt, 8) + lk.row;
+        acc[hb] = mfma3(row_at(s0), row_at(s0 + SUB), ph, pl, acc[hb]);
       }
     }
     // dx1 = acc + dz2 (the residual branch), then back through x1 = LN(z1)

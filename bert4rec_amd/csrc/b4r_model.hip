@@ -293,6 +293,12 @@ bool ffn_fused(const b4r_model_config* c) {
   return on && b4r_ffn_block_supported(c->hidden_size, c->inner_dim) != 0;
 }
 
+// the attention half of a layer as one launch forward (b4r_attn_block.hip); B4R_ATTN_FUSED=0: the three launches of round 1
+bool attn_fused(const b4r_model_config* c, int L) {
+  static const bool on = !(getenv("B4R_ATTN_FUSED") && atoi(getenv("B4R_ATTN_FUSED")) == 0);
+  return on && b4r_attn_block_supported(c->hidden_size, c->num_heads, L) != 0;
+}
+
 // pair kernels (input gradient inside the weight-gradient kernel, b4r_gemm_tn_desc.dgrad_*): B4R_PAIR bit 0 = the 64 x 64 layers
 // (attention output, masked-LM transform), bit 1 = the FFN output layer with its GELU' tail
 int pair_level() {
@@ -451,6 +457,18 @@ extern "C" int b4r_forward(const b4r_model_config* cfg, const b4r_batch* batch, 
                       params + pl.emb_ln_b, H, cfg->ln_eps, ws + w.x0, ws + w.mean0, ws + w.rstd0, rng, od, stream));
   const float* x = ws + w.x0;
   for (int i = 0; i < cfg->num_layers; ++i) {
+    if (attn_fused(cfg, L)) {
+      b4r_attn_block_desc ad{};
+      ad.B = B; ad.L = L; ad.H = H; ad.heads = cfg->num_heads; ad.x = x; ad.input_mask = batch->input_mask;
+      ad.Wqkv = params + pl.wqkv[i]; ad.bqkv = params + pl.bqkv[i]; ad.Wo = params + pl.wo[i]; ad.bo = params + pl.bo[i];
+      ad.ln_gamma = params + pl.ln1_g[i]; ad.ln_beta = params + pl.ln1_b[i]; ad.ln_eps = cfg->ln_eps;
+      ad.rng = (od > 0.f || adp > 0.f) ? rng : nullptr;
+      ad.probs_stream = B4R_STREAM_ATTN_PROBS(i); ad.probs_rate = adp; ad.out_stream = B4R_STREAM_ATTN_OUT(i); ad.out_rate = od;
+      ad.qkv = ws + w.qkv[i];   // b4r_attn_bwd still reads it
+      ad.ctx = ws + w.ctx[i]; ad.lse = ws + w.lse[i]; ad.keep_bits = reinterpret_cast<uint32_t*>(ws + w.keep[i]);
+      ad.z1 = ws + w.z1[i]; ad.x1 = ws + w.x1[i]; ad.mean1 = ws + w.mean1[i]; ad.rstd1 = ws + w.rstd1[i];
+      RC(b4r_attn_block_fwd(&ad, stream));
+    } else {
     RC(gemm(x, H, params + pl.wqkv[i], 3 * H, ws + w.qkv[i], 3 * H, N, 3 * H, H, 0, B4R_EPI_BIAS_QSCALE, params + pl.bqkv[i],
             nullptr, 0, nullptr, 0, qscale, H, nullptr, 0, 0.f, 0, s));
     RC(b4r_attn_fwd(ws + w.qkv[i], batch->input_mask, B, L, cfg->num_heads, ws + w.ctx[i], ws + w.lse[i], rng,
@@ -458,6 +476,7 @@ extern "C" int b4r_forward(const b4r_model_config* cfg, const b4r_batch* batch, 
     RC(dense_res_ln(ws + w.ctx[i], H, params + pl.wo[i], ws + w.z1[i], ws + w.x1[i], ws + w.mean1[i], ws + w.rstd1[i], N, H, H,
                     params + pl.bo[i], x, params + pl.ln1_g[i], params + pl.ln1_b[i], cfg->ln_eps, rng, B4R_STREAM_ATTN_OUT(i),
                     od, s));
+    }
     if (ffn_fused(cfg)) {
       b4r_ffn_desc fd{};
       fd.N = N; fd.H = H; fd.I = I; fd.x1 = ws + w.x1[i];

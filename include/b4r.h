@@ -326,6 +326,27 @@ int64_t b4r_attn_keep_words(int32_t B, int32_t L, int32_t heads);
  * Dropout: element index row*64 + col of site drop_stream (rng == NULL: off).  Gradient outputs are overwritten (deterministic
  * ordered sums over per-workgroup partials in `scratch`, b4r_ffn_block_bwd_scratch_floats floats, 16-byte aligned).
  * b4r_ffn_block_supported: hidden 64, inner 256, bf16x3 mode; other shapes get B4R_E_SHAPE (callers then use b4r_gemm_f32). */
+/* The attention block, forward: one workgroup per sequence (hidden 64, 2 heads, L <= 256, bf16x3 mode; b4r_attn_block_supported):
+ *   q,k,v = x.Wqkv + bqkv (q * 1/sqrt(32)) ; per head ctx = dropout(softmax(q k^T + (1 - mask) * -1e9)) v ;
+ *   z1 = x + dropout(ctx.Wo + bo) ; x1 = LayerNorm(z1) * ln_gamma + ln_beta ; mean1 / rstd1
+ * in ONE launch (= b4r_gemm_f32 BIAS_QSCALE + b4r_attn_fwd + b4r_gemm_f32 BIAS_DROP_RES_LN).  Saved for the backward:
+ * ctx [B*L,H], lse [B,heads,L], keep_bits (b4r_attn_keep_words; required when probs_rate > 0) and, when qkv != NULL, qkv
+ * [B*L,3H] in b4r_attn_fwd's layout (b4r_attn_bwd reads it).  Dropout sites: probs_stream on the probabilities (index as
+ * b4r_attn_fwd), out_stream on the output projection (index row*64 + col); rng == NULL: off. */
+typedef struct b4r_attn_block_desc {
+  int32_t B, L, H, heads;
+  const float* x;                                     /* [B*L,H] block input */
+  const int64_t* input_mask;                          /* [B,L] */
+  const float* Wqkv; const float* bqkv;               /* [H,3H] (query | key | value kernels), [3H] */
+  const float* Wo; const float* bo;                   /* [H,H] attention_output/kernel, [H] */
+  const float* ln_gamma; const float* ln_beta; float ln_eps;   /* self_attention_layer_norm */
+  const uint32_t* rng; uint32_t probs_stream; float probs_rate; uint32_t out_stream; float out_rate;
+  float* qkv; float* ctx; float* lse; uint32_t* keep_bits;
+  float* z1; float* x1; float* mean1; float* rstd1;   /* z1 / mean1 / rstd1 may be NULL */
+} b4r_attn_block_desc;
+int32_t b4r_attn_block_supported(int32_t hidden_size, int32_t num_heads, int32_t L);
+int b4r_attn_block_fwd(const b4r_attn_block_desc* d, b4r_stream_t stream);
+
 typedef struct b4r_ffn_desc {
   int32_t N, H, I;
   const float* x1;                                  /* [N,H] block input */

@@ -123,3 +123,93 @@ def test_ffn_block_refuses_other_shapes():
     _lib.check(lib.b4r_set_gemm_mode(_lib.GEMM_F32))
     assert lib.b4r_ffn_block_supported(64, 256) == 0
     _lib.check(lib.b4r_set_gemm_mode(_lib.GEMM_BF16X3))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# attention block
+# ---------------------------------------------------------------------------------------------------------------------------
+def attn_inputs(B, L, seed):
+    H = 64
+    t = dict(x=rnd(B * L, H, seed=seed + 1), Wqkv=rnd(H, 3 * H, seed=seed + 2, scale=0.1), bqkv=0.1 * rnd(3 * H, seed=seed + 3),
+             Wo=rnd(H, H, seed=seed + 4, scale=0.15), bo=0.1 * rnd(H, seed=seed + 5), g1=1.0 + 0.2 * rnd(H, seed=seed + 6),
+             be1=0.1 * rnd(H, seed=seed + 7))
+    gen = torch.Generator().manual_seed(seed)
+    lens = torch.randint(1, L + 1, (B,), generator=gen)
+    lens[0] = L
+    if B > 2:
+        lens[1] = 1
+    mask = (torch.arange(L)[None, :] < lens[:, None]).to(torch.int64)
+    if B > 3:
+        mask[3] = 0          # a fully masked row: Keras' -1e9 gives a uniform softmax over ALL keys
+    return t, mask
+
+
+def attn_reference(t, mask, B, L, p_rate, o_rate, seed, step, site_p, site_o, eps=1e-12):
+    """fp64 restatement of Keras MultiHeadAttention (2 heads of 32) + output dropout + residual + LayerNorm."""
+    H, heads, dh = 64, 2, 32
+    d = {k: v.double() for k, v in t.items()}
+    x = d["x"].reshape(B, L, H)
+    qkv = x @ d["Wqkv"] + d["bqkv"]
+    q, k, v = (qkv[..., j * H:(j + 1) * H].reshape(B, L, heads, dh) for j in range(3))
+    q = q * (1.0 / math.sqrt(dh))
+    # the mask is added in fp32, as Keras does: -1e9 absorbs the scores of a fully masked row (ulp 64) -> uniform softmax
+    adder = (1.0 - mask.float())[:, None, None, :] * torch.tensor(-1e9, dtype=torch.float32)
+    s = (torch.einsum("bqhd,bkhd->bhqk", q, k).float() + adder).double()
+    a = torch.softmax(s, dim=-1)
+    lse = torch.logsumexp(s, dim=-1)
+    if p_rate > 0:
+        keep = orc.dropout_keep_mask((B, heads, L, L), p_rate, seed, step, site_p, row_pitch=orc.ATTN_PITCH).double()
+        a = a * keep / (1.0 - p_rate)
+    ctx = torch.einsum("bhqk,bkhd->bqhd", a, v).reshape(B * L, H)
+    y = ctx @ d["Wo"] + d["bo"]
+    if o_rate > 0:
+        y = y * orc.dropout_keep_mask((B * L, H), o_rate, seed, step, site_o).double() / (1.0 - o_rate)
+    z1 = d["x"] + y
+    x1, mean1, rstd1 = ln64(z1, d["g1"], d["be1"], eps)
+    qkv_scaled = torch.cat([q.reshape(B * L, H), k.reshape(B * L, H), v.reshape(B * L, H)], dim=1)
+    return dict(qkv=qkv_scaled, ctx=ctx, lse=lse, z1=z1, x1=x1, mean1=mean1, rstd1=rstd1)
+
+
+@pytest.mark.parametrize("B,L,p_rate,o_rate", [(3, 16, 0.0, 0.0), (5, 50, 0.0, 0.0), (4, 200, 0.2, 0.2), (6, 100, 0.0, 0.3),
+                                              (2, 256, 0.2, 0.0), (7, 37, 0.5, 0.5)])
+def test_attn_block_forward_matches_fp64(B, L, p_rate, o_rate):
+    lib = _lib.load()
+    _lib.check(lib.b4r_set_gemm_mode(_lib.GEMM_BF16X3))
+    assert lib.b4r_attn_block_supported(64, 2, L) == 1
+    seed, step, site_p, site_o = 991, 5, 1, 2
+    t, mask = attn_inputs(B, L, seed=B * 1000 + L)
+    ref = attn_reference(t, mask, B, L, p_rate, o_rate, seed, step, site_p, site_o)
+    g = {k: v.to(DEV) for k, v in t.items()}
+    st = T.new_state(seed, step) if (p_rate > 0 or o_rate > 0) else None
+    N, nan = B * L, float("nan")
+    out = {k: torch.full(s, nan, dtype=torch.float32, device=DEV) for k, s in
+           dict(qkv=(N, 192), ctx=(N, 64), lse=(B, 2, L), z1=(N, 64), x1=(N, 64), mean1=(N,), rstd1=(N,)).items()}
+    bits = torch.zeros(lib.b4r_attn_keep_words(B, L, 2), dtype=torch.int32, device=DEV)
+    maskd = mask.to(DEV)
+    d = _lib.AttnBlockDesc()
+    d.B, d.L, d.H, d.heads = B, L, 64, 2
+    d.x, d.input_mask = P(g["x"]), P(maskd)
+    d.Wqkv, d.bqkv, d.Wo, d.bo = P(g["Wqkv"]), P(g["bqkv"]), P(g["Wo"]), P(g["bo"])
+    d.ln_gamma, d.ln_beta, d.ln_eps = P(g["g1"]), P(g["be1"]), 1e-12
+    d.rng, d.probs_stream, d.probs_rate, d.out_stream, d.out_rate = P(st), site_p, p_rate, site_o, o_rate
+    d.qkv, d.ctx, d.lse, d.keep_bits = P(out["qkv"]), P(out["ctx"]), P(out["lse"]), P(bits)
+    d.z1, d.x1, d.mean1, d.rstd1 = P(out["z1"]), P(out["x1"]), P(out["mean1"]), P(out["rstd1"])
+    _lib.check(lib.b4r_attn_block_fwd(C.byref(d), stream()), "b4r_attn_block_fwd")
+    torch.cuda.synchronize()
+    for k in ("qkv", "ctx", "z1", "x1", "mean1"):   # scores reach +-5 here: 2e-4 on the softmax-weighted sums
+        assert T.maxdiff(out[k], ref[k]) < 2e-4, k
+    assert T.maxdiff(out["rstd1"] / ref["rstd1"].float().to(DEV), torch.ones(N)) < 1e-4
+    # lse of rows whose keys are all masked is ~ -1e9 + log(L): compare relative there
+    lse_ref = ref["lse"]
+    assert float(((out["lse"].cpu().double() - lse_ref).abs() / lse_ref.abs().clamp(min=1.0)).max()) < 1e-4
+
+    # the separate kernels of round 1 read what the block saved: b4r_attn_bwd on (qkv, ctx, lse, keep_bits) must agree with the
+    # backward on the outputs of b4r_attn_fwd for the same inputs
+    ctx2 = torch.empty(N, 64, device=DEV)
+    lse2 = torch.empty(B, 2, L, device=DEV)
+    bits2 = torch.zeros_like(bits)
+    _lib.check(lib.b4r_attn_fwd(P(out["qkv"]), P(maskd), B, L, 2, P(ctx2), P(lse2), P(st), site_p, p_rate, P(bits2), stream()))
+    torch.cuda.synchronize()
+    assert T.maxdiff(ctx2, out["ctx"]) < 2e-5
+    if p_rate > 0:
+        assert torch.equal(bits2, bits)

@@ -535,6 +535,30 @@ extern "C" int b4r_forward(const b4r_model_config* cfg, const b4r_batch* batch, 
   return B4R_OK;
 }
 
+extern "C" int b4r_mlm_transform_rows(const b4r_model_config* cfg, const float* params, const float* seq, int64_t n_seq_rows,
+                                      const int64_t* rows, int32_t R, float* out, float* scratch, b4r_stream_t stream) {
+  RC(check_cfg(cfg));
+  B4R_CHECK_ARG(params && seq && rows && out && scratch && R > 0 && n_seq_rows > 0, B4R_E_BADARG, "b4r_mlm_transform_rows: bad argument");
+  B4R_CHECK_ARG(b4r_aligned16(params) && b4r_aligned16(seq) && b4r_aligned16(out) && b4r_aligned16(scratch), B4R_E_ALIGN,
+                "b4r_mlm_transform_rows: buffers must be 16-byte aligned");
+  const ParamLayout pl = make_param_layout(*cfg);
+  const int H = cfg->hidden_size;
+  hipStream_t s = (hipStream_t)stream;
+  float* gath = scratch; float* upre = gath + up4((int64_t)R * H); float* u = upre + up4((int64_t)R * H);
+  float* mean = u + up4((int64_t)R * H); float* rstd = mean + up4(R);
+  b4r_gemm_desc d{};
+  d.A = seq; d.lda = H; d.B = params + pl.wd; d.ldb = H; d.C = u; d.ldc = H; d.M = R; d.N = H; d.K = H;
+  d.a_gather_idx = rows; d.a_gather_add_per = n_seq_rows; d.a_gather_per = R;   // one group: row m reads seq[rows[m]]
+  d.epilogue = B4R_EPI_BIAS_GELU_LN; d.bias = params + pl.bd; d.C2 = out; d.ldc2 = H; d.C3 = upre; d.ldc3 = H;
+  d.qscale = 1.f; d.c_pad_scratch = 0;
+  d.ln_gamma = params + pl.lnm_g; d.ln_beta = params + pl.lnm_b; d.ln_mean = mean; d.ln_rstd = rstd; d.ln_eps = cfg->ln_eps;
+  if (b4r_gemm_ln_supported(&d)) return b4r_gemm_f32(&d, stream);
+  RC(b4r_gather_rows(seq, H, rows, n_seq_rows, R, R, H, gath, stream));
+  RC(gemm(gath, H, params + pl.wd, H, u, H, R, H, H, 0, B4R_EPI_BIAS_GELU, params + pl.bd, upre, H, nullptr, 0, 1.f, 0, nullptr, 0,
+          0.f, 0, s));
+  return b4r_ln_fwd(u, R, H, params + pl.lnm_g, params + pl.lnm_b, cfg->ln_eps, out, mean, rstd, stream);
+}
+
 extern "C" int b4r_loss(const b4r_model_config* cfg, const b4r_batch* batch, void* workspace, int64_t workspace_bytes,
                         b4r_train_state* state, int32_t want_grad, b4r_stream_t stream) {
   RC(check_cfg(cfg));

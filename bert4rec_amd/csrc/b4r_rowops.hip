@@ -578,47 +578,6 @@ __global__ void state_advance_kernel(b4r_train_state* st) {
   if (threadIdx.x == 0 && blockIdx.x == 0) { st->step += 1; st->step_lo = (uint32_t)st->step; }
 }
 
-// -----------------------------------------------------------------------------------------------------------
-// candidate ranking: one workgroup per ranked slot
-// -----------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(128) void rank_kernel(const float* hidden, int hidden_ld, const int64_t* hidden_row,
-                                                   const float* table, const float* bias, int H, const int64_t* cand,
-                                                   int C, const int64_t* gt, int64_t* ranking, int32_t* gt_rank,
-                                                   float* scores_out) {
-  extern __shared__ float sm[];  // [H] hidden row, then [C] scores
-  __shared__ int s_best;
-  float* sh = sm; float* sc = sm + H;
-  const int r = blockIdx.x, tid = threadIdx.x;
-  const int64_t hr = hidden_row ? hidden_row[r] : (int64_t)r;
-  for (int k = tid; k < H; k += 128) sh[k] = hidden[hr * hidden_ld + k];
-  if (tid == 0) s_best = 0x7fffffff;
-  __syncthreads();
-  const int64_t* cr = cand + (int64_t)r * C;
-  for (int j = tid; j < C; j += 128) {
-    const int64_t c = cr[j];
-    const float* e = table + c * H;
-    float acc = 0.f;
-    for (int k = 0; k < H; ++k) acc = __builtin_fmaf(sh[k], e[k], acc);  // k-ordered fp32 fma chain (spec)
-    const float s = acc + bias[c];
-    sc[j] = s;
-    if (scores_out) scores_out[(int64_t)r * C + j] = s;
-  }
-  __syncthreads();
-  const int64_t g = gt ? gt[r] : -1;
-  for (int j = tid; j < C; j += 128) {
-    const float sj = sc[j];
-    int pos = 0;
-    for (int i = 0; i < C; ++i) {
-      const float si = sc[i];
-      pos += (si > sj || (si == sj && i < j)) ? 1 : 0;
-    }
-    if (ranking) ranking[(int64_t)r * C + pos] = cr[j];
-    if (gt && cr[j] == g) atomicMin(&s_best, pos);
-  }
-  __syncthreads();
-  if (tid == 0 && gt_rank) gt_rank[r] = (s_best == 0x7fffffff) ? 0 : s_best + 1;
-}
-
 }  // namespace
 
 // ===============================================================================================================
@@ -1021,20 +980,3 @@ extern "C" int b4r_sample_candidates(const float* logp, int32_t V, const int64_t
   return B4R_OK;
 }
 
-extern "C" int b4r_rank_candidates(const float* hidden, int32_t hidden_ld, const int64_t* hidden_row, const float* table,
-                                   const float* bias, int32_t H, const int64_t* cand, int32_t R, int32_t C,
-                                   const int64_t* gt, int64_t* ranking, int32_t* gt_rank, float* scores,
-                                   b4r_stream_t stream) {
-  B4R_CHECK_ARG(hidden && table && bias && cand, B4R_E_BADARG, "b4r_rank_candidates: null argument");
-  B4R_CHECK_ARG(R > 0 && C > 0 && H > 0 && hidden_ld >= H, B4R_E_SHAPE, "b4r_rank_candidates: bad shape");
-  const size_t sh = (size_t)(H + C) * sizeof(float);
-  B4R_CHECK_ARG(sh <= 160 * 1024 - 64, B4R_E_SHAPE, "b4r_rank_candidates: %d candidates do not fit in LDS", C);
-  if (sh > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)rank_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-    if (e != hipSuccess) { b4r_set_error("b4r_rank_candidates: cannot raise LDS limit: %s", hipGetErrorString(e)); return B4R_E_HIP; }
-  }
-  hipLaunchKernelGGL(rank_kernel, dim3(R), dim3(128), sh, (hipStream_t)stream, hidden, hidden_ld, hidden_row, table, bias,
-                     H, cand, C, gt, ranking, gt_rank, scores);
-  B4R_CHECK_LAUNCH("b4r_rank_candidates");
-  return B4R_OK;
-}

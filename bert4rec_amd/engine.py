@@ -398,20 +398,55 @@ class Engine:
                              f"(since no duplicates are allowed).")
         return cand
 
-    def rank_candidates(self, hidden: torch.Tensor, hidden_rows: Optional[torch.Tensor], cand: torch.Tensor,
-                        gt: Optional[torch.Tensor], want_ranking: bool = True, want_scores: bool = False):
-        """b4r_rank_candidates on `hidden` [*,H] (ld = stride(0)); cand [R,C] int64; gt [R] int64 or None."""
-        R, Cn = cand.shape
-        cand = cand.to(device=self.device, dtype=torch.int64).contiguous()
+    def encoder_forward(self, cb: Batch, training: bool = False) -> Batch:
+        """Encoder only (no masked-LM head): the batch struct without its masked_lm_* pointers -> b4r_forward stops at the
+        sequence output.  Returns that struct (its workspace key is (B, L, 0))."""
+        enc = Batch(cb.input_word_ids, cb.input_mask, None, None, cb.B, cb.L, 0)
+        self.forward(enc, training=training, pooler=False)
+        return enc
+
+    def mlm_transform_rows(self, seq: torch.Tensor, rows: torch.Tensor) -> torch.Tensor:
+        """b4r_mlm_transform_rows: tfm MaskedLM's gather -> dense(gelu) -> LayerNorm on the listed rows of seq [N,H] only."""
+        rows = rows.to(device=self.device, dtype=torch.int64).contiguous()
+        R, H = int(rows.numel()), self.cfg.hidden_size
+        out = torch.empty((R, H), dtype=torch.float32, device=self.device)
+        scratch = torch.empty(3 * (R * H + 4) + 2 * (R + 4), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.b4r_mlm_transform_rows(C.byref(self.cfg), _ptr(self.params), _ptr(seq), seq.shape[0], _ptr(rows), R,
+                                                   _ptr(out), _ptr(scratch), _stream(self.device)), "b4r_mlm_transform_rows")
+        return out
+
+    def rank_candidates(self, hidden: torch.Tensor, hidden_rows: Optional[torch.Tensor], cand: Optional[torch.Tensor],
+                        gt: Optional[torch.Tensor], want_ranking: bool = True, want_scores: bool = False,
+                        n_candidates: Optional[int] = None, n_rows: Optional[int] = None):
+        """b4r_rank_candidates on `hidden` [*,H] (ld = stride(0)); cand [R,C] int64, or None = every row ranks the items
+        0 .. n_candidates-1 (the whole vocabulary; n_rows rows); gt [R] int64 or None."""
+        if cand is None:
+            R, Cn = int(n_rows), int(n_candidates)
+        else:
+            R, Cn = cand.shape
+            cand = cand.to(device=self.device, dtype=torch.int64).contiguous()
         gt_d = None if gt is None else gt.to(device=self.device, dtype=torch.int64).contiguous()
         rows_d = None if hidden_rows is None else hidden_rows.to(device=self.device, dtype=torch.int64).contiguous()
         ranking = torch.empty((R, Cn), dtype=torch.int64, device=self.device) if want_ranking else None
         gt_rank = torch.empty((R,), dtype=torch.int32, device=self.device) if gt is not None else None
         scores = torch.empty((R, Cn), dtype=torch.float32, device=self.device) if want_scores else None
         H = self.cfg.hidden_size
+        need = int(self.lib.b4r_rank_scratch_bytes(R, Cn))
+        scratch = None
+        if need > 0:
+            # large candidate lists: radix argsort in global memory; cap the scratch at 4 GiB (rows are ranked in groups)
+            scratch = torch.empty(min(need, max(Cn * 20, 4 << 30)) // 4 + 4, dtype=torch.float32, device=self.device)
         _lib.check(self.lib.b4r_rank_candidates(_ptr(hidden), hidden.stride(0), _ptr(rows_d),
                                                 _ptr(self.view("word_embeddings/embeddings")),
                                                 _ptr(self.view("cls/predictions/output_bias/bias")), H, _ptr(cand), R, Cn,
-                                                _ptr(gt_d), _ptr(ranking), _ptr(gt_rank), _ptr(scores),
+                                                _ptr(gt_d), _ptr(ranking), _ptr(gt_rank), _ptr(scores), _ptr(scratch),
+                                                0 if scratch is None else scratch.numel() * 4,
                                                 _stream(self.device)), "b4r_rank_candidates")
         return ranking, gt_rank, scores
+
+    def rank_metrics(self, gt_rank: torch.Tensor, families, cutoffs, gain_sums: torch.Tensor, users: torch.Tensor) -> None:
+        """b4r_rank_metrics: add this batch's gain sums to the device accumulators (float64 [n], int64 [1])."""
+        fam = (C.c_int32 * len(families))(*families)
+        cut = (C.c_int32 * len(cutoffs))(*cutoffs)
+        _lib.check(self.lib.b4r_rank_metrics(_ptr(gt_rank), int(gt_rank.numel()), fam, cut, len(families), _ptr(gain_sums),
+                                             _ptr(users), _stream(self.device)), "b4r_rank_metrics")

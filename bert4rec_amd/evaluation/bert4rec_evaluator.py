@@ -3,7 +3,10 @@ with the sampler (excluding the user's items and the ground truth), append the g
 candidates and feed the 1-based rank of the ground truth to every metric.
 
 The ranking itself is one b4r_rank_candidates launch per batch (scores + stable ordering + rank lookup on the GPU)
-instead of the reference's per-user python loop of tf.gather / tf.argsort calls.  With the popularity sampler the 100
+instead of the reference's per-user python loop of tf.gather / tf.argsort calls, the metric sums of a batch are one
+b4r_rank_metrics launch into device accumulators that are read back ONCE per evaluate() (no host synchronisation per batch),
+and under torch.distributed the batches are dealt round-robin to the ranks with one all-reduce of the sums at the end
+("shard users across ranks ... one 8-float all-reduce").  With the popularity sampler the 100
 negatives of every slot of a batch are drawn by one b4r_sample_candidates launch as well (`device_sampling`, default on
 when the model runs on a GPU): same distribution as the reference's per-slot np.random.choice, own random stream;
 `sample_candidates` keeps the reference's host procedure (pinned by the golden vectors)."""
@@ -14,7 +17,7 @@ import torch
 
 from ..dataloaders import samplers
 from .base_evaluator import BaseEvaluator
-from .evaluation_metrics import HR, MAP, NDCG, Counter, EvaluationMetric
+from .evaluation_metrics import HR, MAP, NDCG, Counter, EvaluationMetric, gain_table
 
 
 def default_metrics():
@@ -26,6 +29,7 @@ class BERT4RecEvaluator(BaseEvaluator):
     def __init__(self, metrics: list = None, sampler: Union[str, "samplers.BaseSampler"] = "pop_random", dataloader=None,
                  device_sampling: bool = True, seed: int = 0):
         self.device_sampling = device_sampling
+        self._dev = None   # (engine, float64 gain sums [n_metrics], int64 user count [1]) on the GPU
         self._seed = int(seed)
         self._draws = 0
         self._logp = None
@@ -40,13 +44,51 @@ class BERT4RecEvaluator(BaseEvaluator):
             sampler = samplers.get(sampler, **sampler_config)
         super().__init__(metrics, sampler, dataloader)
 
-    def evaluate(self, model, test_data) -> list:
+    def evaluate(self, model, test_data, group=None) -> list:
+        """bert4rec_evaluator.py:46-58.  With an initialised torch.distributed process group (`group`, default WORLD) rank k
+        evaluates batches k, k + world, ... and every rank ends with the metrics of ALL users."""
         if self.dataloader is None and not self.sampler.is_fully_prepared():
             raise ValueError("The evaluator has to be either initialized with a dataloader or a fully prepared sampler "
                              "has to be given.")
-        for batch in test_data:
-            self.evaluate_batch(model, batch)
+        rank, world = _dist_rank_world(group)
+        before = [m.partial() for m in self._metrics]
+        for i, batch in enumerate(test_data):
+            if i % world == rank:
+                self.evaluate_batch(model, batch)
+        self._flush_device_sums()
+        if world > 1:
+            self._merge_across_ranks(before, group)
         return self._metrics
+
+    # ---- device-side accumulation ---------------------------------------------------------------------------------------
+    def _device_sums(self, engine):
+        if self._dev is None or self._dev[0] is not engine:
+            import torch as _t
+            n = len(self._metrics)
+            self._dev = (engine, _t.zeros(n, dtype=_t.float64, device=engine.device), _t.zeros(1, dtype=_t.int64, device=engine.device))
+        return self._dev
+
+    def _flush_device_sums(self) -> None:
+        """one device -> host copy for the whole evaluation: fold the accumulated sums into the metric objects"""
+        if self._dev is None:
+            return
+        _, sums, users = self._dev
+        sums_h, users_h = sums.cpu().tolist(), int(users.cpu()[0])
+        for m, g in zip(self._metrics, sums_h):
+            m.absorb(g, users_h)
+        sums.zero_()
+        users.zero_()
+
+    def _merge_across_ranks(self, before, group) -> None:
+        """all-reduce what THIS evaluate() call added on each rank: [gain sums | user count] as float64"""
+        import torch.distributed as dist
+        mine = [(m.partial()[0] - b[0], m.partial()[1] - b[1]) for m, b in zip(self._metrics, before)]
+        dev = self._dev[0].device if (self._dev is not None and dist.get_backend(group) == "nccl") else "cpu"
+        buf = torch.tensor([g for g, _ in mine] + [float(mine[0][1]) if mine else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(buf, group=group)
+        tot = buf.cpu().tolist()
+        for m, (g, u), g_all in zip(self._metrics, mine, tot[:-1]):
+            m.absorb(g_all - g, int(round(tot[-1])) - u)
 
     def sample_candidates(self, test_batch: dict):
         """bert4rec_evaluator.py:75-108 -> (candidates [R,101] int64, ground truth [R] int64), slots in batch order."""
@@ -68,6 +110,7 @@ class BERT4RecEvaluator(BaseEvaluator):
         return (self.device_sampling and isinstance(self.sampler, samplers.PopularRandomSampler)
                 and not self.sampler.allow_duplicates and self.sampler.is_fully_prepared()
                 and getattr(model, "engine", None) is not None and model.engine.device.type == "cuda"
+                and model.engine.cfg.vocab_size * 4 <= 150 * 1024   # b4r_sample_candidates keeps the V keys in LDS
                 and all(isinstance(t, (int, np.integer)) for t in self.sampler.vocab[:8]))
 
     def sample_candidates_device(self, model, test_batch: dict):
@@ -97,6 +140,8 @@ class BERT4RecEvaluator(BaseEvaluator):
         return cand, gt
 
     def evaluate_batch(self, model, test_batch: dict, candidates=None, ground_truth=None):
+        """bert4rec_evaluator.py:60-120 for one batch.  Returns the ground-truth ranks: a device int32 tensor when the metric
+        sums are accumulated on the GPU (flushed by evaluate() / get_metrics_results()), else a numpy array."""
         if candidates is None:
             if self._device_sampler_ready(model):
                 candidates, ground_truth = self.sample_candidates_device(model, test_batch)
@@ -104,9 +149,39 @@ class BERT4RecEvaluator(BaseEvaluator):
                 candidates, ground_truth = self.sample_candidates(test_batch)
         if len(candidates) == 0:
             return []
-        _, gt_rank, _, _ = model.rank_items_tensor(test_batch, torch.as_tensor(candidates), torch.as_tensor(ground_truth))
+        _, gt_rank, _, _ = model.rank_items_tensor(test_batch, torch.as_tensor(candidates), torch.as_tensor(ground_truth),
+                                                   want_ranking=False)
+        engine = getattr(model, "engine", None)
+        if engine is not None and gt_rank.is_cuda and len(self._metrics) <= 32:
+            _, sums, users = self._device_sums(engine)
+            table = gain_table(self._metrics)
+            engine.rank_metrics(gt_rank, [f for f, _ in table], [k for _, k in table], sums, users)
+            return gt_rank
         ranks = gt_rank.cpu().numpy().astype(np.int64)
-        for rank in ranks.tolist():
-            for metric in self._metrics:
-                metric.update(rank)
+        for metric in self._metrics:
+            metric.update(ranks)
         return ranks
+
+    def get_metrics(self) -> list:
+        self._flush_device_sums()
+        return self._metrics
+
+    def get_metrics_results(self) -> dict:
+        self._flush_device_sums()
+        return super().get_metrics_results()
+
+    def reset_metrics(self) -> None:
+        if getattr(self, "_dev", None) is not None:
+            self._dev[1].zero_()
+            self._dev[2].zero_()
+        super().reset_metrics()
+
+
+def _dist_rank_world(group):
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(group), dist.get_world_size(group)
+    except Exception:   # pragma: no cover
+        pass
+    return 0, 1

@@ -163,9 +163,11 @@ class BERT4RecModel:
         return self._train_log.results()
 
     def _enqueue_test_step(self, cb):
+        # loss + the two accuracies only: the logits-free head where it exists (no [B*P, V] tensor is written)
+        fused = self.engine.fused_head_supported()
         self.engine.begin_step()
-        self.engine.forward(cb, training=False, pooler=False)
-        self.engine.loss(cb, want_grad=False)
+        self.engine.forward(cb, training=False, pooler=False, fused_head=fused)
+        self.engine.loss(cb, want_grad=False, fused_head=fused)
 
     def test_step(self, inputs) -> Dict[str, float]:
         """bert4rec_model.py:175-192"""
@@ -228,32 +230,44 @@ class BERT4RecModel:
         return history
 
     # ---- ranking ----------------------------------------------------------------------------------------------------------
-    def rank_items_tensor(self, encoder_input: Dict[str, torch.Tensor], candidates: Optional[torch.Tensor] = None,
-                          ground_truth: Optional[torch.Tensor] = None):
-        """Device-side core of rank_items: forward(training=False), then b4r_rank_candidates on every slot with
-        masked_lm_weights == 1 (all slots when the key is absent).  candidates: [R, C] int64 or None (whole vocabulary).
-        Returns (ranking [R,C] int64, gt_rank [R] int32 or None, slot_index [R] int64 (b*P+p), rows_per_batch_entry)."""
+    def _ranked_slot_hidden(self, encoder_input: Dict[str, torch.Tensor]):
+        """Encoder forward (no logits, no head on the slots nobody ranks), then tfm MaskedLM's transform on the R slots with
+        masked_lm_weights == 1 only (all slots when the key is absent).  The reference computes all [B, P, V] logits and
+        keeps the valid slots afterwards (bert4rec_model.py:215-220).  Returns (hidden [R,H], slot index [R] = b*P+p,
+        valid slots per batch row)."""
         cb, keep = self.engine.prepare_batch(encoder_input)
         if cb.P == 0:
             raise ValueError("rank_items needs masked_lm_positions")
-        self.engine.forward(cb, training=False, pooler=False)
         B, L, P = cb.B, cb.L, cb.P
+        self.engine.encoder_forward(cb, training=False)
         if "masked_lm_weights" in encoder_input and encoder_input["masked_lm_weights"] is not None:
             w = torch.as_tensor(encoder_input["masked_lm_weights"]).to(self.device).reshape(B, P) != 0
         else:
             w = torch.ones((B, P), dtype=torch.bool, device=self.device)
         slots = torch.nonzero(w.reshape(-1), as_tuple=False).reshape(-1)  # row-major => batch order, then slot order
         counts = w.sum(dim=1).tolist()
+        if slots.numel() == 0:
+            return None, slots, counts
+        pos = keep["masked_lm_positions"].reshape(-1)[slots].clamp(0, L - 1)   # tfm MaskedLM gathers position + b*L
+        rows = torch.div(slots, P, rounding_mode="floor") * L + pos
+        seq = self.engine.region("sequence_output", B, L, 0)
+        return self.engine.mlm_transform_rows(seq, rows), slots, counts
+
+    def rank_items_tensor(self, encoder_input: Dict[str, torch.Tensor], candidates: Optional[torch.Tensor] = None,
+                          ground_truth: Optional[torch.Tensor] = None, want_ranking: bool = True):
+        """Device-side core of rank_items: b4r_rank_candidates on every slot with masked_lm_weights == 1.  candidates:
+        [R, C] int64 or None (whole vocabulary, ranked without materialising an [R, V] candidate list).
+        Returns (ranking [R,C] int64, gt_rank [R] int32 or None, slot_index [R] int64 (b*P+p), rows_per_batch_entry)."""
+        hidden, slots, counts = self._ranked_slot_hidden(encoder_input)
         R = int(slots.numel())
         if R == 0:
             return None, None, slots, counts
-        if candidates is None:
-            candidates = torch.arange(self.vocab_size, dtype=torch.int64, device=self.device).unsqueeze(0).expand(R, -1)
-        candidates = torch.as_tensor(candidates).to(device=self.device, dtype=torch.int64).contiguous()
-        if candidates.shape[0] != R:
-            raise ValueError(f"{candidates.shape[0]} candidate lists for {R} masked slots")
-        hidden = self.engine.region("mlm_hidden", B, L, P)
-        ranking, gt_rank, _ = self.engine.rank_candidates(hidden, slots, candidates, ground_truth)
+        if candidates is not None:
+            candidates = torch.as_tensor(candidates).to(device=self.device, dtype=torch.int64).contiguous()
+            if candidates.shape[0] != R:
+                raise ValueError(f"{candidates.shape[0]} candidate lists for {R} masked slots")
+        ranking, gt_rank, _ = self.engine.rank_candidates(hidden, None, candidates, ground_truth, want_ranking=want_ranking,
+                                                          n_candidates=self.vocab_size, n_rows=R)
         return ranking, gt_rank, slots, counts
 
     def rank_items(self, encoder_input: dict, items: list = None):
@@ -276,22 +290,18 @@ class BERT4RecModel:
     def _rank_items_ragged(self, encoder_input, items):
         """Candidate lists of different lengths: one kernel call per distinct length."""
         flat = [c for row in items for c in row]
-        cb, keep = self.engine.prepare_batch(encoder_input)
-        self.engine.forward(cb, training=False, pooler=False)
-        B, L, P = cb.B, cb.L, cb.P
-        w = torch.as_tensor(encoder_input["masked_lm_weights"]).reshape(B, P) != 0 if "masked_lm_weights" in encoder_input \
-            else torch.ones((B, P), dtype=torch.bool)
-        slots = torch.nonzero(w.reshape(-1).cpu(), as_tuple=False).reshape(-1)
-        hidden = self.engine.region("mlm_hidden", B, L, P)
+        hidden, slots, counts = self._ranked_slot_hidden(encoder_input)
+        if len(flat) != int(slots.numel()):
+            raise ValueError(f"{len(flat)} candidate lists for {int(slots.numel())} masked slots")
         results: List[Optional[torch.Tensor]] = [None] * len(flat)
         for n in sorted({len(c) for c in flat}):
             idx = [i for i, c in enumerate(flat) if len(c) == n]
             cand = torch.tensor([flat[i] for i in idx], dtype=torch.int64)
-            ranking, _, _ = self.engine.rank_candidates(hidden, slots[idx], cand, None)
+            ranking, _, _ = self.engine.rank_candidates(hidden, torch.tensor(idx, dtype=torch.int64), cand, None)
             for j, i in enumerate(idx):
                 results[i] = ranking[j]
         out, r = [], 0
-        for n in w.sum(dim=1).tolist():
+        for n in counts:
             out.append(results[r:r + n])
             r += n
         return out

@@ -180,10 +180,29 @@ int b4r_sample_candidates(const float* logp, int32_t V, const int64_t* exclude, 
  * gather candidates) and the rank lookup of bert4rec_evaluator.py:113-117.
  * score(r,j) = fma-chain_k(hidden[hidden_row[r]][k] * table[cand[r][j]][k]) + bias[cand[r][j]]  (k ascending, fp32)
  * ranking[r][pos] = cand[r][j] with pos = #{i: s_i > s_j} + #{i<j: s_i == s_j}   (stable descending)
- * gt_rank[r] = 1 + min{pos_j : cand[r][j] == gt[r]}  (0 if gt[r] is not a candidate).  Any output may be NULL. */
+ * gt_rank[r] = 1 + min{pos_j : cand[r][j] == gt[r]}  (0 if gt[r] is not a candidate).  Any output may be NULL.
+ * cand == NULL: the candidates of every row are 0 .. C-1 (rank_items(items=None), bert4rec_model.py:236, C = vocab size).
+ * Only the scores asked for are formed (the reference computes all B*P*V logits and reads 101 per user).  Up to 8192
+ * candidates per row run in one launch; more (the whole vocabulary of Beauty / Reddit) take a radix argsort per row and
+ * need `scratch` (b4r_rank_scratch_bytes(R, C) bytes for one pass over all rows; at least C*20, rows are then ranked in
+ * groups; 16-byte aligned). */
+int64_t b4r_rank_scratch_bytes(int32_t R, int32_t C);
 int b4r_rank_candidates(const float* hidden, int32_t hidden_ld, const int64_t* hidden_row, const float* table,
                         const float* bias, int32_t H, const int64_t* cand, int32_t R, int32_t C, const int64_t* gt,
-                        int64_t* ranking, int32_t* gt_rank, float* scores, b4r_stream_t stream);
+                        int64_t* ranking, int32_t* gt_rank, float* scores, void* scratch, int64_t scratch_bytes,
+                        b4r_stream_t stream);
+/* replaces the metric loop of bert4rec_evaluator.py:118-120 over evaluation_metrics.py:47-112 for a batch of ranks:
+ * gain_sums[m] += sum over gt_rank[i] > 0 of gain_m(gt_rank[i]), users[0] += #{gt_rank[i] > 0}; double / int64 DEVICE
+ * accumulators the caller reads once per evaluate().  family[m]: 0 count (gain 1), 1 hit@cutoff (rank <= k), 2 NDCG@cutoff
+ * (1 if rank == 1 else 1/log2(rank+1), inside the cut-off), 3 reciprocal rank (MAP with one relevant item).  One workgroup,
+ * fixed summation order: bitwise reproducible. */
+int b4r_rank_metrics(const int32_t* gt_rank, int32_t R, const int32_t* family, const int32_t* cutoff, int32_t n_metrics,
+                     double* gain_sums, int64_t* users, b4r_stream_t stream);
+/* tfm MaskedLM's transform (gather -> dense(gelu) -> LayerNorm, bert4rec_model.py:76-81,143) on an explicit list of R rows of
+ * the sequence output [n_seq_rows, H]: out[r] = LN(gelu(seq[rows[r]].Wd + bd)).  The evaluation path transforms only the slots
+ * it ranks (one per user) instead of all B*P.  scratch: 3*R*H + 2*R floats, 16-byte aligned. */
+int b4r_mlm_transform_rows(const b4r_model_config* cfg, const float* params, const float* seq, int64_t n_seq_rows,
+                           const int64_t* rows, int32_t R, float* out, float* scratch, b4r_stream_t stream);
 
 /* ---- op level (each is also a stage of the model-level calls; exposed for parity tests and reuse) ------------ */
 

@@ -85,3 +85,49 @@ def test_shard_rows_partitions_without_overlap():
     for n, w in [(256, 8), (10, 4), (3, 8)]:
         rows = [i for r in range(w) for i in range(*shard_rows(n, r, w).indices(n))]
         assert rows == list(range(n))
+
+
+# ---- evaluation: users dealt to the ranks, one all-reduce of the metric sums -------------------------------
+class _RanksModel:
+    """stands in for the ranking model: the 'rank of the ground truth' of every user is carried by the batch itself"""
+    engine = None
+
+    def rank_items_tensor(self, batch, candidates, ground_truth, want_ranking=True):
+        return None, torch.as_tensor(batch["ranks"], dtype=torch.int32), None, None
+
+
+def _eval_batches():
+    g = torch.Generator().manual_seed(11)
+    return [{"ranks": torch.randint(1, 60, (n,), generator=g)} for n in (7, 5, 9, 4, 6)]
+
+
+def _eval_worker(rank, world, port, ret):
+    from bert4rec_amd import evaluation
+    from bert4rec_amd.dataloaders import samplers
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ev = evaluation.get("bert4rec", sampler=samplers.get("random", vocab=list(range(3, 200)), sample_size=10))
+    ev.evaluate_batch = lambda model, batch: evaluation.BERT4RecEvaluator.evaluate_batch(
+        ev, model, batch, candidates=[[0]] * len(batch["ranks"]), ground_truth=[0] * len(batch["ranks"]))
+    ev.evaluate(_RanksModel(), _eval_batches())
+    ret[rank] = {k: float(v) for k, v in ev.get_metrics_results().items()}
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_evaluation_equals_single_process_metrics():
+    from bert4rec_amd import evaluation
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_eval_worker, args=(2, port, ret), nprocs=2, join=True)
+        r0, r1 = dict(ret[0]), dict(ret[1])
+    ms = evaluation.default_metrics()
+    for b in _eval_batches():
+        for m in ms:
+            m.update(b["ranks"].numpy())
+    want = {m.name: float(m.result()) for m in ms}
+    assert r0 == r1                                   # every rank ends with the metrics of ALL users
+    assert want["Valid Ranks"] == 31 == r0["Valid Ranks"]
+    for k, v in want.items():
+        assert abs(r0[k] - v) < 1e-12, k

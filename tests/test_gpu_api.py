@@ -121,7 +121,14 @@ def test_rank_items_orders_like_the_reference():
     assert len(rankings) == 6 and all(len(r) == 1 and r[0].shape == (101,) for r in rankings)   # bert4rec_model_tests.py:127-139
     cfg_o, params = oracle_of(model)
     logits = orc.model_forward(params, batch, cfg_o)["mlm_logits"]
-    hidden = model.engine.region("mlm_hidden", 6, 24, 6).view(6, 6, 64)[:, 0].cpu().numpy()
+    # the ranked slots' transform output: only the R = 6 valid slots are transformed (no [B*P, V] logits anywhere) ...
+    hid_t, slots, counts = model._ranked_slot_hidden(batch)
+    assert hid_t.shape == (6, 64) and counts == [1] * 6 and slots.cpu().tolist() == [6 * b for b in range(6)]
+    hidden = hid_t.cpu().numpy()
+    # ... and equals what the full forward (all B*P slots) holds for those slots
+    model(batch)
+    full_hidden = model.engine.region("mlm_hidden", 6, 24, 6).view(6, 6, 64)[:, 0].cpu().numpy()
+    assert np.abs(full_hidden - hidden).max() < 1e-6
     E = params["word_embeddings/embeddings"].numpy()
     bias = params["cls/predictions/output_bias/bias"].numpy()
     for b in range(6):
@@ -161,7 +168,7 @@ def test_evaluator_ranks_equal_oracle_ranks_for_given_candidates():
     want = orc.rank_of_ground_truth(ranking, gt)
     margin = np.abs(sc - sc[:, -1:])[:, :-1].min(axis=1)          # closest competitor of the ground truth
     safe = margin > 1e-4
-    assert safe.sum() >= 12 and np.array_equal(np.asarray(ranks)[safe], want[safe])
+    assert safe.sum() >= 12 and np.array_equal(torch.as_tensor(ranks).cpu().numpy()[safe], want[safe])
     assert ev.get_metrics_results()["Valid Ranks"] == 16
     om = orc.EvalMetrics()
     for r in ranks.tolist():

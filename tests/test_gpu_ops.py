@@ -543,7 +543,7 @@ def test_rank_candidates_bit_exact_against_c_oracle(R, Cn, H, V):
     scores = torch.empty(R, Cn, device=DEV)
     hd, td, bd, cd, gd = hidden.to(DEV), table.to(DEV), bias.to(DEV), cand.to(DEV), gt.to(DEV)  # keep alive
     _lib.check(lib.b4r_rank_candidates(P(hd), H, None, P(td), P(bd), H, P(cd), R, Cn, P(gd), P(ranking), P(gt_rank),
-                                       P(scores), stream()))
+                                       P(scores), None, 0, stream()))
     assert np.array_equal(scores.cpu().numpy().view(np.uint32), sc.view(np.uint32)), "scores not bit-identical"
     assert np.array_equal(ranking.cpu().numpy(), rk)
     want_rank = orc.rank_of_ground_truth(rk, gt.numpy())
@@ -552,6 +552,78 @@ def test_rank_candidates_bit_exact_against_c_oracle(R, Cn, H, V):
     r2, _ = orc.rank_candidates(sc, cn)
     assert np.array_equal(r2, rk)
     assert sc[0, 5] == sc[0, 9] and pos[0, 5] + 1 == pos[0, 9]
+
+
+@pytest.mark.parametrize("R,V,H,group_rows", [(3, 9000, 64, 0), (5, 26732, 64, 2), (2, 335423, 64, 0), (2, 10000, 256, 1)])
+def test_whole_vocabulary_ranking_bit_exact_against_c_oracle(R, V, H, group_rows):
+    """rank_items(items=None) (bert4rec_model.py:236): candidates = the whole vocabulary, no candidate list materialised;
+    radix-argsort path of b4r_rank_candidates.  Beauty (54 545) / Reddit (335 423) sizes must work; ties keep the lower id."""
+    lib = _lib.load()
+    co = _c_rank_oracle()
+    hidden, table, bias = rnd(R, H, seed=60), rnd(V, H, seed=61, scale=0.05), rnd(V, seed=62, scale=0.01)
+    # engineered ties (equal table rows and biases), zeros of both signs and a block of identical items
+    table[7] = table[3]; bias[7] = bias[3]
+    table[V - 5:V] = table[11]; bias[V - 5:V] = bias[11]
+    table[100] = 0.0; bias[100] = 0.0
+    table[200] = 0.0; bias[200] = -0.0
+    gt = torch.tensor([(37 * r + 5) % V for r in range(R)], dtype=torch.int64)
+    hn, tn, bn = hidden.numpy(), table.numpy(), bias.numpy()
+    cn = np.tile(np.arange(V, dtype=np.int64), (R, 1))
+    sc = np.zeros((R, V), np.float32)
+    f32p, i64p, i32p = C.POINTER(C.c_float), C.POINTER(C.c_int64), C.POINTER(C.c_int32)
+    co.rank_oracle_scores(hn.ctypes.data_as(f32p), tn.ctypes.data_as(f32p), bn.ctypes.data_as(f32p),
+                          cn.ctypes.data_as(i64p), C.c_int64(R), C.c_int64(V), C.c_int64(H), sc.ctypes.data_as(f32p))
+    order = np.stack([np.argsort(-sc[r].astype(np.float64), kind="stable") for r in range(R)])   # = the counting rule
+    ranking = torch.empty(R, V, dtype=torch.int64, device=DEV)
+    gt_rank = torch.empty(R, dtype=torch.int32, device=DEV)
+    scores = torch.empty(R, V, device=DEV)
+    need = lib.b4r_rank_scratch_bytes(R, V)
+    assert need == R * V * 20
+    nbytes = need if group_rows == 0 else group_rows * V * 20   # a smaller scratch: rows are ranked in groups
+    scratch = torch.empty(nbytes // 4, dtype=torch.float32, device=DEV)
+    hd, td, bd, gd = hidden.to(DEV), table.to(DEV), bias.to(DEV), gt.to(DEV)
+    _lib.check(lib.b4r_rank_candidates(P(hd), H, None, P(td), P(bd), H, None, R, V, P(gd), P(ranking), P(gt_rank), P(scores),
+                                       P(scratch), nbytes, stream()))
+    torch.cuda.synchronize()
+    assert np.array_equal(scores.cpu().numpy().view(np.uint32), sc.view(np.uint32)), "scores not bit-identical"
+    assert np.array_equal(ranking.cpu().numpy(), order)
+    want = np.array([1 + int(np.nonzero(order[r] == int(gt[r]))[0][0]) for r in range(R)])
+    assert np.array_equal(gt_rank.cpu().numpy().astype(np.int64), want)
+    pos3, pos7 = int(np.nonzero(order[0] == 3)[0][0]), int(np.nonzero(order[0] == 7)[0][0])
+    assert sc[0, 3] == sc[0, 7] and pos3 + 1 == pos7
+    # too little scratch is refused, never computed another way
+    assert lib.b4r_rank_candidates(P(hd), H, None, P(td), P(bd), H, None, R, V, P(gd), P(ranking), P(gt_rank), None,
+                                   P(scratch), V * 20 - 16, stream()) == -5
+
+
+def test_rank_metric_sums_match_reference_known_answers():
+    """b4r_rank_metrics against the reference's own known-answer values (tests/evaluators_tests/evaluation_metrics_tests.py:
+    28-104, captured in tests/golden/reference_goldens.json) and against the C oracle's accumulation."""
+    import json
+    import os
+    from bert4rec_amd import evaluation
+    lib = _lib.load()
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_goldens.json")))
+    for key, case in sorted(gold["evaluation_metrics"].items()):
+        ms = evaluation.default_metrics()
+        table = evaluation.gain_table(ms)
+        fam = (C.c_int32 * len(table))(*[f for f, _ in table])
+        cut = (C.c_int32 * len(table))(*[k for _, k in table])
+        sums = torch.zeros(len(table), dtype=torch.float64, device=DEV)
+        users = torch.zeros(1, dtype=torch.int64, device=DEV)
+        ranks = torch.tensor(case["ranks"] + [0], dtype=torch.int32, device=DEV)   # a rank of 0 (ground truth absent) is skipped
+        for _ in range(2):   # two batches accumulate
+            _lib.check(lib.b4r_rank_metrics(P(ranks), ranks.numel(), fam, cut, len(table), P(sums), P(users), stream()))
+        n = int(users.cpu()[0])
+        assert n == 2 * len(case["ranks"])
+        for m, g in zip(ms, sums.cpu().tolist()):
+            m.absorb(g, n)
+        got = {m.name: float(m.result()) for m in ms}
+        for name, want in case["results"].items():
+            if name == "Valid Ranks":
+                assert got[name] == 2 * want
+            else:
+                assert abs(got[name] - want) < 1e-12, (key, name)
 
 
 @pytest.mark.parametrize("M,V,H", [(100, 301, 64), (256, 3709, 64), (32, 33, 64), (1000, 64, 64), (5, 4000, 64),

@@ -137,7 +137,7 @@ PROTOTYPES = {
     "b4r_mlm_head_fused_scratch_floats": (C.c_int64, [_I32, _I32, _I32]),
     "b4r_mlm_head_fused_fwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P, _P, _P, _I32, _P]),
     "b4r_mlm_head_fused_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P, _P]),
-    "b4r_mask_batch": (C.c_int, [_P, _I32, _I32, _I32, _I32, C.c_double, _F, _F, _I32, C.c_uint64, _P, _P, _P, _P, _P, _P, _P]),
+    "b4r_mask_batch": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, C.c_double, _F, _F, _I32, C.c_uint64, _P, _P, _P, _P, _P, _P, _P]),
     "b4r_sample_candidates": (C.c_int, [_P, _I32, _P, _I32, _P, _I32, _I32, C.c_uint64, _P, _P]),
     "b4r_softmax_ce": (C.c_int, [_P, _I32, _I32, _I32, _P, _P, _P, _I32, _P]),
     "b4r_global_sqnorm": (C.c_int, [_P, _I64, _P, _P, _P]),

@@ -829,14 +829,21 @@ extern "C" int b4r_adamw_step(const b4r_adamw_config* hp, float* params, const f
 // num = min(P, max(1, int(n * rate))) positions are a uniform subset of [0, n) (random keys, the num smallest win), visited
 // in ascending order; each becomes [MASK] (1) with probability mask_rate, a uniform id of the vocabulary minus {PAD, UNK}
 // with probability random_rate, else stays.  finetune != 0 restates mask_last_token_only (:264-269).
-__global__ __launch_bounds__(64) void mask_batch_kernel(const int64_t* tokens, int L, int P, int V, double rate, float mask_rate,
-                                                        float random_rate, int finetune, uint32_t seed_lo, uint32_t seed_hi,
+// row_index (optional): output row r is dataset row row_index[r] of `tokens` (the whole [U, L] matrix of a dataset stays in HBM, a
+// batch is an index list); the random stream is keyed by the DATASET row, so a row's mask does not depend on its batch slot.
+// row_finetune (optional, per dataset row): != 0 -> last-token mask for that row (the reference mixes both kinds in one shuffled
+// training set, bert4rec_dataloader.py:100-108).
+__global__ __launch_bounds__(64) void mask_batch_kernel(const int64_t* tokens, const int64_t* row_index, const int64_t* row_finetune,
+                                                        int L, int P, int V, double rate, float mask_rate,
+                                                        float random_rate, int finetune_all, uint32_t seed_lo, uint32_t seed_hi,
                                                         int64_t* ids_out, int64_t* mask_out, int64_t* labels_out,
                                                         int64_t* pos_out, int64_t* mids_out, int64_t* w_out) {
   __shared__ uint32_t s_key[256];
   __shared__ int s_sel[256];
   const int row = blockIdx.x, lane = threadIdx.x;
-  const int64_t* src = tokens + (int64_t)row * L;
+  const int64_t srow = row_index ? row_index[row] : (int64_t)row;
+  const int finetune = (finetune_all != 0 || (row_finetune != nullptr && row_finetune[srow] != 0)) ? 1 : 0;
+  const int64_t* src = tokens + srow * L;
   int len = 0, n = 0;
   for (int i = lane; i < L; i += 64) {
     const int64_t t = src[i];
@@ -845,7 +852,7 @@ __global__ __launch_bounds__(64) void mask_batch_kernel(const int64_t* tokens, i
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { len += __shfl_xor(len, o, 64); n += __shfl_xor(n, o, 64); }
-  const uint32_t rk = b4r_hash32((uint32_t)row * 0x9E3779B9u + seed_hi);
+  const uint32_t rk = b4r_hash32((uint32_t)srow * 0x9E3779B9u + seed_hi);
   int num;
   if (finetune) num = len > 0 ? 1 : 0;
   else num = n > 0 ? min(P, max(1, (int)((double)n * rate))) : 0;
@@ -895,14 +902,15 @@ __global__ __launch_bounds__(64) void mask_batch_kernel(const int64_t* tokens, i
   }
 }
 
-extern "C" int b4r_mask_batch(const int64_t* tokens, int32_t B, int32_t L, int32_t P, int32_t V, double selection_rate,
+extern "C" int b4r_mask_batch(const int64_t* tokens, const int64_t* row_index, const int64_t* row_finetune, int32_t B, int32_t L,
+                              int32_t P, int32_t V, double selection_rate,
                               float mask_token_rate, float random_token_rate, int32_t finetune, uint64_t seed,
                               int64_t* input_word_ids, int64_t* input_mask, int64_t* labels, int64_t* masked_lm_positions,
                               int64_t* masked_lm_ids, int64_t* masked_lm_weights, b4r_stream_t stream) {
   B4R_CHECK_ARG(tokens && input_word_ids && input_mask && labels && masked_lm_positions && masked_lm_ids && masked_lm_weights,
                 B4R_E_BADARG, "b4r_mask_batch: null argument");
   B4R_CHECK_ARG(B > 0 && L > 0 && L <= 256 && P > 0 && V > 3, B4R_E_SHAPE, "b4r_mask_batch: bad shape (L <= 256)");
-  hipLaunchKernelGGL(mask_batch_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, tokens, L, P, V, selection_rate,
+  hipLaunchKernelGGL(mask_batch_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, tokens, row_index, row_finetune, L, P, V, selection_rate,
                      mask_token_rate, random_token_rate, finetune, (uint32_t)seed, (uint32_t)(seed >> 32), input_word_ids,
                      input_mask, labels, masked_lm_positions, masked_lm_ids, masked_lm_weights);
   B4R_CHECK_LAUNCH("b4r_mask_batch");

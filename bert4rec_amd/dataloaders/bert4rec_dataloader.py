@@ -83,13 +83,19 @@ class BERT4RecDataloader(BaseDataloader):
         dss[0] = utils.duplicate_dataset(dss[0], duplication_factor)
         return tuple(dss)
 
-    def process_data(self, ds, apply_mlm: bool = True, finetuning: bool = False):
+    def process_data(self, ds, apply_mlm: bool = True, finetuning: bool = False, device_masking: bool = False):
+        """device_masking: only tokenise + truncate on the host (one [U, L] matrix); the masked-LM task and the padding of the
+        six tensors run per batch on the GPU (b4r_mask_batch via dataloader_utils.make_batches)."""
         self._set_preprocessor_properties()
+        if device_masking:
+            if not apply_mlm:
+                raise ValueError("device_masking builds masked-LM batches; use apply_mlm=True")
+            return self.preprocessor.token_rows(ds, finetuning)
         return self.preprocessor.process_dataset(ds, apply_mlm, finetuning)
 
     def get_data(self, split_data: bool = True, sort_by: str = None, extract_data: list = None, datatypes: list = None,
                  duplication_factor: int = None, group_by: str = None, apply_mlm: bool = True,
-                 finetuning_split: float = 0) -> tuple:
+                 finetuning_split: float = 0, device_masking: bool = False) -> tuple:
         """bert4rec_dataloader.py:56-113: validation/test (datasets 1,2) always use the last-token mask; a
         `finetuning_split` share of the training examples does too (split_dataset seed 12)."""
         if finetuning_split < 0 or finetuning_split > 1:
@@ -97,15 +103,16 @@ class BERT4RecDataloader(BaseDataloader):
         dss = self.load_data(split_data, sort_by, extract_data, datatypes, duplication_factor, group_by)
         processed = []
         for i, ds in enumerate(dss):
+            dm = device_masking
             if i >= 1:
-                processed.append(self.process_data(ds, apply_mlm, finetuning=True))
+                processed.append(self.process_data(ds, apply_mlm, finetuning=True, device_masking=dm))
             elif finetuning_split > 0:
                 train_ds, ft_ds, _ = utils.split_dataset(ds, train_split=1 - finetuning_split,
                                                          val_split=finetuning_split, test_split=0.0)
-                processed.append(self.process_data(train_ds, finetuning=False)
-                                 .concatenate(self.process_data(ft_ds, finetuning=True)))
+                processed.append(self.process_data(train_ds, finetuning=False, device_masking=dm)
+                                 .concatenate(self.process_data(ft_ds, finetuning=True, device_masking=dm)))
             else:
-                processed.append(self.process_data(ds, apply_mlm, finetuning=False))
+                processed.append(self.process_data(ds, apply_mlm, finetuning=False, device_masking=dm))
         return tuple(processed)
 
     def generate_vocab(self, source=None, progress_bar: bool = True) -> bool:
@@ -116,12 +123,17 @@ class BERT4RecDataloader(BaseDataloader):
         return True
 
     def prepare_training(self, sort_by: str = None, extract_data: list = None, datatypes: list = None,
-                         group_by: str = None, finetuning_split: float = 0.1) -> tuple:
+                         group_by: str = None, finetuning_split: float = 0.1, device_masking: bool = False) -> tuple:
+        """bert4rec_dataloader.py:144-158.  device_masking=True: the three datasets come back as token matrices
+        (dataloader_utils.TokenMatrixDataset) whose batches are masked on the GPU by make_batches; with
+        make_batches(..., remask_each_epoch=True) every epoch sees new masks, so the host-side `input_duplication_factor`
+        (ten masked copies of ML-1M) can be 1."""
         if finetuning_split < 0 or finetuning_split > 1:
             raise ValueError(f"The finetuning_split argument has to be a float between 0 and 1. Given: {finetuning_split}")
         self.generate_vocab()
         return self.get_data(split_data=True, sort_by=sort_by, extract_data=extract_data, datatypes=datatypes,
-                             group_by=group_by, finetuning_split=finetuning_split, apply_mlm=True)
+                             group_by=group_by, finetuning_split=finetuning_split, apply_mlm=True,
+                             device_masking=device_masking)
 
     def prepare_inference(self, data):
         self._set_preprocessor_properties()

@@ -110,6 +110,90 @@ class BatchedDataset:
         return self.batches
 
 
+class TokenMatrixDataset:
+    """A dataset as ONE right-padded int64 token matrix [U, L] plus a per-row "last-token mask" flag: what on-device batch
+    construction starts from.  Rows are already truncated by the preprocessor's rule
+    (bert4rec_preprocessor.py:61-67); masking happens per batch on the GPU (b4r_mask_batch)."""
+
+    def __init__(self, tokens: np.ndarray, finetune_rows: np.ndarray, max_predictions_per_seq: int, vocab_size: int,
+                 selection_rate: float, mask_token_rate: float, random_token_rate: float):
+        self.tokens = np.ascontiguousarray(tokens, dtype=np.int64)
+        self.finetune_rows = np.ascontiguousarray(finetune_rows, dtype=np.int64)
+        if self.tokens.ndim != 2 or self.finetune_rows.shape != (self.tokens.shape[0],):
+            raise ValueError("tokens must be [rows, length] with one finetune flag per row")
+        self.max_predictions_per_seq = int(max_predictions_per_seq)
+        self.vocab_size = int(vocab_size)
+        self.selection_rate, self.mask_token_rate, self.random_token_rate = selection_rate, mask_token_rate, random_token_rate
+
+    def __len__(self):
+        return self.tokens.shape[0]
+
+    def cardinality(self) -> int:
+        return len(self)
+
+    def _like(self, tokens, flags) -> "TokenMatrixDataset":
+        return TokenMatrixDataset(tokens, flags, self.max_predictions_per_seq, self.vocab_size, self.selection_rate,
+                                  self.mask_token_rate, self.random_token_rate)
+
+    def concatenate(self, other: "TokenMatrixDataset") -> "TokenMatrixDataset":
+        return self._like(np.concatenate([self.tokens, other.tokens]), np.concatenate([self.finetune_rows, other.finetune_rows]))
+
+    def take(self, n: int) -> "TokenMatrixDataset":
+        return self._like(self.tokens[:n], self.finetune_rows[:n])
+
+    def skip(self, n: int) -> "TokenMatrixDataset":
+        return self._like(self.tokens[n:], self.finetune_rows[n:])
+
+
+class DeviceMaskedBatches:
+    """Batches built on the GPU from a TokenMatrixDataset: the token matrix lives in HBM, a batch is an index list and one
+    b4r_mask_batch launch.  `remask_each_epoch=False` (default) reproduces the reference, whose `.cache()` behind shuffle + batch
+    freezes batch composition AND masks after the first epoch (dataloader_utils.py:341-346): the batches of the first pass are
+    kept.  True draws new masks every epoch (same batch composition) -- what the duplication factor approximates on the host."""
+
+    def __init__(self, dataset: TokenMatrixDataset, order: np.ndarray, batch_size: int, seed: int, remask_each_epoch: bool):
+        self.dataset, self.order, self.batch_size = dataset, np.asarray(order, dtype=np.int64), int(batch_size)
+        self.seed, self.remask_each_epoch = int(seed), bool(remask_each_epoch)
+        self.epoch = 0
+        self._device = None
+        self._tokens = self._flags = self._order = None
+        self._frozen = None
+
+    def __len__(self):
+        return (len(self.order) + self.batch_size - 1) // self.batch_size
+
+    def cardinality(self) -> int:
+        return len(self)
+
+    def cache_on_device(self, device) -> "DeviceMaskedBatches":
+        device = torch.device(device)
+        if self._device != device:
+            self._device = device
+            self._tokens = torch.from_numpy(self.dataset.tokens).to(device)
+            self._flags = torch.from_numpy(self.dataset.finetune_rows).to(device)
+            self._order = torch.from_numpy(self.order).to(device)
+            self._frozen = None
+        return self
+
+    def _build(self, epoch: int):
+        from ..engine import device_mask_batch
+        if self._device is None:
+            self.cache_on_device("cuda")
+        ds = self.dataset
+        for s in range(0, len(self.order), self.batch_size):
+            yield device_mask_batch(self._tokens, ds.max_predictions_per_seq, ds.vocab_size, ds.selection_rate, ds.mask_token_rate,
+                                    ds.random_token_rate, False, (self.seed << 20) + epoch, self._order[s:s + self.batch_size],
+                                    self._flags, self._device)
+
+    def __iter__(self):
+        if self.remask_each_epoch:
+            epoch, self.epoch = self.epoch, self.epoch + 1
+            return self._build(epoch)
+        if self._frozen is None:
+            self._frozen = list(self._build(0))
+        return iter(self._frozen)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # reference utilities
 # ---------------------------------------------------------------------------------------------------------------------
@@ -236,14 +320,20 @@ def split_dataset(ds, ds_size: int = None, train_split: float = 0.8, val_split: 
     return ds.take(train_size), ds.skip(train_size).take(val_size), ds.skip(train_size).skip(val_size)
 
 
-def make_batches(dataset: ExampleDataset, buffer_size: int = None, batch_size: int = 64, squeeze_tensors: bool = False,
-                 reshuffle_each_iteration: bool = False, seed: int = None) -> BatchedDataset:
+def make_batches(dataset, buffer_size: int = None, batch_size: int = 64, squeeze_tensors: bool = False,
+                 reshuffle_each_iteration: bool = False, seed: int = None, remask_each_epoch: bool = False):
     """dataloader_utils.py:306-346: shuffle(all) -> batch (last batch may be partial) -> cache.  Because the reference
-    caches AFTER shuffle+batch, batch composition and masks are frozen after the first epoch; so are they here."""
+    caches AFTER shuffle+batch, batch composition and masks are frozen after the first epoch; so are they here.
+    A TokenMatrixDataset (prepare_training(device_masking=True)) gives batches that are masked on the GPU; only there
+    `remask_each_epoch=True` is available (new masks per epoch, same composition)."""
     if reshuffle_each_iteration:
         raise NotImplementedError("reshuffle_each_iteration has no effect behind the reference's .cache(); not offered")
     n = len(dataset)
     order = np.random.RandomState(seed).permutation(n)
+    if isinstance(dataset, TokenMatrixDataset):
+        return DeviceMaskedBatches(dataset, order, batch_size, 0 if seed is None else seed, remask_each_epoch)
+    if remask_each_epoch:
+        raise ValueError("remask_each_epoch needs a dataset prepared with device_masking=True")
     batches = []
     for s in range(0, n, batch_size):
         idx = order[s:s + batch_size]

@@ -31,15 +31,32 @@ class BERT4RecPreprocessor(BasePreprocessor):
                 setattr(cls, k, v)
 
     @classmethod
+    def _window(cls, tokens: list, finetuning: bool) -> list:
+        """bert4rec_preprocessor.py:61-67: the most recent max_seq_len tokens for finetuning / evaluation rows and for rows that
+        fit; a random window of max_seq_len tokens of a longer training row (python `random`, as the reference)."""
+        if finetuning or len(tokens) <= cls.max_seq_len:
+            return tokens[-cls.max_seq_len:]
+        start_i = random.randint(0, len(tokens) - cls.max_seq_len)
+        return tokens[start_i:start_i + cls.max_seq_len]
+
+    @classmethod
+    def token_rows(cls, ds, finetuning: bool):
+        """The dataset as a right-padded token matrix for on-device batch construction: per sequence tokenise + `_window`,
+        no masking (that is b4r_mask_batch's part).  Returns a dataloader_utils.TokenMatrixDataset."""
+        n = len(ds)
+        rows = np.full((n, cls.max_seq_len), cls.pad_token_id, dtype=np.int64)
+        for r, seq in enumerate(ds):
+            seg = cls._window(cls.tokenizer.tokenize(seq), finetuning)
+            rows[r, :len(seg)] = seg
+        flags = np.full(n, 1 if finetuning else 0, dtype=np.int64)
+        return dataloader_utils.TokenMatrixDataset(rows, flags, cls.max_predictions_per_seq, cls.tokenizer.get_vocab_size(),
+                                                   cls.masked_lm_rate, cls.mask_token_rate, cls.random_token_rate)
+
+    @classmethod
     def process_element(cls, sequence, apply_mlm: bool, finetuning: bool) -> dict:
         """bert4rec_preprocessor.py:48-116"""
         processed = dict()
-        tokens = cls.tokenizer.tokenize(sequence)
-        if finetuning or len(tokens) <= cls.max_seq_len:
-            segments = tokens[-cls.max_seq_len:]
-        else:
-            start_i = random.randint(0, len(tokens) - cls.max_seq_len)
-            segments = tokens[start_i:start_i + cls.max_seq_len]
+        segments = cls._window(cls.tokenizer.tokenize(sequence), finetuning)
         input_word_ids = np.array(segments, dtype=np.int64)
         input_mask = np.ones_like(segments, dtype=np.int64)
         labels = input_word_ids.copy()

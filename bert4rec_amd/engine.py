@@ -81,6 +81,36 @@ def keras_shape(name: str, info: ParamInfo, cfg: ModelConfig) -> Tuple[int, ...]
     return (info.rows, info.cols)
 
 
+def device_mask_batch(tokens: torch.Tensor, max_predictions: int, vocab_size: int, selection_rate: float = 0.2,
+                      mask_token_rate: float = 1.0, random_token_rate: float = 0.0, finetune: bool = False, seed: int = 0,
+                      rows: Optional[torch.Tensor] = None, row_finetune: Optional[torch.Tensor] = None,
+                      device=None) -> Dict[str, torch.Tensor]:
+    """b4r_mask_batch on the current stream (include/b4r.h): the masked-LM task + padding of the six int64 tensors for a whole
+    batch on the GPU.  No model is involved: the dataloader calls this for every batch of an epoch."""
+    device = torch.device(device) if device is not None else torch.as_tensor(tokens).device
+    st = _stream(device)   # raises on a non-GPU device: there is no host path behind this call
+    tokens = torch.as_tensor(tokens).to(device=device, dtype=torch.int64).contiguous()
+    if tokens.dim() != 2:
+        raise ValueError(f"tokens must be rank 2 [rows, length], got shape {tuple(tokens.shape)}")
+    L, P = tokens.shape[1], int(max_predictions)
+    if rows is not None:
+        rows = torch.as_tensor(rows).to(device=device, dtype=torch.int64).contiguous()
+    if row_finetune is not None:
+        row_finetune = torch.as_tensor(row_finetune).to(device=device, dtype=torch.int64).contiguous()
+        if row_finetune.numel() != tokens.shape[0]:
+            raise ValueError("row_finetune needs one flag per row of tokens")
+    B = int(rows.numel()) if rows is not None else tokens.shape[0]
+    out = {k: torch.empty((B, L), dtype=torch.int64, device=device) for k in ("input_word_ids", "input_mask", "labels")}
+    out.update({k: torch.empty((B, P), dtype=torch.int64, device=device)
+                for k in ("masked_lm_positions", "masked_lm_ids", "masked_lm_weights")})
+    _lib.check(_lib.load().b4r_mask_batch(_ptr(tokens), _ptr(rows), _ptr(row_finetune), B, L, P, int(vocab_size),
+                                          float(selection_rate), float(mask_token_rate), float(random_token_rate),
+                                          1 if finetune else 0, int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(out["input_word_ids"]),
+                                          _ptr(out["input_mask"]), _ptr(out["labels"]), _ptr(out["masked_lm_positions"]),
+                                          _ptr(out["masked_lm_ids"]), _ptr(out["masked_lm_weights"]), st), "b4r_mask_batch")
+    return out
+
+
 # hipGraph captures only contain this library's launches on the capturing thread; "thread_local" keeps runtime calls made by
 # other threads of the process during the capture (the RCCL watchdog polls events) from invalidating it
 _CAPTURE_MODE = "thread_local"
@@ -362,24 +392,13 @@ class Engine:
 
     def mask_batch(self, tokens: torch.Tensor, max_predictions: int, selection_rate: float = 0.2,
                    mask_token_rate: float = 1.0, random_token_rate: float = 0.0, finetune: bool = False,
-                   seed: int = 0) -> Dict[str, torch.Tensor]:
+                   seed: int = 0, rows: Optional[torch.Tensor] = None,
+                   row_finetune: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """b4r_mask_batch: tokens [B,L] int64 (right-padded with 0) -> the six-tensor batch dict on the device
-        (bert4rec_preprocessor.py:48-116 for a whole batch; defaults of BERT4RecPreprocessor: rate 0.2, always [MASK])."""
-        tokens = torch.as_tensor(tokens).to(device=self.device, dtype=torch.int64).contiguous()
-        if tokens.dim() != 2:
-            raise ValueError(f"tokens must be rank 2 [batch, length], got shape {tuple(tokens.shape)}")
-        B, L = tokens.shape
-        P = int(max_predictions)
-        out = {k: torch.empty((B, L), dtype=torch.int64, device=self.device) for k in ("input_word_ids", "input_mask", "labels")}
-        out.update({k: torch.empty((B, P), dtype=torch.int64, device=self.device)
-                    for k in ("masked_lm_positions", "masked_lm_ids", "masked_lm_weights")})
-        _lib.check(self.lib.b4r_mask_batch(_ptr(tokens), B, L, P, self.cfg.vocab_size, float(selection_rate),
-                                           float(mask_token_rate), float(random_token_rate), 1 if finetune else 0,
-                                           int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(out["input_word_ids"]),
-                                           _ptr(out["input_mask"]), _ptr(out["labels"]), _ptr(out["masked_lm_positions"]),
-                                           _ptr(out["masked_lm_ids"]), _ptr(out["masked_lm_weights"]),
-                                           _stream(self.device)), "b4r_mask_batch")
-        return out
+        (bert4rec_preprocessor.py:48-116 for a whole batch; defaults of BERT4RecPreprocessor: rate 0.2, always [MASK]).
+        rows [B]: batch = those rows of a dataset matrix tokens [U,L]; row_finetune [U]: per-row last-token-mask flags."""
+        return device_mask_batch(tokens, int(max_predictions), self.cfg.vocab_size, selection_rate, mask_token_rate,
+                                 random_token_rate, finetune, seed, rows, row_finetune, self.device)
 
     def sample_candidates(self, logp: torch.Tensor, exclude: torch.Tensor, gt: torch.Tensor, n_samples: int,
                           seed: int) -> torch.Tensor:

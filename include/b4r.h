@@ -157,11 +157,15 @@ int b4r_train_step(const b4r_model_config* cfg, const b4r_adamw_config* hp, cons
  * finetune != 0) + the padding of the six [B,.] int64 tensors of bert4rec_model.py:15-22.  Same law as the reference
  * (uniform subset of min(P, max(1, int(n*rate))) of the first n positions, ascending; [MASK] / random id / unchanged by
  * mask_token_rate / random_token_rate), own counter-hash random stream: a dataset can be re-masked every epoch on the
- * device instead of being masked `duplication_factor` times on the host. */
-int b4r_mask_batch(const int64_t* tokens, int32_t B, int32_t L, int32_t P, int32_t V, double selection_rate,
-                   float mask_token_rate, float random_token_rate, int32_t finetune, uint64_t seed, int64_t* input_word_ids,
-                   int64_t* input_mask, int64_t* labels, int64_t* masked_lm_positions, int64_t* masked_lm_ids,
-                   int64_t* masked_lm_weights, b4r_stream_t stream);
+ * device instead of being masked `duplication_factor` times on the host.
+ * row_index (optional, [B]): output row r is row row_index[r] of tokens [U, L] -- a dataset's token matrix stays in HBM and a batch
+ * is an index list (make_batches' shuffle + batch, dataloader_utils.py:341-346); the random stream is keyed by the dataset row.
+ * row_finetune (optional, per dataset row): rows with a non-zero flag get the last-token mask (the 10 % finetuning share that
+ * get_data mixes into the training set, bert4rec_dataloader.py:100-108); `finetune` != 0 forces it for every row. */
+int b4r_mask_batch(const int64_t* tokens, const int64_t* row_index, const int64_t* row_finetune, int32_t B, int32_t L, int32_t P,
+                   int32_t V, double selection_rate, float mask_token_rate, float random_token_rate, int32_t finetune,
+                   uint64_t seed, int64_t* input_word_ids, int64_t* input_mask, int64_t* labels, int64_t* masked_lm_positions,
+                   int64_t* masked_lm_ids, int64_t* masked_lm_weights, b4r_stream_t stream);
 
 /* ---- evaluator negatives -------------------------------------------------------------------
  * replaces the per-slot sampler call of bert4rec_evaluator.py:84-104 (PopularRandomSampler.sample:

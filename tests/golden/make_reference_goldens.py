@@ -120,6 +120,53 @@ def main():
                                "sample_without": s.sample(without=list(without))})
     out["samplers"] = s_out
 
+    # ---- 4. preprocessor: truncation / random window / padding, last-token mask ------------------------------------------
+    # process_element never touches TensorFlow when apply_mlm is False (bert4rec_preprocessor.py:48-72,105-116): token lookup,
+    # last-L truncation (finetuning or short rows), the random window of a long training row (python `random`, seeded here)
+    # and the right-padding of input_word_ids / input_mask / labels.  With apply_mlm the training branch reseeds `random`
+    # from the OS (seed=None) and the finetuning branch wraps the label in tf.constant (a placeholder here), so for
+    # mask_last_token_only (dataloader_utils.py:264-269) only its two numpy outputs are captured; prepare_inference
+    # (bert4rec_preprocessor.py:125-168) = process_element(history[-(L-1):] + ["[UNK]"], True, True) + tf.expand_dims and is
+    # pinned through these two captures.
+    import random as _random
+    pre_mod = importlib.import_module("bert4rec.dataloaders.preprocessors.bert4rec_preprocessor")
+    vocab_items = [f"item{j}" for j in range(40)]
+
+    class _Lookup:
+        """the tokenizer is an INPUT of process_element (the reference's SimpleTokenizer needs tf types for list input): a plain
+        string -> id table with the dataloader's id convention PAD 0, MASK 1, UNK 2, items from 3"""
+        table = {t: i for i, t in enumerate(["[PAD]", "[MASK]", "[UNK]"] + vocab_items)}
+
+        def tokenize(self, seq):
+            return [self.table[x] for x in seq]
+
+        def get_vocab_size(self):
+            return len(self.table)
+
+    tok = _Lookup()
+    PP = pre_mod.BERT4RecPreprocessor
+    L_, P_ = 12, 5
+    PP.set_properties(tokenizer=tok, max_seq_len=L_, max_predictions_per_seq=P_, mask_token_id=1, unk_token_id=2, pad_token_id=0,
+                      masked_lm_rate=0.2, mask_token_rate=1.0, random_token_rate=0.0)
+    pe_cases = []
+    for n, finetune, seed in [(3, False, 1), (3, True, 1), (12, False, 2), (12, True, 2), (13, True, 3), (30, True, 4), (30, False, 5),
+                              (30, False, 6), (17, False, 7), (1, True, 8)]:
+        seq = [vocab_items[(7 * j + n) % 40] for j in range(n)]
+        _random.seed(seed)
+        r = PP.process_element(list(seq), False, finetune)
+        pe_cases.append({"sequence": seq, "finetuning": finetune, "python_random_seed": seed,
+                         "input_word_ids": np.asarray(r["input_word_ids"]).tolist(), "input_mask": np.asarray(r["input_mask"]).tolist(),
+                         "labels": np.asarray(r["labels"]).tolist()})
+    out["process_element_no_mlm"] = {"max_seq_len": L_, "max_predictions_per_seq": P_, "vocab": ["[PAD]", "[MASK]", "[UNK]"] + vocab_items,
+                                     "cases": pe_cases}
+    ml_cases = []
+    for n in (1, 2, 7, 12):
+        seq = np.arange(3, 3 + n, dtype=np.int64)
+        toks, pos, _ = du.mask_last_token_only(seq.copy(), 1)
+        ml_cases.append({"sequence": seq.tolist(), "mask_token_id": 1, "masked_token_ids": np.asarray(toks).tolist(),
+                         "masked_lm_positions": np.asarray(pos).tolist(), "masked_lm_ids_by_definition": [int(seq[-1])]})
+    out["mask_last_token_only"] = ml_cases
+
     with open(OUT, "w") as f:
         json.dump(out, f, indent=1)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")

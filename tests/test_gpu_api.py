@@ -264,3 +264,68 @@ def test_ndcg_after_training_matches_the_oracle_trained_the_same_way():
     for k in ("NDCG@10", "HR@10", "NDCG@5", "MAP"):
         assert abs(got[k] - want[k]) <= 0.002, (k, got[k], want[k])
     assert want["NDCG@10"] > 0.07           # the 4 epochs learned something: chance level is 0.045 with 100 negatives
+
+
+def test_device_masked_batches_follow_the_reference_contract():
+    """SURVEY.md §8 f1 wired in: prepare_training(device_masking=True) + make_batches -> batches masked by b4r_mask_batch.
+    Deterministic parts are compared bit for bit with goldens captured from the reference (finetuning branch = last-token mask,
+    padding, counts); the random part by its law (count formula, ascending positions, labels)."""
+    import json
+    import os
+    from bert4rec_amd.engine import device_mask_batch
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_goldens.json")))
+    g = gold["process_element_no_mlm"]
+    L, P = g["max_seq_len"], g["max_predictions_per_seq"]
+    rows = torch.tensor([c["labels"] for c in g["cases"]], dtype=torch.int64)
+    out = {k: v.cpu() for k, v in device_mask_batch(rows.cuda(), P, len(g["vocab"]), finetune=True, seed=5).items()}
+    for r, c in enumerate(g["cases"]):
+        n = sum(c["input_mask"])
+        want_ids = list(c["labels"]); want_ids[n - 1] = 1                     # mask_last_token_only + right padding
+        assert out["input_word_ids"][r].tolist() == want_ids and out["labels"][r].tolist() == c["labels"]
+        assert out["input_mask"][r].tolist() == c["input_mask"]
+        assert out["masked_lm_positions"][r].tolist() == [n - 1] + [0] * (P - 1)
+        assert out["masked_lm_ids"][r].tolist() == [c["labels"][n - 1]] + [0] * (P - 1)
+        assert out["masked_lm_weights"][r].tolist() == [1] + [0] * (P - 1)
+    for c in gold["mask_last_token_only"]:
+        t = torch.tensor([c["sequence"] + [0] * (L - len(c["sequence"]))], dtype=torch.int64)
+        o = device_mask_batch(t.cuda(), P, 100, finetune=True)
+        assert o["input_word_ids"][0, :len(c["sequence"])].cpu().tolist() == c["masked_token_ids"]
+        assert o["masked_lm_positions"][0, 0].item() == c["masked_lm_positions"][0]
+
+    # end to end through the dataloader: 90 / 10 split by per-row flags, frozen masks by default, new masks with remask
+    ds = datasets.synthetic_dataset(n_users=60, n_items=300, min_len=2, max_len=40, seed=1)
+    dl = dataloaders.get_dataloader_factory("bert4rec").create_ml_1m_dataloader(data_source=ds, max_seq_len=20,
+                                                                               max_predictions_per_seq=5, input_duplication_factor=2)
+    train, val, test = dl.prepare_training(finetuning_split=0.1, device_masking=True)
+    frozen = dataloaders.make_batches(train, batch_size=32, seed=3).cache_on_device("cuda")
+    e1 = [{k: v.cpu() for k, v in b.items()} for b in frozen]
+    e2 = [{k: v.cpu() for k, v in b.items()} for b in frozen]
+    assert len(e1) == 4 and [b["input_word_ids"].shape[0] for b in e1] == [32, 32, 32, 24]
+    assert all(torch.equal(a[k], b[k]) for a, b in zip(e1, e2) for k in a)        # == tf .cache(): masks frozen after epoch 1
+    assert set(e1[0]) == {"labels", "input_word_ids", "input_mask", "masked_lm_ids", "masked_lm_positions", "masked_lm_weights"}
+    n_ft = 0
+    for b in e1:
+        for r in range(b["labels"].shape[0]):
+            n = int(b["input_mask"][r].sum())
+            plain = int(((b["labels"][r] != 0) & (b["labels"][r] != 2)).sum())
+            k = int(b["masked_lm_weights"][r].sum())
+            pos = b["masked_lm_positions"][r, :k]
+            last_only = k == 1 and int(pos[0]) == n - 1 and plain * 0.2 >= 2    # a dynamic row would have drawn >= 2 positions
+            n_ft += int(last_only)
+            assert k == 1 or k == min(5, max(1, int(plain * 0.2)))
+            assert pos.tolist() == sorted(pos.tolist()) and (b["input_word_ids"][r, pos] == 1).all()
+            assert torch.equal(b["labels"][r, pos], b["masked_lm_ids"][r, :k])
+            assert (b["masked_lm_positions"][r, k:] == 0).all() and (b["masked_lm_ids"][r, k:] == 0).all()
+    assert 1 <= n_ft <= int(train.finetune_rows.sum())
+    remask = dataloaders.make_batches(train, batch_size=32, seed=3, remask_each_epoch=True).cache_on_device("cuda")
+    r1 = [b["masked_lm_positions"].cpu() for b in remask]
+    r2 = [b["masked_lm_positions"].cpu() for b in remask]
+    assert any(not torch.equal(a, b) for a, b in zip(r1, r2))                     # new masks ...
+    assert all(torch.equal(a["labels"], b["labels"].cpu()) for a, b in zip(e1, remask))   # ... same batch composition
+    # validation / test rows: last-token mask only; the model consumes device-masked batches directly
+    vb = next(iter(dataloaders.make_batches(val, batch_size=16, seed=1).cache_on_device("cuda")))
+    assert (vb["masked_lm_weights"].sum(1) == 1).all()
+    model = make_model(dl.tokenizer.get_vocab_size(), seed=2, L=20)
+    model.compile()
+    hist = model.fit(remask, validation_data=dataloaders.make_batches(val, batch_size=16, seed=1), epochs=2, verbose=0)
+    assert len(hist.history["loss"]) == 2 and all(np.isfinite(hist.history["loss"]))

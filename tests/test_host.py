@@ -148,6 +148,80 @@ def test_prepare_training_and_batches():
         make_loader(input_duplication_factor=0)
 
 
+class _GoldTokenizer:
+    """the string -> id table the golden preprocessor cases were captured with (tests/golden/make_reference_goldens.py)"""
+
+    def __init__(self, vocab):
+        self.table = {t: i for i, t in enumerate(vocab)}
+
+    def tokenize(self, seq):
+        return [self.table[x] for x in seq]
+
+    def get_vocab_size(self):
+        return len(self.table)
+
+
+def _gold_preprocessor():
+    from bert4rec_amd.dataloaders.preprocessors import BERT4RecPreprocessor as PP
+    g = GOLD["process_element_no_mlm"]
+    PP.set_properties(tokenizer=_GoldTokenizer(g["vocab"]), max_seq_len=g["max_seq_len"],
+                      max_predictions_per_seq=g["max_predictions_per_seq"], mask_token_id=1, unk_token_id=2, pad_token_id=0,
+                      masked_lm_rate=0.2, mask_token_rate=1.0, random_token_rate=0.0)
+    return PP, g
+
+
+def test_truncation_window_and_padding_match_reference_process_element():
+    """bert4rec_preprocessor.py:48-72,105-116 run in the build container: last-L truncation, the random window of a long
+    training row (same python `random` draws) and the right-padding; the token matrix of the device path holds the same rows."""
+    import random
+    PP, g = _gold_preprocessor()
+    for c in g["cases"]:
+        random.seed(c["python_random_seed"])
+        e = PP.process_element(list(c["sequence"]), False, c["finetuning"])
+        assert set(e) == {"labels", "input_word_ids", "input_mask"}
+        for k in ("input_word_ids", "input_mask", "labels"):
+            assert e[k].tolist() == c[k] and e[k].dtype == np.int64, (k, c["sequence"])
+        random.seed(c["python_random_seed"])
+        tm = PP.token_rows(du.SequenceDataset([c["sequence"]]), c["finetuning"])
+        assert tm.tokens.tolist() == [c["labels"]] and tm.finetune_rows.tolist() == [int(c["finetuning"])]
+    # prepare_inference = the finetuning branch on history[-(L-1):] + ["[UNK]"] (bert4rec_preprocessor.py:125-168)
+    hist = [f"item{j}" for j in range(30)]
+    inf = PP.prepare_inference(list(hist))
+    L = g["max_seq_len"]
+    want = PP.tokenizer.tokenize(hist[-(L - 1):])
+    assert inf["labels"].tolist() == [want + [2]] and inf["input_word_ids"].tolist() == [want + [1]]
+    assert inf["masked_lm_positions"].tolist() == [[L - 1, 0, 0, 0, 0]] and inf["masked_lm_ids"].tolist() == [[2, 0, 0, 0, 0]]
+    assert inf["masked_lm_weights"].tolist() == [[1, 0, 0, 0, 0]] and inf["input_mask"].tolist() == [[1] * L]
+
+
+def test_mask_last_token_only_matches_reference():
+    for c in GOLD["mask_last_token_only"]:
+        toks, pos, ids = du.mask_last_token_only(np.array(c["sequence"], dtype=np.int64), c["mask_token_id"])
+        assert toks.tolist() == c["masked_token_ids"] and pos.tolist() == c["masked_lm_positions"]
+        assert ids.tolist() == c["masked_lm_ids_by_definition"] and ids.dtype == np.int64
+
+
+def test_device_masking_datasets_are_token_matrices_with_the_reference_split():
+    """prepare_training(device_masking=True): same rows and the same 90 / 10 dynamic / last-token split as the host path
+    (bert4rec_dataloader.py:100-108), but unmasked token matrices; batches need the GPU and fail loudly without one."""
+    dl = make_loader()
+    train, val, test = dl.prepare_training(finetuning_split=0.1, device_masking=True)
+    assert isinstance(train, du.TokenMatrixDataset) and train.tokens.shape == (80, 20) and train.tokens.dtype == np.int64
+    assert int(train.finetune_rows.sum()) == 8 and val.finetune_rows.all() and test.finetune_rows.all()
+    assert train.max_predictions_per_seq == 5 and train.vocab_size == dl.tokenizer.get_vocab_size()
+    # same rows as the host path (sequences no longer than max_seq_len: no random window involved)
+    short = datasets.synthetic_dataset(n_users=40, n_items=300, min_len=2, max_len=18, seed=1)
+    dev_train, _, _ = make_loader(data_source=short).prepare_training(finetuning_split=0.1, device_masking=True)
+    host_train, _, _ = make_loader(data_source=short).prepare_training(finetuning_split=0.1)
+    assert sorted(map(tuple, dev_train.tokens.tolist())) == sorted(tuple(e["labels"].tolist()) for e in host_train.examples)
+    b = dataloaders.make_batches(train, batch_size=32, seed=3, remask_each_epoch=True)
+    assert isinstance(b, du.DeviceMaskedBatches) and len(b) == 3
+    with pytest.raises(_lib.B4RError):
+        next(iter(b.cache_on_device("cpu")))          # no host fallback behind the device masker
+    with pytest.raises(ValueError):
+        dataloaders.make_batches(host_train, batch_size=32, remask_each_epoch=True)
+
+
 def test_factories_raise_value_error_on_unknown_ids():
     """tests/trainers_tests/base_trainer_tests.py:21-27, optimizers :15-21, evaluators :21-27"""
     for fn in (lambda: trainers.get("nope", model=None), lambda: optimizers.get("nope"), lambda: evaluation.get("nope"),

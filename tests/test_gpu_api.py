@@ -329,3 +329,40 @@ def test_device_masked_batches_follow_the_reference_contract():
     model.compile()
     hist = model.fit(remask, validation_data=dataloaders.make_batches(val, batch_size=16, seed=1), epochs=2, verbose=0)
     assert len(hist.history["loss"]) == 2 and all(np.isfinite(hist.history["loss"]))
+
+
+def test_apps_return_what_the_oracle_ranks_first():
+    """apps/recommender.py:14-63 and apps/ranker.py:19-76 on values: the recommended item is the oracle's arg-max over the unseen
+    vocabulary for the masked slot, the Ranker's order is the oracle's descending-logit order (best first: the reference's negated
+    logits, ranker.py:29, are not reproduced)."""
+    from bert4rec_amd.apps import Ranker, Recommender
+    ds = datasets.synthetic_dataset(n_users=30, n_items=200, min_len=5, max_len=30, seed=4)
+    dl = dataloaders.get_dataloader_factory("bert4rec").create_ml_1m_dataloader(data_source=ds, max_seq_len=24, max_predictions_per_seq=6)
+    dl.generate_vocab()
+    V = dl.tokenizer.get_vocab_size()
+    model = make_model(V, seed=5)
+    cfg_o, params = oracle_of(model)
+    items_all = dl.create_item_list()
+    for start in (0, 40, 90):
+        history = items_all[start:start + 15]
+        batch = {k: torch.from_numpy(np.asarray(v)) for k, v in dl.prepare_inference(list(history)).items()}
+        logits = orc.model_forward(params, batch, cfg_o)["mlm_logits"][0, 0].numpy()     # slot 0 = the appended masked token
+        seen = set(dl.tokenizer.tokenize(list(history))) | {0, 1, 2}
+        order = [i for i in np.argsort(-logits.astype(np.float64), kind="stable") if i not in seen]
+        margin = logits[order[0]] - logits[order[1]]
+        rec = Recommender(model, dl)(history)
+        assert rec not in history
+        if margin > 1e-4:
+            assert rec == dl.tokenizer.detokenize(int(order[0]))
+        top5 = Recommender(model, dl)(history, k=5)
+        gaps = np.diff(-logits[order[:6]])
+        if (gaps > 1e-4).all():
+            assert top5 == dl.tokenizer.detokenize([int(i) for i in order[:5]])
+        cands = [it for it in dict.fromkeys(items_all[start + 20:start + 60]) if it not in history][:10]
+        ranked = Ranker(model, dl)(history, cands)
+        ids = dl.tokenizer.tokenize(list(cands))
+        sc = logits[ids]
+        want = [cands[j] for j in np.argsort(-sc.astype(np.float64), kind="stable")]
+        assert sorted(ranked) == sorted(cands)
+        if (np.abs(np.diff(np.sort(sc))) > 1e-4).all():
+            assert ranked == want

@@ -239,10 +239,18 @@ class Engine:
             if nbytes < 0:
                 raise B4RError("b4r_workspace_bytes: " + _lib.last_error())
             if len(self._ws) > 4:
-                self._ws.clear()
+                # drop the least recently created workspaces, never one a captured hipGraph has its pointers baked into
+                # (train_step_graphed / dp_train_step_graphed pin theirs): a replay would read and write freed memory
+                pinned = self.__dict__.setdefault("_ws_pinned", set())
+                for k in [k for k in self._ws if k not in pinned][: max(0, len(self._ws) - 4)]:
+                    del self._ws[k]
             ws = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
             self._ws[key] = ws
         return ws
+
+    def _pin_workspace(self, B: int, L: int, P: int) -> None:
+        self.workspace(B, L, P)
+        self.__dict__.setdefault("_ws_pinned", set()).add((B, L, P))
 
     def region(self, name: str, B: int, L: int, P: int) -> torch.Tensor:
         off, rows, cols, ld = C.c_int64(), C.c_int32(), C.c_int32(), C.c_int32()
@@ -341,6 +349,7 @@ class Engine:
             self.train_step(hp, cb)
             return
         torch.cuda.synchronize(self.device)
+        self._pin_workspace(cb.B, cb.L, cb.P)   # the graph keeps this workspace's addresses
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, capture_error_mode=_CAPTURE_MODE):
             self.train_step(hp, cb)        # capture only enqueues: the step itself runs at the replay below
@@ -364,6 +373,7 @@ class Engine:
             self.ensure_training_buffers()
             fused = self.fused_head_supported()
             torch.cuda.synchronize(self.device)
+            self._pin_workspace(cb.B, cb.L, cb.P)
             g_pre, g_post = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_pre, capture_error_mode=_CAPTURE_MODE):
                 self.begin_step()

@@ -116,14 +116,17 @@ class BERT4RecModel:
 
     call = __call__
 
-    def _outputs(self, cb) -> Dict[str, Any]:
-        out = self.encoder._outputs(cb)
+    def _outputs(self, cb, copy: bool = True) -> Dict[str, Any]:
+        """bert4rec_model.py:139-149.  copy=True (the public call): tensors of their own, as the reference returns; the engine's
+        workspace is overwritten by the next forward / train_step / test_step of the same batch shape."""
+        out = self.encoder._outputs(cb, copy)
         if cb.P > 0:
             B, L, P = cb.B, cb.L, cb.P
             # [B,P,V] view into the (row-padded) logits buffer: values as in the reference, strides differ
             logits = self.engine.region("mlm_logits", B, L, P)
-            out["mlm_logits"] = torch.as_strided(logits, (B, P, self.vocab_size), (P * logits.stride(0), logits.stride(0), 1),
-                                                 logits.storage_offset())
+            view = torch.as_strided(logits, (B, P, self.vocab_size), (P * logits.stride(0), logits.stride(0), 1),
+                                    logits.storage_offset())
+            out["mlm_logits"] = view.contiguous() if copy else view
         return out
 
     # ---- compile / steps ------------------------------------------------------------------------------------------------

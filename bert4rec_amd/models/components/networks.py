@@ -71,12 +71,16 @@ class Bert4RecEncoder:
 
     call = __call__
 
-    def _outputs(self, cb) -> Dict[str, Any]:
+    def _outputs(self, cb, copy: bool = True) -> Dict[str, Any]:
+        """The output dict of Bert4RecEncoder.call (bert4rec_encoder.py:228-231).  The engine writes every forward of one batch
+        shape into the same workspace; like the reference, a call returns tensors of its own (copy=True): results of two calls
+        can be held and compared.  copy=False hands out views into the workspace (internal callers that consume them at once)."""
         B, L, P = cb.B, cb.L, cb.P
         H = self._config["hidden_size"]
         e = self.engine
-        outs = [e.region(f"encoder_output_{i}", B, L, P).view(B, L, H) for i in range(self._config["num_layers"])]
-        return dict(sequence_output=outs[-1], pooled_output=e.region("pooled_output", B, L, P), encoder_outputs=outs)
+        own = (lambda t: t.clone()) if copy else (lambda t: t)
+        outs = [own(e.region(f"encoder_output_{i}", B, L, P).view(B, L, H)) for i in range(self._config["num_layers"])]
+        return dict(sequence_output=outs[-1], pooled_output=own(e.region("pooled_output", B, L, P)), encoder_outputs=outs)
 
     def get_embedding_table(self) -> torch.Tensor:
         return self.engine.view("word_embeddings/embeddings")

@@ -111,6 +111,22 @@ def test_train_and_evaluate_lifecycle(tmp_path):
     assert sorted(ranked) == sorted(dl.create_item_list()[20:30])
 
 
+def test_outputs_of_two_calls_do_not_alias():
+    """the reference returns fresh tensors per call (bert4rec_model.py:139-149); the engine reuses one workspace per batch shape"""
+    model = make_model(120, seed=4)
+    b1 = orc.synthetic_batch(4, 24, 6, 120, seed=1)
+    b2 = orc.synthetic_batch(4, 24, 6, 120, seed=2)
+    o1 = model(b1)
+    keep = {k: (v.clone() if torch.is_tensor(v) else [t.clone() for t in v]) for k, v in o1.items()}
+    o2 = model(b2)
+    for k in ("sequence_output", "pooled_output", "mlm_logits"):
+        assert torch.equal(o1[k], keep[k]) and not torch.equal(o1[k], o2[k]), k
+    assert all(torch.equal(a, b) for a, b in zip(o1["encoder_outputs"], keep["encoder_outputs"]))
+    e1 = model.encoder({"input_word_ids": b1["input_word_ids"], "input_mask": b1["input_mask"]})
+    e2 = model.encoder({"input_word_ids": b2["input_word_ids"], "input_mask": b2["input_mask"]})
+    assert torch.equal(e1["sequence_output"], keep["sequence_output"]) and not torch.equal(e1["sequence_output"], e2["sequence_output"])
+
+
 def test_rank_items_orders_like_the_reference():
     """bert4rec_model.py:203-240: gather candidate logits, stable descending argsort, gather candidates."""
     model = make_model(300, seed=9)

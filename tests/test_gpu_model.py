@@ -200,8 +200,16 @@ def test_graph_replayed_steps_equal_eager_steps():
         eng.set_seed(77)
         cb, keep = eng.prepare_batch(batch)
         losses = []
-        for _ in range(6):
+        for it in range(6):
             (eng.train_step_graphed if graphed else eng.train_step)(hp, cb)
+            torch.cuda.synchronize()
+            # other batch shapes between the replays (evaluation, ranking, a last partial batch): more workspaces than the
+            # engine caches.  The workspace a captured graph points into must survive, and be left alone by the allocator
+            for k in range(6):
+                other = orc.synthetic_batch(2 + k, 8 + 2 * it % 6, 3, cfg_o.vocab_size, seed=k)
+                ocb, okeep = eng.prepare_batch(other)
+                eng.forward(ocb, training=False, pooler=False)
+                torch.empty(1 << 20, device="cuda").fill_(float("nan"))   # would land in a freed workspace
             torch.cuda.synchronize()
             st = eng.read_state()
             losses.append((st["step"], st["loss_sum"], st["lr"]))

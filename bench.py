@@ -8,14 +8,21 @@ B=256 per GPU, L=200, P=40, H=64, 2 layers, 2 heads, inner 256, V=3709, dropout 
         bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0.  `value` = masked positions (slots with masked_lm_ids != 0) consumed per second by the
-whole job, inputs resident in HBM.  `roofline` is measured on the longest kernel of the step, replayed stand-alone on the
-live buffers between two HIP events on the launch stream: with hidden size 64 that is the vocabulary sweep of the fused
-masked-LM head (head_fwd_kernel: logits tiles -> online softmax -> sum_v p E[v], nothing of size [M,V] touches HBM, so
-the bound is the matrix pipe); `roofline_materialising` reports the HBM-bound logits[M,V] = T.E^T + b kernel that the
-forward / evaluation API still uses (and that larger hidden sizes train with).
-`cpu_baseline` is the oracle (CPU restatement of the reference math; TF2 is not installed anywhere) timed on the host.
+whole job, inputs resident in HBM.
+
+`roofline`: after the timed region a few more steps run under the library's launch timer (b4r_timing_begin / _end: a hipEvent on
+the launch stream behind every kernel of the step).  The kernel with the largest time per step IS the roofline kernel -- it is
+picked from the measurement, not named in advance -- and `achieved` = its algorithmic bytes (or FLOPs) per launch / its average
+launch time.  `step_breakdown` lists every launch of one step, `step_hbm` puts the whole step against the HBM roof.
+`roofline_materialising` keeps the HBM-bound logits[M,V] = T.E^T + b kernel of the forward / evaluation API (the north star's
+">= 40 % of HBM roofline on the masked-LM head"; not part of the timed train step, which never writes logits).
+`eval`: BASELINE.json's metric also names NDCG@10 -- a short train + evaluate run on a synthetic Zipf log with learnable
+successor structure (labelled as synthetic), through the product's dataloader / trainer / evaluator surface, with
+evaluation throughput in users/s.
+`cpu_baseline`: the oracle (CPU restatement of the reference math; TF2 is not installed anywhere) timed on the host.
 """
 import argparse
+import collections
 import ctypes as C
 import json
 import os
@@ -40,14 +47,15 @@ CONFIGS = {
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); 6.29 TB/s is the measured copy rate
 BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md); the split-precision kernels run on it
+DTYPE = "f32 (bf16x3 split products on the bf16 matrix cores, fp32 accumulate; softmax / LayerNorm / AdamW in fp32)"
 
 
-def profiled_traffic(kernel_prefix):
-    """HBM bytes per launch of a kernel from the newest committed PMC summary (profiles/r01_*_pmc_ml1m*.txt: separate
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench, gfx950 x2 fetch correction applied by tools/pmc.py).
+def profiled_traffic(kernel_prefix, config):
+    """HBM bytes per launch of a kernel from the newest committed PMC summary of this config (profiles/r*_pmc_<config>.txt:
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench, gfx950 x2 fetch correction applied by tools/pmc.py).
     bench.py cannot collect PMC counters itself; None when no summary names the kernel."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_*_pmc_ml1m*.txt")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{config}.txt")), reverse=True):
         try:
             lines = open(path).read().splitlines()
             hdr = lines[0].split()
@@ -59,6 +67,19 @@ def profiled_traffic(kernel_prefix):
                     return {"bytes": round((float(cols[i_rd + off]) + float(cols[i_wr + off])) * 1e6),
                             "source": os.path.relpath(path, ROOT)}
         except (OSError, ValueError, IndexError):
+            continue
+    return None
+
+
+def profiled_step_bytes(config):
+    """HBM bytes of one whole train step: sum over the kernels of the newest committed PMC summary of (read + written) MB x
+    launches per step (profiles/r*_stepbytes_<config>.json, written by tools/prof.sh); None if absent."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_stepbytes_{config}.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+            return {"bytes": int(d["hbm_bytes_per_step"]), "source": os.path.relpath(path, ROOT)}
+        except (OSError, ValueError, KeyError):
             continue
     return None
 
@@ -90,19 +111,121 @@ def synthetic_batch(B, L, P, V, rate, seed, ragged=False):
             "masked_lm_ids": torch.from_numpy(mids), "masked_lm_weights": torch.from_numpy(w)}
 
 
+def algorithmic_work(label, V, H, NL, NH, I, L, P, B):
+    """(bound, unit work per launch, what) of a launch label of the library: ALGORITHMIC bytes for the HBM-bound kernels (fp32
+    tensors each touched once), fp32-equivalent FLOPs for the matrix-pipe-bound ones (DESIGN.md §4 derives every entry).
+    None for kernels this table does not model (small reductions, scatter, optimizer)."""
+    N, M = B * L, B * P
+    act = N * H * 4                                         # one [N, H] fp32 activation
+    if label.startswith("b4r_ffn_block_fwd"):
+        return "hbm", 3 * act + 2 * N * 4 + 2 * H * I * 4, "x1 in; z2, x2, statistics out; W1, W2"
+    if label.startswith("b4r_ffn_block_bwd (dx)"):
+        return "hbm", 4 * act + 2 * N * 4 + 2 * H * I * 4, "x1, dz2, z1 in; dz1 out; statistics; W1, W2"
+    if label.startswith("b4r_ffn_block_bwd (dw)"):
+        return "hbm", 2 * act + 256 * (2 * H * I + I + H) * 4, "x1, dz2 in; 256 partial slabs of dW1, dW2, db1, db2 out"
+    if label.startswith("b4r_attn_block_fwd"):
+        return "mfma", N * (2 * H * 3 * H + 4 * L * H + 2 * H * H), "QKV + QK^T + PV + output projection of one layer"
+    if label.startswith("b4r_attn_block_bwd"):
+        return "mfma", N * (2 * H * 3 * H + 2 * H * H + 10 * L * H + 2 * 3 * H * H), "QKV recompute, dctx, S / dA once, dQ, dK, dV, dX"
+    if label.startswith("b4r_attn_fwd"):
+        return "mfma", N * 4 * L * H, "QK^T + PV"
+    if label.startswith("b4r_attn_bwd dq"):
+        return "mfma", N * 6 * L * H, "S, dA recomputed + dQ"
+    if label.startswith("b4r_attn_bwd dkv"):
+        return "mfma", N * 8 * L * H, "S, dA recomputed + dK + dV"
+    if label.startswith("masked-LM head forward (fused)"):
+        return "mfma", 2 * (2 * M * V * H), "logit tiles + sum_v p E[v]"
+    if label.startswith("masked-LM head dE (fused)"):
+        return "mfma", 2 * (2 * M * V * H), "logit tiles recomputed + g^T T"
+    return None
+
+
+def measure_step_breakdown(eng, lib, hp, prepared, nb, n_steps=10):
+    """Per-launch times of the train step from the library's own event timer (enqueue order, averaged over n_steps steps)."""
+    from bert4rec_amd import _lib
+    stream = torch.cuda.current_stream().cuda_stream
+    cap = 256 * n_steps
+    torch.cuda.synchronize()
+    _lib.check(lib.b4r_timing_begin(stream, cap), "b4r_timing_begin")
+    for i in range(n_steps):
+        eng.train_step(hp, prepared[i % nb][0])
+    n = C.c_int32(0)
+    us = (C.c_float * cap)()
+    stride = 128
+    names = C.create_string_buffer(cap * stride)
+    _lib.check(lib.b4r_timing_end(C.byref(n), us, names, stride, cap), "b4r_timing_end")
+    per_step = n.value // n_steps
+    assert per_step * n_steps == n.value, "launch count varies between steps"
+    rows = []
+    for j in range(per_step):
+        label = names.raw[j * stride:(j + 1) * stride].split(b"\0", 1)[0].decode()
+        t = float(np.mean([us[s * per_step + j] for s in range(n_steps)]))
+        rows.append((label, t))
+    return rows
+
+
+def eval_leg(device, V_items=3706, users=2048, seed=0):
+    """Train + evaluate through the product surface on a synthetic Zipf log with successor structure (datasets.make_synthetic,
+    order=0.6): dataloader factory -> prepare_training(device_masking) -> trainer -> evaluator (100 popularity negatives per
+    user, bert4rec_evaluator.py:60-120).  Returns NDCG@10 / HR@10 and the evaluation throughput."""
+    from bert4rec_amd import config, dataloaders, datasets, evaluation, models, trainers
+    from bert4rec_amd.dataloaders import dataloader_utils
+    from bert4rec_amd.models.components import networks
+    from bert4rec_amd.trainers import optimizers
+    t0 = time.perf_counter()
+    ds = datasets.synthetic_dataset(n_users=users, n_items=V_items, min_len=20, max_len=200, seed=seed, order=0.6)
+    dl = dataloaders.get_dataloader_factory("bert4rec").create_ml_1m_dataloader(data_source=ds, input_duplication_factor=1)
+    train, val, test = dl.prepare_training(device_masking=True)
+    enc = networks.Bert4RecEncoder(dl.get_tokenizer().get_vocab_size(), seed=5, device=device, **config.get_encoder_config("ml-1m_64"))
+    model = models.BERT4RecModel(enc)
+    trainer = trainers.get(model=model)
+    epochs, lr = 60, 1e-3
+    steps = epochs * ((len(train) + 255) // 256)
+    trainer.initialize_model(optimizer=optimizers.get("adamw", init_lr=lr, num_train_steps=steps, num_warmup_steps=50))
+    tb = dataloader_utils.make_batches(train, batch_size=256, seed=1, remask_each_epoch=True)
+    t_prep = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    hist = model.fit(tb, epochs=epochs, verbose=0)
+    torch.cuda.synchronize()
+    t_train = time.perf_counter() - t0
+    ev = evaluation.get(dataloader=dl, seed=3)
+    test_b = dataloader_utils.make_batches(test, batch_size=256, seed=2).cache_on_device(device)
+    ev.evaluate(model, test_b)                      # warm-up pass (also builds the sampler tables)
+    ev.reset_metrics()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev.evaluate(model, test_b)
+    res = ev.get_metrics_results()                  # one device -> host copy
+    t_eval = time.perf_counter() - t0
+    n_users = int(res["Valid Ranks"])
+    return {"dataset": f"synthetic Zipf(1.2) log, {users} users x {V_items} items, lengths U{{20..200}}, successor structure 0.6 "
+                       f"(NOT MovieLens: no dataset files on the box)",
+            "train": f"{epochs} epochs = {steps} steps of B=256, AdamW lr {lr} (warm-up 50, linear decay), masks redrawn on the GPU "
+                     f"every epoch, final loss {hist.history['loss'][-1]:.3f}",
+            "NDCG@10": round(float(res["NDCG@10"]), 4), "HR@10": round(float(res["HR@10"]), 4),
+            "NDCG@5": round(float(res["NDCG@5"]), 4), "MAP": round(float(res["MAP"]), 4), "users": n_users,
+            "eval_users_per_s": round(n_users / t_eval, 1), "eval_ms": round(t_eval * 1e3, 2),
+            "train_s": round(t_train, 2), "host_prepare_s": round(t_prep, 2),
+            "chance_level_HR@10": round(10 / 101, 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--config", default="ml1m", choices=list(CONFIGS))
-    ap.add_argument("--cpu-steps", type=int, default=2, help="timed oracle steps for cpu_baseline (0 disables)")
+    ap.add_argument("--cpu-steps", type=int, default=3, help="timed oracle steps for cpu_baseline (0 disables)")
+    ap.add_argument("--no-eval", action="store_true", help="skip the train + evaluate leg (NDCG@10 on the synthetic log)")
+    ap.add_argument("--no-breakdown", action="store_true", help="skip the event-timed extra steps (profiling runs: tools/prof.sh)")
     ap.add_argument("--phases", action="store_true", help="also print per-phase timings to stderr")
     ap.add_argument("--ragged", action="store_true", help="diagnostic only: S-ragged rows (lengths U{5..L}); reports the padding "
                                                           "penalty, NOT the headline configuration")
     ap.add_argument("--no-dropout", action="store_true", help="diagnostic only: dropout 0 (NOT the headline configuration)")
     ap.add_argument("--graph", action="store_true", help="replay each batch's step from captured hipGraphs (same GPU time, "
                                                          "~7x less host time per step; N > 1: two graphs around the all-reduce)")
+    ap.add_argument("--force-dist", action="store_true", help="run the RCCL code path (init, broadcast, all-reduce, barriers) with "
+                                                              "ONE rank: the only way to rehearse it on a one-GPU box")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -117,9 +240,7 @@ def main():
     dev_index = local_rank if local_rank < torch.cuda.device_count() else 0
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    # B4R_BENCH_FORCE_DIST=1: run the RCCL code path (init, broadcast, all-reduce, barriers) with one rank -- the only way to
-    # rehearse it on a one-GPU box
-    use_dist = world > 1 or os.environ.get("B4R_BENCH_FORCE_DIST") == "1"
+    use_dist = world > 1 or args.force_dist
     # RCCL prints a version banner on stdout when its first communicator is created: until the warm-up is over, stdout (fd 1) is
     # pointed at stderr so that the one JSON line stays the only thing on stdout
     sys.stdout.flush()
@@ -140,25 +261,27 @@ def main():
     if args.no_dropout:
         od = ad = 0.0
     cfg = make_model_config(V, H, NL, NH, L, I, od, ad)
-    eng = Engine(cfg, device, seed=1234)
+    eng = Engine(cfg, device, seed=1234 + rank)   # per-rank dropout stream: ranks hold different rows
     eng.init_parameters(seed=3)
+    eng.rehearse_collectives = args.force_dist
     broadcast_parameters(eng.params)
     hp = make_adamw_config()
     nb = 4
     batches = [synthetic_batch(B, L, P, V, rate, seed=1000 * rank + i, ragged=args.ragged) for i in range(nb)]
     prepared = [eng.prepare_batch(b) for b in batches]
     valid_per_step = float(sum(int((b["masked_lm_ids"] != 0).sum()) for b in batches)) / nb
+    graphs = args.graph or (use_dist and world > 1)   # N > 1: the host must not become the bottleneck of the step
 
     def step(i):
         cb, _ = prepared[i % nb]
         if use_dist:
-            (eng.dp_train_step_graphed if args.graph else eng.dp_train_step)(hp, cb)
+            (eng.dp_train_step_graphed if graphs else eng.dp_train_step)(hp, cb)
         elif args.graph:
             eng.train_step_graphed(hp, cb)
         else:
             eng.train_step(hp, cb)
 
-    for i in range(args.warmup):
+    for i in range(max(args.warmup, 3 * nb if graphs else 0)):   # graphs: eager, capture, replay once per batch before timing
         step(i)
     torch.cuda.synchronize()
     if use_dist:
@@ -183,14 +306,57 @@ def main():
     loss = st["loss_sum"] / max(st["valid_count"], 1.0)
     assert np.isfinite(loss), "training diverged"
 
-    result = None
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = valid_per_step * world * args.steps / elapsed
-        # ---- roofline: the materialising masked-LM-head projection, replayed on the live buffers ------------------
-        cb, _ = prepared[0]
         lib = _lib.load()
+        cb, _ = prepared[0]
         M = B * P
+        stream = torch.cuda.current_stream().cuda_stream
+
+        # ---- roofline: the dominant kernel of the step, found by timing every launch of the step ------------------------------
+        roofline, breakdown, step_hbm = None, None, None
+        if not args.no_breakdown:
+            rows = measure_step_breakdown(eng, lib, hp, prepared, nb)
+            per_label = collections.OrderedDict()
+            for label, t in rows:
+                a = per_label.setdefault(label, [0.0, 0])
+                a[0] += t
+                a[1] += 1
+            total_us = sum(t for _, t in rows)
+            breakdown = {"launches_per_step": len(rows), "event_timed_us_per_step": round(total_us, 1),
+                         "kernels": [{"launch": k, "n_per_step": v[1], "us_per_step": round(v[0], 1)} for k, v in
+                                     sorted(per_label.items(), key=lambda kv: -kv[1][0])]}
+            for label, (tot, cnt) in sorted(per_label.items(), key=lambda kv: -kv[1][0]):
+                work = algorithmic_work(label, V, H, NL, NH, I, L, P, B)
+                if work is None:
+                    continue
+                bound, amount, what = work
+                avg_us = tot / cnt
+                if bound == "hbm":
+                    ach, peak, unit = amount / (avg_us * 1e-6) / 1e9, HBM_PEAK_GBS, "GB/s"
+                else:
+                    ach, peak, unit = amount / (avg_us * 1e-6) / 1e12, BF16_PEAK_TFLOPS, "TFLOP/s"
+                tr = profiled_traffic(label.split(" ")[0].replace("b4r_", "").replace("_block", ""), args.config)
+                roofline = {"kernel": label, "selection": f"largest time per step of the {len(per_label)} distinct launches "
+                                                          f"({tot:.1f} us = {100 * tot / total_us:.1f} % of the step's kernel time)",
+                            "bound": bound, "achieved": round(ach, 1), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
+                            "traffic": tr["bytes"] if tr else None, "traffic_source": tr["source"] if tr else None,
+                            "algorithmic_" + ("bytes" if bound == "hbm" else "flops"): int(amount), "what_is_counted": what,
+                            "avg_launch_us": round(avg_us, 2), "launches_per_step": cnt,
+                            "timer": "hipEvents on the launch stream behind every launch of 10 extra steps (b4r_timing_begin/_end)"}
+                if bound == "mfma":
+                    roofline["executed_mfma_flops"] = int(3 * amount)
+                    roofline["frac_executed"] = round(3 * ach / peak, 4)
+                break
+            sb = profiled_step_bytes(args.config)
+            if sb:
+                gbs = sb["bytes"] / (ms * 1e-3) / 1e9
+                step_hbm = {"hbm_bytes_per_step": sb["bytes"], "source": sb["source"], "achieved_GBs": round(gbs, 1),
+                            "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+
+        # ---- the materialising masked-LM-head projection (forward / evaluation API), replayed on live buffers ----------------
+        eng.forward(cb, training=False, pooler=False)        # fills mlm_hidden / mlm_logits of this batch shape
         t_h = eng.region("mlm_hidden", B, L, P)
         logits = eng.region("mlm_logits", B, L, P)
         d = _lib.GemmDesc()
@@ -200,7 +366,6 @@ def main():
         d.M, d.N, d.K, d.b_is_nk, d.epilogue = M, V, H, 1, _lib.EPI_BIAS
         d.bias = eng.view("cls/predictions/output_bias/bias").data_ptr()
         d.c_pad_scratch = 1  # exactly as b4r_forward launches it: the pad columns V..Vp-1 of the logits rows are scratch
-        stream = torch.cuda.current_stream().cuda_stream
         for _ in range(5):
             _lib.check(lib.b4r_gemm_f32(C.byref(d), stream))
         reps = 50
@@ -213,39 +378,15 @@ def main():
         k_us = e0.elapsed_time(e1) * 1e3 / reps
         alg_bytes = M * V * 4 + M * H * 4 + V * H * 4 + V * 4 + M * 8
         achieved = alg_bytes / (k_us * 1e-6) / 1e9
-        roofline_mat = {"kernel": "rx_gemm_nk_kernel<BIAS> (mlm_logits = T.E^T + b, bf16x3)", "bound": "hbm",
+        roofline_mat = {"kernel": "mlm_logits = T.E^T + b (b4r_gemm_f32, B4R_EPI_BIAS, bf16x3)", "bound": "hbm",
                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes": alg_bytes,
                         "avg_launch_us": round(k_us, 2), "in_timed_region": not eng.fused_head_supported()}
-        tr = profiled_traffic("rx_gemm_nk_kernel<1, false, 4>") if args.config == "ml1m" else None
+        tr = profiled_traffic("rx_gemm_nk_kernel<1, false, 4>", args.config)
         if tr:
             roofline_mat["traffic"], roofline_mat["traffic_source"] = tr["bytes"], tr["source"]
-        roofline = roofline_mat
-        if eng.fused_head_supported():
-            # the train step's head: replay the vocabulary sweep (the longest kernel of the step) on the live buffers
-            _, keep0 = prepared[0]
-            scratch = torch.empty(lib.b4r_mlm_head_fused_scratch_floats(M, V, H), dtype=torch.float32, device=device)
-            hargs = (t_h.data_ptr(), eng.view("word_embeddings/embeddings").data_ptr(),
-                    eng.view("cls/predictions/output_bias/bias").data_ptr(), keep0["masked_lm_ids"].data_ptr(), M, V, H,
-                    scratch.data_ptr(), None, None, None, None, 1, stream)
-            for _ in range(5):
-                _lib.check(lib.b4r_mlm_head_fused_fwd(*hargs))
-            e0.record()
-            for _ in range(reps):
-                _lib.check(lib.b4r_mlm_head_fused_fwd(*hargs))
-            e1.record()
-            torch.cuda.synchronize()
-            h_us = e0.elapsed_time(e1) * 1e3 / reps
-            alg_flops = 2 * (2 * M * V * H)          # x = T.E^T and sum_v p[m,v] E[v,:], fp32-equivalent multiply-adds
-            tf = alg_flops / (h_us * 1e-6) / 1e12
-            roofline = {"kernel": "head_fwd_kernel (masked-LM head: logit tiles -> online softmax -> p.E, bf16x3)",
-                        "bound": "mfma", "achieved": round(tf, 1), "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(tf / BF16_PEAK_TFLOPS, 4), "traffic": None, "algorithmic_flops": alg_flops,
-                        "executed_mfma_flops": 3 * alg_flops, "frac_executed": round(3 * tf / BF16_PEAK_TFLOPS, 4),
-                        "avg_launch_us": round(h_us, 2)}
-            tr = profiled_traffic("head_fwd_kernel") if args.config == "ml1m" else None
-            if tr:
-                roofline["traffic"], roofline["traffic_source"] = tr["bytes"], tr["source"]
+        if roofline is None:
+            roofline = roofline_mat
 
         if args.phases:
             def timed(fn, n=20):
@@ -258,17 +399,23 @@ def main():
                 b_.record()
                 torch.cuda.synchronize()
                 return a.elapsed_time(b_) / n
+            fused = eng.fused_head_supported()
             eng.begin_step()
-            f_ms = timed(lambda: eng.forward(cb, training=True, pooler=False))
-            l_ms = timed(lambda: (eng.forward(cb, training=True, pooler=False), eng.loss(cb, True)))
-            b_ms = timed(lambda: eng.backward(cb, training=True))
+            f_ms = timed(lambda: eng.forward(cb, training=True, pooler=False, fused_head=fused))
+            l_ms = timed(lambda: (eng.forward(cb, training=True, pooler=False, fused_head=fused), eng.loss(cb, True, fused_head=fused)))
+            b_ms = timed(lambda: eng.backward(cb, training=True, fused_head=fused))
             o_ms = timed(lambda: eng.optimizer_step(hp, cb))
             print(f"[phases] forward {f_ms:.3f} ms, loss {l_ms - f_ms:.3f} ms, backward {b_ms:.3f} ms, optimizer {o_ms:.3f} ms",
                   file=sys.stderr)
 
+        # ---- train + evaluate leg: NDCG@10 (synthetic log) and evaluation throughput ----------------------------------------
+        ev = None
+        if world == 1 and not args.no_eval and args.config == "ml1m":
+            ev = eval_leg(device)
+
         # ---- CPU baseline: the oracle's train step on the host cores (rank 0, N=1 only) ---------------------------
         cpu = None
-        if world == 1 and args.cpu_steps > 0 and args.config == "ml1m":
+        if world == 1 and args.cpu_steps > 0 and args.config in ("ml1m", "steam"):
             from oracle import bert4rec_oracle as orc
             # the GPU box exposes every host core but a one-GPU job owns a 16-core share: more threads only thrash
             try:
@@ -294,13 +441,15 @@ def main():
 
         result = {"metric": "masked positions/sec", "value": round(value, 1), "unit": "masked positions/s",
                   "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
-                  "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                  "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
                   "config": {"workload": f"{args.config}: full train step, B={B}/GPU L={L} P={P} H={H} layers={NL} heads={NH} "
                                          f"inner={I} V={V} dropout {od}/{ad}, full-vocab masked-LM head, {int(valid_per_step)} "
                                          f"masked positions/GPU/step" + (" (S-ragged rows: lengths U{5..L})" if args.ragged else ""),
-                             "global_batch": B * world, "seq_len": L, "parallelism": f"dp{world}"},
+                             "global_batch": B * world, "seq_len": L, "parallelism": f"dp{world}",
+                             "launch_mode": "hipGraph replay" if graphs else "eager"},
                   "per_gpu": round(value / world, 1), "final_loss": round(loss, 5),
-                  "roofline": roofline, "roofline_materialising": roofline_mat, "cpu_baseline": cpu}
+                  "roofline": roofline, "step_hbm": step_hbm, "roofline_materialising": roofline_mat, "eval": ev,
+                  "cpu_baseline": cpu, "step_breakdown": breakdown}
         print(json.dumps(result), flush=True)
     if use_dist:
         dist.barrier()

@@ -80,7 +80,7 @@ ST_LOSS_SUM, ST_VALID, ST_CORRECT_MASKED, ST_CORRECT_ALL, ST_SLOTS_ALL, ST_SQNOR
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_QSCALE, EPI_BIAS_GELU, EPI_BIAS_DROP_RES, EPI_GELU_BWD, EPI_ADD_RES, EPI_BIAS_TANH = range(8)
 EPI_BIAS_DROP_RES_LN, EPI_ADD_RES_LN_BWD, EPI_BIAS_GELU_LN = 8, 9, 10
-FLAG_TRAINING, FLAG_POOLER, FLAG_FUSED_HEAD = 1, 2, 4
+FLAG_TRAINING, FLAG_POOLER, FLAG_FUSED_HEAD, FLAG_GRAD_TAIL = 1, 2, 4, 8
 LOSS_FUSED_HEAD = 2
 GEMM_F32, GEMM_BF16X3 = 0, 1
 
@@ -104,6 +104,7 @@ PROTOTYPES = {
     "b4r_loss": (C.c_int, [C.POINTER(ModelConfig), C.POINTER(Batch), _P, _I64, _P, _I32, _P]),
     "b4r_backward": (C.c_int, [C.POINTER(ModelConfig), C.POINTER(Batch), _P, _P, _P, _I64, _P, _I32, _P]),
     "b4r_optimizer_step": (C.c_int, [C.POINTER(ModelConfig), C.POINTER(AdamWConfig), _P, _P, _P, _P, _P, _I64, _P, _P]),
+    "b4r_optimizer_step_reduced": (C.c_int, [C.POINTER(ModelConfig), C.POINTER(AdamWConfig), _P, _P, _P, _P, _P, _I64, _P, _P]),
     "b4r_state_begin_step": (C.c_int, [_P, _P]),
     "b4r_train_step": (C.c_int, [C.POINTER(ModelConfig), C.POINTER(AdamWConfig), C.POINTER(Batch), _P, _P, _P, _P, _P,
                                  _I64, _P, _P]),
@@ -137,6 +138,8 @@ PROTOTYPES = {
     "b4r_mlm_head_fused_scratch_floats": (C.c_int64, [_I32, _I32, _I32]),
     "b4r_mlm_head_fused_fwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P, _P, _P, _I32, _P]),
     "b4r_mlm_head_fused_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P, _P]),
+    "b4r_timing_begin": (C.c_int, [_P, _I32]),
+    "b4r_timing_end": (C.c_int, [C.POINTER(_I32), C.POINTER(C.c_float), C.c_char_p, _I32, _I32]),
     "b4r_mask_batch": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, C.c_double, _F, _F, _I32, C.c_uint64, _P, _P, _P, _P, _P, _P, _P]),
     "b4r_sample_candidates": (C.c_int, [_P, _I32, _P, _I32, _P, _I32, _I32, C.c_uint64, _P, _P]),
     "b4r_softmax_ce": (C.c_int, [_P, _I32, _I32, _I32, _P, _P, _P, _I32, _P]),

@@ -20,6 +20,10 @@ void b4r_set_error(const char* fmt, ...);
       return (code);                              \
     }                                             \
   } while (0)
+// launch timing (b4r_timing_begin / b4r_timing_end, include/b4r.h): while a recording is active on the calling thread every
+// checked launch is followed by a hipEvent on the recording's stream; both calls are no-ops otherwise
+void b4r_timing_mark(const char* what);
+void b4r_timing_detail(const char* fmt, ...);
 #define B4R_CHECK_LAUNCH(what)                                                   \
   do {                                                                           \
     hipError_t e__ = hipGetLastError();                                          \
@@ -27,6 +31,7 @@ void b4r_set_error(const char* fmt, ...);
       b4r_set_error("%s: launch failed: %s", (what), hipGetErrorString(e__));    \
       return B4R_E_HIP;                                                          \
     }                                                                            \
+    b4r_timing_mark(what);                                                       \
   } while (0)
 
 static inline int b4r_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -510,6 +510,7 @@ extern "C" int b4r_gemm_f32(const b4r_gemm_desc* d, b4r_stream_t stream) {
   B4R_CHECK_ARG(d->lda >= d->K && d->ldc >= d->N && d->ldb >= (d->b_is_nk ? d->K : d->N), B4R_E_SHAPE,
                 "b4r_gemm_f32: leading dimension smaller than the row length");
   const int epi = d->epilogue;
+  b4r_timing_detail("M=%d N=%d K=%d epi=%d%s", d->M, d->N, d->K, d->epilogue, d->b_is_nk ? " B^T" : "");
   const bool needs_bias = epi == B4R_EPI_BIAS || epi == B4R_EPI_BIAS_QSCALE || epi == B4R_EPI_BIAS_GELU ||
                           epi == B4R_EPI_BIAS_DROP_RES || epi == B4R_EPI_BIAS_TANH || epi == B4R_EPI_BIAS_DROP_RES_LN ||
                           epi == B4R_EPI_BIAS_GELU_LN;
@@ -628,6 +629,7 @@ extern "C" int b4r_gemm_tn_f32(const b4r_gemm_tn_desc* d, float* scratch, b4r_st
   B4R_CHECK_ARG(d->A && d->B && d->out, B4R_E_BADARG, "b4r_gemm_tn_f32: null operand");
   B4R_CHECK_ARG(d->R > 0 && d->Mo > 0 && d->No > 0, B4R_E_SHAPE, "b4r_gemm_tn_f32: bad shape");
   B4R_CHECK_ARG(d->lda >= d->Mo && d->ldb >= d->No && d->ldo >= d->No, B4R_E_SHAPE, "b4r_gemm_tn_f32: bad leading dimension");
+  b4r_timing_detail("R=%d Mo=%d No=%d%s", d->R, d->Mo, d->No, d->dgrad_out ? " +dgrad" : "");
   if (d->dgrad_out != nullptr) {
     B4R_CHECK_ARG(d->dgrad_w != nullptr, B4R_E_BADARG, "b4r_gemm_tn_f32: dgrad_out needs dgrad_w");
     B4R_CHECK_ARG(b4r_gemm_tn_dgrad_supported(d), B4R_E_SHAPE,

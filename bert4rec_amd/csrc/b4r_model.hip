@@ -39,9 +39,9 @@ int b4r_attn_bwd_streams(const float* qkv, const int64_t* input_mask, const floa
                          int32_t B, int32_t L, int32_t heads, float qscale, float* dqkv, const uint32_t* rng,
                          uint32_t drop_stream, float drop_rate, const uint32_t* keep_bits, hipStream_t stream,
                          hipStream_t stream_dkv);
-int b4r_zero2(float* a, int64_t na, float* b, int64_t nb, hipStream_t stream);
+int b4r_zero2(float* a, int64_t na, float* b, int64_t nb, hipStream_t stream, float* tail = nullptr, const b4r_train_state* state = nullptr);
 int b4r_optimizer_fused(const b4r_adamw_config* hp, float* params, const float* grads, float* adam_m, float* adam_v, int64_t n,
-                        int64_t n_decay, float* scratch, b4r_train_state* state, hipStream_t stream);
+                        int64_t n_decay, float* scratch, b4r_train_state* state, hipStream_t stream, int sums_from_tail = 0);
 
 // ---- error message (thread local) ---------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -61,6 +61,63 @@ extern "C" size_t b4r_last_error(char* buf, size_t cap) {
   return n;
 }
 extern "C" int b4r_version(void) { return B4R_VERSION; }
+
+// ---- launch timing ----------------------------------------------------------------------------------------------------------
+namespace {
+struct TimingRec {
+  bool on = false;
+  hipStream_t stream = nullptr;
+  std::vector<hipEvent_t> ev;       // ev[0] = begin, ev[i + 1] = after launch i
+  std::vector<std::string> names;
+  char detail[96] = "";
+};
+thread_local TimingRec g_tr;
+}  // namespace
+
+void b4r_timing_detail(const char* fmt, ...) {
+  if (!g_tr.on) return;
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_tr.detail, sizeof(g_tr.detail), fmt, ap);
+  va_end(ap);
+}
+void b4r_timing_mark(const char* what) {
+  if (!g_tr.on || g_tr.names.size() + 1 >= g_tr.ev.size()) return;
+  std::string n(what);
+  if (g_tr.detail[0]) { n += " ["; n += g_tr.detail; n += "]"; g_tr.detail[0] = 0; }
+  if (hipEventRecord(g_tr.ev[g_tr.names.size() + 1], g_tr.stream) == hipSuccess) g_tr.names.push_back(n);
+}
+extern "C" int b4r_timing_begin(b4r_stream_t stream, int32_t max_launches) {
+  B4R_CHECK_ARG(!g_tr.on, B4R_E_BADARG, "b4r_timing_begin: a recording is already active on this thread");
+  B4R_CHECK_ARG(max_launches > 0 && max_launches <= 1 << 16, B4R_E_BADARG, "b4r_timing_begin: bad capacity");
+  g_tr.ev.assign((size_t)max_launches + 1, nullptr);
+  for (auto& e : g_tr.ev)
+    if (hipEventCreate(&e) != hipSuccess) { b4r_set_error("b4r_timing_begin: hipEventCreate failed"); return B4R_E_HIP; }
+  g_tr.names.clear();
+  g_tr.stream = (hipStream_t)stream;
+  g_tr.detail[0] = 0;
+  if (hipEventRecord(g_tr.ev[0], g_tr.stream) != hipSuccess) { b4r_set_error("b4r_timing_begin: hipEventRecord failed"); return B4R_E_HIP; }
+  g_tr.on = true;
+  return B4R_OK;
+}
+extern "C" int b4r_timing_end(int32_t* n_launches, float* micros, char* names, int32_t name_stride, int32_t capacity) {
+  B4R_CHECK_ARG(g_tr.on, B4R_E_BADARG, "b4r_timing_end: no recording is active on this thread");
+  g_tr.on = false;
+  const int n = (int)g_tr.names.size();
+  int rc = B4R_OK;
+  if (n > 0 && hipEventSynchronize(g_tr.ev[n]) != hipSuccess) { b4r_set_error("b4r_timing_end: hipEventSynchronize failed"); rc = B4R_E_HIP; }
+  const int m = n < capacity ? n : capacity;
+  for (int i = 0; i < m && rc == B4R_OK; ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_tr.ev[i], g_tr.ev[i + 1]) != hipSuccess) { b4r_set_error("b4r_timing_end: hipEventElapsedTime failed"); rc = B4R_E_HIP; break; }
+    if (micros) micros[i] = ms * 1e3f;
+    if (names && name_stride > 0) snprintf(names + (size_t)i * name_stride, (size_t)name_stride, "%s", g_tr.names[i].c_str());
+  }
+  for (auto e : g_tr.ev) if (e) (void)hipEventDestroy(e);
+  g_tr.ev.clear();
+  if (n_launches) *n_launches = m;
+  return rc;
+}
 
 namespace {
 
@@ -599,7 +656,9 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
   B4rReduceQueue queue;
   b4r_reduce_queue_begin(&queue);   // every ordered reduction below is summed by ONE launch at the end
 
-  RC(b4r_zero2(grads, pl.total, ws + w.dx, w.da - w.dx, s));   // the gradient buffer; dx and the scatter's hot-row slots
+  // the gradient buffer; dx and the scatter's hot-row slots; with B4R_FLAG_GRAD_TAIL also the step's sums behind the gradients
+  B4R_CHECK_ARG(!(flags & B4R_FLAG_GRAD_TAIL) || state, B4R_E_BADARG, "b4r_backward: B4R_FLAG_GRAD_TAIL needs the state");
+  RC(b4r_zero2(grads, pl.total, ws + w.dx, w.da - w.dx, s, (flags & B4R_FLAG_GRAD_TAIL) ? grads + pl.total : nullptr, state));
 
   // ---- masked-LM head (logits buffer holds d loss_sum / d logits, pad columns zero) --------------------------------
   // s2: independent branches (see SideStream); it is ordered after the memsets here, joined before every reuse of a buffer
@@ -767,6 +826,17 @@ extern "C" int b4r_optimizer_step(const b4r_model_config* cfg, const b4r_adamw_c
   // backward no longer needs: the first floats of the workspace hold x0 which is dead after backward.
   float* scratch = static_cast<float*>(workspace);
   return b4r_optimizer_fused(hp, params, grads, adam_m, adam_v, pl.total, pl.n_decay, scratch, state, (hipStream_t)stream);
+}
+
+extern "C" int b4r_optimizer_step_reduced(const b4r_model_config* cfg, const b4r_adamw_config* hp, float* params, const float* grads,
+                                          float* adam_m, float* adam_v, void* workspace, int64_t workspace_bytes,
+                                          b4r_train_state* state, b4r_stream_t stream) {
+  RC(check_cfg(cfg));
+  B4R_CHECK_ARG(hp && params && grads && adam_m && adam_v && workspace && state, B4R_E_BADARG, "b4r_optimizer_step_reduced: null argument");
+  B4R_CHECK_ARG(workspace_bytes >= 4096 * (int64_t)sizeof(float), B4R_E_NOMEM, "b4r_optimizer_step_reduced: workspace too small");
+  const ParamLayout pl = make_param_layout(*cfg);
+  return b4r_optimizer_fused(hp, params, grads, adam_m, adam_v, pl.total, pl.n_decay, static_cast<float*>(workspace), state,
+                             (hipStream_t)stream, 1);
 }
 
 extern "C" int b4r_train_step(const b4r_model_config* cfg, const b4r_adamw_config* hp, const b4r_batch* batch, float* params,

@@ -432,8 +432,11 @@ __global__ void state_begin_kernel(b4r_train_state* st) {
 // -----------------------------------------------------------------------------------------------------------
 // global norm + AdamW
 // -----------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* g, int64_t n, float* partial) {
+// tail (optional): the reduced sums behind the gradients go back into the state before the optimizer kernel reads valid_count
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* g, int64_t n, float* partial, const float* tail = nullptr,
+                                                             float* state_f = nullptr) {
   __shared__ float s[4];
+  if (tail != nullptr && blockIdx.x == 0 && threadIdx.x < 5) state_f[4 + threadIdx.x] = tail[threadIdx.x];
   const int64_t n4 = n / 4;
   const int64_t per = (n4 + gridDim.x - 1) / gridDim.x;
   const int64_t b = (int64_t)blockIdx.x * per, e = min(n4, b + per);
@@ -739,20 +742,23 @@ extern "C" int b4r_softmax_ce(float* logits, int32_t M, int32_t V, int32_t ld, c
 // zero two float regions (16-byte aligned, sizes multiples of 4 floats) in one launch.  Used instead of hipMemsetAsync by
 // the backward pass: one launch instead of two, and an ordinary kernel node when the step is captured into a hipGraph
 // (memset nodes of a replayed graph were observed to leave the regions untouched from the second replay on).
-__global__ __launch_bounds__(256) void zero2_kernel(float* a, int64_t na4, float* b, int64_t nb4) {
+// tail (optional): the 8 floats behind the gradient buffer receive the step's five sums from the state (loss_sum, valid_count,
+// correct_masked, correct_all, slots_all), so that ONE all-reduce of [gradients | tail] carries them
+__global__ __launch_bounds__(256) void zero2_kernel(float* a, int64_t na4, float* b, int64_t nb4, float* tail, const float* state_f) {
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  if (tail != nullptr && blockIdx.x == 0 && threadIdx.x < 8) tail[threadIdx.x] = threadIdx.x < 5 ? state_f[4 + threadIdx.x] : 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < na4 + nb4; i += (int64_t)gridDim.x * 256) {
     if (i < na4) *reinterpret_cast<f32x4*>(a + 4 * i) = z;
     else *reinterpret_cast<f32x4*>(b + 4 * (i - na4)) = z;
   }
 }
-int b4r_zero2(float* a, int64_t na, float* b, int64_t nb, hipStream_t stream) {
+int b4r_zero2(float* a, int64_t na, float* b, int64_t nb, hipStream_t stream, float* tail, const b4r_train_state* state) {
   B4R_CHECK_ARG(na % 4 == 0 && nb % 4 == 0 && b4r_aligned16(a) && b4r_aligned16(b), B4R_E_ALIGN, "zero2: regions must be 16-byte granular");
   int64_t n4 = (na + nb) / 4;
   int grid = (int)((n4 + 255) / 256);
   if (grid > 2048) grid = 2048;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(zero2_kernel, dim3(grid), dim3(256), 0, stream, a, na / 4, b, nb / 4);
+  hipLaunchKernelGGL(zero2_kernel, dim3(grid), dim3(256), 0, stream, a, na / 4, b, nb / 4, tail, reinterpret_cast<const float*>(state));
   B4R_CHECK_LAUNCH("zero fill");
   return B4R_OK;
 }
@@ -778,7 +784,8 @@ extern "C" int b4r_global_sqnorm(const float* g, int64_t n, float* scratch, b4r_
   int np = (int)((n / 4 + 1023) / 1024);
   if (np > 1024) np = 1024;
   if (np < 1) np = 1;
-  hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(np), dim3(256), 0, (hipStream_t)stream, g, n, scratch);
+  hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(np), dim3(256), 0, (hipStream_t)stream, g, n, scratch, (const float*)nullptr,
+                     (float*)nullptr);
   B4R_CHECK_LAUNCH("b4r_global_sqnorm");
   hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, np, state);
   B4R_CHECK_LAUNCH("b4r_global_sqnorm final");
@@ -788,12 +795,13 @@ extern "C" int b4r_global_sqnorm(const float* g, int64_t n, float* scratch, b4r_
 // model-level optimizer step: global norm partials, then everything else in one launch.  scratch: >= 1024 floats.  The
 // ticket is reserved[0] of the state (zero-initialised by the caller like the rest of the state, reset by the kernel).
 int b4r_optimizer_fused(const b4r_adamw_config* hp, float* params, const float* grads, float* adam_m, float* adam_v, int64_t n,
-                        int64_t n_decay, float* scratch, b4r_train_state* state, hipStream_t stream) {
+                        int64_t n_decay, float* scratch, b4r_train_state* state, hipStream_t stream, int sums_from_tail) {
   int np = (int)((n / 4 + 1023) / 1024);
   if (np > 1024) np = 1024;
   if (np < 1) np = 1;
   unsigned int* ticket = reinterpret_cast<unsigned int*>(&state->reserved[0]);
-  hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(np), dim3(256), 0, stream, grads, n, scratch);
+  hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(np), dim3(256), 0, stream, grads, n, scratch,
+                     sums_from_tail ? grads + n : (const float*)nullptr, reinterpret_cast<float*>(state));
   B4R_CHECK_LAUNCH("global norm");
   AdamP a;
   a.p = params; a.g = grads; a.m = adam_m; a.v = adam_v; a.n = n; a.n_decay = n_decay; a.hp = *hp; a.st = state;

@@ -110,16 +110,28 @@ class Reddit(_PairFile):
 
 
 def make_synthetic(columns=("uid", "movie_name", "timestamp"), n_users: int = 200, n_items: int = 300,
-                   min_len: int = 5, max_len: int = 60, zipf_a: float = 1.2, seed: int = 0) -> pd.DataFrame:
-    """Zipf-popularity interaction log; column names follow the requested dataset flavour."""
+                   min_len: int = 5, max_len: int = 60, zipf_a: float = 1.2, seed: int = 0, order: float = 0.0) -> pd.DataFrame:
+    """Zipf-popularity interaction log; column names follow the requested dataset flavour.
+    order > 0 adds something a sequence model can learn: with that probability the next item is the fixed successor of the
+    previous one (a random permutation of the catalogue), else a popularity draw -- so NDCG of a trained model rises well above
+    the popularity baseline, which makes the number a check of the whole train + evaluate pipeline."""
     rng = np.random.default_rng(seed)
     p = 1.0 / np.arange(1, n_items + 1) ** zipf_a
     p /= p.sum()
+    succ = rng.permutation(n_items)
     rows = []
     t = 0
     for u in range(1, n_users + 1):
         n = int(rng.integers(min_len, max_len + 1))
-        seq = rng.choice(n_items, size=min(n, n_items), replace=False, p=p)
+        if order > 0:
+            draws = rng.choice(n_items, size=n, p=p)
+            follow = rng.random(n) < order
+            seq = np.empty(n, dtype=np.int64)
+            seq[0] = draws[0]
+            for j in range(1, n):
+                seq[j] = succ[seq[j - 1]] if follow[j] else draws[j]
+        else:
+            seq = rng.choice(n_items, size=min(n, n_items), replace=False, p=p)
         for it in seq:
             t += 1
             rows.append((u, f"item_{int(it):05d}", t))

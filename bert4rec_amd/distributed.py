@@ -8,13 +8,10 @@ of that gradient).  Backend: torch.distributed "nccl" = RCCL over xGMI on ROCm; 
 """
 from __future__ import annotations
 
-import os
 from typing import Optional
 
 import torch
 import torch.distributed as dist
-
-from . import _lib
 
 N_SUMS = 5  # loss_sum, valid_count, correct_masked, correct_all, slots_all: state words ST_LOSS_SUM .. ST_SLOTS_ALL
 TAIL = 8    # floats reserved behind the gradients (keeps the buffer a multiple of 4 floats)
@@ -25,26 +22,15 @@ def alloc_grad_buffer(n_params: int, device) -> torch.Tensor:
     return torch.zeros(n_params + TAIL, dtype=torch.float32, device=device)
 
 
-def pack_sums(grad_ext: torch.Tensor, state: torch.Tensor, n_params: int) -> None:
-    f = state.view(torch.float32)
-    grad_ext[n_params:n_params + N_SUMS].copy_(f[_lib.ST_LOSS_SUM:_lib.ST_LOSS_SUM + N_SUMS])
-
-
-def unpack_sums(grad_ext: torch.Tensor, state: torch.Tensor, n_params: int) -> None:
-    f = state.view(torch.float32)
-    f[_lib.ST_LOSS_SUM:_lib.ST_LOSS_SUM + N_SUMS].copy_(grad_ext[n_params:n_params + N_SUMS])
-
-
-def allreduce_step(grad_ext: torch.Tensor, state: torch.Tensor, n_params: int,
-                   group: Optional[dist.ProcessGroup] = None) -> None:
-    """Sum gradients and loss/metric sums over the data-parallel group (in place)."""
+def allreduce_step(grad_ext: torch.Tensor, group: Optional[dist.ProcessGroup] = None, single_rank_too: bool = False) -> None:
+    """Sum [gradients | per-step sums] over the data-parallel group, in place: one collective, nothing else.  The backward wrote
+    the sums into the tail (B4R_FLAG_GRAD_TAIL) and the optimizer step reads them back from there (b4r_optimizer_step_reduced).
+    single_rank_too: issue the collective even in a group of one (rehearsal of the RCCL path on a one-GPU box)."""
     if not (dist.is_available() and dist.is_initialized()):
         return
-    if dist.get_world_size(group) == 1 and os.environ.get("B4R_BENCH_FORCE_DIST") != "1":   # the override rehearses RCCL with one rank
+    if dist.get_world_size(group) == 1 and not single_rank_too:
         return
-    pack_sums(grad_ext, state, n_params)
     dist.all_reduce(grad_ext, op=dist.ReduceOp.SUM, group=group)
-    unpack_sums(grad_ext, state, n_params)
 
 
 def broadcast_parameters(params: torch.Tensor, src: int = 0, group: Optional[dist.ProcessGroup] = None) -> None:

@@ -137,6 +137,7 @@ class Engine:
         # b4r_train_state: 16 words (seed, step_lo, step(int64), 8 floats, 4 reserved)
         self.state = torch.zeros(_lib.STATE_WORDS, dtype=torch.int32, device=self.device)
         self._ws: Dict[Tuple[int, int, int], torch.Tensor] = {}
+        self.rehearse_collectives = False   # True: dp_train_step issues its all-reduce even in a process group of one
         self.set_seed(seed)
 
     # ---- parameters -----------------------------------------------------------------------------------------------
@@ -308,19 +309,22 @@ class Engine:
                                      (1 if want_grad else 0) | (_lib.LOSS_FUSED_HEAD if fused_head else 0),
                                      _stream(self.device)), "b4r_loss")
 
-    def backward(self, cb: Batch, training: bool = True, fused_head: bool = False) -> None:
+    def backward(self, cb: Batch, training: bool = True, fused_head: bool = False, grad_tail: bool = False) -> None:
+        """grad_tail: also write the step's sums behind the gradients (data-parallel steps all-reduce grad_ext as one buffer)"""
         self.ensure_training_buffers()
         ws = self.workspace(cb.B, cb.L, cb.P)
-        flags = (_lib.FLAG_TRAINING if training else 0) | (_lib.FLAG_FUSED_HEAD if fused_head else 0)
+        flags = (_lib.FLAG_TRAINING if training else 0) | (_lib.FLAG_FUSED_HEAD if fused_head else 0) | \
+                (_lib.FLAG_GRAD_TAIL if grad_tail else 0)
         _lib.check(self.lib.b4r_backward(C.byref(self.cfg), C.byref(cb), _ptr(self.params), _ptr(self.grads), _ptr(ws),
                                          ws.numel() * 4, _ptr(self.state), flags, _stream(self.device)), "b4r_backward")
 
-    def optimizer_step(self, hp: AdamWConfig, cb: Batch) -> None:
+    def optimizer_step(self, hp: AdamWConfig, cb: Batch, reduced: bool = False) -> None:
+        """reduced: the gradient buffer (with its tail of sums) went through the data-parallel all-reduce"""
         self.ensure_training_buffers()
         ws = self.workspace(cb.B, cb.L, cb.P)
-        _lib.check(self.lib.b4r_optimizer_step(C.byref(self.cfg), C.byref(hp), _ptr(self.params), _ptr(self.grads),
-                                               _ptr(self.adam_m), _ptr(self.adam_v), _ptr(ws), ws.numel() * 4,
-                                               _ptr(self.state), _stream(self.device)), "b4r_optimizer_step")
+        fn = self.lib.b4r_optimizer_step_reduced if reduced else self.lib.b4r_optimizer_step
+        _lib.check(fn(C.byref(self.cfg), C.byref(hp), _ptr(self.params), _ptr(self.grads), _ptr(self.adam_m), _ptr(self.adam_v),
+                      _ptr(ws), ws.numel() * 4, _ptr(self.state), _stream(self.device)), "b4r_optimizer_step")
 
     def train_step(self, hp: AdamWConfig, cb: Batch) -> None:
         """BERT4RecModel.train_step (bert4rec_model.py:151-173) as one enqueue; metrics stay on the device."""
@@ -379,12 +383,12 @@ class Engine:
                 self.begin_step()
                 self.forward(cb, training=True, pooler=False, fused_head=fused)
                 self.loss(cb, want_grad=True, fused_head=fused)
-                self.backward(cb, training=True, fused_head=fused)
+                self.backward(cb, training=True, fused_head=fused, grad_tail=True)
             with torch.cuda.graph(g_post, capture_error_mode=_CAPTURE_MODE):
-                self.optimizer_step(hp, cb)
+                self.optimizer_step(hp, cb, reduced=True)
             pair = graphs[key] = (g_pre, g_post)
         pair[0].replay()
-        allreduce_step(self.grad_ext, self.state, self.n_params, group)
+        allreduce_step(self.grad_ext, group, self.rehearse_collectives)
         pair[1].replay()
 
     def dp_train_step(self, hp: AdamWConfig, cb: Batch, group=None) -> None:
@@ -396,9 +400,9 @@ class Engine:
         self.begin_step()
         self.forward(cb, training=True, pooler=False, fused_head=fused)
         self.loss(cb, want_grad=True, fused_head=fused)
-        self.backward(cb, training=True, fused_head=fused)
-        allreduce_step(self.grad_ext, self.state, self.n_params, group)
-        self.optimizer_step(hp, cb)
+        self.backward(cb, training=True, fused_head=fused, grad_tail=True)
+        allreduce_step(self.grad_ext, group, self.rehearse_collectives)
+        self.optimizer_step(hp, cb, reduced=True)
 
     def mask_batch(self, tokens: torch.Tensor, max_predictions: int, selection_rate: float = 0.2,
                    mask_token_rate: float = 1.0, random_token_rate: float = 0.0, finetune: bool = False,

@@ -131,6 +131,11 @@ int b4r_workspace_region(const b4r_model_config* cfg, int32_t B, int32_t L, int3
  * d loss_sum / d transform in the workspace instead of "mlm_logits"; b4r_loss must then be called with
  * want_grad | B4R_LOSS_FUSED_HEAD and b4r_backward with the same flag.  b4r_train_step uses it whenever it is supported. */
 #define B4R_FLAG_FUSED_HEAD 4
+/* b4r_backward only: `grads` is followed by 8 more floats (a multiple of 16 bytes) that receive the step's sums
+ * [loss_sum, valid_count, correct_masked, correct_all, slots_all, 0, 0, 0] from the state, so that a data-parallel caller
+ * all-reduces ONE flat buffer [gradients | sums] and then calls b4r_optimizer_step_reduced, which takes the
+ * reduced sums from there.  No copy kernels around the collective. */
+#define B4R_FLAG_GRAD_TAIL 8
 #define B4R_LOSS_FUSED_HEAD 2
 #define B4R_LOSS_OVERWRITE 4 /* b4r_loss: set the state's sums instead of adding to them (= b4r_state_begin_step first) */
 int32_t b4r_fused_head_supported(const b4r_model_config* cfg);
@@ -144,6 +149,11 @@ int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch, const floa
 int b4r_optimizer_step(const b4r_model_config* cfg, const b4r_adamw_config* hp, float* params, const float* grads,
                        float* adam_m, float* adam_v, void* workspace, int64_t workspace_bytes,
                        b4r_train_state* state, b4r_stream_t stream);
+/* b4r_optimizer_step for a gradient buffer that went through the data-parallel all-reduce with its 8-float tail
+ * (B4R_FLAG_GRAD_TAIL): the reduced loss / count sums are moved from the tail into the state first */
+int b4r_optimizer_step_reduced(const b4r_model_config* cfg, const b4r_adamw_config* hp, float* params, const float* grads,
+                               float* adam_m, float* adam_v, void* workspace, int64_t workspace_bytes,
+                               b4r_train_state* state, b4r_stream_t stream);
 /* zero the per-step sums of the state (loss_sum .. grad_norm); call before b4r_loss */
 int b4r_state_begin_step(b4r_train_state* state, b4r_stream_t stream);
 /* BERT4RecModel.train_step, bert4rec_model.py:151-173 = begin_step + forward + loss + backward + optimizer_step */
@@ -423,6 +433,14 @@ int b4r_global_sqnorm(const float* g, int64_t n, float* scratch, b4r_train_state
  * state->{step, valid_count, grad_sqnorm}; writes state->{grad_norm, lr} and advances state->step. */
 int b4r_adamw_step(const b4r_adamw_config* hp, float* params, const float* grads, float* adam_m, float* adam_v,
                    int64_t n, int64_t n_decay, b4r_train_state* state, b4r_stream_t stream);
+
+/* ---- measurement aid (bench.py's roofline leg; not on any product path) -----------------------------------------------------
+ * Between b4r_timing_begin and b4r_timing_end every kernel launch the library enqueues from the calling thread is followed by a
+ * hipEvent on `stream`; b4r_timing_end waits for the last one and returns, per launch in enqueue order, the time since the previous
+ * event (= the kernel's duration plus its launch boundary, kernels of one stream run back to back) and a label ("b4r_gemm_f32
+ * (bf16x3) [M=51200 N=192 K=64 epi=2]").  names: capacity strings of name_stride bytes.  Not for use inside a graph capture. */
+int b4r_timing_begin(b4r_stream_t stream, int32_t max_launches);
+int b4r_timing_end(int32_t* n_launches, float* micros, char* names, int32_t name_stride, int32_t capacity);
 
 #ifdef __cplusplus
 }

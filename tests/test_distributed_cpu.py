@@ -51,10 +51,13 @@ def _worker(rank, world, port, ret):
     for n, g in grads.items():
         v = eng.view(n, eng.grads)
         v.copy_(g.reshape(v.shape))
+    # what b4r_backward(B4R_FLAG_GRAD_TAIL) leaves behind the gradients: [loss_sum, valid_count, correct_masked, correct_all,
+    # slots_all, 0, 0, 0]; what b4r_optimizer_step_reduced reads back after the ONE collective
+    tail = eng.grad_ext[eng.n_params:]
+    tail[:5] = torch.tensor([loss_sum, count, 1.0 + rank, 2.0, float(local["masked_lm_ids"].numel())])
+    allreduce_step(eng.grad_ext)
     f = eng.state.view(torch.float32)
-    f[_lib.ST_LOSS_SUM], f[_lib.ST_VALID] = loss_sum, count
-    f[_lib.ST_CORRECT_MASKED], f[_lib.ST_CORRECT_ALL], f[_lib.ST_SLOTS_ALL] = 1.0 + rank, 2.0, float(local["masked_lm_ids"].numel())
-    allreduce_step(eng.grad_ext, eng.state, eng.n_params)
+    f[_lib.ST_LOSS_SUM:_lib.ST_LOSS_SUM + 5] = tail[:5]
     if rank == 0:
         ret["state"] = eng.state.view(torch.float32).clone()
         ret["grads"] = {n: eng.view(n, eng.grads).clone() for n in grads}

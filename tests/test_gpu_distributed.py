@@ -92,8 +92,9 @@ def test_bench_runs_its_rccl_path_with_one_rank(graph):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, B4R_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "3", "--cpu-steps", "0"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "3", "--cpu-steps", "0", "--no-eval",
+           "--force-dist"]
     if graph:
         cmd.append("--graph")
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)

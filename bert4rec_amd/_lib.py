@@ -64,6 +64,17 @@ class AttnBlockDesc(C.Structure):
                 ("x1", C.c_void_p), ("mean1", C.c_void_p), ("rstd1", C.c_void_p)]
 
 
+class AttnBlockBwdDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("heads", C.c_int32), ("x", C.c_void_p), ("dz1", C.c_void_p),
+                ("ctx", C.c_void_p), ("lse", C.c_void_p), ("keep_bits", C.c_void_p), ("input_mask", C.c_void_p),
+                ("Wqkv", C.c_void_p), ("bqkv", C.c_void_p), ("Wo", C.c_void_p), ("rng", C.c_void_p), ("probs_stream", C.c_uint32),
+                ("probs_rate", C.c_float), ("out_stream", C.c_uint32), ("out_rate", C.c_float), ("prev_z", C.c_void_p),
+                ("prev_mean", C.c_void_p), ("prev_rstd", C.c_void_p), ("prev_gamma", C.c_void_p), ("emb_ids", C.c_void_p),
+                ("emb_table", C.c_void_p), ("emb_pos", C.c_void_p), ("emb_vocab", C.c_int32), ("emb_stream", C.c_uint32),
+                ("emb_rate", C.c_float), ("dqkv", C.c_void_p), ("dx_prev", C.c_void_p), ("dprev_gamma", C.c_void_p),
+                ("scratch", C.c_void_p)]
+
+
 class FfnDesc(C.Structure):
     _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("I", C.c_int32), ("x1", C.c_void_p), ("W1", C.c_void_p), ("b1", C.c_void_p),
                 ("W2", C.c_void_p), ("b2", C.c_void_p), ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float),
@@ -129,6 +140,9 @@ PROTOTYPES = {
     "b4r_attn_keep_words": (C.c_int64, [_I32, _I32, _I32]),
     "b4r_attn_block_supported": (_I32, [_I32, _I32, _I32]),
     "b4r_attn_block_fwd": (C.c_int, [C.POINTER(AttnBlockDesc), _P]),
+    "b4r_attn_block_bwd_supported": (_I32, [_I32, _I32, _I32]),
+    "b4r_attn_block_bwd_scratch_floats": (_I64, [_I32]),
+    "b4r_attn_block_bwd": (C.c_int, [C.POINTER(AttnBlockBwdDesc), _P]),
     "b4r_ffn_block_supported": (_I32, [_I32, _I32]),
     "b4r_ffn_block_bwd_scratch_floats": (_I64, [_I32]),
     "b4r_ffn_block_fwd": (C.c_int, [C.POINTER(FfnDesc), _P]),

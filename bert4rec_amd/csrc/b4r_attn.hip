@@ -90,6 +90,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_fwd_kernel(AttnP p) {
   const int b = blockIdx.z, hd = blockIdx.y, q0 = blockIdx.x * ROWS_WG;
   const int L = p.L, H = p.H, ld3 = 3 * H;
   const int64_t row0 = (int64_t)b * L;
+  const float amax = b4r_seq_amax(p.mask + row0, L);   // all threads, before any early exit
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
 
   load_head_rows(sK, p.qkv + hd * 32, row0 + q0, ld3, ROWS_WG, L - q0);   // Q tile in the K region
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_fwd_kernel(AttnP p) {
   sum += __shfl_xor(sum, 16, 64);
   sum += __shfl_xor(sum, 32, 64);
   const float inv = 1.0f / sum;
-  if (g == 0 && q < L && p.lse_out) p.lse_out[((int64_t)b * p.heads + hd) * L + q] = m + __logf(sum);
+  if (g == 0 && q < L && p.lse_out) p.lse_out[((int64_t)b * p.heads + hd) * L + q] = (m - amax) + __logf(sum);
 
   DropCtx dctx = b4r_drop_ctx(p.drop);
   const uint64_t dbase = (((uint64_t)b * p.heads + hd) * L + (uint64_t)(q < L ? q : 0)) * (uint64_t)B4R_ATTN_PITCH;
@@ -171,6 +172,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_dq_kernel(AttnP p) {
   const int b = blockIdx.z, hd = blockIdx.y, q0 = blockIdx.x * ROWS_WG;
   const int L = p.L, H = p.H, ld3 = 3 * H;
   const int64_t row0 = (int64_t)b * L;
+  const float amax = b4r_seq_amax(p.mask + row0, L);   // all threads, before any early exit
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
 
   load_head_rows(sK, p.qkv + hd * 32, row0 + q0, ld3, ROWS_WG, L - q0);   // Q tile
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_dq_kernel(AttnP p) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int key = 16 * t + 4 * g + s;
-      const float pr = __expf(sc[s] + ad[s] - lse);
+      const float pr = __expf(((sc[s] + ad[s]) - amax) - lse);
       float dA = da[s];
       if (dctx.on) dA = ((k4 >> s) & 1u) ? dA * dctx.scale : 0.f;
       const float ds = pr * (dA - Dq);
@@ -241,6 +243,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_dkv_kernel(AttnP p) {
   const int b = blockIdx.z, hd = blockIdx.y;
   const int L = p.L, H = p.H, ld3 = 3 * H;
   const int64_t row0 = (int64_t)b * L;
+  const float amax = b4r_seq_amax(p.mask + row0, L);   // all threads, before any early exit
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
 
   load_head_rows(sQ, p.qkv + hd * 32, row0, ld3, Lp, L);
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_dkv_kernel(AttnP p) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int qq = 16 * t + 4 * g + s;
-      const float pr = __expf(sc[s] + add - ls[s]);
+      const float pr = __expf(((sc[s] + add) - amax) - ls[s]);
       float ad = pr, dA = da[s];
       if (dctx.on) {
         const bool keep = b4r_keep(dctx, (hbase + (uint64_t)(qq < L ? qq : 0)) * (uint64_t)B4R_ATTN_PITCH + (uint64_t)(klive ? key : 0));

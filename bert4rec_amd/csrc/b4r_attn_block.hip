@@ -89,6 +89,7 @@ __global__ __launch_bounds__(1024) void attn_block_fwd_kernel(AbP p) {
 
   // ---- phase 0: weights and the key mask ------------------------------------------------------------------------------
   const int tok = 16 * wave + i, tokc = min(tok, L - 1);
+  const float amax = b4r_seq_amax(p.mask + row0, L);
   f32x8 xv[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) xv[ks] = load8(p.x + (row0 + tokc) * HID + 32 * ks + 8 * g);   // in flight during the staging
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(1024) void attn_block_fwd_kernel(AbP p) {
     const float sum = quad_sum(sum4(sum4v));
     const float inv = 1.0f / sum;
     const int64_t bh = (int64_t)b * 2 + hd;
-    if (g == 0 && live && p.lse) p.lse[bh * L + tok] = m + __logf(sum);
+    if (g == 0 && live && p.lse) p.lse[bh * L + tok] = (m - amax) + __logf(sum);
     if (dcp.on) {
       const uint64_t dbase = ((uint64_t)bh * L + (uint64_t)(live ? tok : 0)) * (uint64_t)B4R_ATTN_PITCH;
       uint32_t w[2] = {0u, 0u};
@@ -296,6 +297,336 @@ __global__ __launch_bounds__(1024) void attn_block_fwd_kernel(AbP p) {
   }
 }
 
+// -----------------------------------------------------------------------------------------------------------
+// backward.  One workgroup per sequence, wave w owns token tile w as queries AND as keys; every 16 x 16 block of the score
+// matrix is formed ONCE (round 1 formed it twice: in the dQ kernel by its query rows, in the dK/dV kernel by its key rows,
+// with all of the exp / dropout / hi-lo split work around it):
+//   step s, wave w:  key tile t = (w + s) mod KT
+//     S^T = K_t.Q_w^T, dA^T = V_t.dO_w^T (K = 32 features)        -> pr, dropped pr, dS in registers (keys on rows, queries on lanes)
+//     dQ_w^T += K_t^T.dS^T        (sums over the block's 16 keys: the accumulator tile is the B operand, v_mfma_f32_16x16x16_bf16)
+//     dK_t^T += Q_w^T.dS, dV_t^T += dO_w^T.Pd   (sum over the block's 16 queries: dS / Pd transposed through a wave-private LDS
+//                                tile, 8-byte writes + ds_read_b64_tr_b16), added into fp32 accumulators of key tile t in LDS
+//   In one step every wave works on a different key tile, a barrier separates the steps: the accumulation order of a key
+//   tile is fixed (waves t, t-1, t-2, ...), so dK / dV are bitwise reproducible without atomics.
+// Per head: q, k, v are RECOMPUTED from x (the forward does not have to store qkv: 39 MB per layer), dctx = dropmask(dz1).Wo^T is
+// formed in registers, K / V rows go to the attention images; the Q / dO rows of a wave are only ever read by that wave (as
+// transposed A operands), their image space becomes the dK / dV accumulators.  After both heads:
+//   dX^T = Wqkv.dqkv^T + dz1^T, then the backward of the LayerNorm that produced x (the previous layer's output LayerNorm, or
+//   for layer 0 the embedding stage: dropout, then LayerNorm of table[id] + position) -> `da`, gamma / beta partial sums.
+// dqkv [N, 3H] is written for the weight-gradient product dWqkv = x^T.dqkv (b4r_gemm_tn_f32), the only consumer left.
+// LDS: [tile][K hi, K lo, V hi, V lo | Q hi, Q lo, dO hi, dO lo -> dK^T, dV^T accumulators] 8 KB per 16 tokens (the weight
+// images overlay it between the heads), 2 KB of transposition scratch per wave, the key mask, biases.
+// -----------------------------------------------------------------------------------------------------------
+struct AbBwdP {
+  const float* x; const float* dz1; const float* ctx; const float* lse; const uint32_t* bits; const int64_t* mask;
+  const float* Wqkv; const float* bqkv; const float* Wo;
+  const float* zprev; const float* meanp; const float* rstdp; const float* gprev;     // the LayerNorm that produced x
+  const int64_t* ids; const float* table; const float* pos; int V;                    // ... or the embedding stage (ids != NULL)
+  float* dqkv; float* da; float* ln_part;
+  int B, L, KT;
+  float qscale;
+  DropArgs drop_p, drop_o, drop_e;
+};
+
+constexpr int BT = 8 * 1024;   // bytes of one token tile of the backward's LDS region
+constexpr int BX = 4 * IMG_BYTES;   // offset of the Q / dO images (later the accumulators) inside a tile
+
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma16(const bf16x4 a, const bf16x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, a), __builtin_bit_cast(s16x4_t, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16x3(const bf16x4 ah, const bf16x4 al, const bf16x4 bh, const bf16x4 bl, f32x4 c) {
+  c = mfma16(al, bh, c);
+  c = mfma16(ah, bl, c);
+  c = mfma16(ah, bh, c);
+  return c;
+}
+__device__ __forceinline__ bf16x4 tr_one(const char* a) {
+  return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)a));
+}
+__device__ __forceinline__ bf16x8 row16(const char* a) { return *reinterpret_cast<const bf16x8*>(a); }
+
+template <bool EMBED>
+__global__ __launch_bounds__(1024) void attn_block_bwd_kernel(AbBwdP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_ab[];
+  const int KT = p.KT, L = p.L;
+  const int rbytes = KT * BT > 64 * 1024 ? KT * BT : 64 * 1024;
+  char* R = smem_ab;                                   // tiles; between the heads: [Wqkv image 48 KB | Wo image 16 KB]
+  char* scratch_all = smem_ab + rbytes;                // 2 KB per wave
+  float* sAdd = reinterpret_cast<float*>(scratch_all + KT * 2048);   // [KT * 16]
+  float* sbq = sAdd + KT * 16;                         // bqkv [192]
+  float* sred = sbq + 3 * HID;                         // [KT][128] LayerNorm partials (end of the kernel)
+
+  const int nthreads = blockDim.x;
+  const int b = blockIdx.x;
+  const int64_t row0 = (int64_t)b * L;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4, qq = i >> 2, pp = i & 3;
+  const int tok = 16 * wave + i, tokc = min(tok, L - 1);
+  const bool live = tok < L;
+  char* scratch = scratch_all + wave * 2048;
+  char* woimg = R + 48 * 1024;
+  const float amax = b4r_seq_amax(p.mask + row0, L);
+
+  for (int k = threadIdx.x; k < KT * 16; k += nthreads) sAdd[k] = k < L ? (1.0f - (float)p.mask[row0 + k]) * -1e9f : -INFINITY;
+  for (int k = threadIdx.x; k < 3 * HID; k += nthreads) sbq[k] = p.bqkv[k];
+
+  // lane constants.  tr_w: transposed fragment whose 16 columns are the interleaved features 8p' + 4a + e (b4r_ffn_rx.hip);
+  // rows = a natural 32-deep k block (weights) or one 16-row tile (images)
+  const int trw_w[2][2] = {{sub_off(8 * (g & 1) + qq, pp), sub_off(8 * (g & 1) + 4 + qq, pp)},
+                           {sub_off(8 * (g & 1) + qq, pp) + 8, sub_off(8 * (g & 1) + 4 + qq, pp) + 8}};
+  const int trw_t[2] = {sub_off(4 * g + qq, pp), sub_off(4 * g + qq, pp) + 8};   // rows 4g .. 4g+3 of a tile, features 8p'+4a+e
+  const int row_i = sub_off(i, g);                                               // row i, columns 8g .. 8g+7
+  const DropCtx dcp = b4r_drop_ctx(p.drop_p);
+  const float pscale = dcp.on ? dcp.scale : 1.0f;
+
+  f32x4 dxacc[4];
+#pragma unroll
+  for (int hb = 0; hb < 4; ++hb) dxacc[hb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 gq[2], gk[2], gv[2];   // dq (scaled), dk, dv of the head just finished: own tokens, interleaved feature tiles
+
+  for (int hd = 0; hd <= 2; ++hd) {
+    __syncthreads();   // the tile region is free (previous head done; first pass: sAdd / sbq written)
+    stage_weight(R, p.Wqkv, HID, 3 * HID, nthreads);
+    if (hd < 2) stage_weight(woimg, p.Wo, HID, HID, nthreads);
+    __syncthreads();
+    if (hd > 0) {
+      // dX^T[16 hb + ..][token] += Wqkv[.., features of head hd-1] . dqkv^T: A = rows of the Wqkv image (natural k order)
+      const int ph = hd - 1;
+      bf16x8 bh_[3], bl_[3];
+      split8(cat(gq[0], gq[1]), bh_[0], bl_[0]);
+      split8(cat(gk[0], gk[1]), bh_[1], bl_[1]);
+      split8(cat(gv[0], gv[1]), bh_[2], bl_[2]);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int fb = 2 * j + ph;
+#pragma unroll
+        for (int hb = 0; hb < 4; ++hb) {
+          const char* s0 = R + sub_base(hb, fb, 6) + row_i;
+          dxacc[hb] = mfma3(row16(s0), row16(s0 + SUB), bh_[j], bl_[j], dxacc[hb]);
+        }
+      }
+    }
+    if (hd == 2) break;
+
+    // ---- q, k, v of this head for the wave's tokens (recomputed) and dctx = dropmask(dz1).Wo^T -------------------------
+    f32x4 qt[2], kt[2], vt[2], dct[2];
+    {
+      bf16x8 xh[2], xl[2], yh[2], yl[2];
+      const DropCtx dco = b4r_drop_ctx(p.drop_o);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        split8(load8(p.x + (row0 + tokc) * HID + 32 * ks + 8 * g), xh[ks], xl[ks]);
+        f32x8 dy = load8(p.dz1 + (row0 + tokc) * HID + 32 * ks + 8 * g);
+        if (dco.on) {
+          const uint64_t e0 = (uint64_t)(row0 + tok) * HID + (uint64_t)(32 * ks + 8 * g);
+          dy = cat(b4r_drop4(dco, lo4(dy), e0), b4r_drop4(dco, hi4(dy), e0 + 4));
+        }
+        split8(dy, yh[ks], yl[ks]);
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int fb = 2 * j + hd;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          f32x4 c = *reinterpret_cast<const f32x4*>(&sbq[32 * fb + 8 * g + 4 * a]);
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            const char* t = R + sub_base(2 * ks + (g >> 1), fb, 6);
+            c = mfma3(tr_pair(t + trw_w[a][0], t + trw_w[a][1]), tr_pair(t + SUB + trw_w[a][0], t + SUB + trw_w[a][1]), xh[ks], xl[ks], c);
+          }
+          if (j == 0) qt[a] = c * p.qscale; else if (j == 1) kt[a] = c; else vt[a] = c;
+        }
+      }
+      // dctx^T tile a: rows 4p + e = context columns 32 hd + 8p + 4a + e  =  rows of the Wo image (natural k = output column)
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int wrow = 32 * hd + 8 * qq + 4 * a + pp;
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const char* s0 = woimg + sub_base(wrow >> 4, ks, 2) + sub_off(wrow & 15, g);
+          c = mfma3(row16(s0), row16(s0 + SUB), yh[ks], yl[ks], c);
+        }
+        dct[a] = c;
+      }
+    }
+    // D = sum_c dctx * ctx over this head's 32 columns (the softmax backward's row term)
+    float Dq;
+    {
+      const float* cr = p.ctx + (row0 + tokc) * HID + 32 * hd + 8 * g;
+      const f32x4 c0 = *reinterpret_cast<const f32x4*>(cr), c1 = *reinterpret_cast<const f32x4*>(cr + 4);
+      Dq = quad_sum(sum4(dct[0] * c0) + sum4(dct[1] * c1));
+    }
+    const int64_t bh = (int64_t)b * 2 + hd;
+    const float lse_q = live ? p.lse[bh * L + tok] : INFINITY;   // +inf: probability 0 for pad queries
+    uint32_t wbits[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+    if (dcp.on) {
+      const uint32_t* wi = p.bits + ((bh * KT + wave) * 2) * 64 + lane;
+      wbits[0] = wi[0];
+      wbits[1] = wi[64];
+    }
+    __syncthreads();   // every wave is done with the weight images
+
+    // ---- own rows of the K, V, Q, dO images ------------------------------------------------------------------------------
+    char* mytile = R + wave * BT;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      bf16x4 h, l;
+      char* dst = mytile + sub_off(i, g) + 8 * a;
+      b4r_split4(kt[a], h, l);
+      *reinterpret_cast<bf16x4*>(dst) = h; *reinterpret_cast<bf16x4*>(dst + IMG_BYTES) = l;
+      b4r_split4(vt[a], h, l);
+      *reinterpret_cast<bf16x4*>(dst + 2 * IMG_BYTES) = h; *reinterpret_cast<bf16x4*>(dst + 3 * IMG_BYTES) = l;
+      b4r_split4(qt[a], h, l);
+      *reinterpret_cast<bf16x4*>(dst + BX) = h; *reinterpret_cast<bf16x4*>(dst + BX + IMG_BYTES) = l;
+      b4r_split4(dct[a], h, l);
+      *reinterpret_cast<bf16x4*>(dst + BX + 2 * IMG_BYTES) = h; *reinterpret_cast<bf16x4*>(dst + BX + 3 * IMG_BYTES) = l;
+    }
+    // the wave reads back only what it wrote itself: LDS operations of one wave are ordered
+    bf16x8 qh, ql, doh, dol;       // B operands of S^T = K.Q^T and dA^T = V.dO^T (k = feature, natural order)
+    bf16x4 qT[2][2], dT[2][2];     // [a][hi, lo]: Q^T / dO^T as A operands (row = feature 8p+4a+e, k = query 4g+j)
+    split8(cat(qt[0], qt[1]), qh, ql);
+    split8(cat(dct[0], dct[1]), doh, dol);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      qT[a][0] = tr_one(mytile + BX + trw_t[a]);
+      qT[a][1] = tr_one(mytile + BX + IMG_BYTES + trw_t[a]);
+      dT[a][0] = tr_one(mytile + BX + 2 * IMG_BYTES + trw_t[a]);
+      dT[a][1] = tr_one(mytile + BX + 3 * IMG_BYTES + trw_t[a]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the transposed reads have landed before the space is zeroed
+    __builtin_amdgcn_sched_barrier(0);
+    // the Q / dO space of this wave's tile becomes its dK^T / dV^T accumulators: [dk a0 | dk a1 | dv a0 | dv a1], 1 KB each
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(mytile + BX + j * 1024 + lane * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();   // K / V rows of every tile are in place, every accumulator is zero
+
+    // ---- the sweep: one 16 x 16 block of the score matrix per step ------------------------------------------------------------
+    f32x4 dq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (int s = 0; s < KT; ++s) {
+      int t = wave + s;
+      if (t >= KT) t -= KT;
+      const char* tile = R + t * BT;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 sc = mfma3(row16(tile + row_i), row16(tile + IMG_BYTES + row_i), qh, ql, z);                       // S^T
+      const f32x4 dA = mfma3(row16(tile + 2 * IMG_BYTES + row_i), row16(tile + 3 * IMG_BYTES + row_i), doh, dol, z);   // dA^T
+      const f32x4 ad = *reinterpret_cast<const f32x4*>(&sAdd[16 * t + 4 * g]);
+      const uint32_t nib = wbits[(t >> 3) & 1] >> (4 * (t & 7));
+      f32x4 ds, pd;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pr = __expf(((sc[r] + ad[r]) - amax) - lse_q);
+        const bool keep = (nib >> r) & 1u;
+        pd[r] = keep ? pr * pscale : 0.f;
+        const float da_ = keep ? dA[r] * pscale : 0.f;
+        ds[r] = pr * (da_ - Dq);
+      }
+      bf16x4 dsh, dsl, pdh, pdl;
+      b4r_split4(ds, dsh, dsl);
+      b4r_split4(pd, pdh, pdl);
+      // dQ^T[feature][query] += K_t^T[feature][keys] . dS^T[keys][query]
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+        dq[a] = mfma16x3(tr_one(tile + trw_t[a]), tr_one(tile + IMG_BYTES + trw_t[a]), dsh, dsl, dq[a]);
+      // transpose dS^T, Pd^T (keys on rows, queries on lanes) -> [query][key] tiles, read back with queries on the k slots
+      {
+        char* w = scratch + i * 32 + g * 8;
+        *reinterpret_cast<bf16x4*>(w) = dsh; *reinterpret_cast<bf16x4*>(w + 512) = dsl;
+        *reinterpret_cast<bf16x4*>(w + 1024) = pdh; *reinterpret_cast<bf16x4*>(w + 1536) = pdl;
+      }
+      const char* rd = scratch + (4 * g + qq) * 32 + pp * 8;
+      const bf16x4 dsTh = tr_one(rd), dsTl = tr_one(rd + 512), pdTh = tr_one(rd + 1024), pdTl = tr_one(rd + 1536);
+      // dK_t^T[feature][key] += Q_w^T[feature][queries] . dS[queries][key] ;  dV_t^T += dO_w^T . Pd
+      char* acc = R + t * BT + BX + lane * 16;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const f32x4 dkp = mfma16x3(qT[a][0], qT[a][1], dsTh, dsTl, z);
+        const f32x4 dvp = mfma16x3(dT[a][0], dT[a][1], pdTh, pdTl, z);
+        f32x4* ak = reinterpret_cast<f32x4*>(acc + a * 1024);
+        f32x4* av = reinterpret_cast<f32x4*>(acc + (2 + a) * 1024);
+        *ak = *ak + dkp;
+        *av = *av + dvp;
+      }
+      __syncthreads();   // the next step adds into other tiles; fixed order of the additions into each tile
+    }
+    // results of this head for the wave's tokens
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      gq[a] = dq[a] * p.qscale;
+      gk[a] = *reinterpret_cast<const f32x4*>(mytile + BX + a * 1024 + lane * 16);
+      gv[a] = *reinterpret_cast<const f32x4*>(mytile + BX + (2 + a) * 1024 + lane * 16);
+    }
+    if (live) {
+      float* dst = p.dqkv + (row0 + tok) * (3 * HID) + 32 * hd + 8 * g;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        *reinterpret_cast<f32x4*>(dst + 4 * a) = gq[a];
+        *reinterpret_cast<f32x4*>(dst + HID + 4 * a) = gk[a];
+        *reinterpret_cast<f32x4*>(dst + 2 * HID + 4 * a) = gv[a];
+      }
+    }
+  }
+
+  // ---- dx = dX + dz1 (residual), then back through the LayerNorm (and, for layer 0, the dropout) that produced x -------------
+  const DropCtx dce = b4r_drop_ctx(p.drop_e);
+  const float mean = p.meanp[row0 + tokc], rstd = p.rstdp[row0 + tokc];
+  f32x4 ge[4], xhat[4], dgam[4], dbet[4];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int hb = 0; hb < 4; ++hb) {
+    const int col = 16 * hb + 4 * g;
+    f32x4 dx = dxacc[hb] + *reinterpret_cast<const f32x4*>(p.dz1 + (row0 + tokc) * HID + col);
+    f32x4 zz;
+    if (EMBED) {
+      dx = b4r_drop4(dce, dx, (uint64_t)(row0 + tok) * HID + (uint64_t)col);
+      int64_t id = p.ids[row0 + tokc];
+      if (id < 0 || id >= p.V) id = 0;   // as the forward: out-of-range ids read the PAD row
+      zz = *reinterpret_cast<const f32x4*>(p.table + id * HID + col) + *reinterpret_cast<const f32x4*>(p.pos + (int64_t)tokc * HID + col);
+    } else {
+      zz = *reinterpret_cast<const f32x4*>(p.zprev + (row0 + tokc) * HID + col);
+    }
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gprev + col);
+    xhat[hb] = (zz - mean) * rstd;
+    ge[hb] = dx * gm;
+    s1 += sum4(ge[hb]);
+    s2 += sum4(ge[hb] * xhat[hb]);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    dgam[hb] = live ? dx * xhat[hb] : zero;
+    dbet[hb] = live ? dx : zero;
+  }
+  const float c1 = quad_sum(s1) * (1.0f / HID), c2 = quad_sum(s2) * (1.0f / HID);
+  if (live) {
+#pragma unroll
+    for (int hb = 0; hb < 4; ++hb) {
+      f32x4 dz;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dz[e] = rstd * (ge[hb][e] - c1 - xhat[hb][e] * c2);
+      *reinterpret_cast<f32x4*>(p.da + (row0 + tok) * HID + 16 * hb + 4 * g) = dz;
+    }
+  }
+#pragma unroll
+  for (int hb = 0; hb < 4; ++hb) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a = dgam[hb][e], bb = dbet[hb][e];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); bb += __shfl_xor(bb, o, 64); }
+      if (i == 0) { sred[wave * 128 + 16 * hb + 4 * g + e] = a; sred[wave * 128 + 64 + 16 * hb + 4 * g + e] = bb; }
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < 128; k += nthreads) {   // a workgroup may be a single wave (L <= 16)
+    float r = 0.f;
+    for (int w = 0; w < KT; ++w) r += sred[w * 128 + k];
+    p.ln_part[(int64_t)b * 128 + k] = r;
+  }
+}
+
+size_t bwd_lds(int KT) {
+  const size_t r = (size_t)KT * BT > 64 * 1024 ? (size_t)KT * BT : 64 * 1024;
+  return r + (size_t)KT * 2048 + ((size_t)KT * 16 + 3 * HID + (size_t)KT * 128) * sizeof(float);
+}
+
 template <int KTT>
 size_t fwd_lds() {
   constexpr int KTE = (KTT + 1) & ~1;
@@ -310,6 +641,58 @@ bool al16(const void* q) { return q == nullptr || b4r_aligned16(q); }
 
 extern "C" int32_t b4r_attn_block_supported(int32_t hidden_size, int32_t num_heads, int32_t L) {
   return (hidden_size == HID && num_heads == 2 && L > 0 && L <= 256 && b4r_get_gemm_mode() == B4R_GEMM_BF16X3) ? 1 : 0;
+}
+
+extern "C" int32_t b4r_attn_block_bwd_supported(int32_t hidden_size, int32_t num_heads, int32_t L) {
+  return (b4r_attn_block_supported(hidden_size, num_heads, L) && L <= 208) ? 1 : 0;   // 10 KB of LDS per 16 tokens
+}
+extern "C" int64_t b4r_attn_block_bwd_scratch_floats(int32_t B) { return (int64_t)(B > 0 ? B : 0) * 128; }
+
+int b4r_launch_slab_reduce_full(const float* slab, int S, int Mo, int No, float* out, int ldo, int accumulate,
+                                const float* cslab, float* colsum, const float* caslab, float* colsum_a, hipStream_t stream);
+
+extern "C" int b4r_attn_block_bwd(const b4r_attn_block_bwd_desc* d, b4r_stream_t stream) {
+  B4R_CHECK_ARG(d != nullptr, B4R_E_BADARG, "b4r_attn_block_bwd: null descriptor");
+  B4R_CHECK_ARG(b4r_attn_block_bwd_supported(d->H, d->heads, d->L), B4R_E_SHAPE,
+                "b4r_attn_block_bwd: needs hidden size 64, 2 heads, L <= 208 and the bf16x3 mode (H=%d heads=%d L=%d)", d->H, d->heads,
+                d->L);
+  B4R_CHECK_ARG(d->B > 0 && d->x && d->dz1 && d->ctx && d->lse && d->input_mask && d->Wqkv && d->bqkv && d->Wo && d->prev_mean &&
+                    d->prev_rstd && d->prev_gamma && d->dqkv && d->dx_prev && d->dprev_gamma && d->scratch,
+                B4R_E_BADARG, "b4r_attn_block_bwd: null argument");
+  const bool embed = d->emb_ids != nullptr;
+  B4R_CHECK_ARG(embed ? (d->emb_table && d->emb_pos && d->emb_vocab > 0) : (d->prev_z != nullptr), B4R_E_BADARG,
+                "b4r_attn_block_bwd: needs prev_z, or emb_ids + emb_table + emb_pos");
+  B4R_CHECK_ARG(al16(d->x) && al16(d->dz1) && al16(d->ctx) && al16(d->Wqkv) && al16(d->Wo) && al16(d->prev_z) && al16(d->prev_gamma) &&
+                    al16(d->emb_table) && al16(d->emb_pos) && al16(d->dqkv) && al16(d->dx_prev) && al16(d->keep_bits),
+                B4R_E_ALIGN, "b4r_attn_block_bwd: operands must be 16-byte aligned");
+  AbBwdP p{};
+  p.x = d->x; p.dz1 = d->dz1; p.ctx = d->ctx; p.lse = d->lse; p.bits = d->keep_bits; p.mask = d->input_mask;
+  p.Wqkv = d->Wqkv; p.bqkv = d->bqkv; p.Wo = d->Wo;
+  p.zprev = d->prev_z; p.meanp = d->prev_mean; p.rstdp = d->prev_rstd; p.gprev = d->prev_gamma;
+  p.ids = d->emb_ids; p.table = d->emb_table; p.pos = d->emb_pos; p.V = d->emb_vocab;
+  p.dqkv = d->dqkv; p.da = d->dx_prev; p.ln_part = d->scratch;
+  p.B = d->B; p.L = d->L; p.KT = b4r_cdiv(d->L, 16);
+  p.qscale = 1.0f / sqrtf(32.0f);
+  p.drop_p = b4r_make_drop(d->rng, d->probs_stream, d->probs_rate, d->rng != nullptr);
+  p.drop_o = b4r_make_drop(d->rng, d->out_stream, d->out_rate, d->rng != nullptr);
+  p.drop_e = b4r_make_drop(d->rng, d->emb_stream, d->emb_rate, d->rng != nullptr && embed);
+  B4R_CHECK_ARG(!p.drop_p.rng || d->keep_bits, B4R_E_BADARG, "b4r_attn_block_bwd: attention dropout needs the forward's keep_bits");
+  const size_t sh = bwd_lds(p.KT);
+  const dim3 grid((unsigned)d->B), block((unsigned)(64 * p.KT));
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if (embed) {
+    rc = b4r_raise_lds((const void*)attn_block_bwd_kernel<true>, sh, "b4r_attn_block_bwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL((attn_block_bwd_kernel<true>), grid, block, sh, s, p);
+  } else {
+    rc = b4r_raise_lds((const void*)attn_block_bwd_kernel<false>, sh, "b4r_attn_block_bwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL((attn_block_bwd_kernel<false>), grid, block, sh, s, p);
+  }
+  B4R_CHECK_LAUNCH("b4r_attn_block_bwd");
+  // gamma / beta gradients of the previous LayerNorm: ordered sum over the sequences (queued with the caller's reductions)
+  return b4r_launch_slab_reduce_full(d->scratch, d->B, 1, 128, d->dprev_gamma, 128, 0, nullptr, nullptr, nullptr, nullptr, s);
 }
 
 extern "C" int b4r_attn_block_fwd(const b4r_attn_block_desc* d, b4r_stream_t stream) {

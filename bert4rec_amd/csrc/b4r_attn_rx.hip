@@ -85,6 +85,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_rx_fwd_kernel(AttnRxP p) {
   const int L = p.L, H = p.H, ld3 = 3 * H;
   const int64_t row0 = (int64_t)b * L;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+  const float amax = b4r_seq_amax(p.mask + row0, L);
 
   const int q = q0 + 16 * wave + i;
   const f32x8 qx = load8(p.qkv + (row0 + min(q, L - 1)) * ld3 + hd * 32 + 8 * g);   // in flight while K / V are staged
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_rx_fwd_kernel(AttnRxP p) {
   sum += __shfl_xor(sum, 32, 64);
   const float inv = 1.0f / sum;
   const int64_t bh = (int64_t)b * p.heads + hd;
-  if (g == 0 && q < L && p.lse_out) p.lse_out[bh * L + q] = m + __logf(sum);
+  if (g == 0 && q < L && p.lse_out) p.lse_out[bh * L + q] = (m - amax) + __logf(sum);
 
   const DropCtx dctx = b4r_drop_ctx(p.drop);
   if (dctx.on) {
@@ -189,6 +190,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_rx_dq_kernel(AttnRxP p) {
   const int L = p.L, H = p.H, ld3 = 3 * H;
   const int64_t row0 = (int64_t)b * L;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+  const float amax = b4r_seq_amax(p.mask + row0, L);
 
   const int q = q0 + 16 * wave + i;
   const bool qlive = q < L;
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_rx_dq_kernel(AttnRxP p) {
       const uint32_t nib = w[(t >> 3) & 1] >> (4 * (t & 7));
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const float pr = __expf(sc[s] + ad[s] - lse);
+        const float pr = __expf(((sc[s] + ad[s]) - amax) - lse);
         const float dA = ((nib >> s) & 1u) ? da[s] * dscale : 0.f;
         ds[u][s] = pr * (dA - Dq);
       }
@@ -275,6 +277,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_rx_dkv_kernel(AttnRxP p) {
   const int64_t row0 = (int64_t)b * L;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
   const int64_t bh = (int64_t)b * p.heads + hd;
+  const float amax = b4r_seq_amax(p.mask + row0, L);
 
   const int k0 = (wg.x * WAVES + wave) * 16;
   const int key = k0 + i;
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_rx_dkv_kernel(AttnRxP p) {
       const f32x4 dd = *reinterpret_cast<const f32x4*>(&sD[16 * t + 4 * g]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float pr = __expf(sc[u][r] + add - ls[r]);
+        const float pr = __expf(((sc[u][r] + add) - amax) - ls[r]);
         const bool keep = (wq[u][r] >> wshift) & 1u;
         pd[u][r] = keep ? pr * dscale : 0.f;
         const float dA = keep ? da[u][r] * dscale : 0.f;

@@ -261,6 +261,19 @@ __device__ __forceinline__ float b4r_gelu_grad_fast(float x) {
   return fmaf(x * 0.39894228040143267794f, e, 0.5f * (1.0f + er));
 }
 
+// The largest additive key mask of one sequence: 0 when at least one key is valid, -1e9 when the whole row of input_mask is zero.
+// Keras adds (1 - mask) * -1e9 in fp32; on a fully masked sequence every score rounds to -1e9 (ulp 64) and the softmax is exactly
+// uniform, but log-sum-exp = -1e9 + log(L) cannot hold its log(L) in fp32 -- a backward that recomputes exp(score - lse) would see
+// probability 1 for every key.  All attention kernels therefore store lse relative to this shift,
+//     lse = (max - amax) + log(sum) ,   p = exp(((score + mask) - amax) - lse) ,
+// which changes nothing when a key is valid (amax = 0) and keeps the rounding of (score + mask) that makes the row uniform.
+// Contains a barrier: every thread of the workgroup calls it, with block-uniform arguments.
+__device__ __forceinline__ float b4r_seq_amax(const int64_t* mask_row, int L) {
+  int any = 0;
+  for (int k = threadIdx.x; k < L; k += blockDim.x) any |= (mask_row[k] != 0) ? 1 : 0;
+  return __syncthreads_or(any) ? 0.0f : -1e9f;
+}
+
 __device__ __forceinline__ float b4r_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -259,6 +259,7 @@ WsLayout make_ws_layout(const b4r_model_config& c, int B, int L, int P) {
     add(b4r_gemm_tn_scratch_floats((int)N, (int)I, (int)H));
     add(2 * std::max(b4r_ln_bwd_scratch_floats((int)N, (int)H), b4r_gemm_ln_bwd_partial_floats((int)N)));
     if (H == 64 && I == 256) add(b4r_ffn_block_bwd_scratch_floats((int)N));   // partial slabs of the fused feed-forward backward
+    add(b4r_attn_block_bwd_scratch_floats(B));
   }
   add(std::max(b4r_ln_bwd_scratch_floats((int)N, (int)H), b4r_gemm_ln_bwd_partial_floats((int)N)));
   if (M > 0) {
@@ -354,6 +355,12 @@ bool ffn_fused(const b4r_model_config* c) {
 bool attn_fused(const b4r_model_config* c, int L) {
   static const bool on = !(getenv("B4R_ATTN_FUSED") && atoi(getenv("B4R_ATTN_FUSED")) == 0);
   return on && b4r_attn_block_supported(c->hidden_size, c->num_heads, L) != 0;
+}
+
+// ... and one launch backward (b4r_attn_block_bwd; then the forward need not store qkv); B4R_ATTN_BWD_FUSED=0: round 1's kernels
+bool attn_bwd_fused(const b4r_model_config* c, int L) {
+  static const bool on = !(getenv("B4R_ATTN_BWD_FUSED") && atoi(getenv("B4R_ATTN_BWD_FUSED")) == 0);
+  return on && attn_fused(c, L) && b4r_attn_block_bwd_supported(c->hidden_size, c->num_heads, L) != 0;
 }
 
 // pair kernels (input gradient inside the weight-gradient kernel, b4r_gemm_tn_desc.dgrad_*): B4R_PAIR bit 0 = the 64 x 64 layers
@@ -521,7 +528,7 @@ extern "C" int b4r_forward(const b4r_model_config* cfg, const b4r_batch* batch, 
       ad.ln_gamma = params + pl.ln1_g[i]; ad.ln_beta = params + pl.ln1_b[i]; ad.ln_eps = cfg->ln_eps;
       ad.rng = (od > 0.f || adp > 0.f) ? rng : nullptr;
       ad.probs_stream = B4R_STREAM_ATTN_PROBS(i); ad.probs_rate = adp; ad.out_stream = B4R_STREAM_ATTN_OUT(i); ad.out_rate = od;
-      ad.qkv = ws + w.qkv[i];   // b4r_attn_bwd still reads it
+      ad.qkv = attn_bwd_fused(cfg, L) ? nullptr : ws + w.qkv[i];   // only round 1's backward kernels read it
       ad.ctx = ws + w.ctx[i]; ad.lse = ws + w.lse[i]; ad.keep_bits = reinterpret_cast<uint32_t*>(ws + w.keep[i]);
       ad.z1 = ws + w.z1[i]; ad.x1 = ws + w.x1[i]; ad.mean1 = ws + w.mean1[i]; ad.rstd1 = ws + w.rstd1[i];
       RC(b4r_attn_block_fwd(&ad, stream));
@@ -762,6 +769,31 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
     RC(gemm_tn(ws + w.x1[i], H, ws + w.df, I, grads + pl.w1[i], I, N, H, I, grads + pl.b1[i], nullptr, nullptr, 0, 0.f, 0,
                take(b4r_gemm_tn_scratch_floats(N, H, I)), s_tn));
     }
+    if (attn_bwd_fused(cfg, L)) {
+      // dWo = ctx^T . dropmask(dz1) (+ bias gradient); then the attention block's backward in one launch: dqkv and, through the
+      // LayerNorm in front of this layer, da (for layer 0: through the embedding stage's dropout and LayerNorm)
+      RC(gemm_tn(ws + w.ctx[i], H, ws + w.db, H, grads + pl.wo[i], H, N, H, H, grads + pl.bo[i], nullptr, rng, B4R_STREAM_ATTN_OUT(i),
+                 od, 1, take(b4r_gemm_tn_scratch_floats(N, H, H)), s));
+      b4r_attn_block_bwd_desc bd{};
+      bd.B = B; bd.L = L; bd.H = H; bd.heads = cfg->num_heads;
+      bd.x = x_in; bd.dz1 = ws + w.db; bd.ctx = ws + w.ctx[i]; bd.lse = ws + w.lse[i];
+      bd.keep_bits = reinterpret_cast<const uint32_t*>(ws + w.keep[i]); bd.input_mask = batch->input_mask;
+      bd.Wqkv = params + pl.wqkv[i]; bd.bqkv = params + pl.bqkv[i]; bd.Wo = params + pl.wo[i];
+      bd.rng = (od > 0.f || adp > 0.f) ? rng : nullptr;
+      bd.probs_stream = B4R_STREAM_ATTN_PROBS(i); bd.probs_rate = adp; bd.out_stream = B4R_STREAM_ATTN_OUT(i); bd.out_rate = od;
+      if (i > 0) {
+        bd.prev_z = ws + w.z2[i - 1]; bd.prev_mean = ws + w.mean2[i - 1]; bd.prev_rstd = ws + w.rstd2[i - 1];
+        bd.prev_gamma = params + pl.ln2_g[i - 1]; bd.dprev_gamma = grads + pl.ln2_g[i - 1];
+      } else {
+        bd.prev_mean = ws + w.mean0; bd.prev_rstd = ws + w.rstd0; bd.prev_gamma = params + pl.emb_ln_g;
+        bd.dprev_gamma = grads + pl.emb_ln_g;
+        bd.emb_ids = batch->input_word_ids; bd.emb_table = params + pl.word_emb; bd.emb_pos = params + pl.pos_emb; bd.emb_vocab = V;
+        bd.emb_stream = B4R_STREAM_EMB; bd.emb_rate = od;
+      }
+      bd.dqkv = ws + w.dqkv; bd.dx_prev = ws + w.da;
+      bd.scratch = take(b4r_attn_block_bwd_scratch_floats(B));
+      RC(b4r_attn_block_bwd(&bd, stream));
+    } else {
     // attention output projection: dctx = dropmask(dz1) . Wo^T and dWo = ctx^T . dropmask(dz1) (+ bias gradient) read dz1
     // once where the pair kernel applies (hidden size 64), else as two products
     {
@@ -795,6 +827,7 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
       RC(dgrad_ln_bwd(ws + w.dqkv, 3 * H, params + pl.wqkv[i], 3 * H, ws + w.db, ws + w.da, N, H, nullptr, ws + w.mean0, ws + w.rstd0,
                       params + pl.emb_ln_g, grads + pl.emb_ln_g, grads + pl.emb_ln_b, take(ln_scratch), s, batch->input_word_ids,
                       params + pl.word_emb, params + pl.pos_emb, L, V, rng, B4R_STREAM_EMB, od));
+    }
     RC(order_after(s, s_tn));
     RC(gemm_tn(x_in, H, ws + w.dqkv, 3 * H, grads + pl.wqkv[i], 3 * H, N, H, 3 * H, grads + pl.bqkv[i], nullptr, nullptr, 0, 0.f,
                0, take(b4r_gemm_tn_scratch_floats(N, H, 3 * H)), s_tn));

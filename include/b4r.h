@@ -380,6 +380,32 @@ typedef struct b4r_attn_block_desc {
 int32_t b4r_attn_block_supported(int32_t hidden_size, int32_t num_heads, int32_t L);
 int b4r_attn_block_fwd(const b4r_attn_block_desc* d, b4r_stream_t stream);
 
+/* The attention block, backward: one launch, one workgroup per sequence (b4r_attn_block_bwd_supported: as the forward, L <= 208).
+ * From dz1 = d loss / d z1 (z1 = x + dropout(ctx.Wo + bo)), the forward's ctx / lse / keep_bits and the block input x:
+ *   dqkv [B*L,3H]   gradient wrt the q | k | v projections (dq already times 1/sqrt(32)): dWqkv = x^T.dqkv and dbqkv = its column
+ *                   sums are left to b4r_gemm_tn_f32, like dWo = ctx^T.dropmask(dz1) / dbo
+ *   dx_prev [B*L,H] gradient wrt the INPUT of the LayerNorm that produced x:  LN'(dqkv.Wqkv^T + dz1) -- prev_z / prev_mean /
+ *                   prev_rstd / prev_gamma describe that LayerNorm (the previous layer's output_layer_norm); for the first layer
+ *                   pass emb_ids [B,L], emb_table [emb_vocab,H], emb_pos [>=L,H] instead of prev_z: x = dropout(LN(table[id] + pos))
+ *                   (bert4rec_encoder.py:198-211; emb_stream / emb_rate: that dropout, element index row*64 + col)
+ *   dprev_gamma     [128]: that LayerNorm's dgamma, then dbeta
+ * q, k, v are recomputed from x (the forward need not store qkv), every score block is formed once, dK / dV accumulate in LDS in
+ * a fixed order (bitwise reproducible).  scratch: b4r_attn_block_bwd_scratch_floats(B) floats. */
+typedef struct b4r_attn_block_bwd_desc {
+  int32_t B, L, H, heads;
+  const float* x; const float* dz1; const float* ctx; const float* lse; const uint32_t* keep_bits;
+  const int64_t* input_mask;
+  const float* Wqkv; const float* bqkv; const float* Wo;
+  const uint32_t* rng; uint32_t probs_stream; float probs_rate; uint32_t out_stream; float out_rate;
+  const float* prev_z; const float* prev_mean; const float* prev_rstd; const float* prev_gamma;
+  const int64_t* emb_ids; const float* emb_table; const float* emb_pos; int32_t emb_vocab; uint32_t emb_stream; float emb_rate;
+  float* dqkv; float* dx_prev; float* dprev_gamma;
+  float* scratch;
+} b4r_attn_block_bwd_desc;
+int32_t b4r_attn_block_bwd_supported(int32_t hidden_size, int32_t num_heads, int32_t L);
+int64_t b4r_attn_block_bwd_scratch_floats(int32_t B);
+int b4r_attn_block_bwd(const b4r_attn_block_bwd_desc* d, b4r_stream_t stream);
+
 typedef struct b4r_ffn_desc {
   int32_t N, H, I;
   const float* x1;                                  /* [N,H] block input */

@@ -199,9 +199,12 @@ def test_attn_block_forward_matches_fp64(B, L, p_rate, o_rate):
     for k in ("qkv", "ctx", "z1", "x1", "mean1"):   # scores reach +-5 here: 2e-4 on the softmax-weighted sums
         assert T.maxdiff(out[k], ref[k]) < 2e-4, k
     assert T.maxdiff(out["rstd1"] / ref["rstd1"].float().to(DEV), torch.ones(N)) < 1e-4
-    # lse of rows whose keys are all masked is ~ -1e9 + log(L): compare relative there
-    lse_ref = ref["lse"]
-    assert float(((out["lse"].cpu().double() - lse_ref).abs() / lse_ref.abs().clamp(min=1.0)).max()) < 1e-4
+    # lse is stored relative to the sequence's largest mask adder (b4r_seq_amax): log(L) for a fully masked sequence, whose
+    # log-sum-exp -1e9 + log(L) has no fp32 representation that keeps the log(L)
+    lse_ref = ref["lse"].clone()
+    dead = mask.sum(1) == 0
+    lse_ref[dead] = math.log(L)
+    assert float((out["lse"].cpu().double() - lse_ref).abs().max()) < 1e-4
 
     # the separate kernels of round 1 read what the block saved: b4r_attn_bwd on (qkv, ctx, lse, keep_bits) must agree with the
     # backward on the outputs of b4r_attn_fwd for the same inputs
@@ -213,3 +216,109 @@ def test_attn_block_forward_matches_fp64(B, L, p_rate, o_rate):
     assert T.maxdiff(ctx2, out["ctx"]) < 2e-5
     if p_rate > 0:
         assert torch.equal(bits2, bits)
+
+
+def attn_bwd_reference(t, mask, B, L, p_rate, o_rate, e_rate, seed, step, site_p, site_o, site_e, prev, eps=1e-12):
+    """fp64 autograd through [previous LayerNorm (+ embedding dropout)] -> attention block; loss = sum(z1 * dz1)."""
+    H, heads, dh = 64, 2, 32
+    d = {k: v.double() for k, v in t.items()}
+    g_prev, b_prev = prev["g"].double().requires_grad_(True), prev["b"].double().requires_grad_(True)
+    zprev = prev["z"].double().requires_grad_(True)
+    xn, mean_p, rstd_p = ln64(zprev, g_prev, b_prev, eps)
+    x = xn
+    if e_rate > 0:
+        x = x * orc.dropout_keep_mask((B * L, H), e_rate, seed, step, site_e).double() / (1.0 - e_rate)
+    x3 = x.reshape(B, L, H)
+    qkv = x3 @ d["Wqkv"] + d["bqkv"]
+    qkv.retain_grad()
+    q, k, v = (qkv[..., j * H:(j + 1) * H].reshape(B, L, heads, dh) for j in range(3))
+    q = q * (1.0 / math.sqrt(dh))
+    adder = ((1.0 - mask.float())[:, None, None, :] * torch.tensor(-1e9, dtype=torch.float32)).double()
+    s = torch.einsum("bqhd,bkhd->bhqk", q, k) + adder
+    # a fully masked row: the fp32 addition of -1e9 rounds every score away and the softmax is exactly uniform, while the gradient
+    # of that addition is still the identity (autograd / tf.gradients do not differentiate the rounding): value 0, gradient 1
+    dead = (mask.sum(1) == 0)
+    if bool(dead.any()):
+        s = torch.where(dead[:, None, None, None], s - s.detach(), s)
+    a = torch.softmax(s, dim=-1)
+    if p_rate > 0:
+        a = a * orc.dropout_keep_mask((B, heads, L, L), p_rate, seed, step, site_p, row_pitch=orc.ATTN_PITCH).double() / (1.0 - p_rate)
+    ctx = torch.einsum("bhqk,bkhd->bqhd", a, v).reshape(B * L, H)
+    y = ctx @ d["Wo"] + d["bo"]
+    if o_rate > 0:
+        y = y * orc.dropout_keep_mask((B * L, H), o_rate, seed, step, site_o).double() / (1.0 - o_rate)
+    z1 = x + y
+    (z1 * t["dz1"].double()).sum().backward()
+    return dict(x=x.detach(), mean_p=mean_p.detach(), rstd_p=rstd_p.detach(), dqkv=qkv.grad.reshape(B * L, 3 * H),
+                dzprev=zprev.grad, dg=g_prev.grad, db=b_prev.grad)
+
+
+@pytest.mark.parametrize("B,L,p_rate,o_rate,embed", [(3, 16, 0.0, 0.0, False), (5, 50, 0.0, 0.0, False), (4, 200, 0.2, 0.2, False),
+                                                     (6, 100, 0.0, 0.3, True), (3, 208, 0.2, 0.0, False), (7, 37, 0.5, 0.5, True)])
+def test_attn_block_backward_matches_fp64_autograd(B, L, p_rate, o_rate, embed):
+    """b4r_attn_block_bwd (q, k, v recomputed, every score block formed once, dK / dV accumulated in LDS) against autograd, on
+    what b4r_attn_block_fwd saved (ctx, lse, keep_bits); both LayerNorm variants in front of the block."""
+    lib = _lib.load()
+    _lib.check(lib.b4r_set_gemm_mode(_lib.GEMM_BF16X3))
+    assert lib.b4r_attn_block_bwd_supported(64, 2, L) == 1 and lib.b4r_attn_block_bwd_supported(64, 2, 209) == 0
+    seed, step, site_p, site_o, site_e = 313, 9, 1, 2, 0
+    N, V = B * L, 97
+    t, mask = attn_inputs(B, L, seed=B * 1000 + L + 7)
+    t["dz1"] = rnd(N, 64, seed=B + L)
+    e_rate = 0.25 if embed else 0.0
+    if embed:
+        ids = torch.randint(0, V, (B, L), generator=torch.Generator().manual_seed(5))
+        table, pos = rnd(V, 64, seed=70), 0.3 * rnd(L, 64, seed=71)
+        zprev = table[ids.reshape(-1)] + pos.repeat(B, 1)
+    else:
+        zprev = rnd(N, 64, seed=72)
+    prev = dict(z=zprev, g=1.0 + 0.2 * rnd(64, seed=73), b=0.1 * rnd(64, seed=74))
+    ref = attn_bwd_reference(t, mask, B, L, p_rate, o_rate, e_rate, seed, step, site_p, site_o, site_e, prev)
+    g = {k: v.to(DEV) for k, v in t.items()}
+    st = T.new_state(seed, step) if (p_rate > 0 or o_rate > 0 or e_rate > 0) else None
+    nan = float("nan")
+    x = ref["x"].float().to(DEV)
+    maskd = mask.to(DEV)
+    # forward first (what the backward consumes: ctx, lse, keep_bits); qkv is NOT stored
+    out = {k: torch.full(s_, nan, dtype=torch.float32, device=DEV) for k, s_ in
+           dict(ctx=(N, 64), lse=(B, 2, L), z1=(N, 64), x1=(N, 64), dqkv=(N, 192), da=(N, 64), dln=(128,)).items()}
+    bits = torch.zeros(lib.b4r_attn_keep_words(B, L, 2), dtype=torch.int32, device=DEV)
+    fd = _lib.AttnBlockDesc()
+    fd.B, fd.L, fd.H, fd.heads = B, L, 64, 2
+    fd.x, fd.input_mask = P(x), P(maskd)
+    fd.Wqkv, fd.bqkv, fd.Wo, fd.bo = P(g["Wqkv"]), P(g["bqkv"]), P(g["Wo"]), P(g["bo"])
+    fd.ln_gamma, fd.ln_beta, fd.ln_eps = P(g["g1"]), P(g["be1"]), 1e-12
+    fd.rng, fd.probs_stream, fd.probs_rate, fd.out_stream, fd.out_rate = P(st), site_p, p_rate, site_o, o_rate
+    fd.qkv, fd.ctx, fd.lse, fd.keep_bits = None, P(out["ctx"]), P(out["lse"]), P(bits)
+    fd.z1, fd.x1 = P(out["z1"]), P(out["x1"])
+    _lib.check(lib.b4r_attn_block_fwd(C.byref(fd), stream()), "b4r_attn_block_fwd")
+    mean_p, rstd_p = ref["mean_p"].float().to(DEV), ref["rstd_p"].float().to(DEV)
+    zp, gp = prev["z"].to(DEV), prev["g"].to(DEV)
+    scratch = torch.empty(lib.b4r_attn_block_bwd_scratch_floats(B), dtype=torch.float32, device=DEV)
+    bd = _lib.AttnBlockBwdDesc()
+    bd.B, bd.L, bd.H, bd.heads = B, L, 64, 2
+    bd.x, bd.dz1, bd.ctx, bd.lse, bd.keep_bits, bd.input_mask = P(x), P(g["dz1"]), P(out["ctx"]), P(out["lse"]), P(bits), P(maskd)
+    bd.Wqkv, bd.bqkv, bd.Wo = P(g["Wqkv"]), P(g["bqkv"]), P(g["Wo"])
+    bd.rng, bd.probs_stream, bd.probs_rate, bd.out_stream, bd.out_rate = P(st), site_p, p_rate, site_o, o_rate
+    bd.prev_mean, bd.prev_rstd, bd.prev_gamma = P(mean_p), P(rstd_p), P(gp)
+    if embed:
+        idd, tabd, posd = ids.to(DEV), table.to(DEV), pos.to(DEV)
+        bd.emb_ids, bd.emb_table, bd.emb_pos, bd.emb_vocab, bd.emb_stream, bd.emb_rate = P(idd), P(tabd), P(posd), V, site_e, e_rate
+    else:
+        bd.prev_z = P(zp)
+    bd.dqkv, bd.dx_prev, bd.dprev_gamma, bd.scratch = P(out["dqkv"]), P(out["da"]), P(out["dln"]), P(scratch)
+    _lib.check(lib.b4r_attn_block_bwd(C.byref(bd), stream()), "b4r_attn_block_bwd")
+    torch.cuda.synchronize()
+
+    def close(got, want, what, rel=3e-5):
+        err = (got.detach().cpu().double() - want).abs()
+        assert float(err.max()) < rel * max(1.0, float(want.abs().max())) + 1e-5, (what, float(err.max()), int(err.argmax()))
+    close(out["dqkv"], ref["dqkv"], "dqkv")
+    close(out["da"], ref["dzprev"], "dx_prev")
+    close(out["dln"][:64], ref["dg"], "dgamma")
+    close(out["dln"][64:], ref["db"], "dbeta")
+    first = {k: out[k].clone() for k in ("dqkv", "da", "dln")}
+    _lib.check(lib.b4r_attn_block_bwd(C.byref(bd), stream()), "b4r_attn_block_bwd")
+    torch.cuda.synchronize()
+    for k, v in first.items():
+        assert torch.equal(v, out[k]), k     # ordered accumulation of dK / dV in LDS: bitwise reproducible

@@ -356,6 +356,13 @@ def main():
                             "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
 
         # ---- the materialising masked-LM-head projection (forward / evaluation API), replayed on live buffers ----------------
+        if args.no_breakdown:      # profiling runs (tools/prof.sh): the train step only, no replays in the kernel statistics
+            print(json.dumps({"metric": "masked positions/sec", "value": round(value, 1), "ms_per_step": round(ms, 4),
+                              "note": "--no-breakdown: timing only"}), flush=True)
+            if use_dist:
+                dist.barrier()
+                dist.destroy_process_group()
+            return
         eng.forward(cb, training=False, pooler=False)        # fills mlm_hidden / mlm_logits of this batch shape
         t_h = eng.region("mlm_hidden", B, L, P)
         logits = eng.region("mlm_logits", B, L, P)

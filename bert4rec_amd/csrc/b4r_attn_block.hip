@@ -328,6 +328,11 @@ struct AbBwdP {
   DropArgs drop_p, drop_o, drop_e;
 };
 
+// timing experiments only (tools/build_variant.sh): 1 = no sweep, 2 = no accumulator read-modify-write, 4 = no barrier per step,
+// 8 = one weight staging instead of three
+#ifndef AB_EXP
+#define AB_EXP 0
+#endif
 constexpr int BT = 8 * 1024;   // bytes of one token tile of the backward's LDS region
 constexpr int BX = 4 * IMG_BYTES;   // offset of the Q / dO images (later the accumulators) inside a tile
 
@@ -386,8 +391,10 @@ __global__ __launch_bounds__(1024) void attn_block_bwd_kernel(AbBwdP p) {
 
   for (int hd = 0; hd <= 2; ++hd) {
     __syncthreads();   // the tile region is free (previous head done; first pass: sAdd / sbq written)
+    if (!(AB_EXP & 8) || hd == 0) {
     stage_weight(R, p.Wqkv, HID, 3 * HID, nthreads);
     if (hd < 2) stage_weight(woimg, p.Wo, HID, HID, nthreads);
+    }
     __syncthreads();
     if (hd > 0) {
       // dX^T[16 hb + ..][token] += Wqkv[.., features of head hd-1] . dqkv^T: A = rows of the Wqkv image (natural k order)
@@ -503,7 +510,7 @@ __global__ __launch_bounds__(1024) void attn_block_bwd_kernel(AbBwdP p) {
 
     // ---- the sweep: one 16 x 16 block of the score matrix per step ------------------------------------------------------------
     f32x4 dq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    for (int s = 0; s < KT; ++s) {
+    for (int s = 0; s < ((AB_EXP & 1) ? 0 : KT); ++s) {
       int t = wave + s;
       if (t >= KT) t -= KT;
       const char* tile = R + t * BT;
@@ -544,10 +551,11 @@ __global__ __launch_bounds__(1024) void attn_block_bwd_kernel(AbBwdP p) {
         const f32x4 dvp = mfma16x3(dT[a][0], dT[a][1], pdTh, pdTl, z);
         f32x4* ak = reinterpret_cast<f32x4*>(acc + a * 1024);
         f32x4* av = reinterpret_cast<f32x4*>(acc + (2 + a) * 1024);
+        if (AB_EXP & 2) { asm volatile("" :: "v"(dkp), "v"(dvp)); continue; }
         *ak = *ak + dkp;
         *av = *av + dvp;
       }
-      __syncthreads();   // the next step adds into other tiles; fixed order of the additions into each tile
+      if (!(AB_EXP & 4)) __syncthreads();   // the next step adds into other tiles; fixed order of the additions into each tile
     }
     // results of this head for the wave's tokens
 #pragma unroll

@@ -767,3 +767,32 @@ def test_mask_batch_follows_the_preprocessor_law():
     eng.init_parameters(seed=1)
     eng.forward(cb)
     torch.cuda.synchronize()
+
+
+def test_fused_mlm_head_at_the_ml20m_vocabulary_matches_fp64_autograd():
+    """b4r_mlm_head_fused_fwd / _bwd at V = 26 732, H = 256 (BASELINE.json configs[3]) against fp64 logits -> softmax CE -> autograd:
+    loss rows, lse, dT, dE, d bias (M = 256 rows is enough to run every vocabulary tile of the NKH = 8 sweeps)."""
+    lib = _lib.load()
+    _lib.check(lib.b4r_set_gemm_mode(_lib.GEMM_BF16X3))
+    M, V, H = 256, 26732, 256
+    Tm, E, bias = rnd(M, H, seed=80), rnd(V, H, seed=81, scale=0.03), rnd(V, seed=82, scale=0.01)
+    y = torch.randint(1, V, (M,), generator=torch.Generator().manual_seed(83))
+    y[::7] = 0                                                       # ignored slots (y_true == 0)
+    T64, E64, b64 = Tm.double().requires_grad_(True), E.double().requires_grad_(True), bias.double().requires_grad_(True)
+    logits = T64 @ E64.t() + b64
+    lse_ref = torch.logsumexp(logits, 1)
+    rows = lse_ref - logits[torch.arange(M), y]
+    valid = (y != 0)
+    (rows * valid).sum().backward()
+    Td, Ed, bd, yd = Tm.to(DEV), E.to(DEV), bias.to(DEV), y.to(DEV)
+    scratch = torch.empty(lib.b4r_mlm_head_fused_scratch_floats(M, V, H), dtype=torch.float32, device=DEV)
+    dT = torch.empty(M, H, device=DEV); rs = torch.empty(4 * M, device=DEV); lse = torch.empty(M, device=DEV)
+    lab = torch.empty(M, dtype=torch.int32, device=DEV); dE = torch.empty(V, H, device=DEV); db = torch.empty(V, device=DEV)
+    _lib.check(lib.b4r_mlm_head_fused_fwd(P(Td), P(Ed), P(bd), P(yd), M, V, H, P(scratch), P(dT), P(rs), P(lse), P(lab), 0, stream()))
+    _lib.check(lib.b4r_mlm_head_fused_bwd(P(Td), P(Ed), P(bd), P(lse), P(lab), M, V, H, P(scratch), P(dE), P(db), stream()))
+    torch.cuda.synchronize()
+    v = valid.to(DEV)
+    assert T.maxdiff(lse[v], lse_ref.detach()[valid]) < 1e-4
+    assert T.maxdiff(dT, T64.grad) < 1e-4
+    assert T.maxdiff(dE, E64.grad) < 1e-4 * max(1.0, float(E64.grad.abs().max()))
+    assert T.maxdiff(db, b64.grad) < 1e-4

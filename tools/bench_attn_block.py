@@ -1,0 +1,46 @@
+"""micro-benchmark of the fused attention block (b4r_attn_block_fwd / _bwd) at the ML-1M shape"""
+import ctypes as C, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bert4rec_amd import _lib
+lib = _lib.load()
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+L = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+rate = float(sys.argv[3]) if len(sys.argv) > 3 else 0.2
+H, N = 64, B * L
+g = torch.Generator(device="cuda").manual_seed(1)
+r = lambda *s, sc=1.0: torch.randn(*s, device="cuda", generator=g) * sc
+x, dz1, zprev = r(N, H), r(N, H), r(N, H)
+Wqkv, bqkv, Wo, bo = r(H, 3 * H, sc=0.1), r(3 * H, sc=0.1), r(H, H, sc=0.1), r(H, sc=0.1)
+g1, be1 = 1 + r(H, sc=0.1), r(H, sc=0.1)
+meanp, rstdp = r(N, sc=0.1), 1 + r(N, sc=0.1).abs()
+mask = torch.ones(B, L, dtype=torch.int64, device="cuda")
+ctx, z1, x1, da = (torch.empty(N, H, device="cuda") for _ in range(4))
+lse = torch.empty(B, 2, L, device="cuda"); dqkv = torch.empty(N, 3 * H, device="cuda"); dln = torch.empty(128, device="cuda")
+bits = torch.zeros(lib.b4r_attn_keep_words(B, L, 2), dtype=torch.int32, device="cuda")
+scratch = torch.empty(lib.b4r_attn_block_bwd_scratch_floats(B), device="cuda")
+state = torch.zeros(16, dtype=torch.int32, device="cuda"); state[0] = 77
+P = lambda t: t.data_ptr()
+rng = P(state) if rate > 0 else None
+fd = _lib.AttnBlockDesc()
+fd.B, fd.L, fd.H, fd.heads, fd.x, fd.input_mask = B, L, H, 2, P(x), P(mask)
+fd.Wqkv, fd.bqkv, fd.Wo, fd.bo, fd.ln_gamma, fd.ln_beta, fd.ln_eps = P(Wqkv), P(bqkv), P(Wo), P(bo), P(g1), P(be1), 1e-12
+fd.rng, fd.probs_stream, fd.probs_rate, fd.out_stream, fd.out_rate = rng, 1, rate, 2, rate
+fd.qkv, fd.ctx, fd.lse, fd.keep_bits, fd.z1, fd.x1 = None, P(ctx), P(lse), P(bits), P(z1), P(x1)
+bd = _lib.AttnBlockBwdDesc()
+bd.B, bd.L, bd.H, bd.heads = B, L, H, 2
+bd.x, bd.dz1, bd.ctx, bd.lse, bd.keep_bits, bd.input_mask = P(x), P(dz1), P(ctx), P(lse), P(bits), P(mask)
+bd.Wqkv, bd.bqkv, bd.Wo = P(Wqkv), P(bqkv), P(Wo)
+bd.rng, bd.probs_stream, bd.probs_rate, bd.out_stream, bd.out_rate = rng, 1, rate, 2, rate
+bd.prev_z, bd.prev_mean, bd.prev_rstd, bd.prev_gamma = P(zprev), P(meanp), P(rstdp), P(g1)
+bd.dqkv, bd.dx_prev, bd.dprev_gamma, bd.scratch = P(dqkv), P(da), P(dln), P(scratch)
+st = torch.cuda.current_stream().cuda_stream
+fwd = lambda: _lib.check(lib.b4r_attn_block_fwd(C.byref(fd), st), "fwd")
+bwd = lambda: _lib.check(lib.b4r_attn_block_bwd(C.byref(bd), st), "bwd")
+def timeit(f, reps=100):
+    for _ in range(10): f()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): f()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+print("B %d L %d rate %.2f  attention block forward %.1f us  backward (+ LayerNorm partial reduce) %.1f us" % (B, L, rate, timeit(fwd), timeit(bwd)))

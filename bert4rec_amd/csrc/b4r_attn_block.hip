@@ -38,14 +38,17 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* a, const char* b) {
 
 // W [R][C] fp32 row-major -> natural hi / lo image in 16 x 32 sub-tiles, all `nthreads` threads of the workgroup
 __device__ __forceinline__ void stage_weight(char* img, const float* W, int R, int C, int nthreads) {
-  const int c4n = C >> 2, ncb = C >> 5, nf4 = R * c4n;
+  // one float4 per thread and turn, sub-tile by sub-tile: the 64 lanes of a wave-instruction fill 8 whole rows (512 bytes) of one
+  // sub-tile, so the 8-byte LDS stores are conflict-free (row-major order put a wave across 8 sub-tiles 2 KB apart: 8-way)
+  const int ncb = C >> 5, nf4 = (R * C) >> 2;
   for (int f = threadIdx.x; f < nf4; f += nthreads) {
-    const int r = f / c4n, c = 4 * (f - r * c4n);
-    const f32x4 v = *reinterpret_cast<const f32x4*>(W + (int64_t)r * C + c);
+    const int st = f >> 7, u = f & 127;
+    const int rt = st / ncb, cb = st - rt * ncb;
+    const int r16 = u >> 3, q4 = u & 7;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(W + (int64_t)(16 * rt + r16) * C + 32 * cb + 4 * q4);
     bf16x4 h, l;
     b4r_split4(v, h, l);
-    const int cc = c & 31;
-    char* dst = img + sub_base(r >> 4, c >> 5, ncb) + sub_off(r & 15, cc >> 3) + 8 * ((cc >> 2) & 1);
+    char* dst = img + sub_base(rt, cb, ncb) + sub_off(r16, q4 >> 1) + 8 * (q4 & 1);
     *reinterpret_cast<bf16x4*>(dst) = h;
     *reinterpret_cast<bf16x4*>(dst + SUB) = l;
   }

@@ -91,14 +91,17 @@ __device__ __forceinline__ bf16x8 row_at(const char* a) { return *reinterpret_ca
 
 // W [R][C] fp32 row-major -> natural hi / lo image (R % 16 == 0, C % 32 == 0), all threads of the workgroup
 __device__ __forceinline__ void stage_weight(char* img, const float* W, int R, int C) {
-  const int c4n = C >> 2, ncb = C >> 5, nf4 = R * c4n;
+  // one float4 per thread and turn, sub-tile by sub-tile: the 64 lanes of a wave-instruction fill 8 whole rows (512 bytes) of one
+  // sub-tile, so the 8-byte LDS stores are conflict-free (row-major order put a wave across 8 sub-tiles 2 KB apart: 8-way)
+  const int ncb = C >> 5, nf4 = (R * C) >> 2;
   for (int f = threadIdx.x; f < nf4; f += 64 * FW) {
-    const int r = f / c4n, c = 4 * (f - r * c4n);
-    const f32x4 v = *reinterpret_cast<const f32x4*>(W + (int64_t)r * C + c);
+    const int st = f >> 7, u = f & 127;
+    const int rt = st / ncb, cb = st - rt * ncb;
+    const int r16 = u >> 3, q4 = u & 7;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(W + (int64_t)(16 * rt + r16) * C + 32 * cb + 4 * q4);
     bf16x4 h, l;
     b4r_split4(v, h, l);
-    const int cc = c & 31;
-    char* dst = img + sub_base(r >> 4, c >> 5, ncb) + sub_off(r & 15, cc >> 3) + 8 * ((cc >> 2) & 1);
+    char* dst = img + sub_base(rt, cb, ncb) + sub_off(r16, q4 >> 1) + 8 * (q4 & 1);
     *reinterpret_cast<bf16x4*>(dst) = h;
     *reinterpret_cast<bf16x4*>(dst + SUB) = l;
   }
@@ -129,6 +132,16 @@ __device__ __forceinline__ float quad_sum(float s) {   // over the four lanes i,
   s += __shfl_xor(s, 16, 64);
   s += __shfl_xor(s, 32, 64);
   return s;
+}
+
+// sum over the 16 lanes of a DPP row (the 16 tokens of a lane group), valid in lane 15 of the row: four v_add_f32 with a row_shr
+// modifier, no LDS crossbar traffic (a __shfl_xor butterfly compiles to ds_bpermute_b32)
+__device__ __forceinline__ float row_sum15(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));   // row_shr:1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));   // row_shr:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));   // row_shr:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));   // row_shr:8
+  return v;
 }
 
 // fpre^T tile `a` of inner block kt (rows 4p + e = inner columns 32 kt + 8p + 4a + e, the wave's 16 tokens on the columns),
@@ -264,9 +277,11 @@ __global__ __launch_bounds__(64 * FW) void ffn_bwd_dx_kernel(FfnP p) {
   const LaneK lk = lane_consts(lane);
   const DropCtx dctx = b4r_drop_ctx(p.drop);
   const int ntiles = (p.N + 15) >> 4;
-  f32x4 dgam[4], dbet[4];   // this lane's share of sum_tokens dx1 * xhat / dx1 (columns 16 hb + 4g .. +3)
-#pragma unroll
-  for (int hb = 0; hb < 4; ++hb) { dgam[hb] = (f32x4){0.f, 0.f, 0.f, 0.f}; dbet[hb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  // LayerNorm gamma / beta sums of this wave live in its 128 floats of LDS (32 more live registers per lane spilled 37 VGPRs to
+  // scratch: 30 MB of extra HBM writes per launch in profiles/r02_a)
+  float* myred = sred + wave * 128;
+  myred[lane] = 0.f;
+  myred[64 + lane] = 0.f;
 
   for (int t = blockIdx.x + gridDim.x * wave; t < ntiles; t += gridDim.x * FW) {
     const int tok = 16 * t + i, tokc = min(tok, p.N - 1);
@@ -335,7 +350,17 @@ __global__ __launch_bounds__(64 * FW) void ffn_bwd_dx_kernel(FfnP p) {
       ge[hb] = dx * gm;
       s1 += sum4(ge[hb]);
       s2 += sum4(ge[hb] * xhat[hb]);
-      if (live) { dgam[hb] += dx * xhat[hb]; dbet[hb] += dx; }
+      // column sums over the tile's 16 tokens (DPP row sums, lane 15 of every lane group adds them to the wave's LDS strip)
+      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+      f32x4 pg = live ? dx * xhat[hb] : zero4, pb = live ? dx : zero4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { pg[e] = row_sum15(pg[e]); pb[e] = row_sum15(pb[e]); }
+      if (i == 15) {
+        f32x4* rg = reinterpret_cast<f32x4*>(myred + 16 * hb + 4 * g);
+        f32x4* rb = reinterpret_cast<f32x4*>(myred + 64 + 16 * hb + 4 * g);
+        *rg = *rg + pg;
+        *rb = *rb + pb;
+      }
     }
     const float c1 = quad_sum(s1) * (1.0f / HID), c2 = quad_sum(s2) * (1.0f / HID);
     if (live) {
@@ -348,17 +373,7 @@ __global__ __launch_bounds__(64 * FW) void ffn_bwd_dx_kernel(FfnP p) {
       }
     }
   }
-  // LayerNorm gamma / beta partial sums: over the 16 tokens of a lane group (fixed butterfly), then over the waves in order
-#pragma unroll
-  for (int hb = 0; hb < 4; ++hb) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float a = dgam[hb][e], b = dbet[hb][e];
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-      if (i == 0) { sred[wave * 128 + 16 * hb + 4 * g + e] = a; sred[wave * 128 + 64 + 16 * hb + 4 * g + e] = b; }
-    }
-  }
+  // LayerNorm gamma / beta partial sums of the workgroup: the waves' strips in order
   __syncthreads();
   if (threadIdx.x < 128) {
     float r = 0.f;

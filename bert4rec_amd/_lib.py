@@ -81,7 +81,9 @@ class FfnDesc(C.Structure):
                 ("rng", C.c_void_p), ("drop_stream", C.c_uint32), ("drop_rate", C.c_float), ("z2", C.c_void_p), ("x2", C.c_void_p),
                 ("mean2", C.c_void_p), ("rstd2", C.c_void_p), ("dz2", C.c_void_p), ("z1", C.c_void_p), ("mean1", C.c_void_p),
                 ("rstd1", C.c_void_p), ("ln1_gamma", C.c_void_p), ("dz1", C.c_void_p), ("dW1", C.c_void_p), ("db1", C.c_void_p),
-                ("dW2", C.c_void_p), ("db2", C.c_void_p), ("dln1_gamma", C.c_void_p), ("scratch", C.c_void_p)]
+                ("dW2", C.c_void_p), ("db2", C.c_void_p), ("dln1_gamma", C.c_void_p), ("scratch", C.c_void_p),
+                ("rows", C.c_void_p), ("n_rows", C.c_void_p), ("max_rows", C.c_int32), ("row_slot", C.c_void_p),
+                ("slot_grad", C.c_void_p), ("dln_gamma", C.c_void_p), ("dz2_rows", C.c_void_p)]
 
 
 # b4r_train_state: 16 x 32-bit words; word indices of the float fields
@@ -91,7 +93,7 @@ ST_LOSS_SUM, ST_VALID, ST_CORRECT_MASKED, ST_CORRECT_ALL, ST_SLOTS_ALL, ST_SQNOR
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_QSCALE, EPI_BIAS_GELU, EPI_BIAS_DROP_RES, EPI_GELU_BWD, EPI_ADD_RES, EPI_BIAS_TANH = range(8)
 EPI_BIAS_DROP_RES_LN, EPI_ADD_RES_LN_BWD, EPI_BIAS_GELU_LN = 8, 9, 10
-FLAG_TRAINING, FLAG_POOLER, FLAG_FUSED_HEAD, FLAG_GRAD_TAIL = 1, 2, 4, 8
+FLAG_TRAINING, FLAG_POOLER, FLAG_FUSED_HEAD, FLAG_GRAD_TAIL, FLAG_HEAD_ROWS_ONLY = 1, 2, 4, 8, 16
 LOSS_FUSED_HEAD = 2
 GEMM_F32, GEMM_BF16X3 = 0, 1
 
@@ -143,6 +145,7 @@ PROTOTYPES = {
     "b4r_attn_block_bwd_supported": (_I32, [_I32, _I32, _I32]),
     "b4r_attn_block_bwd_scratch_floats": (_I64, [_I32]),
     "b4r_attn_block_bwd": (C.c_int, [C.POINTER(AttnBlockBwdDesc), _P]),
+    "b4r_mlm_rows": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P, _P, _P]),
     "b4r_ffn_block_supported": (_I32, [_I32, _I32]),
     "b4r_ffn_block_bwd_scratch_floats": (_I64, [_I32]),
     "b4r_ffn_block_fwd": (C.c_int, [C.POINTER(FfnDesc), _P]),

@@ -125,7 +125,17 @@ struct FfnP {
   float* slab_w1; float* slab_b1; float* slab_w2; float* slab_b2;
   int N; float eps;
   DropArgs drop;
+  // row list (the last layer of a train step: only the rows the masked-LM head gathers carry a gradient, b4r_mlm_rows):
+  // compact index j -> row rows[j], j < *n_dev.  slotof[j]: the valid masked-LM slot of row j (-1: none), dgr [M,64] the
+  // gradient per slot; then dz2 is formed in the kernel as the output LayerNorm's backward of that row (z2 / mean2 / rstd2 / g2)
+  const int* rows; const int* n_dev; const int* slotof; const float* dgr;
+  float* dz2c;      // [cap,64] compact dz2 for the weight-gradient kernel
+  float* ln2_part;  // [grid][128] gamma / beta partials of the output LayerNorm
 };
+
+// number of (compact) rows and the actual row of compact index j
+__device__ __forceinline__ int ffn_rows(const FfnP& p) { return p.n_dev ? *p.n_dev : p.N; }
+__device__ __forceinline__ int ffn_row(const FfnP& p, int j) { return p.rows ? p.rows[j] : j; }
 
 __device__ __forceinline__ float sum4(const f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
 __device__ __forceinline__ float quad_sum(float s) {   // over the four lanes i, i+16, i+32, i+48 that share a token
@@ -181,9 +191,11 @@ __global__ __launch_bounds__(64 * FW) void ffn_fwd_kernel(FfnP p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
   const LaneK lk = lane_consts(lane);
   const DropCtx dctx = b4r_drop_ctx(p.drop);
-  const int ntiles = (p.N + 15) >> 4;
+  const int Nn = ffn_rows(p);
+  const int ntiles = (Nn + 15) >> 4;
   for (int t = blockIdx.x + gridDim.x * wave; t < ntiles; t += gridDim.x * FW) {   // wave-uniform: EXEC stays full
-    const int tok = 16 * t + i, tokc = min(tok, p.N - 1);
+    const int j = 16 * t + i;
+    const int tok = ffn_row(p, min(j, Nn - 1)), tokc = tok;   // tok: the row in the [N, 64] tensors; pad lanes repeat the last row
     bf16x8 xh[2], xl[2];
     {
       f32x8 xv[2];
@@ -236,7 +248,7 @@ __global__ __launch_bounds__(64 * FW) void ffn_fwd_kernel(FfnP p) {
       q += sum4(d * d);
     }
     const float rstd = rsqrtf(quad_sum(q) * (1.0f / HID) + p.eps);
-    if (tok < p.N && (!(FFN_EXP & 4) || rstd == 12345.f)) {
+    if (j < Nn && (!(FFN_EXP & 4) || rstd == 12345.f)) {
 #pragma unroll
       for (int hb = 0; hb < 4; ++hb) {
         const int64_t o = (int64_t)tok * HID + 16 * hb + 4 * g;
@@ -267,7 +279,7 @@ __global__ __launch_bounds__(64 * FW) void ffn_bwd_dx_kernel(FfnP p) {
   char* w1img = smem_ffn;
   char* w2img = smem_ffn + W_IMG;
   float* sb1 = reinterpret_cast<float*>(smem_ffn + 2 * W_IMG);
-  float* sred = sb1 + INNER;   // [FW][128]
+  float* sred = sb1 + INNER;   // [FW][128], then [FW][128] for the output LayerNorm (row-list mode)
   stage_weight(w1img, p.W1, HID, INNER);
   stage_weight(w2img, p.W2, INNER, HID);
   if (threadIdx.x < INNER) sb1[threadIdx.x] = p.b1[threadIdx.x];
@@ -276,21 +288,54 @@ __global__ __launch_bounds__(64 * FW) void ffn_bwd_dx_kernel(FfnP p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
   const LaneK lk = lane_consts(lane);
   const DropCtx dctx = b4r_drop_ctx(p.drop);
-  const int ntiles = (p.N + 15) >> 4;
+  const int Nn = ffn_rows(p);
+  const int ntiles = (Nn + 15) >> 4;
+  const bool rowmode = p.slotof != nullptr;
   // LayerNorm gamma / beta sums of this wave live in its 128 floats of LDS (32 more live registers per lane spilled 37 VGPRs to
   // scratch: 30 MB of extra HBM writes per launch in profiles/r02_a)
   float* myred = sred + wave * 128;
+  float* myred2 = sred + (FW + wave) * 128;
   myred[lane] = 0.f;
   myred[64 + lane] = 0.f;
+  myred2[lane] = 0.f;
+  myred2[64 + lane] = 0.f;
 
   for (int t = blockIdx.x + gridDim.x * wave; t < ntiles; t += gridDim.x * FW) {
-    const int tok = 16 * t + i, tokc = min(tok, p.N - 1);
+    const int j = 16 * t + i, jc = min(j, Nn - 1);
+    const int tok = ffn_row(p, jc), tokc = tok;
     const int64_t rowo = (int64_t)tokc * HID + 4 * g;
+    // row-list mode: dz2 = LN2'(dx2) with dx2 = the head's gradient of this row's slot (zero if the row only serves padded slots)
+    const int slot = rowmode ? p.slotof[jc] : -1;
+    float ln2_mean = 0.f, ln2_rstd = 0.f, ln2_c1 = 0.f, ln2_c2 = 0.f;
     bf16x8 xh[2], xl[2], gh[2], gl[2];
     {
       f32x8 xv[2], dg[2];
       load_rows(p.x1, tokc, g, xv);
-      load_rows(p.dz2, tokc, g, dg);
+      if (rowmode) {
+        ln2_mean = p.mean2[tokc]; ln2_rstd = p.rstd2[tokc];
+        f32x8 zz[2], gm[2];
+        load_rows(p.z2, tokc, g, zz);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const f32x8 zero8 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          dg[ks] = slot >= 0 ? load8(p.dgr + (int64_t)slot * HID + 32 * ks + 8 * g) : zero8;
+          gm[ks] = load8(p.g2 + 32 * ks + 8 * g);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float xe = (zz[ks][e] - ln2_mean) * ln2_rstd, ge = dg[ks][e] * gm[ks][e];
+            zz[ks][e] = xe; dg[ks][e] = ge;
+            s1 += ge; s2 += ge * xe;
+          }
+        }
+        ln2_c1 = quad_sum(s1) * (1.0f / HID); ln2_c2 = quad_sum(s2) * (1.0f / HID);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dg[ks][e] = ln2_rstd * (dg[ks][e] - ln2_c1 - zz[ks][e] * ln2_c2);
+      } else {
+        load_rows(p.dz2, tokc, g, dg);
+      }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         if (dctx.on) {
@@ -338,12 +383,33 @@ __global__ __launch_bounds__(64 * FW) void ffn_bwd_dx_kernel(FfnP p) {
     }
     // dx1 = acc + dz2 (the residual branch), then back through x1 = LN(z1)
     const float mean = p.mean1[tokc], rstd = p.rstd1[tokc];
-    const bool live = tok < p.N;
+    const bool live = j < Nn;
     f32x4 ge[4], xhat[4];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int hb = 0; hb < 4; ++hb) {
-      const f32x4 dx = acc[hb] + *reinterpret_cast<const f32x4*>(p.dz2 + rowo + 16 * hb);
+      f32x4 dz2e;   // dz2 of this lane's output columns 16 hb + 4g .. (the residual branch)
+      if (rowmode) {
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 dx2 = slot >= 0 ? *reinterpret_cast<const f32x4*>(p.dgr + (int64_t)slot * HID + 16 * hb + 4 * g) : zero4;
+        const f32x4 xh2 = (*reinterpret_cast<const f32x4*>(p.z2 + rowo + 16 * hb) - ln2_mean) * ln2_rstd;
+        const f32x4 g2v = *reinterpret_cast<const f32x4*>(p.g2 + 16 * hb + 4 * g);
+        dz2e = (dx2 * g2v - ln2_c1 - xh2 * ln2_c2) * ln2_rstd;
+        // gamma / beta sums of the output LayerNorm, and the compact dz2 for the weight-gradient kernel
+        f32x4 pg2 = live ? dx2 * xh2 : zero4, pb2 = live ? dx2 : zero4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { pg2[e] = row_sum15(pg2[e]); pb2[e] = row_sum15(pb2[e]); }
+        if (i == 15) {
+          f32x4* rg = reinterpret_cast<f32x4*>(myred2 + 16 * hb + 4 * g);
+          f32x4* rb = reinterpret_cast<f32x4*>(myred2 + 64 + 16 * hb + 4 * g);
+          *rg = *rg + pg2;
+          *rb = *rb + pb2;
+        }
+        if (live) *reinterpret_cast<f32x4*>(p.dz2c + (int64_t)j * HID + 16 * hb + 4 * g) = dz2e;
+      } else {
+        dz2e = *reinterpret_cast<const f32x4*>(p.dz2 + rowo + 16 * hb);
+      }
+      const f32x4 dx = acc[hb] + dz2e;
       const f32x4 zz = *reinterpret_cast<const f32x4*>(p.z1 + rowo + 16 * hb);
       const f32x4 gm = *reinterpret_cast<const f32x4*>(p.g1 + 16 * hb + 4 * g);
       xhat[hb] = (zz - mean) * rstd;
@@ -363,7 +429,7 @@ __global__ __launch_bounds__(64 * FW) void ffn_bwd_dx_kernel(FfnP p) {
       }
     }
     const float c1 = quad_sum(s1) * (1.0f / HID), c2 = quad_sum(s2) * (1.0f / HID);
-    if (live) {
+    if (live && (!rowmode || slot >= 0)) {   // an entry without a slot has dz1 = 0 exactly and may repeat another entry's row
 #pragma unroll
       for (int hb = 0; hb < 4; ++hb) {
         f32x4 dz;
@@ -380,6 +446,11 @@ __global__ __launch_bounds__(64 * FW) void ffn_bwd_dx_kernel(FfnP p) {
 #pragma unroll
     for (int w = 0; w < FW; ++w) r += sred[w * 128 + threadIdx.x];
     p.ln_part[(int64_t)blockIdx.x * 128 + threadIdx.x] = r;
+  } else if (threadIdx.x < 256 && rowmode) {
+    float r = 0.f;
+#pragma unroll
+    for (int w = 0; w < FW; ++w) r += sred[(FW + w) * 128 + threadIdx.x - 128];
+    p.ln2_part[(int64_t)blockIdx.x * 128 + threadIdx.x - 128] = r;
   }
 }
 
@@ -411,20 +482,25 @@ __global__ __launch_bounds__(64 * FW) void ffn_bwd_dw_kernel(FfnP p) {
   // staging role of this thread: threads 0..511 carry x1, 512..1023 carry dz2; one float4 of the chunk each
   const int sid = threadIdx.x & 511, stok = sid >> 4, sc4 = sid & 15;
   const bool is_dz = threadIdx.x >= 512;
-  const float* ssrc = is_dz ? p.dz2 : p.x1;
+  const bool rowmode = p.rows != nullptr;
+  const float* ssrc = is_dz ? (rowmode ? p.dz2c : p.dz2) : p.x1;
+  const int Nn = ffn_rows(p);
   const int soff = (is_dz ? CH_IMG : 0) + sub_base(stok >> 4, sc4 >> 3, 2) + sub_off(stok & 15, (sc4 & 7) >> 1) + 8 * (sc4 & 1);
-  const int nchunks = (p.N + CH_TOK - 1) / CH_TOK;
+  const int nchunks = (Nn + CH_TOK - 1) / CH_TOK;
   f32x4 sv;
+  int srow = 0;   // the row in the [N, 64] tensors (dropout index) of the staged piece
   f32x4 db2 = {0.f, 0.f, 0.f, 0.f};
   auto fetch = [&](int c) {
-    const int tok = min(CH_TOK * c + stok, p.N - 1);
-    sv = *reinterpret_cast<const f32x4*>(ssrc + (int64_t)tok * HID + 4 * sc4);
+    const int j = min(CH_TOK * c + stok, Nn - 1);
+    srow = ffn_row(p, j);
+    const int64_t src_row = (is_dz && rowmode) ? j : srow;   // the compact dz2 is indexed by j
+    sv = *reinterpret_cast<const f32x4*>(ssrc + src_row * HID + 4 * sc4);
   };
   auto put = [&](int c, int stage) {
-    const int tok = CH_TOK * c + stok;
+    const int j = CH_TOK * c + stok;
     f32x4 v = sv;
-    if (is_dz) v = b4r_drop4(dctx, v, (uint64_t)tok * HID + (uint64_t)(4 * sc4));
-    if (tok >= p.N) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (is_dz) v = b4r_drop4(dctx, v, (uint64_t)srow * HID + (uint64_t)(4 * sc4));
+    if (j >= Nn) v = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (is_dz) db2 += v;
     bf16x4 h, l;
     b4r_split4(v, h, l);
@@ -517,7 +593,7 @@ int ffn_grid(int units) {
 }
 
 constexpr size_t FWD_LDS = 2 * W_IMG + INNER * sizeof(float);
-constexpr size_t DX_LDS = FWD_LDS + FW * 128 * sizeof(float);
+constexpr size_t DX_LDS = FWD_LDS + 2 * FW * 128 * sizeof(float);
 
 FfnP make_p(const b4r_ffn_desc* d) {
   FfnP p{};
@@ -526,6 +602,7 @@ FfnP make_p(const b4r_ffn_desc* d) {
   p.dz2 = d->dz2; p.z1 = d->z1; p.mean1 = d->mean1; p.rstd1 = d->rstd1; p.g1 = d->ln1_gamma; p.dz1 = d->dz1;
   p.N = d->N; p.eps = d->ln_eps;
   p.drop = b4r_make_drop(d->rng, d->drop_stream, d->drop_rate, d->rng != nullptr);
+  p.rows = d->rows; p.n_dev = d->n_rows;
   return p;
 }
 
@@ -541,7 +618,7 @@ extern "C" int32_t b4r_ffn_block_supported(int32_t hidden_size, int32_t inner_di
 extern "C" int64_t b4r_ffn_block_bwd_scratch_floats(int32_t N) {
   const int64_t slabs = 256;   // an upper bound of the grid (one workgroup per CU)
   (void)N;
-  return slabs * (2 * HID * INNER + INNER + HID + 128);
+  return slabs * (2 * HID * INNER + INNER + HID + 128 + 128);
 }
 
 extern "C" int b4r_ffn_block_fwd(const b4r_ffn_desc* d, b4r_stream_t stream) {
@@ -553,10 +630,13 @@ extern "C" int b4r_ffn_block_fwd(const b4r_ffn_desc* d, b4r_stream_t stream) {
   B4R_CHECK_ARG(al16(d->x1) && al16(d->W1) && al16(d->W2) && al16(d->b2) && al16(d->ln_gamma) && al16(d->ln_beta) && al16(d->z2) &&
                     al16(d->x2),
                 B4R_E_ALIGN, "b4r_ffn_block_fwd: operands must be 16-byte aligned");
+  B4R_CHECK_ARG((d->rows == nullptr) == (d->n_rows == nullptr) && (d->rows == nullptr || d->max_rows > 0), B4R_E_BADARG,
+                "b4r_ffn_block_fwd: rows, n_rows and max_rows go together");
   const FfnP p = make_p(d);
+  const int units = d->rows ? d->max_rows : d->N;
   int rc = b4r_raise_lds((const void*)ffn_fwd_kernel, FWD_LDS, "b4r_ffn_block_fwd");
   if (rc) return rc;
-  hipLaunchKernelGGL(ffn_fwd_kernel, dim3(ffn_grid(b4r_cdiv(d->N, 16))), dim3(64 * FW), FWD_LDS, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(ffn_fwd_kernel, dim3(ffn_grid(b4r_cdiv(units, 16))), dim3(64 * FW), FWD_LDS, (hipStream_t)stream, p);
   B4R_CHECK_LAUNCH("b4r_ffn_block_fwd");
   return B4R_OK;
 }
@@ -568,21 +648,29 @@ extern "C" int b4r_ffn_block_bwd(const b4r_ffn_desc* d, b4r_stream_t stream) {
   B4R_CHECK_ARG(d != nullptr, B4R_E_BADARG, "b4r_ffn_block_bwd: null descriptor");
   B4R_CHECK_ARG(b4r_ffn_block_supported(d->H, d->I), B4R_E_SHAPE,
                 "b4r_ffn_block_bwd: needs hidden size 64, inner size 256 and the bf16x3 mode (H=%d I=%d)", d->H, d->I);
-  B4R_CHECK_ARG(d->N > 0 && d->x1 && d->W1 && d->b1 && d->W2 && d->dz2 && d->z1 && d->mean1 && d->rstd1 && d->ln1_gamma && d->dz1 &&
-                    d->dW1 && d->db1 && d->dW2 && d->db2 && d->dln1_gamma && d->scratch,
+  const bool rowmode = d->rows != nullptr;
+  B4R_CHECK_ARG(d->N > 0 && d->x1 && d->W1 && d->b1 && d->W2 && (d->dz2 || rowmode) && d->z1 && d->mean1 && d->rstd1 && d->ln1_gamma &&
+                    d->dz1 && d->dW1 && d->db1 && d->dW2 && d->db2 && d->dln1_gamma && d->scratch,
                 B4R_E_BADARG, "b4r_ffn_block_bwd: null argument");
+  B4R_CHECK_ARG(!rowmode || (d->n_rows && d->max_rows > 0 && d->row_slot && d->slot_grad && d->z2 && d->mean2 && d->rstd2 && d->ln_gamma &&
+                             d->dln_gamma && d->dz2_rows),
+                B4R_E_BADARG, "b4r_ffn_block_bwd: the row-list mode needs n_rows, max_rows, row_slot, slot_grad, z2, mean2, rstd2, "
+                "ln_gamma, dln_gamma and dz2_rows");
   B4R_CHECK_ARG(al16(d->x1) && al16(d->W1) && al16(d->W2) && al16(d->dz2) && al16(d->z1) && al16(d->ln1_gamma) && al16(d->dz1) &&
                     al16(d->scratch),
                 B4R_E_ALIGN, "b4r_ffn_block_bwd: operands must be 16-byte aligned");
   FfnP p = make_p(d);
   hipStream_t s = (hipStream_t)stream;
-  const int gdx = ffn_grid(b4r_cdiv(d->N, 16)), gdw = ffn_grid(b4r_cdiv(d->N, CH_TOK));
+  const int units = rowmode ? d->max_rows : d->N;
+  const int gdx = ffn_grid(b4r_cdiv(units, 16)), gdw = ffn_grid(b4r_cdiv(units, CH_TOK));
   float* sc = d->scratch;
   p.slab_w1 = sc; sc += (int64_t)gdw * HID * INNER;
   p.slab_w2 = sc; sc += (int64_t)gdw * HID * INNER;
   p.slab_b1 = sc; sc += (int64_t)gdw * INNER;
   p.slab_b2 = sc; sc += (int64_t)gdw * HID;
-  p.ln_part = sc;
+  p.ln_part = sc; sc += (int64_t)gdx * 128;
+  p.ln2_part = sc;
+  if (rowmode) { p.slotof = d->row_slot; p.dgr = d->slot_grad; p.dz2c = d->dz2_rows; }
   int rc = b4r_raise_lds((const void*)ffn_bwd_dx_kernel, DX_LDS, "b4r_ffn_block_bwd");
   if (rc) return rc;
   hipLaunchKernelGGL(ffn_bwd_dx_kernel, dim3(gdx), dim3(64 * FW), DX_LDS, s, p);
@@ -594,5 +682,7 @@ extern "C" int b4r_ffn_block_bwd(const b4r_ffn_desc* d, b4r_stream_t stream) {
   if (rc) return rc;
   rc = b4r_launch_slab_reduce_full(p.slab_w2, gdw, INNER, HID, d->dW2, HID, 0, p.slab_b2, d->db2, nullptr, nullptr, s);
   if (rc) return rc;
-  return b4r_launch_slab_reduce_full(p.ln_part, gdx, 1, 128, d->dln1_gamma, 128, 0, nullptr, nullptr, nullptr, nullptr, s);
+  rc = b4r_launch_slab_reduce_full(p.ln_part, gdx, 1, 128, d->dln1_gamma, 128, 0, nullptr, nullptr, nullptr, nullptr, s);
+  if (rc || !rowmode) return rc;
+  return b4r_launch_slab_reduce_full(p.ln2_part, gdx, 1, 128, d->dln_gamma, 128, 0, nullptr, nullptr, nullptr, nullptr, s);
 }

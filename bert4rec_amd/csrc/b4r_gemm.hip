@@ -325,8 +325,16 @@ __device__ __forceinline__ void slab_reduce_block(const ReduceJobView& job, int 
     if (vec) {
       if (e < total) {
         const float* src = job.slab + e;
-#pragma unroll 4
-        for (int z = zl; z < job.S; z += RZ) s += *reinterpret_cast<const f32x4*>(src + (int64_t)z * total);
+        // up to 16 slabs per wave (S <= 256): all loads of a wave in flight at once, summed in slab order
+        int z = zl;
+        for (; z + 7 * RZ < job.S; z += 8 * RZ) {
+          f32x4 v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (int64_t)(z + u * RZ) * total);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; z < job.S; z += RZ) s += *reinterpret_cast<const f32x4*>(src + (int64_t)z * total);
       }
     } else {
       for (int z = zl; z < job.S; z += RZ) {

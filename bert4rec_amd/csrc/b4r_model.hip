@@ -223,7 +223,8 @@ struct WsLayout {
       rstd1[B4R_MAX_LAYERS], x1[B4R_MAX_LAYERS], fpre[B4R_MAX_LAYERS], f[B4R_MAX_LAYERS], z2[B4R_MAX_LAYERS],
       mean2[B4R_MAX_LAYERS], rstd2[B4R_MAX_LAYERS], x2[B4R_MAX_LAYERS];
   int64_t gath, upre, u, meanm, rstdm, t, logits, rowsc, pooled, head_lse, head_ylab;
-  int64_t dx, hot, da, db, dctx, dqkv, df, dt, dg;   // hot directly behind dx: one memset clears both
+  int64_t dx, hot, da, db, dctx, dqkv, df, dt, dg;   // dx | hot | db adjacent: one fill clears dx + hot, or hot + db (row-list mode)
+  int64_t rows, nrows, rowslot, dz2c, maxrows;   // the rows the masked-LM head reads (b4r_mlm_rows), ints
   int64_t scratch, scratch_floats;
 };
 
@@ -246,7 +247,9 @@ WsLayout make_ws_layout(const b4r_model_config& c, int B, int L, int P) {
   w.gath = take(M * H); w.upre = take(M * H); w.u = take(M * H); w.meanm = take(M); w.rstdm = take(M);
   w.t = take(M * H); w.logits = take(M * w.Vp); w.rowsc = take(4 * M); w.pooled = take((int64_t)B * H);
   w.head_lse = take(M); w.head_ylab = take(M);
-  w.dx = take(N * H); w.hot = take(b4r_scatter_hot_scratch_floats(3, (int)H)); w.da = take(N * H); w.db = take(N * H); w.dctx = take(N * H);
+  w.dx = take(N * H); w.hot = take(b4r_scatter_hot_scratch_floats(3, (int)H)); w.db = take(N * H); w.da = take(N * H); w.dctx = take(N * H);
+  w.maxrows = M;
+  w.rows = take(w.maxrows); w.nrows = take(4); w.rowslot = take(w.maxrows); w.dz2c = take(w.maxrows * H);
   w.dqkv = take(N * 3 * H); w.df = take(N * I); w.dt = take(M * H); w.dg = take(M * H);
   // scratch: every two-stage reduction of the backward pass keeps its partials until the single deferred reduce launch,
   // so the regions are summed (not max-ed); the two immediate reductions (split-K dT, position table) have their own
@@ -361,6 +364,12 @@ bool attn_fused(const b4r_model_config* c, int L) {
 bool attn_bwd_fused(const b4r_model_config* c, int L) {
   static const bool on = !(getenv("B4R_ATTN_BWD_FUSED") && atoi(getenv("B4R_ATTN_BWD_FUSED")) == 0);
   return on && attn_fused(c, L) && b4r_attn_block_bwd_supported(c->hidden_size, c->num_heads, L) != 0;
+}
+
+// B4R_FLAG_HEAD_ROWS_ONLY is honoured where the last layer's feed-forward half runs as the fused block and the row list fits
+bool head_rows_ok(const b4r_model_config* c, const b4r_batch* b) {
+  static const bool on = !(getenv("B4R_HEAD_ROWS") && atoi(getenv("B4R_HEAD_ROWS")) == 0);
+  return on && ffn_fused(c) && b->masked_lm_positions && b->masked_lm_ids && b->P > 0;
 }
 
 // pair kernels (input gradient inside the weight-gradient kernel, b4r_gemm_tn_desc.dgrad_*): B4R_PAIR bit 0 = the 64 x 64 layers
@@ -519,6 +528,11 @@ extern "C" int b4r_forward(const b4r_model_config* cfg, const b4r_batch* batch, 
 
   RC(b4r_embed_ln_fwd(batch->input_word_ids, B, L, params + pl.word_emb, V, params + pl.pos_emb, params + pl.emb_ln_g,
                       params + pl.emb_ln_b, H, cfg->ln_eps, ws + w.x0, ws + w.mean0, ws + w.rstd0, rng, od, stream));
+  const bool head_rows = (flags & B4R_FLAG_HEAD_ROWS_ONLY) && head_rows_ok(cfg, batch);
+  int32_t* ws_i = reinterpret_cast<int32_t*>(ws);
+  if (head_rows)   // the rows of the last layer's output that the head will gather (valid and padded slots)
+    RC(b4r_mlm_rows(batch->masked_lm_positions, batch->masked_lm_ids, B, L, batch->P, ws_i + w.rows, ws_i + w.nrows, ws_i + w.rowslot,
+                    stream));
   const float* x = ws + w.x0;
   for (int i = 0; i < cfg->num_layers; ++i) {
     if (attn_fused(cfg, L)) {
@@ -548,6 +562,9 @@ extern "C" int b4r_forward(const b4r_model_config* cfg, const b4r_batch* batch, 
       fd.ln_gamma = params + pl.ln2_g[i]; fd.ln_beta = params + pl.ln2_b[i]; fd.ln_eps = cfg->ln_eps;
       fd.rng = od > 0.f ? rng : nullptr; fd.drop_stream = B4R_STREAM_FFN_OUT(i); fd.drop_rate = od;
       fd.z2 = ws + w.z2[i]; fd.x2 = ws + w.x2[i]; fd.mean2 = ws + w.mean2[i]; fd.rstd2 = ws + w.rstd2[i];
+      if (head_rows && i == cfg->num_layers - 1) {   // only the rows the head reads: nothing else of this output is looked at
+        fd.rows = ws_i + w.rows; fd.n_rows = ws_i + w.nrows; fd.max_rows = (int32_t)w.maxrows;
+      }
       RC(b4r_ffn_block_fwd(&fd, stream));
     } else {
     RC(gemm(ws + w.x1[i], H, params + pl.w1[i], I, ws + w.f[i], I, N, I, H, 0, B4R_EPI_BIAS_GELU, params + pl.b1[i],
@@ -663,9 +680,13 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
   B4rReduceQueue queue;
   b4r_reduce_queue_begin(&queue);   // every ordered reduction below is summed by ONE launch at the end
 
-  // the gradient buffer; dx and the scatter's hot-row slots; with B4R_FLAG_GRAD_TAIL also the step's sums behind the gradients
+  // the gradient buffer; dx and the scatter's hot-row slots (row-list mode: the hot-row slots and db, whose rows outside the list
+  // carry no gradient); with B4R_FLAG_GRAD_TAIL also the step's sums behind the gradients
   B4R_CHECK_ARG(!(flags & B4R_FLAG_GRAD_TAIL) || state, B4R_E_BADARG, "b4r_backward: B4R_FLAG_GRAD_TAIL needs the state");
-  RC(b4r_zero2(grads, pl.total, ws + w.dx, w.da - w.dx, s, (flags & B4R_FLAG_GRAD_TAIL) ? grads + pl.total : nullptr, state));
+  const bool head_rows = (flags & B4R_FLAG_HEAD_ROWS_ONLY) && head_rows_ok(cfg, batch);
+  int32_t* ws_i = reinterpret_cast<int32_t*>(ws);
+  RC(b4r_zero2(grads, pl.total, ws + (head_rows ? w.hot : w.dx), head_rows ? w.da - w.hot : w.db - w.dx, s,
+               (flags & B4R_FLAG_GRAD_TAIL) ? grads + pl.total : nullptr, state));
 
   // ---- masked-LM head (logits buffer holds d loss_sum / d logits, pad columns zero) --------------------------------
   // s2: independent branches (see SideStream); it is ordered after the memsets here, joined before every reuse of a buffer
@@ -718,8 +739,10 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
               nullptr, 0, 0.f, 0, s));
     }
   }
-  // scatter into d sequence_output (slots with y_true == 0 carry exactly zero gradient and are skipped)
-  RC(b4r_scatter_add_rows_impl(ws + w.dg, batch->masked_lm_positions, L, P, M, H, ws + w.dx, H, batch->masked_lm_ids, N, 0, nullptr, s));
+  // scatter into d sequence_output (slots with y_true == 0 carry exactly zero gradient and are skipped); in the row-list mode the last
+  // layer's feed-forward backward reads the slot gradients directly
+  if (!head_rows)
+    RC(b4r_scatter_add_rows_impl(ws + w.dg, batch->masked_lm_positions, L, P, M, H, ws + w.dx, H, batch->masked_lm_ids, N, 0, nullptr, s));
 
   // ---- encoder layers, last to first ---------------------------------------------------------------------------------
   const int64_t ln_scratch = std::max(b4r_ln_bwd_scratch_floats(N, H), b4r_gemm_ln_bwd_partial_floats(N));
@@ -727,7 +750,8 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
     const float* x_in = (i == 0) ? ws + w.x0 : ws + w.x2[i - 1];
     RC(order_after(s_tn, s));   // the branches of the previous layer still read da / df / db / dqkv, which this layer rewrites
     // output LayerNorm (for every layer but the last its backward rode on the QKV input-gradient product of layer i + 1)
-    if (i == cfg->num_layers - 1)
+    const bool rows_here = head_rows && i == cfg->num_layers - 1;
+    if (i == cfg->num_layers - 1 && !rows_here)
       RC(b4r_ln_bwd_launch(ws + w.dx, ws + w.z2[i], ws + w.mean2[i], ws + w.rstd2[i], params + pl.ln2_g[i], N, H, ws + w.da,
                            grads + pl.ln2_g[i], grads + pl.ln2_b[i], take(ln_scratch), nullptr, nullptr, nullptr, 1, 1, nodrop, s));
     if (ffn_fused(cfg)) {
@@ -742,6 +766,12 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
       fd.dW1 = grads + pl.w1[i]; fd.db1 = grads + pl.b1[i]; fd.dW2 = grads + pl.w2[i]; fd.db2 = grads + pl.b2[i];
       fd.dln1_gamma = grads + pl.ln1_g[i];
       fd.scratch = take(b4r_ffn_block_bwd_scratch_floats(N));
+      if (rows_here) {   // the output LayerNorm's backward runs inside, on the rows with a gradient; dz1 elsewhere stays zero
+        fd.dz2 = nullptr;
+        fd.rows = ws_i + w.rows; fd.n_rows = ws_i + w.nrows; fd.max_rows = (int32_t)w.maxrows; fd.row_slot = ws_i + w.rowslot;
+        fd.slot_grad = ws + w.dg; fd.z2 = ws + w.z2[i]; fd.mean2 = ws + w.mean2[i]; fd.rstd2 = ws + w.rstd2[i];
+        fd.ln_gamma = params + pl.ln2_g[i]; fd.dln_gamma = grads + pl.ln2_g[i]; fd.dz2_rows = ws + w.dz2c;
+      }
       RC(b4r_ffn_block_bwd(&fd, stream));
     } else {
     // FFN: dFpre = (dropmask(dz2) . W2^T) * gelu'(fpre) and dW2 = f^T . dropmask(dz2) (+ bias gradient): one pass over dz2
@@ -877,11 +907,13 @@ extern "C" int b4r_train_step(const b4r_model_config* cfg, const b4r_adamw_confi
                               b4r_train_state* state, b4r_stream_t stream) {
   const int fused = b4r_fused_head_supported(cfg) ? 1 : 0;   // the train step never needs the logits themselves
   // no b4r_state_begin_step launch: the loss reduction overwrites the sums (B4R_LOSS_OVERWRITE)
+  // nothing but the loss, the metrics and the gradients leave a train step: the last layer's feed-forward half runs on the rows the
+  // head gathers only (B4R_FLAG_HEAD_ROWS_ONLY; the same flag goes to forward and backward)
   RC(b4r_forward(cfg, batch, params, nullptr, workspace, workspace_bytes, state,
-                 B4R_FLAG_TRAINING | (fused ? B4R_FLAG_FUSED_HEAD : 0), stream));
+                 B4R_FLAG_TRAINING | B4R_FLAG_HEAD_ROWS_ONLY | (fused ? B4R_FLAG_FUSED_HEAD : 0), stream));
   RC(b4r_loss(cfg, batch, workspace, workspace_bytes, state, 1 | B4R_LOSS_OVERWRITE | (fused ? B4R_LOSS_FUSED_HEAD : 0), stream));
   RC(b4r_backward(cfg, batch, params, grads, workspace, workspace_bytes, state,
-                  B4R_FLAG_TRAINING | (fused ? B4R_FLAG_FUSED_HEAD : 0), stream));
+                  B4R_FLAG_TRAINING | B4R_FLAG_HEAD_ROWS_ONLY | (fused ? B4R_FLAG_FUSED_HEAD : 0), stream));
   RC(b4r_optimizer_step(cfg, hp, params, grads, adam_m, adam_v, workspace, workspace_bytes, state, stream));
   return B4R_OK;
 }

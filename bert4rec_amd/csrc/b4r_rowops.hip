@@ -926,6 +926,31 @@ extern "C" int b4r_mask_batch(const int64_t* tokens, const int64_t* row_index, c
 }
 
 // -----------------------------------------------------------------------------------------------------------
+// the rows the masked-LM head reads (b4r_mlm_rows): one entry per masked-LM slot
+// -----------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mlm_rows_kernel(const int64_t* pos, const int64_t* ids, int L, int P, int M, int* rows, int* n_rows,
+                                                       int* row_slot) {
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m == 0) *n_rows = M;
+  if (m >= M) return;
+  const int64_t q = pos[m];
+  rows[m] = (m / P) * L + (q < 0 ? 0 : (q >= L ? L - 1 : (int)q));   // out-of-range positions are clamped like b4r_gather_rows
+  row_slot[m] = ids[m] != 0 ? m : -1;
+}
+
+extern "C" int b4r_mlm_rows(const int64_t* masked_lm_positions, const int64_t* masked_lm_ids, int32_t B, int32_t L, int32_t P, int32_t* rows,
+                            int32_t* n_rows, int32_t* row_slot, b4r_stream_t stream) {
+  B4R_CHECK_ARG(masked_lm_positions && masked_lm_ids && rows && n_rows && row_slot, B4R_E_BADARG, "b4r_mlm_rows: null argument");
+  B4R_CHECK_ARG(B > 0 && L > 0 && P > 0 && (int64_t)B * L < (1ll << 31) && (int64_t)B * P < (1ll << 31), B4R_E_SHAPE,
+                "b4r_mlm_rows: bad shape (B=%d L=%d P=%d)", B, L, P);
+  const int M = B * P;
+  hipLaunchKernelGGL(mlm_rows_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, masked_lm_positions, masked_lm_ids, L, P, M,
+                     rows, n_rows, row_slot);
+  B4R_CHECK_LAUNCH("b4r_mlm_rows");
+  return B4R_OK;
+}
+
+// -----------------------------------------------------------------------------------------------------------
 // negative sampling for the evaluator: one workgroup per ranked slot
 // -----------------------------------------------------------------------------------------------------------
 // Weighted sampling without replacement (what np.random.choice(vocab, size, False, p) followed by dropping the excluded

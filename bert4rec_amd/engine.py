@@ -291,12 +291,14 @@ class Engine:
         """train-step masked-LM head that never materialises the logits (include/b4r.h, B4R_FLAG_FUSED_HEAD)"""
         return bool(self.lib.b4r_fused_head_supported(C.byref(self.cfg)))
 
-    def forward(self, cb: Batch, training: bool = False, pooler: bool = True, fused_head: bool = False) -> None:
+    def forward(self, cb: Batch, training: bool = False, pooler: bool = True, fused_head: bool = False,
+                head_rows_only: bool = False) -> None:
         """fused_head: the loss / backward of the same step must be called with fused_head=True as well, and the
-        "mlm_logits" region is not written"""
+        "mlm_logits" region is not written.  head_rows_only (train steps: forward AND backward): the last layer's feed-forward half
+        only on the rows the masked-LM head gathers; "sequence_output" is then defined on those rows only."""
         ws = self.workspace(cb.B, cb.L, cb.P)
         flags = (_lib.FLAG_TRAINING if training else 0) | (_lib.FLAG_POOLER if pooler else 0) | \
-                (_lib.FLAG_FUSED_HEAD if fused_head else 0)
+                (_lib.FLAG_FUSED_HEAD if fused_head else 0) | (_lib.FLAG_HEAD_ROWS_ONLY if head_rows_only else 0)
         _lib.check(self.lib.b4r_forward(C.byref(self.cfg), C.byref(cb), _ptr(self.params), _ptr(self.pooler), _ptr(ws),
                                         ws.numel() * 4, _ptr(self.state), flags, _stream(self.device)), "b4r_forward")
 
@@ -309,12 +311,14 @@ class Engine:
                                      (1 if want_grad else 0) | (_lib.LOSS_FUSED_HEAD if fused_head else 0),
                                      _stream(self.device)), "b4r_loss")
 
-    def backward(self, cb: Batch, training: bool = True, fused_head: bool = False, grad_tail: bool = False) -> None:
-        """grad_tail: also write the step's sums behind the gradients (data-parallel steps all-reduce grad_ext as one buffer)"""
+    def backward(self, cb: Batch, training: bool = True, fused_head: bool = False, grad_tail: bool = False,
+                 head_rows_only: bool = False) -> None:
+        """grad_tail: also write the step's sums behind the gradients (data-parallel steps all-reduce grad_ext as one buffer);
+        head_rows_only: as given to the forward of the same step"""
         self.ensure_training_buffers()
         ws = self.workspace(cb.B, cb.L, cb.P)
         flags = (_lib.FLAG_TRAINING if training else 0) | (_lib.FLAG_FUSED_HEAD if fused_head else 0) | \
-                (_lib.FLAG_GRAD_TAIL if grad_tail else 0)
+                (_lib.FLAG_GRAD_TAIL if grad_tail else 0) | (_lib.FLAG_HEAD_ROWS_ONLY if head_rows_only else 0)
         _lib.check(self.lib.b4r_backward(C.byref(self.cfg), C.byref(cb), _ptr(self.params), _ptr(self.grads), _ptr(ws),
                                          ws.numel() * 4, _ptr(self.state), flags, _stream(self.device)), "b4r_backward")
 
@@ -381,9 +385,9 @@ class Engine:
             g_pre, g_post = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_pre, capture_error_mode=_CAPTURE_MODE):
                 self.begin_step()
-                self.forward(cb, training=True, pooler=False, fused_head=fused)
+                self.forward(cb, training=True, pooler=False, fused_head=fused, head_rows_only=True)
                 self.loss(cb, want_grad=True, fused_head=fused)
-                self.backward(cb, training=True, fused_head=fused, grad_tail=True)
+                self.backward(cb, training=True, fused_head=fused, grad_tail=True, head_rows_only=True)
             with torch.cuda.graph(g_post, capture_error_mode=_CAPTURE_MODE):
                 self.optimizer_step(hp, cb, reduced=True)
             pair = graphs[key] = (g_pre, g_post)
@@ -398,9 +402,9 @@ class Engine:
         self.ensure_training_buffers()
         fused = self.fused_head_supported()
         self.begin_step()
-        self.forward(cb, training=True, pooler=False, fused_head=fused)
+        self.forward(cb, training=True, pooler=False, fused_head=fused, head_rows_only=True)
         self.loss(cb, want_grad=True, fused_head=fused)
-        self.backward(cb, training=True, fused_head=fused, grad_tail=True)
+        self.backward(cb, training=True, fused_head=fused, grad_tail=True, head_rows_only=True)
         allreduce_step(self.grad_ext, group, self.rehearse_collectives)
         self.optimizer_step(hp, cb, reduced=True)
 

@@ -136,6 +136,12 @@ int b4r_workspace_region(const b4r_model_config* cfg, int32_t B, int32_t L, int3
  * all-reduces ONE flat buffer [gradients | sums] and then calls b4r_optimizer_step_reduced, which takes the
  * reduced sums from there.  No copy kernels around the collective. */
 #define B4R_FLAG_GRAD_TAIL 8
+/* b4r_forward + b4r_backward of one TRAIN step (both or neither): the last encoder layer's feed-forward half is evaluated only on the
+ * rows of the sequence output that the masked-LM head gathers (about P/L of them: 20 % at ML-1M) -- forward and backward.  Loss, metrics
+ * and every gradient are unchanged (the other rows of that output reach neither the loss nor, through attention, any row that does);
+ * "sequence_output" / "encoder_output_<last>" are then only defined on those rows, which is why the forward / evaluation API never sets
+ * the flag.  b4r_train_step uses it; ignored where the fused feed-forward block does not apply. */
+#define B4R_FLAG_HEAD_ROWS_ONLY 16
 #define B4R_LOSS_FUSED_HEAD 2
 #define B4R_LOSS_OVERWRITE 4 /* b4r_loss: set the state's sums instead of adding to them (= b4r_state_begin_step first) */
 int32_t b4r_fused_head_supported(const b4r_model_config* cfg);
@@ -419,7 +425,24 @@ typedef struct b4r_ffn_desc {
   float* dz1;                                       /* [N,H] */
   float* dW1; float* db1; float* dW2; float* db2; float* dln1_gamma;
   float* scratch;
+  /* optional ROW LIST (all NULL / 0 otherwise): the block only processes rows rows[j], j < *n_rows (a DEVICE count; max_rows is its
+   * host-side bound, used to size the launch).  The last encoder layer of a TRAIN step needs its feed-forward half only on the rows
+   * the masked-LM head gathers (b4r_mlm_rows): the forward then writes x2 / z2 / mean2 / rstd2 of those rows only, and the backward
+   * takes, instead of dz2, the head's gradient per masked-LM slot slot_grad [B*P,H] and row_slot[j] (the slot whose gradient entry j
+   * carries, -1: none; rows may repeat among the entries with -1, never among the others): it forms dz2 = LayerNorm'(gradient of
+   * x2) itself from z2 / mean2 / rstd2 / ln_gamma (inputs here), returns that LayerNorm's dgamma | dbeta in dln_gamma [128], writes
+   * dz1 ONLY at the rows of entries with a slot (the caller zero-fills the rest: those rows carry no gradient) and uses dz2_rows
+   * [max_rows,H] as scratch. */
+  const int32_t* rows; const int32_t* n_rows; int32_t max_rows;
+  const int32_t* row_slot; const float* slot_grad; float* dln_gamma; float* dz2_rows;
 } b4r_ffn_desc;
+/* The rows of the sequence output that the masked-LM head of this batch reads, one entry per masked-LM slot m = b*P + p:
+ * rows[m] = b*L + clamp(position[m]) (padded slots gather position 0, as tfm MaskedLM does: their entries repeat a row, which the
+ * forward then writes more than once with the same values), row_slot[m] = m where masked_lm_ids[m] != 0, else -1 (no gradient:
+ * the backward writes nothing for that entry), *n_rows = B*P.  Two valid slots of one sequence never share a position
+ * (dataloader_utils.py:221-226 samples positions without replacement), so every row has at most one entry that writes dz1. */
+int b4r_mlm_rows(const int64_t* masked_lm_positions, const int64_t* masked_lm_ids, int32_t B, int32_t L, int32_t P, int32_t* rows,
+                 int32_t* n_rows, int32_t* row_slot, b4r_stream_t stream);
 int32_t b4r_ffn_block_supported(int32_t hidden_size, int32_t inner_dim);
 int64_t b4r_ffn_block_bwd_scratch_floats(int32_t N);
 int b4r_ffn_block_fwd(const b4r_ffn_desc* d, b4r_stream_t stream);

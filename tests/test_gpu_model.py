@@ -84,14 +84,17 @@ def test_forward_matches_oracle(name, ragged):
     assert d < 2e-4, d
 
 
-def run_loss_and_grads(eng, batch, training, seed=0, step=0, fused_head=False):
+def run_loss_and_grads(eng, batch, training, seed=0, step=0, fused_head=False, head_rows_only=None):
+    """fused_head=True runs what b4r_train_step runs: the logits-free head AND the last layer's feed-forward half restricted to the
+    rows the head gathers (B4R_FLAG_HEAD_ROWS_ONLY); False the materialising head on all rows."""
     cb, keep = eng.prepare_batch(batch)
     eng.set_seed(seed)
     eng.set_step(step)
     eng.begin_step()
-    eng.forward(cb, training=training, pooler=False, fused_head=fused_head)
+    rows = fused_head if head_rows_only is None else head_rows_only
+    eng.forward(cb, training=training, pooler=False, fused_head=fused_head, head_rows_only=rows)
     eng.loss(cb, want_grad=True, fused_head=fused_head)
-    eng.backward(cb, training=training, fused_head=fused_head)
+    eng.backward(cb, training=training, fused_head=fused_head, head_rows_only=rows)
     torch.cuda.synchronize()
     st = eng.read_state()
     return st, eng.export_named(eng.grads)

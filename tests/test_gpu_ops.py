@@ -796,3 +796,22 @@ def test_fused_mlm_head_at_the_ml20m_vocabulary_matches_fp64_autograd():
     assert T.maxdiff(dT, T64.grad) < 1e-4
     assert T.maxdiff(dE, E64.grad) < 1e-4 * max(1.0, float(E64.grad.abs().max()))
     assert T.maxdiff(db, b64.grad) < 1e-4
+
+
+@pytest.mark.parametrize("B,L,P", [(256, 200, 40), (7, 37, 5), (1, 16, 3), (256, 50, 20)])
+def test_mlm_rows_lists_the_rows_the_head_gathers(B, L, P):
+    """b4r_mlm_rows: one entry per slot, rows[m] = b*L + clamp(position), row_slot[m] = m for slots with an id, -1 for padded ones"""
+    lib = _lib.load()
+    batch = orc.synthetic_batch(B, L, P, 500, seed=B + L, ragged=True)
+    pos, ids = batch["masked_lm_positions"].clone(), batch["masked_lm_ids"].clone()
+    pos[0, -1], ids[0, -1] = L + 5, 0        # out of range on a padded slot: clamped like the gather
+    want_rows = (torch.arange(B)[:, None] * L + pos.clamp(0, L - 1)).reshape(-1).tolist()
+    want_slot = [m if int(v) != 0 else -1 for m, v in enumerate(ids.reshape(-1).tolist())]
+    rows = torch.full((B * P,), -7, dtype=torch.int32, device=DEV)
+    slot = torch.full((B * P,), -7, dtype=torch.int32, device=DEV)
+    n = torch.zeros(1, dtype=torch.int32, device=DEV)
+    pd, idd = pos.to(DEV), ids.to(DEV)
+    _lib.check(lib.b4r_mlm_rows(T.P(pd), T.P(idd), B, L, P, T.P(rows), T.P(n), T.P(slot), stream()))
+    torch.cuda.synchronize()
+    assert int(n.cpu()[0]) == B * P
+    assert rows.cpu().tolist() == want_rows and slot.cpu().tolist() == want_slot

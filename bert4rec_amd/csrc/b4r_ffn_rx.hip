@@ -129,13 +129,24 @@ struct FfnP {
   // compact index j -> row rows[j], j < *n_dev.  slotof[j]: the valid masked-LM slot of row j (-1: none), dgr [M,64] the
   // gradient per slot; then dz2 is formed in the kernel as the output LayerNorm's backward of that row (z2 / mean2 / rstd2 / g2)
   const int* rows; const int* n_dev; const int* slotof; const float* dgr;
+  // ... or the list in its implicit form (slot mode): entry j = masked-LM slot j of n_slots, row (j / sP) * sL + clamp(spos[j]),
+  // slot j where sids[j] != 0
+  const int64_t* spos; const int64_t* sids; int sP, sL, n_slots;
   float* dz2c;      // [cap,64] compact dz2 for the weight-gradient kernel
   float* ln2_part;  // [grid][128] gamma / beta partials of the output LayerNorm
 };
 
 // number of (compact) rows and the actual row of compact index j
-__device__ __forceinline__ int ffn_rows(const FfnP& p) { return p.n_dev ? *p.n_dev : p.N; }
-__device__ __forceinline__ int ffn_row(const FfnP& p, int j) { return p.rows ? p.rows[j] : j; }
+__device__ __forceinline__ int ffn_rows(const FfnP& p) { return p.spos ? p.n_slots : (p.n_dev ? *p.n_dev : p.N); }
+__device__ __forceinline__ int ffn_row(const FfnP& p, int j) {
+  if (p.spos) {
+    const int64_t q = p.spos[j];
+    return (j / p.sP) * p.sL + (q < 0 ? 0 : (q >= p.sL ? p.sL - 1 : (int)q));   // clamped like b4r_gather_rows
+  }
+  return p.rows ? p.rows[j] : j;
+}
+__device__ __forceinline__ bool ffn_listed(const FfnP& p) { return p.rows != nullptr || p.spos != nullptr; }
+__device__ __forceinline__ int ffn_slot(const FfnP& p, int j) { return p.spos ? (p.sids[j] != 0 ? j : -1) : p.slotof[j]; }
 
 __device__ __forceinline__ float sum4(const f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
 __device__ __forceinline__ float quad_sum(float s) {   // over the four lanes i, i+16, i+32, i+48 that share a token
@@ -290,7 +301,7 @@ __global__ __launch_bounds__(64 * FW) void ffn_bwd_dx_kernel(FfnP p) {
   const DropCtx dctx = b4r_drop_ctx(p.drop);
   const int Nn = ffn_rows(p);
   const int ntiles = (Nn + 15) >> 4;
-  const bool rowmode = p.slotof != nullptr;
+  const bool rowmode = p.slotof != nullptr || p.spos != nullptr;
   // LayerNorm gamma / beta sums of this wave live in its 128 floats of LDS (32 more live registers per lane spilled 37 VGPRs to
   // scratch: 30 MB of extra HBM writes per launch in profiles/r02_a)
   float* myred = sred + wave * 128;
@@ -305,7 +316,7 @@ __global__ __launch_bounds__(64 * FW) void ffn_bwd_dx_kernel(FfnP p) {
     const int tok = ffn_row(p, jc), tokc = tok;
     const int64_t rowo = (int64_t)tokc * HID + 4 * g;
     // row-list mode: dz2 = LN2'(dx2) with dx2 = the head's gradient of this row's slot (zero if the row only serves padded slots)
-    const int slot = rowmode ? p.slotof[jc] : -1;
+    const int slot = rowmode ? ffn_slot(p, jc) : -1;
     float ln2_mean = 0.f, ln2_rstd = 0.f, ln2_c1 = 0.f, ln2_c2 = 0.f;
     bf16x8 xh[2], xl[2], gh[2], gl[2];
     {
@@ -482,7 +493,7 @@ __global__ __launch_bounds__(64 * FW) void ffn_bwd_dw_kernel(FfnP p) {
   // staging role of this thread: threads 0..511 carry x1, 512..1023 carry dz2; one float4 of the chunk each
   const int sid = threadIdx.x & 511, stok = sid >> 4, sc4 = sid & 15;
   const bool is_dz = threadIdx.x >= 512;
-  const bool rowmode = p.rows != nullptr;
+  const bool rowmode = ffn_listed(p);
   const float* ssrc = is_dz ? (rowmode ? p.dz2c : p.dz2) : p.x1;
   const int Nn = ffn_rows(p);
   const int soff = (is_dz ? CH_IMG : 0) + sub_base(stok >> 4, sc4 >> 3, 2) + sub_off(stok & 15, (sc4 & 7) >> 1) + 8 * (sc4 & 1);
@@ -603,10 +614,18 @@ FfnP make_p(const b4r_ffn_desc* d) {
   p.N = d->N; p.eps = d->ln_eps;
   p.drop = b4r_make_drop(d->rng, d->drop_stream, d->drop_rate, d->rng != nullptr);
   p.rows = d->rows; p.n_dev = d->n_rows;
+  p.spos = d->slot_positions; p.sids = d->slot_ids; p.sP = d->slots_per_seq; p.sL = d->seq_len; p.n_slots = d->max_rows;
   return p;
 }
 
 bool al16(const void* q) { return q == nullptr || b4r_aligned16(q); }
+
+// slot mode: all of its fields or none, never together with an explicit list, the rows it names inside [0, N)
+bool slot_mode_ok(const b4r_ffn_desc* d) {
+  if (d->slot_positions == nullptr) return d->slot_ids == nullptr;
+  return d->slot_ids && d->rows == nullptr && d->n_rows == nullptr && d->slots_per_seq > 0 && d->seq_len > 0 && d->max_rows > 0 &&
+         d->max_rows % d->slots_per_seq == 0 && (int64_t)(d->max_rows / d->slots_per_seq) * d->seq_len <= d->N;
+}
 
 }  // namespace
 
@@ -632,8 +651,10 @@ extern "C" int b4r_ffn_block_fwd(const b4r_ffn_desc* d, b4r_stream_t stream) {
                 B4R_E_ALIGN, "b4r_ffn_block_fwd: operands must be 16-byte aligned");
   B4R_CHECK_ARG((d->rows == nullptr) == (d->n_rows == nullptr) && (d->rows == nullptr || d->max_rows > 0), B4R_E_BADARG,
                 "b4r_ffn_block_fwd: rows, n_rows and max_rows go together");
+  B4R_CHECK_ARG(slot_mode_ok(d), B4R_E_BADARG,
+                "b4r_ffn_block_fwd: the slot mode needs slot_positions, slot_ids, slots_per_seq, seq_len, max_rows and no explicit list");
   const FfnP p = make_p(d);
-  const int units = d->rows ? d->max_rows : d->N;
+  const int units = (d->rows || d->slot_positions) ? d->max_rows : d->N;
   int rc = b4r_raise_lds((const void*)ffn_fwd_kernel, FWD_LDS, "b4r_ffn_block_fwd");
   if (rc) return rc;
   hipLaunchKernelGGL(ffn_fwd_kernel, dim3(ffn_grid(b4r_cdiv(units, 16))), dim3(64 * FW), FWD_LDS, (hipStream_t)stream, p);
@@ -648,11 +669,14 @@ extern "C" int b4r_ffn_block_bwd(const b4r_ffn_desc* d, b4r_stream_t stream) {
   B4R_CHECK_ARG(d != nullptr, B4R_E_BADARG, "b4r_ffn_block_bwd: null descriptor");
   B4R_CHECK_ARG(b4r_ffn_block_supported(d->H, d->I), B4R_E_SHAPE,
                 "b4r_ffn_block_bwd: needs hidden size 64, inner size 256 and the bf16x3 mode (H=%d I=%d)", d->H, d->I);
-  const bool rowmode = d->rows != nullptr;
+  const bool slotmode = d->slot_positions != nullptr;
+  const bool rowmode = d->rows != nullptr || slotmode;
+  B4R_CHECK_ARG(slot_mode_ok(d), B4R_E_BADARG,
+                "b4r_ffn_block_bwd: the slot mode needs slot_positions, slot_ids, slots_per_seq, seq_len, max_rows and no explicit list");
   B4R_CHECK_ARG(d->N > 0 && d->x1 && d->W1 && d->b1 && d->W2 && (d->dz2 || rowmode) && d->z1 && d->mean1 && d->rstd1 && d->ln1_gamma &&
                     d->dz1 && d->dW1 && d->db1 && d->dW2 && d->db2 && d->dln1_gamma && d->scratch,
                 B4R_E_BADARG, "b4r_ffn_block_bwd: null argument");
-  B4R_CHECK_ARG(!rowmode || (d->n_rows && d->max_rows > 0 && d->row_slot && d->slot_grad && d->z2 && d->mean2 && d->rstd2 && d->ln_gamma &&
+  B4R_CHECK_ARG(!rowmode || ((slotmode || (d->n_rows && d->row_slot)) && d->max_rows > 0 && d->slot_grad && d->z2 && d->mean2 && d->rstd2 && d->ln_gamma &&
                              d->dln_gamma && d->dz2_rows),
                 B4R_E_BADARG, "b4r_ffn_block_bwd: the row-list mode needs n_rows, max_rows, row_slot, slot_grad, z2, mean2, rstd2, "
                 "ln_gamma, dln_gamma and dz2_rows");
@@ -662,7 +686,9 @@ extern "C" int b4r_ffn_block_bwd(const b4r_ffn_desc* d, b4r_stream_t stream) {
   FfnP p = make_p(d);
   hipStream_t s = (hipStream_t)stream;
   const int units = rowmode ? d->max_rows : d->N;
-  const int gdx = ffn_grid(b4r_cdiv(units, 16)), gdw = ffn_grid(b4r_cdiv(units, CH_TOK));
+  // the weight-gradient grid: the fewest workgroups (= partial slabs) that keep the longest workgroup's chunk count
+  const int chunks = b4r_cdiv(units, CH_TOK), per_wg = b4r_cdiv(chunks, ffn_grid(chunks));
+  const int gdx = ffn_grid(b4r_cdiv(units, 16)), gdw = b4r_cdiv(chunks, per_wg);
   float* sc = d->scratch;
   p.slab_w1 = sc; sc += (int64_t)gdw * HID * INNER;
   p.slab_w2 = sc; sc += (int64_t)gdw * HID * INNER;

@@ -312,29 +312,61 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnP p) {
 // order: bitwise reproducible.  16-byte loads need (Mo * No) % 4 == 0 and 16-byte aligned slabs (the model's scratch
 // regions are); otherwise the same lanes fall back to 4 scalar loads per slab (same summation order).
 constexpr int RZ = 16;
-constexpr int RE = 256;   // elements per workgroup
+constexpr int RE = 256;    // elements per workgroup when the slabs are shared out over the waves
+constexpr int RQ = 4096;   // elements per workgroup when every thread walks all (<= 16) slabs itself
 typedef B4rReduceJob ReduceJobView;
+__device__ __forceinline__ int reduce_mat_blocks(int S, int64_t total) { return (int)((total + (S <= RZ ? RQ : RE) - 1) / (S <= RZ ? RQ : RE)); }
+__device__ __forceinline__ void reduce_store(const ReduceJobView& job, int64_t eo, float r) {
+  const int row = (int)(eo / job.No), col = (int)(eo % job.No);
+  float* o = job.out + (int64_t)row * job.ldo + col;
+  *o = job.accumulate ? (*o + r) : r;
+}
 __device__ __forceinline__ void slab_reduce_block(const ReduceJobView& job, int block, float (*sp)[RE]) {
   const int64_t total = (int64_t)job.Mo * job.No;
-  const int mat_blocks = (int)((total + RE - 1) / RE);
+  const int mat_blocks = reduce_mat_blocks(job.S, total);
   const int lane = threadIdx.x & 63, zl = threadIdx.x >> 6;
+  const bool vec = (total % 4 == 0) && ((reinterpret_cast<uintptr_t>(job.slab) & 15) == 0);   // block-uniform
+  if (block < mat_blocks && job.S <= RZ) {
+    // few slabs (the head's table gradient: 16 slabs of V x H): a thread owns 4 elements and reads all slabs itself, every load in
+    // flight at once.  Same value as the shared-out form below: there wave z's partial sum is slab z alone.
+    const int64_t e = (int64_t)block * RQ + 4 * (int64_t)threadIdx.x;
+    if (e >= total) return;
+    f32x4 v[RZ];
+#pragma unroll
+    for (int z = 0; z < RZ; ++z) {
+      v[z] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (z < job.S) {
+        if (vec) v[z] = *reinterpret_cast<const f32x4*>(job.slab + (int64_t)z * total + e);
+        else
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (e + k < total) v[z][k] = job.slab[(int64_t)z * total + e + k];
+      }
+    }
+    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int z = 0; z < RZ; ++z) r += v[z];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (e + k < total) reduce_store(job, e + k, r[k]);
+    return;
+  }
   if (block < mat_blocks) {
     const int64_t e = (int64_t)block * RE + 4 * lane;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    const bool vec = (total % 4 == 0) && ((reinterpret_cast<uintptr_t>(job.slab) & 15) == 0);   // block-uniform
     if (vec) {
       if (e < total) {
         const float* src = job.slab + e;
-        // up to 16 slabs per wave (S <= 256): all loads of a wave in flight at once, summed in slab order
-        int z = zl;
-        for (; z + 7 * RZ < job.S; z += 8 * RZ) {
+        // up to 16 slabs per wave (S <= 256): all loads of a wave in flight at once (slabs past the end read as zero), summed
+        // in slab order
+        for (int z = zl; z < job.S; z += 8 * RZ) {
           f32x4 v[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(src + (int64_t)(z + u * RZ) * total);
+          for (int u = 0; u < 8; ++u)
+            v[u] = z + u * RZ < job.S ? *reinterpret_cast<const f32x4*>(src + (int64_t)(z + u * RZ) * total) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int u = 0; u < 8; ++u) s += v[u];
         }
-        for (; z < job.S; z += RZ) s += *reinterpret_cast<const f32x4*>(src + (int64_t)z * total);
       }
     } else {
       for (int z = zl; z < job.S; z += RZ) {
@@ -352,9 +384,7 @@ __device__ __forceinline__ void slab_reduce_block(const ReduceJobView& job, int 
         float r = 0.f;
 #pragma unroll
         for (int z = 0; z < RZ; ++z) r += sp[z][l];
-        const int row = (int)(eo / job.No), col = (int)(eo % job.No);
-        float* o = job.out + (int64_t)row * job.ldo + col;
-        *o = job.accumulate ? (*o + r) : r;
+        reduce_store(job, eo, r);
       }
     }
     return;
@@ -368,7 +398,13 @@ __device__ __forceinline__ void slab_reduce_block(const ReduceJobView& job, int 
   else if (e < n_cs + n_csa) { src = job.caslab; stride = job.Mo; idx = e - n_cs; }
   float s = 0.f;
   if (src) {
-    for (int z = zl; z < job.S; z += RZ) s += src[(int64_t)z * stride + idx];
+    for (int z = zl; z < job.S; z += 8 * RZ) {   // 8 loads in flight, summed in slab order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = z + u * RZ < job.S ? src[(int64_t)(z + u * RZ) * stride + idx] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
   }
   sp[zl][lane] = s;
   __syncthreads();
@@ -386,8 +422,8 @@ __global__ __launch_bounds__(64 * RZ) void slab_reduce_kernel(ReduceJobView job)
   slab_reduce_block(job, (int)blockIdx.x, sp);
 }
 
-int slab_reduce_grid(int Mo, int No, bool cs, bool csa) {
-  return b4r_cdiv((int64_t)Mo * No, RE) + b4r_cdiv((int64_t)(cs ? No : 0) + (csa ? Mo : 0), 64);
+int slab_reduce_grid(int S, int Mo, int No, bool cs, bool csa) {
+  return b4r_cdiv((int64_t)Mo * No, S <= RZ ? RQ : RE) + b4r_cdiv((int64_t)(cs ? No : 0) + (csa ? Mo : 0), 64);
 }
 
 int tn_split(int R, int Mo, int No) {
@@ -431,7 +467,7 @@ int dispatch_epi(const GemmP& p, int epi, int a_drop, dim3 grid, hipStream_t s) 
 int b4r_launch_slab_reduce(const float* slab, int S, int Mo, int No, float* out, int ldo, int accumulate,
                            hipStream_t stream) {
   ReduceJobView job{slab, nullptr, nullptr, out, nullptr, nullptr, S, Mo, No, ldo, accumulate};
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(slab_reduce_grid(Mo, No, false, false)), dim3(64 * RZ), 0, stream, job);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(slab_reduce_grid(S, Mo, No, false, false)), dim3(64 * RZ), 0, stream, job);
   B4R_CHECK_LAUNCH("slab_reduce");
   return B4R_OK;
 }
@@ -470,7 +506,7 @@ int b4r_reduce_queue_flush(hipStream_t stream) {
   for (int j = 0; j < q->n; ++j) {
     p.jobs[j] = q->jobs[j];
     p.block_begin[j] = blocks;
-    blocks += slab_reduce_grid(q->jobs[j].Mo, q->jobs[j].No, q->jobs[j].colsum != nullptr, q->jobs[j].colsum_a != nullptr);
+    blocks += slab_reduce_grid(q->jobs[j].S, q->jobs[j].Mo, q->jobs[j].No, q->jobs[j].colsum != nullptr, q->jobs[j].colsum_a != nullptr);
   }
   p.block_begin[q->n] = blocks;
   hipLaunchKernelGGL(multi_slab_reduce_kernel, dim3(blocks), dim3(64 * RZ), 0, stream, p);
@@ -483,7 +519,7 @@ int b4r_launch_slab_reduce_full(const float* slab, int S, int Mo, int No, float*
   B4rReduceJob job{slab, cslab, caslab, out, colsum, colsum_a, S, Mo, No, ldo, accumulate};
   if (b4r_reduce_queue_push(job)) return B4R_OK;
   ReduceJobView view{slab, cslab, caslab, out, colsum, colsum_a, S, Mo, No, ldo, accumulate};
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(slab_reduce_grid(Mo, No, colsum != nullptr, colsum_a != nullptr)), dim3(64 * RZ),
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(slab_reduce_grid(S, Mo, No, colsum != nullptr, colsum_a != nullptr)), dim3(64 * RZ),
                      0, stream, view);
   B4R_CHECK_LAUNCH("slab_reduce");
   return B4R_OK;

@@ -224,7 +224,7 @@ struct WsLayout {
       mean2[B4R_MAX_LAYERS], rstd2[B4R_MAX_LAYERS], x2[B4R_MAX_LAYERS];
   int64_t gath, upre, u, meanm, rstdm, t, logits, rowsc, pooled, head_lse, head_ylab;
   int64_t dx, hot, da, db, dctx, dqkv, df, dt, dg;   // dx | hot | db adjacent: one fill clears dx + hot, or hot + db (row-list mode)
-  int64_t rows, nrows, rowslot, dz2c, maxrows;   // the rows the masked-LM head reads (b4r_mlm_rows), ints
+  int64_t dz2c, maxrows;   // row-list mode of the last layer's feed-forward half: one entry per masked-LM slot
   int64_t scratch, scratch_floats;
 };
 
@@ -249,7 +249,7 @@ WsLayout make_ws_layout(const b4r_model_config& c, int B, int L, int P) {
   w.head_lse = take(M); w.head_ylab = take(M);
   w.dx = take(N * H); w.hot = take(b4r_scatter_hot_scratch_floats(3, (int)H)); w.db = take(N * H); w.da = take(N * H); w.dctx = take(N * H);
   w.maxrows = M;
-  w.rows = take(w.maxrows); w.nrows = take(4); w.rowslot = take(w.maxrows); w.dz2c = take(w.maxrows * H);
+  w.dz2c = take(w.maxrows * H);
   w.dqkv = take(N * 3 * H); w.df = take(N * I); w.dt = take(M * H); w.dg = take(M * H);
   // scratch: every two-stage reduction of the backward pass keeps its partials until the single deferred reduce launch,
   // so the regions are summed (not max-ed); the two immediate reductions (split-K dT, position table) have their own
@@ -529,10 +529,6 @@ extern "C" int b4r_forward(const b4r_model_config* cfg, const b4r_batch* batch, 
   RC(b4r_embed_ln_fwd(batch->input_word_ids, B, L, params + pl.word_emb, V, params + pl.pos_emb, params + pl.emb_ln_g,
                       params + pl.emb_ln_b, H, cfg->ln_eps, ws + w.x0, ws + w.mean0, ws + w.rstd0, rng, od, stream));
   const bool head_rows = (flags & B4R_FLAG_HEAD_ROWS_ONLY) && head_rows_ok(cfg, batch);
-  int32_t* ws_i = reinterpret_cast<int32_t*>(ws);
-  if (head_rows)   // the rows of the last layer's output that the head will gather (valid and padded slots)
-    RC(b4r_mlm_rows(batch->masked_lm_positions, batch->masked_lm_ids, B, L, batch->P, ws_i + w.rows, ws_i + w.nrows, ws_i + w.rowslot,
-                    stream));
   const float* x = ws + w.x0;
   for (int i = 0; i < cfg->num_layers; ++i) {
     if (attn_fused(cfg, L)) {
@@ -563,7 +559,8 @@ extern "C" int b4r_forward(const b4r_model_config* cfg, const b4r_batch* batch, 
       fd.rng = od > 0.f ? rng : nullptr; fd.drop_stream = B4R_STREAM_FFN_OUT(i); fd.drop_rate = od;
       fd.z2 = ws + w.z2[i]; fd.x2 = ws + w.x2[i]; fd.mean2 = ws + w.mean2[i]; fd.rstd2 = ws + w.rstd2[i];
       if (head_rows && i == cfg->num_layers - 1) {   // only the rows the head reads: nothing else of this output is looked at
-        fd.rows = ws_i + w.rows; fd.n_rows = ws_i + w.nrows; fd.max_rows = (int32_t)w.maxrows;
+        fd.slot_positions = batch->masked_lm_positions; fd.slot_ids = batch->masked_lm_ids; fd.slots_per_seq = batch->P; fd.seq_len = L;
+        fd.max_rows = (int32_t)w.maxrows;
       }
       RC(b4r_ffn_block_fwd(&fd, stream));
     } else {
@@ -684,7 +681,6 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
   // carry no gradient); with B4R_FLAG_GRAD_TAIL also the step's sums behind the gradients
   B4R_CHECK_ARG(!(flags & B4R_FLAG_GRAD_TAIL) || state, B4R_E_BADARG, "b4r_backward: B4R_FLAG_GRAD_TAIL needs the state");
   const bool head_rows = (flags & B4R_FLAG_HEAD_ROWS_ONLY) && head_rows_ok(cfg, batch);
-  int32_t* ws_i = reinterpret_cast<int32_t*>(ws);
   RC(b4r_zero2(grads, pl.total, ws + (head_rows ? w.hot : w.dx), head_rows ? w.da - w.hot : w.db - w.dx, s,
                (flags & B4R_FLAG_GRAD_TAIL) ? grads + pl.total : nullptr, state));
 
@@ -768,7 +764,8 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
       fd.scratch = take(b4r_ffn_block_bwd_scratch_floats(N));
       if (rows_here) {   // the output LayerNorm's backward runs inside, on the rows with a gradient; dz1 elsewhere stays zero
         fd.dz2 = nullptr;
-        fd.rows = ws_i + w.rows; fd.n_rows = ws_i + w.nrows; fd.max_rows = (int32_t)w.maxrows; fd.row_slot = ws_i + w.rowslot;
+        fd.slot_positions = batch->masked_lm_positions; fd.slot_ids = batch->masked_lm_ids; fd.slots_per_seq = batch->P; fd.seq_len = L;
+        fd.max_rows = (int32_t)w.maxrows;
         fd.slot_grad = ws + w.dg; fd.z2 = ws + w.z2[i]; fd.mean2 = ws + w.mean2[i]; fd.rstd2 = ws + w.rstd2[i];
         fd.ln_gamma = params + pl.ln2_g[i]; fd.dln_gamma = grads + pl.ln2_g[i]; fd.dz2_rows = ws + w.dz2c;
       }

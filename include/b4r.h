@@ -435,6 +435,10 @@ typedef struct b4r_ffn_desc {
    * [max_rows,H] as scratch. */
   const int32_t* rows; const int32_t* n_rows; int32_t max_rows;
   const int32_t* row_slot; const float* slot_grad; float* dln_gamma; float* dz2_rows;
+  /* SLOT MODE: the same list in its implicit form, straight from the batch (no b4r_mlm_rows launch): entry j = masked-LM slot j of
+   * max_rows = B*P, rows[j] = (j / slots_per_seq) * seq_len + clamp(slot_positions[j]), row_slot[j] = j where slot_ids[j] != 0,
+   * else -1.  rows / n_rows / row_slot stay NULL. */
+  const int64_t* slot_positions; const int64_t* slot_ids; int32_t slots_per_seq, seq_len;
 } b4r_ffn_desc;
 /* The rows of the sequence output that the masked-LM head of this batch reads, one entry per masked-LM slot m = b*P + p:
  * rows[m] = b*L + clamp(position[m]) (padded slots gather position 0, as tfm MaskedLM does: their entries repeat a row, which the

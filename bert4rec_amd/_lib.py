@@ -147,6 +147,10 @@ PROTOTYPES = {
     "b4r_attn_block_bwd_scratch_floats": (_I64, [_I32]),
     "b4r_attn_block_bwd": (C.c_int, [C.POINTER(AttnBlockBwdDesc), _P]),
     "b4r_mlm_rows": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P, _P, _P]),
+    "b4r_encoder_layer_supported": (_I32, [_I32, _I32, _I32, _I32]),
+    "b4r_encoder_layer_bwd_scratch_floats": (_I64, [_I32]),
+    "b4r_encoder_layer_fwd": (C.c_int, [C.POINTER(AttnBlockDesc), C.POINTER(FfnDesc), _P]),
+    "b4r_encoder_layer_bwd": (C.c_int, [C.POINTER(FfnDesc), C.POINTER(AttnBlockBwdDesc), _P, _P, _P, _P, _P, _P]),
     "b4r_ffn_block_supported": (_I32, [_I32, _I32]),
     "b4r_ffn_block_bwd_scratch_floats": (_I64, [_I32]),
     "b4r_ffn_block_fwd": (C.c_int, [C.POINTER(FfnDesc), _P]),

@@ -665,7 +665,12 @@ extern "C" int b4r_ffn_block_fwd(const b4r_ffn_desc* d, b4r_stream_t stream) {
 int b4r_launch_slab_reduce_full(const float* slab, int S, int Mo, int No, float* out, int ldo, int accumulate,
                                 const float* cslab, float* colsum, const float* caslab, float* colsum_a, hipStream_t stream);
 
+// after_dx (optional): recorded between the two kernels -- dz1 is complete there, the weight gradients are not
+int b4r_ffn_block_bwd_marked(const b4r_ffn_desc* d, hipStream_t stream, hipEvent_t after_dx);
 extern "C" int b4r_ffn_block_bwd(const b4r_ffn_desc* d, b4r_stream_t stream) {
+  return b4r_ffn_block_bwd_marked(d, (hipStream_t)stream, nullptr);
+}
+int b4r_ffn_block_bwd_marked(const b4r_ffn_desc* d, hipStream_t stream, hipEvent_t after_dx) {
   B4R_CHECK_ARG(d != nullptr, B4R_E_BADARG, "b4r_ffn_block_bwd: null descriptor");
   B4R_CHECK_ARG(b4r_ffn_block_supported(d->H, d->I), B4R_E_SHAPE,
                 "b4r_ffn_block_bwd: needs hidden size 64, inner size 256 and the bf16x3 mode (H=%d I=%d)", d->H, d->I);
@@ -701,6 +706,10 @@ extern "C" int b4r_ffn_block_bwd(const b4r_ffn_desc* d, b4r_stream_t stream) {
   if (rc) return rc;
   hipLaunchKernelGGL(ffn_bwd_dx_kernel, dim3(gdx), dim3(64 * FW), DX_LDS, s, p);
   B4R_CHECK_LAUNCH("b4r_ffn_block_bwd (dx)");
+  if (after_dx != nullptr && hipEventRecord(after_dx, s) != hipSuccess) {
+    b4r_set_error("b4r_ffn_block_bwd: event record failed");
+    return B4R_E_HIP;
+  }
   hipLaunchKernelGGL(ffn_bwd_dw_kernel, dim3(gdw), dim3(64 * FW), 0, s, p);
   B4R_CHECK_LAUNCH("b4r_ffn_block_bwd (dw)");
   // ordered sums over the workgroups (queued when the caller collects its reductions into one launch)

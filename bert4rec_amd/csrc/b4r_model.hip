@@ -34,6 +34,7 @@ int b4r_head_rx_fwd_launch(const float* T, const float* E, const float* bias, co
                            float* scratch, float* dT, float* row_out, float* lse, int32_t* ylab, hipStream_t stream);
 int b4r_head_rx_dE_launch(const float* T, const float* E, const float* bias, const float* lse, const int32_t* ylab, int M, int V,
                           int H, float* scratch, float* dE, float* db, hipStream_t stream);
+int b4r_ffn_block_bwd_marked(const b4r_ffn_desc* d, hipStream_t stream, hipEvent_t after_dx);
 int b4r_ce_finalize_launch(const float* row_scratch, int M, b4r_train_state* state, int overwrite, hipStream_t stream);
 int b4r_attn_bwd_streams(const float* qkv, const int64_t* input_mask, const float* ctx, const float* lse, const float* dctx,
                          int32_t B, int32_t L, int32_t heads, float qscale, float* dqkv, const uint32_t* rng,
@@ -392,7 +393,7 @@ struct SideStream {
 };
 thread_local SideStream g_side;
 
-int side_level() {   // 0: off; 1: everything independent; 2: head dE + dK/dV; 3: head dE only
+int side_level() {   // 0: off; 1: everything independent; 2: head dE + dK/dV; 3: head dE only; 4: dWo / dWqkv of the fused-block path
   static const int lv = getenv("B4R_SIDE_STREAM") ? atoi(getenv("B4R_SIDE_STREAM")) : 0;
   return lv;
 }
@@ -421,6 +422,17 @@ int order_after(hipStream_t from, hipStream_t to) {
   return B4R_OK;
 }
 
+hipEvent_t side_event() { return g_side.ev[(g_side.next++) & 63]; }
+int side_mark(hipStream_t on, hipEvent_t* e) {
+  *e = side_event();
+  if (hipEventRecord(*e, on) != hipSuccess) { b4r_set_error("b4r_backward: event record failed"); return B4R_E_HIP; }
+  return B4R_OK;
+}
+int side_wait(hipStream_t s, hipEvent_t e) {
+  if (e != nullptr && hipStreamWaitEvent(s, e, 0) != hipSuccess) { b4r_set_error("b4r_backward: stream wait failed"); return B4R_E_HIP; }
+  return B4R_OK;
+}
+
 int gemm_tn(const float* A, int lda, const float* Bm, int ldb, float* out, int ldo, int R, int Mo, int No, float* colsum,
             float* colsum_a, const uint32_t* rng, uint32_t stream_id, float rate, int b_dropout, float* scratch,
             hipStream_t s) {
@@ -432,6 +444,37 @@ int gemm_tn(const float* A, int lda, const float* Bm, int ldb, float* out, int l
 }
 
 }  // namespace
+
+// ===============================================================================================================
+// one encoder layer = the attention block + the feed-forward block (include/b4r.h)
+extern "C" int32_t b4r_encoder_layer_supported(int32_t hidden_size, int32_t num_heads, int32_t inner_dim, int32_t L) {
+  return (b4r_attn_block_supported(hidden_size, num_heads, L) && b4r_attn_block_bwd_supported(hidden_size, num_heads, L) &&
+          b4r_ffn_block_supported(hidden_size, inner_dim)) ? 1 : 0;
+}
+extern "C" int64_t b4r_encoder_layer_bwd_scratch_floats(int32_t N) {
+  return b4r_gemm_tn_scratch_floats(N, 64, 64) + b4r_gemm_tn_scratch_floats(N, 64, 192);
+}
+extern "C" int b4r_encoder_layer_fwd(const b4r_attn_block_desc* attn, const b4r_ffn_desc* ffn, b4r_stream_t stream) {
+  B4R_CHECK_ARG(attn && ffn, B4R_E_BADARG, "b4r_encoder_layer_fwd: null descriptor");
+  B4R_CHECK_ARG(attn->x1 != nullptr && attn->x1 == ffn->x1 && (int64_t)attn->B * attn->L == ffn->N && attn->H == ffn->H, B4R_E_BADARG,
+                "b4r_encoder_layer_fwd: the attention half's x1 [B*L,H] must be the feed-forward half's input");
+  RC(b4r_attn_block_fwd(attn, stream));
+  return b4r_ffn_block_fwd(ffn, stream);
+}
+extern "C" int b4r_encoder_layer_bwd(const b4r_ffn_desc* ffn, const b4r_attn_block_bwd_desc* attn, float* dWo, float* dbo, float* dWqkv,
+                                     float* dbqkv, float* tn_scratch, b4r_stream_t stream) {
+  B4R_CHECK_ARG(attn && ffn && dWo && dbo && dWqkv && dbqkv && tn_scratch, B4R_E_BADARG, "b4r_encoder_layer_bwd: null argument");
+  B4R_CHECK_ARG(ffn->dz1 != nullptr && attn->dz1 == ffn->dz1 && (int64_t)attn->B * attn->L == ffn->N && attn->H == ffn->H, B4R_E_BADARG,
+                "b4r_encoder_layer_bwd: the feed-forward half's dz1 [B*L,H] must be the attention half's input gradient");
+  const int N = ffn->N, H = ffn->H;
+  hipStream_t s = (hipStream_t)stream;
+  RC(b4r_ffn_block_bwd(ffn, stream));
+  RC(gemm_tn(attn->ctx, H, attn->dz1, H, dWo, H, N, H, H, dbo, nullptr, attn->out_rate > 0.f ? attn->rng : nullptr, attn->out_stream,
+             attn->out_rate, 1, tn_scratch, s));
+  RC(b4r_attn_block_bwd(attn, stream));
+  return gemm_tn(attn->x, H, attn->dqkv, 3 * H, dWqkv, 3 * H, N, H, 3 * H, dbqkv, nullptr, nullptr, 0, 0.f, 0,
+                 tn_scratch + b4r_gemm_tn_scratch_floats(N, H, H), s);
+}
 
 // ===============================================================================================================
 extern "C" int64_t b4r_param_total_floats(const b4r_model_config* cfg) {
@@ -742,9 +785,12 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
 
   // ---- encoder layers, last to first ---------------------------------------------------------------------------------
   const int64_t ln_scratch = std::max(b4r_ln_bwd_scratch_floats(N, H), b4r_gemm_ln_bwd_partial_floats(N));
+  const bool side4 = side_level() == 4 && s2 != s && ffn_fused(cfg) && attn_bwd_fused(cfg, L);
+  hipEvent_t ev_dx = nullptr, ev_wo = nullptr, ev_wqkv = nullptr;
   for (int i = cfg->num_layers - 1; i >= 0; --i) {
     const float* x_in = (i == 0) ? ws + w.x0 : ws + w.x2[i - 1];
     RC(order_after(s_tn, s));   // the branches of the previous layer still read da / df / db / dqkv, which this layer rewrites
+    if (side4) RC(side_wait(s, ev_wo));   // dWo of the layer above reads db, which this layer's feed-forward backward rewrites
     // output LayerNorm (for every layer but the last its backward rode on the QKV input-gradient product of layer i + 1)
     const bool rows_here = head_rows && i == cfg->num_layers - 1;
     if (i == cfg->num_layers - 1 && !rows_here)
@@ -769,7 +815,12 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
         fd.slot_grad = ws + w.dg; fd.z2 = ws + w.z2[i]; fd.mean2 = ws + w.mean2[i]; fd.rstd2 = ws + w.rstd2[i];
         fd.ln_gamma = params + pl.ln2_g[i]; fd.dln_gamma = grads + pl.ln2_g[i]; fd.dz2_rows = ws + w.dz2c;
       }
-      RC(b4r_ffn_block_bwd(&fd, stream));
+      if (side4) {
+        ev_dx = side_event();
+        RC(b4r_ffn_block_bwd_marked(&fd, s, ev_dx));
+      } else {
+        RC(b4r_ffn_block_bwd(&fd, stream));
+      }
     } else {
     // FFN: dFpre = (dropmask(dz2) . W2^T) * gelu'(fpre) and dW2 = f^T . dropmask(dz2) (+ bias gradient): one pass over dz2
     // where the pair kernel applies (B4R_PAIR bit 1), else two products
@@ -799,8 +850,13 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
     if (attn_bwd_fused(cfg, L)) {
       // dWo = ctx^T . dropmask(dz1) (+ bias gradient); then the attention block's backward in one launch: dqkv and, through the
       // LayerNorm in front of this layer, da (for layer 0: through the embedding stage's dropout and LayerNorm)
+      if (side4) RC(side_wait(s2, ev_dx));   // next to the feed-forward weight-gradient kernel, which leaves room on every CU
       RC(gemm_tn(ws + w.ctx[i], H, ws + w.db, H, grads + pl.wo[i], H, N, H, H, grads + pl.bo[i], nullptr, rng, B4R_STREAM_ATTN_OUT(i),
-                 od, 1, take(b4r_gemm_tn_scratch_floats(N, H, H)), s));
+                 od, 1, take(b4r_gemm_tn_scratch_floats(N, H, H)), side4 ? s2 : s));
+      if (side4) {
+        RC(side_mark(s2, &ev_wo));
+        RC(side_wait(s, ev_wqkv));   // dWqkv of the layer above reads dqkv, which this launch rewrites
+      }
       b4r_attn_block_bwd_desc bd{};
       bd.B = B; bd.L = L; bd.H = H; bd.heads = cfg->num_heads;
       bd.x = x_in; bd.dz1 = ws + w.db; bd.ctx = ws + w.ctx[i]; bd.lse = ws + w.lse[i];
@@ -854,6 +910,13 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
       RC(dgrad_ln_bwd(ws + w.dqkv, 3 * H, params + pl.wqkv[i], 3 * H, ws + w.db, ws + w.da, N, H, nullptr, ws + w.mean0, ws + w.rstd0,
                       params + pl.emb_ln_g, grads + pl.emb_ln_g, grads + pl.emb_ln_b, take(ln_scratch), s, batch->input_word_ids,
                       params + pl.word_emb, params + pl.pos_emb, L, V, rng, B4R_STREAM_EMB, od));
+    }
+    if (side4 && attn_bwd_fused(cfg, L)) {   // next to the feed-forward backward of the layer below
+      RC(order_after(s, s2));
+      RC(gemm_tn(x_in, H, ws + w.dqkv, 3 * H, grads + pl.wqkv[i], 3 * H, N, H, 3 * H, grads + pl.bqkv[i], nullptr, nullptr, 0, 0.f,
+                 0, take(b4r_gemm_tn_scratch_floats(N, H, 3 * H)), s2));
+      RC(side_mark(s2, &ev_wqkv));
+      continue;
     }
     RC(order_after(s, s_tn));
     RC(gemm_tn(x_in, H, ws + w.dqkv, 3 * H, grads + pl.wqkv[i], 3 * H, N, H, 3 * H, grads + pl.bqkv[i], nullptr, nullptr, 0, 0.f,

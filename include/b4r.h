@@ -452,6 +452,22 @@ int64_t b4r_ffn_block_bwd_scratch_floats(int32_t N);
 int b4r_ffn_block_fwd(const b4r_ffn_desc* d, b4r_stream_t stream);
 int b4r_ffn_block_bwd(const b4r_ffn_desc* d, b4r_stream_t stream);
 
+/* ---- one whole encoder layer ---------------------------------------------------------------------------------------------
+ * One call of the Keras TransformerEncoderBlock (bert4rec_encoder.py:136-147 builds it post-LN, :220-222 calls it once per
+ * layer) and its backward, sequence-resident: the two halves above back to back, nothing of size [N, 3H], [N, inner] or
+ * [B, heads, L, L] crosses HBM in the forward, and the backward recomputes q / k / v and the pre-activation from x and x1.
+ *   b4r_encoder_layer_fwd: attn (x -> ctx, lse, keep_bits, z1, x1, mean1, rstd1) then ffn (x1 -> z2, x2, mean2, rstd2);
+ *     attn->x1 must be ffn->x1.  2 launches.
+ *   b4r_encoder_layer_bwd: ffn (dz2 -> dz1, dW1, db1, dW2, db2, dln1_gamma), dWo / dbo = ctx^T.dropmask(dz1) and its column sums,
+ *     attn (dz1 -> dqkv, dx_prev, dprev_gamma), dWqkv / dbqkv = x^T.dqkv.  attn->dz1 must be ffn->dz1.  5 launches + the ordered
+ *     reduction.  tn_scratch: b4r_encoder_layer_bwd_scratch_floats(B * L) floats, 16-byte aligned.
+ * b4r_encoder_layer_supported = both halves supported (hidden 64, 2 heads, inner 256, L <= 208, bf16x3 mode). */
+int32_t b4r_encoder_layer_supported(int32_t hidden_size, int32_t num_heads, int32_t inner_dim, int32_t L);
+int64_t b4r_encoder_layer_bwd_scratch_floats(int32_t N);
+int b4r_encoder_layer_fwd(const b4r_attn_block_desc* attn, const b4r_ffn_desc* ffn, b4r_stream_t stream);
+int b4r_encoder_layer_bwd(const b4r_ffn_desc* ffn, const b4r_attn_block_bwd_desc* attn, float* dWo, float* dbo, float* dWqkv,
+                          float* dbqkv, float* tn_scratch, b4r_stream_t stream);
+
 /* rows gather / scatter-add:  dst[i,:] = src[idx[i],:]   /   dst[idx[i],:] += src[i,:] (fp32 atomics) */
 int b4r_gather_rows(const float* src, int32_t src_ld, const int64_t* idx, int64_t idx_add_per, int32_t per,
                     int32_t n, int32_t H, float* dst, b4r_stream_t stream);

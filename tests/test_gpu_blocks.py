@@ -322,3 +322,85 @@ def test_attn_block_backward_matches_fp64_autograd(B, L, p_rate, o_rate, embed):
     torch.cuda.synchronize()
     for k, v in first.items():
         assert torch.equal(v, out[k]), k     # ordered accumulation of dK / dV in LDS: bitwise reproducible
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# one whole encoder layer = the two halves (b4r_encoder_layer_fwd / _bwd)
+# ---------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,L,rate", [(4, 200, 0.2), (3, 37, 0.0)])
+def test_encoder_layer_is_the_two_halves_plus_the_two_weight_gradient_products(B, L, rate):
+    """bert4rec_encoder.py:220-222 (one TransformerEncoderBlock call): the layer entry points give bit for bit what the halves give
+    when called one by one (each half is checked against fp64 autograd above), and the two products they add are
+    dWo = ctx^T . dropmask(dz1), dbo = its column sums, dWqkv = x^T . dqkv, dbqkv = column sums of dqkv."""
+    lib = _lib.load()
+    _lib.check(lib.b4r_set_gemm_mode(_lib.GEMM_BF16X3))
+    assert lib.b4r_encoder_layer_supported(64, 2, 256, L) == 1 and lib.b4r_encoder_layer_supported(64, 2, 512, L) == 0
+    seed, step, N = 77, 2, B * L
+    t, mask = attn_inputs(B, L, seed=L)
+    f = ffn_inputs(N, seed=L + 1)
+    g = {k: v.to(DEV) for k, v in {**t, **{k: f[k] for k in ("W1", "b1", "W2", "b2", "g2", "be2")}}.items()}
+    maskd = mask.to(DEV)
+    st = T.new_state(seed, step) if rate > 0 else None
+    dz2 = rnd(N, 64, seed=5).to(DEV)
+    zprev, gprev = rnd(N, 64, seed=6).to(DEV), (1.0 + 0.2 * rnd(64, seed=7)).to(DEV)
+    mean_p = zprev.mean(1).contiguous()
+    rstd_p = (zprev.var(1, unbiased=False) + 1e-12).rsqrt().contiguous()
+    bits = torch.zeros(lib.b4r_attn_keep_words(B, L, 2), dtype=torch.int32, device=DEV)
+    shapes = dict(ctx=(N, 64), lse=(B, 2, L), z1=(N, 64), x1=(N, 64), mean1=(N,), rstd1=(N,), z2=(N, 64), x2=(N, 64), mean2=(N,),
+                  rstd2=(N,), dz1=(N, 64), dW1=(64, 256), db1=(256,), dW2=(256, 64), db2=(64,), dln1=(128,), dqkv=(N, 192),
+                  da=(N, 64), dlnp=(128,), dWo=(64, 64), dbo=(64,), dWqkv=(64, 192), dbqkv=(192,))
+
+    def run(layer_calls):
+        o = {k: torch.full(s_, float("nan"), dtype=torch.float32, device=DEV) for k, s_ in shapes.items()}
+        bits.zero_()
+        ad = _lib.AttnBlockDesc()
+        ad.B, ad.L, ad.H, ad.heads = B, L, 64, 2
+        ad.x, ad.input_mask = P(g["x"]), P(maskd)
+        ad.Wqkv, ad.bqkv, ad.Wo, ad.bo = P(g["Wqkv"]), P(g["bqkv"]), P(g["Wo"]), P(g["bo"])
+        ad.ln_gamma, ad.ln_beta, ad.ln_eps = P(g["g1"]), P(g["be1"]), 1e-12
+        ad.rng, ad.probs_stream, ad.probs_rate, ad.out_stream, ad.out_rate = P(st), 1, rate, 2, rate
+        ad.ctx, ad.lse, ad.keep_bits = P(o["ctx"]), P(o["lse"]), P(bits)
+        ad.z1, ad.x1, ad.mean1, ad.rstd1 = P(o["z1"]), P(o["x1"]), P(o["mean1"]), P(o["rstd1"])
+        fd = _lib.FfnDesc()
+        fd.N, fd.H, fd.I = N, 64, 256
+        fd.x1, fd.W1, fd.b1, fd.W2, fd.b2 = P(o["x1"]), P(g["W1"]), P(g["b1"]), P(g["W2"]), P(g["b2"])
+        fd.ln_gamma, fd.ln_beta, fd.ln_eps = P(g["g2"]), P(g["be2"]), 1e-12
+        fd.rng, fd.drop_stream, fd.drop_rate = P(st), 3, rate
+        fd.z2, fd.x2, fd.mean2, fd.rstd2 = P(o["z2"]), P(o["x2"]), P(o["mean2"]), P(o["rstd2"])
+        fd.dz2, fd.z1, fd.mean1, fd.rstd1, fd.ln1_gamma = P(dz2), P(o["z1"]), P(o["mean1"]), P(o["rstd1"]), P(g["g1"])
+        fd.dz1, fd.dW1, fd.db1, fd.dW2, fd.db2, fd.dln1_gamma = P(o["dz1"]), P(o["dW1"]), P(o["db1"]), P(o["dW2"]), P(o["db2"]), P(o["dln1"])
+        scr_f = torch.empty(lib.b4r_ffn_block_bwd_scratch_floats(N), dtype=torch.float32, device=DEV)
+        fd.scratch = P(scr_f)
+        bd = _lib.AttnBlockBwdDesc()
+        bd.B, bd.L, bd.H, bd.heads = B, L, 64, 2
+        bd.x, bd.dz1, bd.ctx, bd.lse, bd.keep_bits, bd.input_mask = P(g["x"]), P(o["dz1"]), P(o["ctx"]), P(o["lse"]), P(bits), P(maskd)
+        bd.Wqkv, bd.bqkv, bd.Wo = P(g["Wqkv"]), P(g["bqkv"]), P(g["Wo"])
+        bd.rng, bd.probs_stream, bd.probs_rate, bd.out_stream, bd.out_rate = P(st), 1, rate, 2, rate
+        bd.prev_z, bd.prev_mean, bd.prev_rstd, bd.prev_gamma = P(zprev), P(mean_p), P(rstd_p), P(gprev)
+        scr_a = torch.empty(lib.b4r_attn_block_bwd_scratch_floats(B), dtype=torch.float32, device=DEV)
+        bd.dqkv, bd.dx_prev, bd.dprev_gamma, bd.scratch = P(o["dqkv"]), P(o["da"]), P(o["dlnp"]), P(scr_a)
+        scr_t = torch.empty(lib.b4r_encoder_layer_bwd_scratch_floats(N), dtype=torch.float32, device=DEV)
+        if layer_calls:
+            _lib.check(lib.b4r_encoder_layer_fwd(C.byref(ad), C.byref(fd), stream()), "b4r_encoder_layer_fwd")
+            _lib.check(lib.b4r_encoder_layer_bwd(C.byref(fd), C.byref(bd), P(o["dWo"]), P(o["dbo"]), P(o["dWqkv"]), P(o["dbqkv"]),
+                                                 P(scr_t), stream()), "b4r_encoder_layer_bwd")
+        else:
+            _lib.check(lib.b4r_attn_block_fwd(C.byref(ad), stream()))
+            _lib.check(lib.b4r_ffn_block_fwd(C.byref(fd), stream()))
+            _lib.check(lib.b4r_ffn_block_bwd(C.byref(fd), stream()))
+            _lib.check(lib.b4r_attn_block_bwd(C.byref(bd), stream()))
+        torch.cuda.synchronize()
+        return o
+
+    whole, halves = run(True), run(False)
+    for k in shapes:
+        if k not in ("dWo", "dbo", "dWqkv", "dbqkv"):
+            assert torch.equal(whole[k], halves[k]), k
+        assert bool(torch.isfinite(whole[k]).all()), k
+    dz1 = whole["dz1"].cpu().double()
+    if rate > 0:
+        dz1 = dz1 * orc.dropout_keep_mask((N, 64), rate, seed, step, 2).double() / (1 - rate)
+    ctx, x, dqkv = whole["ctx"].cpu().double(), t["x"].double(), whole["dqkv"].cpu().double()
+    for got, want, what in ((whole["dWo"], ctx.T @ dz1, "dWo"), (whole["dbo"], dz1.sum(0), "dbo"), (whole["dWqkv"], x.T @ dqkv, "dWqkv"),
+                            (whole["dbqkv"], dqkv.sum(0), "dbqkv")):
+        assert T.maxdiff(got, want) < 3e-5 * max(1.0, float(want.abs().max())), what

@@ -336,6 +336,13 @@ struct AbBwdP {
 #ifndef AB_EXP
 #define AB_EXP 0
 #endif
+// AB_PROF (tools/build_variant.sh ... -DAB_PROF): wave 0 of workgroup 0 stamps the shader clock at phase boundaries
+#ifdef AB_PROF
+__device__ long long g_ab_prof[64];
+#define AB_MARK(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_ab_prof[k] = clock64(); } while (0)
+#else
+#define AB_MARK(k) do { } while (0)
+#endif
 constexpr int BT = 8 * 1024;   // bytes of one token tile of the backward's LDS region
 constexpr int BX = 4 * IMG_BYTES;   // offset of the Q / dO images (later the accumulators) inside a tile
 
@@ -353,6 +360,15 @@ __device__ __forceinline__ bf16x4 tr_one(const char* a) {
   return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)a));
 }
 __device__ __forceinline__ bf16x8 row16(const char* a) { return *reinterpret_cast<const bf16x8*>(a); }
+// sum over the 16 lanes of a DPP row, valid in lane 15 of the row (four v_add_f32 with a row_shr modifier: a __shfl_xor butterfly
+// compiles to ds_bpermute_b32 and cost 5 us here)
+__device__ __forceinline__ float row_sum15(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));   // row_shr:1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));   // row_shr:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));   // row_shr:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));   // row_shr:8
+  return v;
+}
 
 template <bool EMBED>
 __global__ __launch_bounds__(1024) void attn_block_bwd_kernel(AbBwdP p) {
@@ -392,13 +408,16 @@ __global__ __launch_bounds__(1024) void attn_block_bwd_kernel(AbBwdP p) {
   for (int hb = 0; hb < 4; ++hb) dxacc[hb] = (f32x4){0.f, 0.f, 0.f, 0.f};
   f32x4 gq[2], gk[2], gv[2];   // dq (scaled), dk, dv of the head just finished: own tokens, interleaved feature tiles
 
+  AB_MARK(0);
   for (int hd = 0; hd <= 2; ++hd) {
     __syncthreads();   // the tile region is free (previous head done; first pass: sAdd / sbq written)
+    AB_MARK(1 + 10 * hd);
     if (!(AB_EXP & 8) || hd == 0) {
     stage_weight(R, p.Wqkv, HID, 3 * HID, nthreads);
     if (hd < 2) stage_weight(woimg, p.Wo, HID, HID, nthreads);
     }
     __syncthreads();
+    AB_MARK(2 + 10 * hd);
     if (hd > 0) {
       // dX^T[16 hb + ..][token] += Wqkv[.., features of head hd-1] . dqkv^T: A = rows of the Wqkv image (natural k order)
       const int ph = hd - 1;
@@ -416,6 +435,7 @@ __global__ __launch_bounds__(1024) void attn_block_bwd_kernel(AbBwdP p) {
         }
       }
     }
+    AB_MARK(3 + 10 * hd);
     if (hd == 2) break;
 
     // ---- q, k, v of this head for the wave's tokens (recomputed) and dctx = dropmask(dz1).Wo^T -------------------------
@@ -460,6 +480,7 @@ __global__ __launch_bounds__(1024) void attn_block_bwd_kernel(AbBwdP p) {
         dct[a] = c;
       }
     }
+    AB_MARK(4 + 10 * hd);
     // D = sum_c dctx * ctx over this head's 32 columns (the softmax backward's row term)
     float Dq;
     {
@@ -476,6 +497,7 @@ __global__ __launch_bounds__(1024) void attn_block_bwd_kernel(AbBwdP p) {
       wbits[1] = wi[64];
     }
     __syncthreads();   // every wave is done with the weight images
+    AB_MARK(5 + 10 * hd);
 
     // ---- own rows of the K, V, Q, dO images ------------------------------------------------------------------------------
     char* mytile = R + wave * BT;
@@ -510,6 +532,7 @@ __global__ __launch_bounds__(1024) void attn_block_bwd_kernel(AbBwdP p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(mytile + BX + j * 1024 + lane * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads();   // K / V rows of every tile are in place, every accumulator is zero
+    AB_MARK(6 + 10 * hd);
 
     // ---- the sweep: one 16 x 16 block of the score matrix per step ------------------------------------------------------------
     f32x4 dq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -547,6 +570,7 @@ __global__ __launch_bounds__(1024) void attn_block_bwd_kernel(AbBwdP p) {
       const char* rd = scratch + (4 * g + qq) * 32 + pp * 8;
       const bf16x4 dsTh = tr_one(rd), dsTl = tr_one(rd + 512), pdTh = tr_one(rd + 1024), pdTl = tr_one(rd + 1536);
       // dK_t^T[feature][key] += Q_w^T[feature][queries] . dS[queries][key] ;  dV_t^T += dO_w^T . Pd
+      // (LDS-side adds, ds_add_f32, were measured here: 12x slower than this read-modify-write)
       char* acc = R + t * BT + BX + lane * 16;
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
@@ -560,6 +584,7 @@ __global__ __launch_bounds__(1024) void attn_block_bwd_kernel(AbBwdP p) {
       }
       if (!(AB_EXP & 4)) __syncthreads();   // the next step adds into other tiles; fixed order of the additions into each tile
     }
+    AB_MARK(7 + 10 * hd);
     // results of this head for the wave's tokens
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
@@ -578,6 +603,7 @@ __global__ __launch_bounds__(1024) void attn_block_bwd_kernel(AbBwdP p) {
     }
   }
 
+  AB_MARK(30);
   // ---- dx = dX + dz1 (residual), then back through the LayerNorm (and, for layer 0, the dropout) that produced x -------------
   const DropCtx dce = b4r_drop_ctx(p.drop_e);
   const float mean = p.meanp[row0 + tokc], rstd = p.rstdp[row0 + tokc];
@@ -606,6 +632,7 @@ __global__ __launch_bounds__(1024) void attn_block_bwd_kernel(AbBwdP p) {
     dbet[hb] = live ? dx : zero;
   }
   const float c1 = quad_sum(s1) * (1.0f / HID), c2 = quad_sum(s2) * (1.0f / HID);
+  AB_MARK(32);
   if (live) {
 #pragma unroll
     for (int hb = 0; hb < 4; ++hb) {
@@ -615,22 +642,25 @@ __global__ __launch_bounds__(1024) void attn_block_bwd_kernel(AbBwdP p) {
       *reinterpret_cast<f32x4*>(p.da + (row0 + tok) * HID + 16 * hb + 4 * g) = dz;
     }
   }
+  AB_MARK(33);
 #pragma unroll
-  for (int hb = 0; hb < 4; ++hb) {
+  for (int hb = 0; hb < 4; ++hb) {   // column sums over the wave's 16 tokens
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float a = dgam[hb][e], bb = dbet[hb][e];
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); bb += __shfl_xor(bb, o, 64); }
-      if (i == 0) { sred[wave * 128 + 16 * hb + 4 * g + e] = a; sred[wave * 128 + 64 + 16 * hb + 4 * g + e] = bb; }
+    for (int e = 0; e < 4; ++e) { dgam[hb][e] = row_sum15(dgam[hb][e]); dbet[hb][e] = row_sum15(dbet[hb][e]); }
+    if (i == 15) {
+      *reinterpret_cast<f32x4*>(&sred[wave * 128 + 16 * hb + 4 * g]) = dgam[hb];
+      *reinterpret_cast<f32x4*>(&sred[wave * 128 + 64 + 16 * hb + 4 * g]) = dbet[hb];
     }
   }
+  AB_MARK(34);
   __syncthreads();
+  AB_MARK(35);
   for (int k = threadIdx.x; k < 128; k += nthreads) {   // a workgroup may be a single wave (L <= 16)
     float r = 0.f;
     for (int w = 0; w < KT; ++w) r += sred[w * 128 + k];
     p.ln_part[(int64_t)b * 128 + k] = r;
   }
+  AB_MARK(31);
 }
 
 size_t bwd_lds(int KT) {
@@ -657,6 +687,11 @@ extern "C" int32_t b4r_attn_block_supported(int32_t hidden_size, int32_t num_hea
 extern "C" int32_t b4r_attn_block_bwd_supported(int32_t hidden_size, int32_t num_heads, int32_t L) {
   return (b4r_attn_block_supported(hidden_size, num_heads, L) && L <= 208) ? 1 : 0;   // 10 KB of LDS per 16 tokens
 }
+#ifdef AB_PROF
+extern "C" int b4r_debug_ab_prof(long long* host_out) {   // 64 stamps of the last backward launch (after a device synchronisation)
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ab_prof), 64 * sizeof(long long)) == hipSuccess ? 0 : -4;
+}
+#endif
 extern "C" int64_t b4r_attn_block_bwd_scratch_floats(int32_t B) { return (int64_t)(B > 0 ? B : 0) * 128; }
 
 int b4r_launch_slab_reduce_full(const float* slab, int S, int Mo, int No, float* out, int ldo, int accumulate,

@@ -44,3 +44,17 @@ def timeit(f, reps=100):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / reps
 print("B %d L %d rate %.2f  attention block forward %.1f us  backward (+ LayerNorm partial reduce) %.1f us" % (B, L, rate, timeit(fwd), timeit(bwd)))
+if hasattr(lib, "b4r_debug_ab_prof"):   # a -DAB_PROF build: phase stamps of workgroup 0 (shader clock cycles -> us at 2.4 GHz is only a guess: print ratios too)
+    bwd(); torch.cuda.synchronize()
+    buf = (C.c_longlong * 64)()
+    lib.b4r_debug_ab_prof.argtypes = [C.c_void_p]
+    assert lib.b4r_debug_ab_prof(buf) == 0
+    t = list(buf)
+    names = {0: "start", 1: "h0 region free", 2: "h0 weights staged", 3: "h0 dX of prev head", 4: "h0 qkv+dctx recomputed", 5: "h0 loads+barrier",
+             6: "h0 images written+barrier", 7: "h0 sweep done", 11: "h1 region free (dqkv stored)", 12: "h1 weights staged", 13: "h1 dX",
+             14: "h1 qkv+dctx", 15: "h1 loads+barrier", 16: "h1 images+barrier", 17: "h1 sweep done", 21: "tail region free", 22: "tail weights staged",
+             23: "tail dX", 30: "before epilogue", 32: "epi: loads + row sums", 33: "epi: da stored", 34: "epi: column sums shuffled", 35: "epi: barrier", 31: "end"}
+    prev = t[0]
+    for k in sorted(names, key=lambda k: t[k]):
+        print("%-32s +%7d cycles  (total %8d)" % (names[k], t[k] - prev, t[k] - t[0]))
+        prev = t[k]

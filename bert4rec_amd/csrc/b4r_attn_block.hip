@@ -74,6 +74,16 @@ __device__ __forceinline__ f32x4 lo4(const f32x8 v) { return (f32x4){v[0], v[1],
 __device__ __forceinline__ f32x4 hi4(const f32x8 v) { return (f32x4){v[4], v[5], v[6], v[7]}; }
 
 // KTT: compile-time bound of the 16-key tiles (the score row lives in registers); block = 64 * KT threads, KT = ceil(L / 16)
+// AB_PROF (tools/build_variant.sh ... -DAB_PROF): wave 0 of workgroup 0 stamps the shader clock at phase boundaries
+#ifdef AB_PROF
+__device__ long long g_ab_prof[64];
+__device__ long long g_af_prof[16];
+#define AF_MARK(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_af_prof[k] = clock64(); } while (0)
+#define AB_MARK(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_ab_prof[k] = clock64(); } while (0)
+#else
+#define AB_MARK(k) do { } while (0)
+#define AF_MARK(k) do { } while (0)
+#endif
 template <int KTT>
 __global__ __launch_bounds__(1024) void attn_block_fwd_kernel(AbP p) {
   extern __shared__ __attribute__((aligned(16))) char smem_ab[];
@@ -91,6 +101,7 @@ __global__ __launch_bounds__(1024) void attn_block_fwd_kernel(AbP p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4, qq = i >> 2, pp = i & 3;
 
   // ---- phase 0: weights and the key mask ------------------------------------------------------------------------------
+  AF_MARK(0);
   const int tok = 16 * wave + i, tokc = min(tok, L - 1);
   const float amax = b4r_seq_amax(p.mask + row0, L);
   f32x8 xv[2];
@@ -104,7 +115,9 @@ __global__ __launch_bounds__(1024) void attn_block_fwd_kernel(AbP p) {
   bf16x8 xh[2], xl[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) split8(xv[ks], xh[ks], xl[ks]);
+  AF_MARK(1);
   __syncthreads();
+  AF_MARK(2);
 
   // ---- phase 1: q, k, v of this wave's 16 tokens.  Tile a of feature block fb holds features 32 fb + 8p + 4a + e on its
   // rows 4p + e, so that a stacked pair is a B operand in natural feature order (b4r_ffn_rx.hip) ---------------------------
@@ -137,7 +150,9 @@ __global__ __launch_bounds__(1024) void attn_block_fwd_kernel(AbP p) {
   bf16x8 qh[2], ql[2];
 #pragma unroll
   for (int hd = 0; hd < 2; ++hd) split8(cat(qkv[hd][0], qkv[hd][1]), qh[hd], ql[hd]);
+  AF_MARK(3);
   __syncthreads();   // every wave is done with the Wqkv image: the K / V images may overwrite it
+  AF_MARK(4);
 
   // ---- phase 2: this wave's rows of the K / V images (zero rows for pad tokens), and the zero tiles beyond KT ----------
 #pragma unroll
@@ -164,7 +179,9 @@ __global__ __launch_bounds__(1024) void attn_block_fwd_kernel(AbP p) {
       *reinterpret_cast<f32x4*>(big + hd * KTE * TILE_BYTES + kt_live * TILE_BYTES + 16 * r) = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
   }
+  AF_MARK(5);
   __syncthreads();
+  AF_MARK(6);
 
   // ---- phase 3: attention per head (attn_rx_fwd_kernel's body) --------------------------------------------------------------
   const FragAddr fa = frag_addr(lane);
@@ -173,6 +190,7 @@ __global__ __launch_bounds__(1024) void attn_block_fwd_kernel(AbP p) {
 #pragma unroll
   for (int hd = 0; hd < 2; ++hd) {
     const char* img = big + hd * KTE * TILE_BYTES;
+    AF_MARK(7 + hd);
     f32x4 acc[KTE];
 #pragma unroll
     for (int t = 0; t < KTE; ++t) {
@@ -234,6 +252,7 @@ __global__ __launch_bounds__(1024) void attn_block_fwd_kernel(AbP p) {
       }
     }
   }
+  AF_MARK(9);
   if (live && p.ctx) {
     float* dst = p.ctx + (row0 + tok) * HID + 4 * g;
 #pragma unroll
@@ -260,6 +279,7 @@ __global__ __launch_bounds__(1024) void attn_block_fwd_kernel(AbP p) {
       y[hb] = mfma3(tr_pair(t0, t1), tr_pair(t0 + SUB, t1 + SUB), ch, cl, y[hb]);
     }
   }
+  AF_MARK(10);
   const DropCtx dco = b4r_drop_ctx(p.drop_o);
   f32x4 z[4];
   float s = 0.f;
@@ -278,6 +298,7 @@ __global__ __launch_bounds__(1024) void attn_block_fwd_kernel(AbP p) {
     q += sum4(d * d);
   }
   const float rstd = rsqrtf(quad_sum(q) * (1.0f / HID) + p.eps);
+  AF_MARK(11);
   if (live) {
 #pragma unroll
     for (int hb = 0; hb < 4; ++hb) {
@@ -298,6 +319,7 @@ __global__ __launch_bounds__(1024) void attn_block_fwd_kernel(AbP p) {
       if (p.rstd1) p.rstd1[row0 + tok] = rstd;
     }
   }
+  AF_MARK(12);
 }
 
 // -----------------------------------------------------------------------------------------------------------
@@ -335,13 +357,6 @@ struct AbBwdP {
 // 8 = one weight staging instead of three
 #ifndef AB_EXP
 #define AB_EXP 0
-#endif
-// AB_PROF (tools/build_variant.sh ... -DAB_PROF): wave 0 of workgroup 0 stamps the shader clock at phase boundaries
-#ifdef AB_PROF
-__device__ long long g_ab_prof[64];
-#define AB_MARK(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_ab_prof[k] = clock64(); } while (0)
-#else
-#define AB_MARK(k) do { } while (0)
 #endif
 constexpr int BT = 8 * 1024;   // bytes of one token tile of the backward's LDS region
 constexpr int BX = 4 * IMG_BYTES;   // offset of the Q / dO images (later the accumulators) inside a tile
@@ -688,6 +703,9 @@ extern "C" int32_t b4r_attn_block_bwd_supported(int32_t hidden_size, int32_t num
   return (b4r_attn_block_supported(hidden_size, num_heads, L) && L <= 208) ? 1 : 0;   // 10 KB of LDS per 16 tokens
 }
 #ifdef AB_PROF
+extern "C" int b4r_debug_af_prof(long long* host_out) {   // 16 stamps of the last forward launch
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_af_prof), 16 * sizeof(long long)) == hipSuccess ? 0 : -4;
+}
 extern "C" int b4r_debug_ab_prof(long long* host_out) {   // 64 stamps of the last backward launch (after a device synchronisation)
   return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ab_prof), 64 * sizeof(long long)) == hipSuccess ? 0 : -4;
 }

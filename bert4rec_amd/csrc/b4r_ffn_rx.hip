@@ -116,6 +116,13 @@ __device__ __forceinline__ void gelu_both(float x, float& gl, float& gr) {
   gr = fmaf(x * 0.39894228040143267794f, e, cdf);
 }
 
+// FFN_PROF (tools/build_variant.sh ... -DFFN_PROF): thread 0 of workgroup 0 stamps the shader clock at phase boundaries
+#ifdef FFN_PROF
+__device__ long long g_ff_prof[64];
+#define FF_MARK(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_ff_prof[k] = clock64(); } while (0)
+#else
+#define FF_MARK(k) do { } while (0)
+#endif
 struct FfnP {
   const float* x1; const float* W1; const float* b1; const float* W2; const float* b2;
   const float* g2; const float* be2;
@@ -188,6 +195,7 @@ __device__ __forceinline__ void load_rows(const float* src, int tokc, int g, f32
 // forward.  LDS: [W1 image 64 KB | W2 image 64 KB | b1]
 // -----------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * FW) void ffn_fwd_kernel(FfnP p) {
+  FF_MARK(0);
   extern __shared__ __attribute__((aligned(16))) char smem_ffn[];
   char* w1img = smem_ffn;
   char* w2img = smem_ffn + W_IMG;
@@ -197,7 +205,9 @@ __global__ __launch_bounds__(64 * FW) void ffn_fwd_kernel(FfnP p) {
   stage_weight(w2img, p.W2, INNER, HID);
   }
   if (threadIdx.x < INNER) sb1[threadIdx.x] = p.b1[threadIdx.x];
+  FF_MARK(1);
   __syncthreads();
+  FF_MARK(2);
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
   const LaneK lk = lane_consts(lane);
@@ -214,6 +224,7 @@ __global__ __launch_bounds__(64 * FW) void ffn_fwd_kernel(FfnP p) {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) split8(xv[ks], xh[ks], xl[ks]);
     }
+    FF_MARK(3);
     f32x4 acc[4];
 #pragma unroll
     for (int hb = 0; hb < 4; ++hb) acc[hb] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -241,6 +252,7 @@ __global__ __launch_bounds__(64 * FW) void ffn_fwd_kernel(FfnP p) {
                         fh, fl, acc[hb]);
       }
     }
+    FF_MARK(4);
     // bias + dropout + residual + LayerNorm: lane (i, g) holds columns 16 hb + 4g .. +3 of token i
     f32x4 z[4];
     float s = 0.f;
@@ -259,6 +271,7 @@ __global__ __launch_bounds__(64 * FW) void ffn_fwd_kernel(FfnP p) {
       q += sum4(d * d);
     }
     const float rstd = rsqrtf(quad_sum(q) * (1.0f / HID) + p.eps);
+    FF_MARK(5);
     if (j < Nn && (!(FFN_EXP & 4) || rstd == 12345.f)) {
 #pragma unroll
       for (int hb = 0; hb < 4; ++hb) {
@@ -279,13 +292,16 @@ __global__ __launch_bounds__(64 * FW) void ffn_fwd_kernel(FfnP p) {
         if (p.rstd2) p.rstd2[tok] = rstd;
       }
     }
+    FF_MARK(6);
   }
+  FF_MARK(7);
 }
 
 // -----------------------------------------------------------------------------------------------------------
 // backward, input gradient + the attention LayerNorm's backward.  LDS: [W1 image | W2 image | b1 | LayerNorm partials]
 // -----------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * FW) void ffn_bwd_dx_kernel(FfnP p) {
+  FF_MARK(10);
   extern __shared__ __attribute__((aligned(16))) char smem_ffn[];
   char* w1img = smem_ffn;
   char* w2img = smem_ffn + W_IMG;
@@ -310,6 +326,7 @@ __global__ __launch_bounds__(64 * FW) void ffn_bwd_dx_kernel(FfnP p) {
   myred[64 + lane] = 0.f;
   myred2[lane] = 0.f;
   myred2[64 + lane] = 0.f;
+  FF_MARK(11);
 
   for (int t = blockIdx.x + gridDim.x * wave; t < ntiles; t += gridDim.x * FW) {
     const int j = 16 * t + i, jc = min(j, Nn - 1);
@@ -359,6 +376,7 @@ __global__ __launch_bounds__(64 * FW) void ffn_bwd_dx_kernel(FfnP p) {
         split8(dg[ks], gh[ks], gl[ks]);
       }
     }
+    FF_MARK(12);
     f32x4 acc[4];
 #pragma unroll
     for (int hb = 0; hb < 4; ++hb) acc[hb] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -392,6 +410,7 @@ __global__ __launch_bounds__(64 * FW) void ffn_bwd_dx_kernel(FfnP p) {
         acc[hb] = mfma3(row_at(s0), row_at(s0 + SUB), ph, pl, acc[hb]);
       }
     }
+    FF_MARK(13);
     // dx1 = acc + dz2 (the residual branch), then back through x1 = LN(z1)
     const float mean = p.mean1[tokc], rstd = p.rstd1[tokc];
     const bool live = j < Nn;
@@ -440,6 +459,7 @@ __global__ __launch_bounds__(64 * FW) void ffn_bwd_dx_kernel(FfnP p) {
       }
     }
     const float c1 = quad_sum(s1) * (1.0f / HID), c2 = quad_sum(s2) * (1.0f / HID);
+    FF_MARK(14);
     if (live && (!rowmode || slot >= 0)) {   // an entry without a slot has dz1 = 0 exactly and may repeat another entry's row
 #pragma unroll
       for (int hb = 0; hb < 4; ++hb) {
@@ -450,8 +470,10 @@ __global__ __launch_bounds__(64 * FW) void ffn_bwd_dx_kernel(FfnP p) {
       }
     }
   }
+  FF_MARK(15);
   // LayerNorm gamma / beta partial sums of the workgroup: the waves' strips in order
   __syncthreads();
+  FF_MARK(16);
   if (threadIdx.x < 128) {
     float r = 0.f;
 #pragma unroll
@@ -474,6 +496,7 @@ constexpr int CH_IMG = CH_TOK * HID * 4;   // hi + lo image of one [32, 64] chun
 
 __global__ __launch_bounds__(64 * FW) void ffn_bwd_dw_kernel(FfnP p) {
   __shared__ __attribute__((aligned(16))) char smem_dw[4 * CH_IMG];
+  FF_MARK(30);
   const int lane = threadIdx.x & 63, ib = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
   const LaneK lk = lane_consts(lane);
   const DropCtx dctx = b4r_drop_ctx(p.drop);
@@ -525,9 +548,11 @@ __global__ __launch_bounds__(64 * FW) void ffn_bwd_dw_kernel(FfnP p) {
   for (int hb = 0; hb < 4; ++hb) { dw1[hb] = (f32x4){0.f, 0.f, 0.f, 0.f}; dw2[hb] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
   float db1 = 0.f;
 
+  FF_MARK(31);
   int c = blockIdx.x;
   if (c < nchunks) { fetch(c); put(c, 0); }
   __syncthreads();
+  FF_MARK(32);
   for (int it = 0; c < nchunks; c += gridDim.x, ++it) {
     const int cn = c + gridDim.x;
     if (cn < nchunks) fetch(cn);   // in flight while this chunk is multiplied
@@ -566,7 +591,9 @@ __global__ __launch_bounds__(64 * FW) void ffn_bwd_dw_kernel(FfnP p) {
     }
     if (cn < nchunks) put(cn, (it + 1) & 1);
     __syncthreads();
+    if (it < 8) FF_MARK(33 + it);
   }
+  FF_MARK(41);
 
   // partial results of this workgroup -> slabs (summed over the workgroups in slab order by the deferred reduction)
   const int64_t wg = blockIdx.x;
@@ -590,6 +617,7 @@ __global__ __launch_bounds__(64 * FW) void ffn_bwd_dw_kernel(FfnP p) {
     for (int s = 0; s < CH_TOK; ++s) r += red[s * HID + threadIdx.x];
     p.slab_b2[wg * HID + threadIdx.x] = r;
   }
+  FF_MARK(42);
 }
 
 int ffn_grid(int units) {
@@ -629,6 +657,11 @@ bool slot_mode_ok(const b4r_ffn_desc* d) {
 
 }  // namespace
 
+#ifdef FFN_PROF
+extern "C" int b4r_debug_ff_prof(long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ff_prof), 64 * sizeof(long long)) == hipSuccess ? 0 : -4;
+}
+#endif
 extern "C" int32_t b4r_ffn_block_supported(int32_t hidden_size, int32_t inner_dim) {
   return (hidden_size == HID && inner_dim == INNER && b4r_get_gemm_mode() == B4R_GEMM_BF16X3) ? 1 : 0;
 }

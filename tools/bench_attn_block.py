@@ -58,3 +58,13 @@ if hasattr(lib, "b4r_debug_ab_prof"):   # a -DAB_PROF build: phase stamps of wor
     for k in sorted(names, key=lambda k: t[k]):
         print("%-32s +%7d cycles  (total %8d)" % (names[k], t[k] - prev, t[k] - t[0]))
         prev = t[k]
+if hasattr(lib, "b4r_debug_af_prof"):
+    fwd(); torch.cuda.synchronize()
+    buf = (C.c_longlong * 16)()
+    lib.b4r_debug_af_prof.argtypes = [C.c_void_p]
+    assert lib.b4r_debug_af_prof(buf) == 0
+    t = list(buf)
+    names = ["start", "x loaded, weights staged", "barrier", "qkv computed", "barrier", "K/V images written", "barrier", "head 0 start", "head 1 start",
+             "attention done", "ctx stored, out-proj done", "residual + LN stats", "end"]
+    for k in range(1, 13):
+        print("fwd %-28s +%7d cycles  (total %8d)" % (names[k], t[k] - t[k - 1], t[k] - t[0]))

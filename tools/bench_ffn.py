@@ -37,3 +37,18 @@ def timeit(f, reps=200):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / reps
 print("N %d rate %.2f  ffn forward %.1f us  backward (dx + dw + 3 reductions) %.1f us" % (N, rate, timeit(fwd), timeit(bwd)))
+if hasattr(lib, "b4r_debug_ff_prof"):   # -DFFN_PROF build: phase stamps of workgroup 0, thread 0
+    fwd(); bwd(); torch.cuda.synchronize()
+    buf = (C.c_longlong * 64)()
+    lib.b4r_debug_ff_prof.argtypes = [C.c_void_p]
+    assert lib.b4r_debug_ff_prof(buf) == 0
+    t = list(buf)
+    names = {0: "fwd start", 1: "fwd weights staged", 2: "fwd barrier", 3: "fwd x rows loaded", 4: "fwd kt loop", 5: "fwd residual + LN stats", 6: "fwd stores issued", 7: "fwd end",
+             10: "dx start", 11: "dx staged + barrier", 12: "dx rows loaded", 13: "dx kt loop", 14: "dx LN' sums", 15: "dx stores issued", 16: "dx barrier",
+             30: "dw start", 31: "dw operands in registers", 32: "dw first chunk staged", 33: "dw chunk 0", 34: "dw chunk 1", 35: "dw chunk 2", 36: "dw chunk 3",
+             37: "dw chunk 4", 38: "dw chunk 5", 39: "dw chunk 6", 40: "dw chunk 7", 41: "dw loop done", 42: "dw end"}
+    for base in (0, 10, 30):
+        prev = t[base]
+        for k in sorted(k for k in names if base <= k < base + 20 and t[k] >= t[base]):
+            print("%-28s +%7d cycles  (total %8d)" % (names[k], t[k] - prev, t[k] - t[base]))
+            prev = t[k]

@@ -3,13 +3,14 @@
 # kernel trace + stats of the TRAIN STEP ONLY (bench.py --no-breakdown --no-eval --cpu-steps 0: no roofline replays, no event-timed
 # extra steps, no evaluation leg -> the per-step table is a true breakdown), then three PMC passes (SQ, FETCH_SIZE, WRITE_SIZE) as
 # MI355X_MICROARCH.md prescribes, then the summaries: <tag>_kernel_stats_<cfg>.{csv,txt}, <tag>_pmc_<cfg>.txt,
-# <tag>_step_sequence_<cfg>.txt, <tag>_stepbytes_<cfg>.json under gpurun_out/<tag>/summary/ (copy them into profiles/).
+# <tag>_step_sequence_<cfg>.txt, <tag>_stepbytes_<cfg>.json under gpurun_out/<tag>_<cfg>/summary/ (copy them into profiles/).
 tag=$1; shift
 root=${GRAFT_REPO_ROOT:-$(pwd)}
-out=$root/gpurun_out/$tag
-mkdir -p $out/summary
 cfg=ml1m
 for a in "$@"; do if [ "$prev" = "--config" ]; then cfg=$a; fi; prev=$a; done
+out=$root/gpurun_out/${tag}_${cfg}   # one directory per (tag, configuration): the summary scripts take the only trace they find
+rm -rf $out
+mkdir -p $out/summary
 common="--no-breakdown --no-eval --cpu-steps 0"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $root/bench.py --steps 20 --warmup 5 $common "$@" > $out/trace.log 2>&1 || exit 1
@@ -20,7 +21,7 @@ cd $root
 cp $out/trace/*/*_kernel_stats.csv $out/summary/${tag}_kernel_stats_${cfg}.csv
 python3 tools/stats.py $out/trace 25 40 > $out/summary/${tag}_kernel_stats_${cfg}.txt
 python3 tools/seq.py $out/trace > $out/summary/${tag}_step_sequence_${cfg}.txt
-python3 tools/pmc.py gpurun_out/$tag 40 > $out/summary/${tag}_pmc_${cfg}.txt
+python3 tools/pmc.py gpurun_out/${tag}_${cfg} 40 > $out/summary/${tag}_pmc_${cfg}.txt
 python3 tools/stepbytes.py $out $cfg $tag > $out/summary/${tag}_stepbytes_${cfg}.json
 python3 $root/bench.py --steps 200 --warmup 30 "$@" > $out/summary/${tag}_bench_${cfg}.json 2> $out/bench.err
 cat $out/summary/${tag}_kernel_stats_${cfg}.txt $out/summary/${tag}_pmc_${cfg}.txt $out/summary/${tag}_stepbytes_${cfg}.json

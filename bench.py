@@ -238,6 +238,9 @@ def main():
     ap.add_argument("--phases", action="store_true", help="also print per-phase timings to stderr")
     ap.add_argument("--ragged", action="store_true", help="diagnostic only: S-ragged rows (lengths U{5..L}); reports the padding "
                                                           "penalty, NOT the headline configuration")
+    ap.add_argument("--bucketed", action="store_true", help="with --ragged: what make_batches(bucket_by_length=4, trim_padding=True) does to "
+                                                            "the same rows -- the 4 batches are re-formed by length and cut to their longest "
+                                                            "sequence (timing line only)")
     ap.add_argument("--no-dropout", action="store_true", help="diagnostic only: dropout 0 (NOT the headline configuration)")
     ap.add_argument("--graph", action="store_true", help="replay each batch's step from captured hipGraphs (same GPU time, "
                                                          "~7x less host time per step; N > 1: two graphs around the all-reduce)")
@@ -285,6 +288,18 @@ def main():
     hp = make_adamw_config()
     nb = 4
     batches = [synthetic_batch(B, L, P, V, rate, seed=1000 * rank + i, ragged=args.ragged) for i in range(nb)]
+    if args.bucketed:   # same rows, batches re-formed by length and trimmed (dataloader_utils.bucket_order / trimmed_length)
+        from bert4rec_amd.dataloaders import dataloader_utils as du
+        pool = {k: torch.cat([b[k] for b in batches]) for k in batches[0]}
+        lens = pool["input_mask"].sum(1).numpy()
+        order = du.bucket_order(np.arange(nb * B), lens, B, nb, seed=0)
+        batches = []
+        for s_ in range(0, nb * B, B):
+            idx = torch.from_numpy(order[s_:s_ + B])
+            cols = du.trimmed_length(lens[order[s_:s_ + B]].max(), L)
+            slots = du.trimmed_length(int((pool["masked_lm_weights"][idx] != 0).sum(1).max()), P, 4)
+            batches.append({k: v[idx][:, :(cols if k in du.PER_TOKEN_KEYS else slots)].contiguous() for k, v in pool.items()})
+        args.no_breakdown = True
     prepared = [eng.prepare_batch(b) for b in batches]
     valid_per_step = float(sum(int((b["masked_lm_ids"] != 0).sum()) for b in batches)) / nb
     graphs = args.graph or (use_dist and world > 1)   # N > 1: the host must not become the bottleneck of the step
@@ -383,8 +398,12 @@ def main():
 
         # ---- the materialising masked-LM-head projection (forward / evaluation API), replayed on live buffers ----------------
         if args.no_breakdown:      # profiling runs (tools/prof.sh): the train step only, no replays in the kernel statistics
+            note = "--no-breakdown: timing only"
+            if args.bucketed:
+                note += "; batches re-formed by length and trimmed to " + "/".join(
+                    f"{b['input_word_ids'].shape[1]}x{b['masked_lm_ids'].shape[1]}" for b in batches) + " token x slot columns"
             print(json.dumps({"metric": "masked positions/sec", "value": round(value, 1), "ms_per_step": round(ms, 4),
-                              "note": "--no-breakdown: timing only"}), flush=True)
+                              "note": note}), flush=True)
             if use_dist:
                 dist.barrier()
                 dist.destroy_process_group()

@@ -145,19 +145,59 @@ class TokenMatrixDataset:
         return self._like(self.tokens[n:], self.finetune_rows[n:])
 
 
+def bucket_order(order: np.ndarray, lengths: np.ndarray, batch_size: int, bucket_batches: int, seed: int) -> np.ndarray:
+    """Length bucketing: every window of `bucket_batches` consecutive batches of the (already shuffled) order is sorted by sequence
+    length (stable), so that a batch holds sequences of similar length and `trim_padding` can cut the padding they share; the
+    batches of a window are then put back in a random order.  bucket_batches <= 1: the order as it is."""
+    order = np.asarray(order, dtype=np.int64)
+    if bucket_batches <= 1:
+        return order
+    rng = np.random.RandomState(seed)
+    out = []
+    win = batch_size * bucket_batches
+    for s in range(0, len(order), win):
+        chunk = order[s:s + win]
+        chunk = chunk[np.argsort(lengths[chunk], kind="stable")]
+        parts = [chunk[b:b + batch_size] for b in range(0, len(chunk), batch_size)]
+        full = [p for p in parts if len(p) == batch_size]
+        rest = [p for p in parts if len(p) != batch_size]      # the data set's partial batch stays last
+        out.extend(full[i] for i in rng.permutation(len(full)))
+        out.extend(rest)
+    return np.concatenate(out) if out else order
+
+
+def trimmed_length(longest: int, full: int, multiple: int = 16) -> int:
+    """Columns a batch keeps under trim_padding: its longest sequence rounded up to a multiple of 16 (one token tile)."""
+    return int(min(full, max(multiple, -(-int(longest) // multiple) * multiple)))
+
+
 class DeviceMaskedBatches:
     """Batches built on the GPU from a TokenMatrixDataset: the token matrix lives in HBM, a batch is an index list and one
     b4r_mask_batch launch.  `remask_each_epoch=False` (default) reproduces the reference, whose `.cache()` behind shuffle + batch
     freezes batch composition AND masks after the first epoch (dataloader_utils.py:341-346): the batches of the first pass are
-    kept.  True draws new masks every epoch (same batch composition) -- what the duplication factor approximates on the host."""
+    kept.  True draws new masks every epoch (same batch composition) -- what the duplication factor approximates on the host.
+    `trim_padding`: a batch keeps only the columns its longest sequence needs (make_batches)."""
 
-    def __init__(self, dataset: TokenMatrixDataset, order: np.ndarray, batch_size: int, seed: int, remask_each_epoch: bool):
+    def __init__(self, dataset: TokenMatrixDataset, order: np.ndarray, batch_size: int, seed: int, remask_each_epoch: bool,
+                 trim_padding: bool = False):
         self.dataset, self.order, self.batch_size = dataset, np.asarray(order, dtype=np.int64), int(batch_size)
         self.seed, self.remask_each_epoch = int(seed), bool(remask_each_epoch)
+        self.trim_padding = bool(trim_padding)
         self.epoch = 0
         self._device = None
         self._tokens = self._flags = self._order = None
         self._frozen = None
+        # columns per batch, known on the host (no device round trip while an epoch runs)
+        full = dataset.tokens.shape[1]
+        lens = sequence_lengths(dataset.tokens)
+        self.batch_columns = [trimmed_length(lens[self.order[s:s + self.batch_size]].max(), full) if self.trim_padding else full
+                              for s in range(0, len(self.order), self.batch_size)]
+        # masked-LM slots a row can use: the count rule of apply_dynamic_masking_task on its length (an upper bound: special tokens
+        # inside a row only lower the count), one slot for a last-token row
+        P = dataset.max_predictions_per_seq
+        slots = np.where(dataset.finetune_rows != 0, 1, np.minimum(P, np.maximum(1, (lens * dataset.selection_rate).astype(np.int64))))
+        self.batch_slots = [trimmed_length(slots[self.order[s:s + self.batch_size]].max(), P, 4) if self.trim_padding else P
+                            for s in range(0, len(self.order), self.batch_size)]
 
     def __len__(self):
         return (len(self.order) + self.batch_size - 1) // self.batch_size
@@ -180,10 +220,15 @@ class DeviceMaskedBatches:
         if self._device is None:
             self.cache_on_device("cuda")
         ds = self.dataset
-        for s in range(0, len(self.order), self.batch_size):
-            yield device_mask_batch(self._tokens, ds.max_predictions_per_seq, ds.vocab_size, ds.selection_rate, ds.mask_token_rate,
-                                    ds.random_token_rate, False, (self.seed << 20) + epoch, self._order[s:s + self.batch_size],
-                                    self._flags, self._device)
+        full = ds.tokens.shape[1]
+        for j, s in enumerate(range(0, len(self.order), self.batch_size)):
+            batch = device_mask_batch(self._tokens, ds.max_predictions_per_seq, ds.vocab_size, ds.selection_rate, ds.mask_token_rate,
+                                      ds.random_token_rate, False, (self.seed << 20) + epoch, self._order[s:s + self.batch_size],
+                                      self._flags, self._device)
+            cols, slots = self.batch_columns[j], self.batch_slots[j]
+            if cols < full or slots < ds.max_predictions_per_seq:
+                batch = {k: v[:, :(cols if k in PER_TOKEN_KEYS else slots)].contiguous() for k, v in batch.items()}
+            yield batch
 
     def __iter__(self):
         if self.remask_each_epoch:
@@ -192,6 +237,15 @@ class DeviceMaskedBatches:
         if self._frozen is None:
             self._frozen = list(self._build(0))
         return iter(self._frozen)
+
+
+PER_TOKEN_KEYS = ("input_word_ids", "input_mask", "labels")
+
+
+def sequence_lengths(tokens: np.ndarray) -> np.ndarray:
+    """Length of every right-padded row: one past its last token that is not [PAD] (id 0)."""
+    nz = tokens != 0
+    return np.where(nz.any(1), tokens.shape[1] - np.argmax(nz[:, ::-1], axis=1), 0).astype(np.int64)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -321,22 +375,40 @@ def split_dataset(ds, ds_size: int = None, train_split: float = 0.8, val_split: 
 
 
 def make_batches(dataset, buffer_size: int = None, batch_size: int = 64, squeeze_tensors: bool = False,
-                 reshuffle_each_iteration: bool = False, seed: int = None, remask_each_epoch: bool = False):
+                 reshuffle_each_iteration: bool = False, seed: int = None, remask_each_epoch: bool = False,
+                 bucket_by_length: int = 0, trim_padding: bool = False):
     """dataloader_utils.py:306-346: shuffle(all) -> batch (last batch may be partial) -> cache.  Because the reference
     caches AFTER shuffle+batch, batch composition and masks are frozen after the first epoch; so are they here.
     A TokenMatrixDataset (prepare_training(device_masking=True)) gives batches that are masked on the GPU; only there
-    `remask_each_epoch=True` is available (new masks per epoch, same composition)."""
+    `remask_each_epoch=True` is available (new masks per epoch, same composition).
+    Not in the reference (it pads every row to max_seq_len, bert4rec_preprocessor.py:105-110), both off by default:
+    `trim_padding=True` cuts every batch to the columns its longest sequence needs (a multiple of 16) and to the masked-LM slots
+    its rows can use (a multiple of 4) -- padded keys are masked, padded positions and padded slots carry no loss, so loss,
+    masked accuracy and gradients are unchanged while the kernels skip the common padding (only `sparse_categorical_accuracy`,
+    which the reference averages over ALL slots including the padded ones, now averages over the slots that are kept);
+    `bucket_by_length=W` (> 1) sorts every window of W batches by length first, so that the batches have padding to cut."""
     if reshuffle_each_iteration:
         raise NotImplementedError("reshuffle_each_iteration has no effect behind the reference's .cache(); not offered")
     n = len(dataset)
     order = np.random.RandomState(seed).permutation(n)
     if isinstance(dataset, TokenMatrixDataset):
-        return DeviceMaskedBatches(dataset, order, batch_size, 0 if seed is None else seed, remask_each_epoch)
+        order = bucket_order(order, sequence_lengths(dataset.tokens), batch_size, bucket_by_length, 0 if seed is None else seed)
+        return DeviceMaskedBatches(dataset, order, batch_size, 0 if seed is None else seed, remask_each_epoch, trim_padding)
     if remask_each_epoch:
         raise ValueError("remask_each_epoch needs a dataset prepared with device_masking=True")
+    lens = np.array([int(np.asarray(e["input_mask"]).sum()) for e in dataset.examples], dtype=np.int64)
+    order = bucket_order(order, lens, batch_size, bucket_by_length, 0 if seed is None else seed)
     batches = []
     for s in range(0, n, batch_size):
         idx = order[s:s + batch_size]
         keys = dataset.examples[idx[0]].keys()
-        batches.append({k: torch.from_numpy(np.stack([dataset.examples[i][k] for i in idx]).astype(np.int64)) for k in keys})
+        batch = {k: torch.from_numpy(np.stack([dataset.examples[i][k] for i in idx]).astype(np.int64)) for k in keys}
+        if trim_padding:
+            full = batch["input_word_ids"].shape[1]
+            cols = trimmed_length(lens[idx].max(), full)
+            slots = batch["masked_lm_weights"].shape[1] if "masked_lm_weights" in batch else 0
+            if slots:
+                slots = trimmed_length(int((batch["masked_lm_weights"] != 0).sum(1).max()), slots, 4)
+            batch = {k: v[:, :(cols if k in PER_TOKEN_KEYS else slots)].contiguous() for k, v in batch.items()}
+        batches.append(batch)
     return BatchedDataset(batches)

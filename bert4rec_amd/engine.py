@@ -239,13 +239,22 @@ class Engine:
             nbytes = self.lib.b4r_workspace_bytes(C.byref(self.cfg), B, L, P)
             if nbytes < 0:
                 raise B4RError("b4r_workspace_bytes: " + _lib.last_error())
-            if len(self._ws) > 4:
-                # drop the least recently created workspaces, never one a captured hipGraph has its pointers baked into
-                # (train_step_graphed / dp_train_step_graphed pin theirs): a replay would read and write freed memory
-                pinned = self.__dict__.setdefault("_ws_pinned", set())
-                for k in [k for k in self._ws if k not in pinned][: max(0, len(self._ws) - 4)]:
-                    del self._ws[k]
-            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
+            # the workspace is pure scratch (nothing in it outlives a call sequence on one batch) and the library lays its regions out
+            # from (B, L, P) alone, so a shape may use any buffer that is large enough: batches trimmed to their longest sequence
+            # (dataloader_utils.make_batches(trim_padding=True)) share the buffer of the longest shape instead of owning one each
+            fits = [w for w in self._ws.values() if w.numel() * 4 >= nbytes]
+            if fits:
+                ws = min(fits, key=lambda w: w.numel())
+            else:
+                distinct = {id(w) for w in self._ws.values()}
+                if len(distinct) > 4:
+                    # drop the least recently created workspaces, never one a captured hipGraph has its pointers baked into
+                    # (train_step_graphed / dp_train_step_graphed pin theirs): a replay would read and write freed memory
+                    pinned = self.__dict__.setdefault("_ws_pinned", set())
+                    keep = {id(self._ws[k]) for k in pinned if k in self._ws}
+                    for k in [k for k in self._ws if id(self._ws[k]) not in keep][: max(0, len(self._ws) - 4)]:
+                        del self._ws[k]
+                ws = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
             self._ws[key] = ws
         return ws
 

@@ -346,6 +346,27 @@ def test_device_masked_batches_follow_the_reference_contract():
     hist = model.fit(remask, validation_data=dataloaders.make_batches(val, batch_size=16, seed=1), epochs=2, verbose=0)
     assert len(hist.history["loss"]) == 2 and all(np.isfinite(hist.history["loss"]))
 
+    # bucketed + trimmed batches (not in the reference): what is cut is padding only, and the model trains on the mixed widths
+    ds2 = datasets.synthetic_dataset(n_users=96, n_items=300, min_len=2, max_len=70, seed=4)
+    dl2 = dataloaders.get_dataloader_factory("bert4rec").create_ml_1m_dataloader(data_source=ds2, max_seq_len=64,
+                                                                                max_predictions_per_seq=12, input_duplication_factor=1)
+    tr2, va2, _ = dl2.prepare_training(finetuning_split=0.1, device_masking=True)
+    wide = dataloaders.make_batches(tr2, batch_size=16, seed=5, bucket_by_length=3).cache_on_device("cuda")
+    cut = dataloaders.make_batches(tr2, batch_size=16, seed=5, bucket_by_length=3, trim_padding=True).cache_on_device("cuda")
+    widths = set()
+    for a, b in zip(wide, cut):
+        w, p = b["input_word_ids"].shape[1], b["masked_lm_ids"].shape[1]
+        widths.add((w, p))
+        assert w % 16 == 0 and p % 4 == 0 and (w < 64 or p < 12 or (w, p) == (64, 12))
+        for k in a:
+            n = w if a[k].shape[1] == 64 else p
+            assert torch.equal(a[k][:, :n], b[k]) and int(a[k][:, n:].abs().sum()) == 0, k   # same masks, only zeros are cut
+    assert len(widths) > 1
+    model2 = make_model(dl2.tokenizer.get_vocab_size(), seed=2, L=64)
+    model2.compile()
+    h2 = model2.fit(cut, validation_data=dataloaders.make_batches(va2, batch_size=16, seed=1, trim_padding=True), epochs=2, verbose=0)
+    assert len(h2.history["loss"]) == 2 and all(np.isfinite(h2.history["loss"]))
+
 
 def test_apps_return_what_the_oracle_ranks_first():
     """apps/recommender.py:14-63 and apps/ranker.py:19-76 on values: the recommended item is the oracle's arg-max over the unseen

@@ -170,3 +170,29 @@ def test_ml20m_model_slice_at_the_full_vocabulary_matches_oracle():
         st, grads = run_loss_and_grads(eng, batch, training=False, fused_head=fused)
         assert abs(st["loss_sum"] / st["valid_count"] - float(loss_ref)) < LOGIT_TOL
         compare_grads(grads, grads_ref, st["valid_count"])
+
+
+def test_trimmed_batch_gives_the_loss_and_gradients_of_the_padded_batch():
+    """make_batches(trim_padding=True) cuts a batch to the columns its longest sequence needs (the reference pads every row to
+    max_seq_len, bert4rec_preprocessor.py:105-110): padded keys are masked and padded positions carry no loss, so the loss sums and
+    every gradient are those of the full-width batch -- in eval mode and in train mode (dropout is indexed by row*H + column of the
+    [B*L, H] tensor, so the masks of the two widths differ: train mode is compared through the dropout-free sums only)."""
+    from bert4rec_amd.dataloaders import dataloader_utils as du
+    eng, _ = build(ML1M)
+    B, L, P = 64, 200, 40
+    full = orc.synthetic_batch(B, L, P, ML1M.vocab_size, seed=11, ragged=True)
+    keep = full["input_mask"].sum(1) <= 90          # rows that fit 96 columns
+    full = {k: v[keep].contiguous() for k, v in full.items()}
+    cols = du.trimmed_length(int(full["input_mask"].sum(1).max()), L)
+    assert cols == 96 and int(keep.sum()) >= 16
+    slots = du.trimmed_length(int((full["masked_lm_weights"] != 0).sum(1).max()), P, 4)
+    assert slots < P
+    cut = {k: v[:, :(cols if k in du.PER_TOKEN_KEYS else slots)].contiguous() for k, v in full.items()}
+    for fused in (False, True):
+        st_f, g_f = run_loss_and_grads(eng, full, training=False, fused_head=fused)
+        st_c, g_c = run_loss_and_grads(eng, cut, training=False, fused_head=fused)
+        assert st_c["valid_count"] == st_f["valid_count"] and st_c["correct_masked"] == st_f["correct_masked"]
+        assert abs(st_c["loss_sum"] - st_f["loss_sum"]) < 1e-5 * st_f["loss_sum"]
+        pos_rows = g_f["position_embedding/embeddings"][cols:]
+        assert float(pos_rows.abs().max()) == 0.0      # positions nobody occupies: no gradient in the padded batch either
+        compare_grads(g_c, {k: v for k, v in g_f.items()}, 1.0, rel=2e-5)

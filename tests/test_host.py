@@ -315,3 +315,37 @@ def test_evaluator_candidate_sampling_contract():
     ev2 = evaluation.get(sampler=samplers.get("random", sample_size=100))
     with pytest.raises(ValueError):
         ev2.evaluate(model=None, test_data=[])
+
+
+def test_length_bucketing_and_padding_trim_keep_the_rows_and_cut_only_padding():
+    """make_batches(bucket_by_length=W, trim_padding=True): not in the reference (it pads every row to max_seq_len,
+    bert4rec_preprocessor.py:105-110).  Same rows as without, every batch cut to a multiple of 16 columns that still holds its
+    longest sequence and every masked position; the cut columns are padding only."""
+    assert du.sequence_lengths(np.array([[5, 6, 0, 0], [0, 0, 0, 0], [1, 2, 3, 4], [7, 0, 0, 0]])).tolist() == [2, 0, 4, 1]
+    assert [du.trimmed_length(n, 200) for n in (0, 1, 16, 17, 199, 200)] == [16, 16, 16, 32, 200, 200]
+    order = du.bucket_order(np.arange(12), np.array([5, 1, 9, 3, 7, 2, 8, 4, 6, 10, 11, 0]), 2, 3, seed=0)
+    assert sorted(order.tolist()) == list(range(12)) and sorted(order[:6].tolist()) == [0, 1, 2, 3, 4, 5]   # windows keep their rows
+    assert (du.bucket_order(np.arange(12), np.arange(12), 2, 0, seed=0) == np.arange(12)).all()
+    ds = datasets.synthetic_dataset(n_users=60, n_items=300, min_len=2, max_len=70, seed=2)
+    dl = make_loader(data_source=ds, max_seq_len=64, max_predictions_per_seq=8, input_duplication_factor=1)
+    train, _, _ = dl.prepare_training(finetuning_split=0.1)
+    plain = dataloaders.make_batches(train, batch_size=16, seed=3)
+    cut = dataloaders.make_batches(train, batch_size=16, seed=3, bucket_by_length=4, trim_padding=True)
+    rows = lambda bs: sorted(tuple(r[r != 0].tolist()) for b in bs for r in b["labels"].numpy())
+    assert rows(plain) == rows(cut) and len(plain) == len(cut)
+    widths = [b["input_word_ids"].shape[1] for b in cut]
+    assert all(w % 16 == 0 and 16 <= w <= 64 for w in widths) and min(widths) < 64
+    for b in cut:
+        w = b["input_word_ids"].shape[1]
+        assert b["input_mask"].shape[1] == w and b["labels"].shape[1] == w
+        p = b["masked_lm_positions"].shape[1]
+        assert p in (4, 8) and b["masked_lm_ids"].shape[1] == p and b["masked_lm_weights"].shape[1] == p
+        assert int(b["masked_lm_weights"].sum(1).max()) > p - 4        # the slots that are cut are padded slots
+        assert int(b["input_mask"].sum(1).max()) > w - 16 or w == 16          # no narrower multiple of 16 would do
+        assert int(b["masked_lm_positions"].max()) < w
+    dev_train, _, _ = dl.prepare_training(finetuning_split=0.1, device_masking=True)
+    dev = dataloaders.make_batches(dev_train, batch_size=16, seed=3, bucket_by_length=4, trim_padding=True)
+    lens = du.sequence_lengths(dev_train.tokens)
+    assert sorted(dev.order.tolist()) == list(range(len(dev_train)))
+    assert dev.batch_columns == [du.trimmed_length(lens[dev.order[s:s + 16]].max(), 64) for s in range(0, len(dev_train), 16)]
+    assert all(p in (4, 8) for p in dev.batch_slots) and min(dev.batch_slots) == 4

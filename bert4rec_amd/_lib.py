@@ -30,7 +30,7 @@ class Batch(C.Structure):
 class AdamWConfig(C.Structure):
     _fields_ = [("init_lr", C.c_float), ("end_lr", C.c_float), ("num_train_steps", C.c_int32),
                 ("num_warmup_steps", C.c_int32), ("weight_decay_rate", C.c_float), ("beta_1", C.c_float),
-                ("beta_2", C.c_float), ("epsilon", C.c_float), ("clip_norm", C.c_float)]
+                ("beta_2", C.c_float), ("epsilon", C.c_float), ("clip_norm", C.c_float), ("decay_mask", C.c_void_p)]
 
 
 class GemmDesc(C.Structure):

@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamP a) {
     for (int e = 0; e < 4; ++e) {
       const float ge = (g[e] * inv_cnt) * clip_scale;
       float pe = p[e];
-      if (wd != 0.f && 4 * i + e < a.n_decay) pe -= lr_t * pe * wd;   // _decay_weights_op, before Adam
+      if (wd != 0.f && (a.hp.decay_mask ? a.hp.decay_mask[4 * i + e] != 0 : 4 * i + e < a.n_decay)) pe -= lr_t * pe * wd;   // _decay_weights_op, before Adam
       m[e] += (ge - m[e]) * omb1;
       v[e] += (ge * ge - v[e]) * omb2;
       pe -= (m[e] * alpha) / (sqrtf(v[e]) + eps);
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256) void adamw_fused_kernel(AdamP a, const float* 
     for (int e = 0; e < 4; ++e) {
       const float ge = (g[e] * inv_cnt) * clip_scale;
       float pe = p[e];
-      if (wd != 0.f && 4 * i + e < a.n_decay) pe -= lr_t * pe * wd;   // _decay_weights_op, before Adam
+      if (wd != 0.f && (a.hp.decay_mask ? a.hp.decay_mask[4 * i + e] != 0 : 4 * i + e < a.n_decay)) pe -= lr_t * pe * wd;   // _decay_weights_op, before Adam
       m[e] += (ge - m[e]) * omb1;
       v[e] += (ge * ge - v[e]) * omb2;
       pe -= (m[e] * alpha) / (sqrtf(v[e]) + eps);

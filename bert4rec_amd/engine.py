@@ -37,11 +37,18 @@ def make_model_config(vocab_size: int, hidden_size: int, num_layers: int, num_at
 
 def make_adamw_config(init_lr: float = 1e-4, num_train_steps: int = 400000, num_warmup_steps: int = 100,
                       end_lr: float = 0.0, weight_decay_rate: float = 0.01, beta_1: float = 0.9, beta_2: float = 0.999,
-                      epsilon: float = 1e-6, gradient_clip_norm: float = 5.0) -> AdamWConfig:
+                      epsilon: float = 1e-6, gradient_clip_norm: float = 5.0, decay_mask: torch.Tensor = None) -> AdamWConfig:
     """Defaults of create_adam_w_optimizer, bert4rec/trainers/optimizers/__init__.py:7-15, and of
-    AdamWeightDecay.gradient_clip_norm, adam_w_optimizer.py:67."""
-    return AdamWConfig(float(init_lr), float(end_lr), int(num_train_steps), int(num_warmup_steps or 0),
-                       float(weight_decay_rate), float(beta_1), float(beta_2), float(epsilon), float(gradient_clip_norm))
+    AdamWeightDecay.gradient_clip_norm, adam_w_optimizer.py:67.  decay_mask: optional uint8 DEVICE tensor, one byte per float of
+    the flat parameter buffer (a custom weight-decay selection); the config keeps it alive."""
+    hp = AdamWConfig(float(init_lr), float(end_lr), int(num_train_steps), int(num_warmup_steps or 0),
+                     float(weight_decay_rate), float(beta_1), float(beta_2), float(epsilon), float(gradient_clip_norm), None)
+    if decay_mask is not None:
+        if decay_mask.dtype != torch.uint8 or not decay_mask.is_cuda or not decay_mask.is_contiguous():
+            raise ValueError("decay_mask must be a contiguous uint8 tensor on the GPU")
+        hp.decay_mask = decay_mask.data_ptr()
+        hp._decay_mask_tensor = decay_mask
+    return hp
 
 
 class ParamInfo:

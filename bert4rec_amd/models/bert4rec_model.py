@@ -140,7 +140,7 @@ class BERT4RecModel:
         self.optimizer = optimizer
         self.loss = self.compiled_loss = loss
         self.compiled_metrics = metrics if metrics is not None else ["sparse_categorical_accuracy", trainer_utils.masked_accuracy]
-        self._hp = optimizer.kernel_config([(e.name, e.decay) for e in self.engine.table])
+        self._hp = optimizer.kernel_config(self.engine.table, self.engine.n_params, self.engine.device)
 
     def _require_compiled(self):
         if self._hp is None:

@@ -91,15 +91,25 @@ class AdamWeightDecay:
         s = self.learning_rate
         return float(s(step)) if callable(s) else float(s)
 
-    def kernel_config(self, variable_names_and_decay):
-        """Translate into the by-value b4r_adamw_config.  The kernel decays exactly the 'decay region' of the flat
-        buffer (kernels + embedding tables), which is what the default exclusion list selects; any other selection
-        cannot be expressed and is rejected loudly."""
-        for name, decays in variable_names_and_decay:
-            if self._do_use_weight_decay(name) != bool(decays) and self.weight_decay_rate != 0:
-                raise NotImplementedError(
-                    f"weight-decay selection differs from the flat-buffer layout for variable '{name}': only the "
-                    f"reference's default exclude_from_weight_decay=['LayerNorm','layer_norm','bias'] is supported")
+    def kernel_config(self, variables, n_params: int = None, device=None):
+        """Translate into the by-value b4r_adamw_config.  The kernel's built-in rule decays the 'decay region' of the flat buffer
+        (kernels + embedding tables) = what the default exclusion list selects.  Any other include / exclude selection
+        (adam_w_optimizer.py:154-168) becomes a per-element mask: `variables` are then the engine's table entries (name, decay,
+        offset, rows, cols, ld), `n_params` the length of the flat buffer, `device` where the mask goes."""
+        entries = [(v.name, v.decay, v) if hasattr(v, "name") else (v[0], v[1], None) for v in variables]
+        mask = None
+        if self.weight_decay_rate != 0 and any(self._do_use_weight_decay(n) != bool(d) for n, d, _ in entries):
+            if n_params is None or device is None or any(e is None for _, _, e in entries):
+                raise ValueError("a custom weight-decay selection needs the parameter table (name, offset, rows, cols, ld), the "
+                                 "buffer length and the device")
+            import numpy as np
+            import torch
+            m = np.zeros(int(n_params), dtype=np.uint8)
+            for name, _, e in entries:
+                if self._do_use_weight_decay(name):
+                    for r in range(e.rows):
+                        m[e.offset + r * e.ld: e.offset + r * e.ld + e.cols] = 1
+            mask = torch.from_numpy(m).to(device)
         s = self.learning_rate
         if isinstance(s, WarmUp):
             d = s.decay_schedule_fn
@@ -113,7 +123,7 @@ class AdamWeightDecay:
         else:
             raise NotImplementedError(f"unsupported learning-rate schedule {type(s).__name__}")
         return make_adamw_config(init, steps, warm, end, self.weight_decay_rate, self.beta_1, self.beta_2, self.epsilon,
-                                 self.gradient_clip_norm)
+                                 self.gradient_clip_norm, decay_mask=mask)
 
     def get_config(self):
         return {"name": self.name, "beta_1": self.beta_1, "beta_2": self.beta_2, "epsilon": self.epsilon,

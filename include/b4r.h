@@ -66,6 +66,10 @@ typedef struct b4r_adamw_config {
   float beta_1, beta_2;     /* 0.9, 0.999 */
   float epsilon;            /* 1e-6 */
   float clip_norm;          /* 5.0 (gradient_clip_norm, adam_w_optimizer.py:67); <= 0 disables */
+  /* optional DEVICE pointer, one byte per float of the flat parameter buffer, nonzero = this element is weight-decayed: a custom
+   * include_in_weight_decay / exclude_from_weight_decay selection (adam_w_optimizer.py:154-168).  NULL = the layout's rule: the
+   * first b4r_param_decay_floats() floats (= the reference's default exclusion list ["LayerNorm", "layer_norm", "bias"]). */
+  const uint8_t* decay_mask;
 } b4r_adamw_config;
 
 /* Device-resident state, 64 bytes, owned by the caller (one torch tensor).  Kernels read and write it; the host reads

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_struct_sizes_match_the_header():
-    assert C.sizeof(_lib.ModelConfig) == 36 and C.sizeof(_lib.AdamWConfig) == 36
+    assert C.sizeof(_lib.ModelConfig) == 36 and C.sizeof(_lib.AdamWConfig) == 48   # 9 x 4 bytes, padding, the decay-mask pointer
     assert C.sizeof(_lib.Batch) == 4 * 8 + 3 * 4 + 4     # padded to 8
     assert _lib.STATE_WORDS * 4 == 64
 

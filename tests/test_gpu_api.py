@@ -403,3 +403,33 @@ def test_apps_return_what_the_oracle_ranks_first():
         assert sorted(ranked) == sorted(cands)
         if (np.abs(np.diff(np.sort(sc))) > 1e-4).all():
             assert ranked == want
+
+
+def test_custom_weight_decay_selection_decays_exactly_the_selected_variables():
+    """AdamWeightDecay._do_use_weight_decay (adam_w_optimizer.py:154-168) with a non-default exclusion list: the flat buffer's built-in
+    rule no longer applies, the optimizer kernel takes a per-element mask.  One step from the same weights on the same batch with
+    exclude=["bias"] and with the default list: the LayerNorm variables (now decayed) differ by -lr * rate * value, nothing else."""
+    from bert4rec_amd.trainers import optimizers
+    batch = orc.synthetic_batch(8, 24, 5, 60, seed=1)
+    out = []
+    for excl in (None, ["bias"]):
+        model = make_model(60, seed=2)
+        opt = optimizers.get("adamw", init_lr=1e-2, num_warmup_steps=0, weight_decay_rate=0.1, exclude_from_weight_decay=excl)
+        model.compile(optimizer=opt)
+        before = {k: v.clone() for k, v in model.get_weights().items()}
+        model.train_step(batch)
+        out.append((before, model.get_weights(), model._hp))
+    (b0, w0, hp0), (b1, w1, hp1) = out
+    assert not hp0.decay_mask and hp1.decay_mask
+    lr = 1e-2   # step 0 of PolynomialDecay without warm-up
+    n_ln = 0
+    for k in w0:
+        assert torch.equal(b0[k], b1[k])
+        d = (w1[k] - w0[k]).double()
+        if "layer_norm" in k or "LayerNorm" in k:
+            n_ln += 1
+            want = (-lr * 0.1 * b0[k]).double()
+            assert float((d - want).abs().max()) < 1e-6 * max(1.0, float(b0[k].abs().max())), k
+        else:
+            assert float(d.abs().max()) < 1e-7, k     # (the item table's gradient is summed with float atomics: last-bit noise)
+    assert n_ln >= 6

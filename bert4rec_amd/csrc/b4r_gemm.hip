@@ -531,6 +531,9 @@ bool b4r_gemm_rx_supported(const b4r_gemm_desc* d);
 bool b4r_gemm_rx_tn_supported(const b4r_gemm_tn_desc* d);
 int64_t b4r_gemm_rx_tn_scratch_floats(int R, int Mo, int No);
 int b4r_gemm_rx_tn_launch(const b4r_gemm_tn_desc* d, float* scratch, hipStream_t stream);
+bool b4r_gemm_rx_tn_pair_supported(const b4r_gemm_tn_desc* d0, const b4r_gemm_tn_desc* d1);
+int b4r_gemm_rx_tn_pair_launch(const b4r_gemm_tn_desc* d0, float* scratch0, const b4r_gemm_tn_desc* d1, float* scratch1,
+                               hipStream_t stream);
 static int g_gemm_mode = B4R_GEMM_BF16X3;
 extern "C" int b4r_set_gemm_mode(int mode) {
   B4R_CHECK_ARG(mode == B4R_GEMM_F32 || mode == B4R_GEMM_BF16X3, B4R_E_BADARG, "b4r_set_gemm_mode: unknown mode %d", mode);
@@ -702,3 +705,18 @@ extern "C" int b4r_gemm_tn_f32(const b4r_gemm_tn_desc* d, float* scratch, b4r_st
   return b4r_launch_slab_reduce_full(p.slab, S, d->Mo, d->No, d->out, d->ldo, d->accumulate, p.colsum_slab, d->colsum,
                                      p.colsum_a_slab, d->colsum_a, (hipStream_t)stream);
 }
+
+// two independent weight-gradient products, in one launch where the bf16x3 kernel takes both (d0 may drop its B operand, d1 not;
+// no input-gradient tails), else one after the other: same results either way
+int b4r_gemm_tn_pair(const b4r_gemm_tn_desc* d0, float* scratch0, const b4r_gemm_tn_desc* d1, float* scratch1, hipStream_t stream) {
+  static const bool on = !(getenv("B4R_TN_PAIR") && atoi(getenv("B4R_TN_PAIR")) == 0);
+  const bool plain = d0 && d1 && scratch0 && scratch1 && d0->A && d0->B && d0->out && d1->A && d1->B && d1->out && d0->R > 0 &&
+                     d1->R > 0 && d0->Mo > 0 && d0->No > 0 && d1->Mo > 0 && d1->No > 0 && d0->lda >= d0->Mo && d0->ldb >= d0->No &&
+                     d0->ldo >= d0->No && d1->lda >= d1->Mo && d1->ldb >= d1->No && d1->ldo >= d1->No;
+  if (on && plain && g_gemm_mode == B4R_GEMM_BF16X3 && b4r_gemm_rx_tn_pair_supported(d0, d1))
+    return b4r_gemm_rx_tn_pair_launch(d0, scratch0, d1, scratch1, stream);
+  int rc = b4r_gemm_tn_f32(d0, scratch0, (b4r_stream_t)stream);
+  if (rc) return rc;
+  return b4r_gemm_tn_f32(d1, scratch1, (b4r_stream_t)stream);
+}
+

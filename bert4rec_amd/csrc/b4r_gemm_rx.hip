@@ -961,7 +961,7 @@ struct RxTnP {
 
 
 template <int KS, bool B_DROP, int DGRAD>
-__global__ __launch_bounds__(256) void rx_gemm_tn_kernel(RxTnP p) {
+__device__ __forceinline__ void rx_gemm_tn_body(const RxTnP& p, const int block) {
   constexpr int NLD = KS / 16;                       // float4 per thread per operand per chunk
   constexpr int PLANE = KS * 128;                    // bytes per image
   extern __shared__ __attribute__((aligned(16))) char s_tn[];   // [A hi | A lo | B hi | B lo]
@@ -969,7 +969,7 @@ __global__ __launch_bounds__(256) void rx_gemm_tn_kernel(RxTnP p) {
   const int r = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   const int n_items = p.tiles_i * p.tiles_j * p.S;
-  const int item = xcd_logical_id(blockIdx.x, n_items);   // the tiles of one row slice share its chunks of A and B
+  const int item = xcd_logical_id(block, n_items);   // the tiles of one row slice share its chunks of A and B
   if (item >= n_items) return;                            // block-uniform, before any barrier
   const int z = item / (p.tiles_i * p.tiles_j);
   const int t = item % (p.tiles_i * p.tiles_j);
@@ -1118,6 +1118,19 @@ __global__ __launch_bounds__(256) void rx_gemm_tn_kernel(RxTnP p) {
   }
 }
 
+template <int KS, bool B_DROP, int DGRAD>
+__global__ __launch_bounds__(256) void rx_gemm_tn_kernel(RxTnP p) {
+  rx_gemm_tn_body<KS, B_DROP, DGRAD>(p, (int)blockIdx.x);
+}
+// two independent weight-gradient products in ONE launch (the workgroups of the second follow those of the first; n0 is a
+// multiple of 8, so both keep their XCD mapping): dWo = ctx^T.dropmask(dz1) and dWqkv = x^T.dqkv of an encoder layer are each too
+// short (12 / 17 us) to reach the memory system's rate on their own
+template <int KS, bool B_DROP0, bool B_DROP1>
+__global__ __launch_bounds__(256) void rx_gemm_tn_pair_kernel(RxTnP p0, RxTnP p1, int n0) {
+  if ((int)blockIdx.x < n0) rx_gemm_tn_body<KS, B_DROP0, 0>(p0, (int)blockIdx.x);
+  else rx_gemm_tn_body<KS, B_DROP1, 0>(p1, (int)blockIdx.x - n0);
+}
+
 constexpr int TN_KS = 64;   // measured on the ML-1M shapes: 32 -> 1.185, 64 -> 1.173, 128 -> 1.197 ms/step
 
 inline int tn_single_tile_cap() {
@@ -1251,8 +1264,7 @@ int64_t b4r_gemm_rx_tn_scratch_floats(int R, int Mo, int No) {
   return (int64_t)S * Mo * No + (int64_t)S * No + (int64_t)S * Mo;
 }
 
-int b4r_gemm_rx_tn_launch(const b4r_gemm_tn_desc* d, float* scratch, hipStream_t stream) {
-  const int S = rx_tn_split(d->R, d->Mo, d->No);
+static RxTnP make_tn_params(const b4r_gemm_tn_desc* d, float* scratch, int S) {
   RxTnP p;
   p.A = d->A; p.B = d->B; p.lda = d->lda; p.ldb = d->ldb;
   p.R = d->R; p.Mo = d->Mo; p.No = d->No;
@@ -1263,9 +1275,15 @@ int b4r_gemm_rx_tn_launch(const b4r_gemm_tn_desc* d, float* scratch, hipStream_t
   p.colsum_slab = d->colsum ? scratch + (int64_t)S * d->Mo * d->No : nullptr;
   p.colsum_a_slab = d->colsum_a ? scratch + (int64_t)S * d->Mo * d->No + (int64_t)S * d->No : nullptr;
   p.drop = b4r_make_drop(d->rng, d->drop_stream, d->drop_rate, 1);
+  p.W = d->dgrad_w; p.ldw = d->dgrad_ldw; p.dX = d->dgrad_out; p.lddx = d->dgrad_ldo; p.G = d->dgrad_gelu_pre; p.ldg = d->dgrad_ldg;
+  return p;
+}
+
+int b4r_gemm_rx_tn_launch(const b4r_gemm_tn_desc* d, float* scratch, hipStream_t stream) {
+  const int S = rx_tn_split(d->R, d->Mo, d->No);
+  const RxTnP p = make_tn_params(d, scratch, S);
   const bool b_drop = d->b_dropout && p.drop.rng != nullptr;
   const int dgrad = d->dgrad_out == nullptr ? 0 : (d->dgrad_gelu_pre ? 2 : 1);   // b4r_gemm_tn_f32 has checked the shape contract
-  p.W = d->dgrad_w; p.ldw = d->dgrad_ldw; p.dX = d->dgrad_out; p.lddx = d->dgrad_ldo; p.G = d->dgrad_gelu_pre; p.ldg = d->dgrad_ldg;
   const int64_t items = (int64_t)p.tiles_i * p.tiles_j * S;
   dim3 grid(xcd_grid(items));
   constexpr size_t lds = (size_t)4 * TN_KS * 128;
@@ -1288,4 +1306,32 @@ int b4r_gemm_rx_tn_launch(const b4r_gemm_tn_desc* d, float* scratch, hipStream_t
   B4R_CHECK_LAUNCH("b4r_gemm_tn_f32 (bf16x3)");
   return b4r_launch_slab_reduce_full(p.slab, S, d->Mo, d->No, d->out, d->ldo, d->accumulate, p.colsum_slab, d->colsum,
                                      p.colsum_a_slab, d->colsum_a, stream);
+}
+
+// d0 with dropout on its B operand, d1 without, neither with an input-gradient tail: the two products of b4r_encoder_layer_bwd
+bool b4r_gemm_rx_tn_pair_supported(const b4r_gemm_tn_desc* d0, const b4r_gemm_tn_desc* d1) {
+  return b4r_gemm_rx_tn_supported(d0) && b4r_gemm_rx_tn_supported(d1) && !d0->dgrad_out && !d1->dgrad_out &&
+         !(d1->b_dropout && d1->rng && d1->drop_rate > 0.f);
+}
+int b4r_gemm_rx_tn_pair_launch(const b4r_gemm_tn_desc* d0, float* scratch0, const b4r_gemm_tn_desc* d1, float* scratch1,
+                               hipStream_t stream) {
+  const int S0 = rx_tn_split(d0->R, d0->Mo, d0->No), S1 = rx_tn_split(d1->R, d1->Mo, d1->No);
+  const RxTnP p0 = make_tn_params(d0, scratch0, S0), p1 = make_tn_params(d1, scratch1, S1);
+  const bool drop0 = d0->b_dropout && p0.drop.rng != nullptr;
+  const int n0 = (int)xcd_grid((int64_t)p0.tiles_i * p0.tiles_j * S0), n1 = (int)xcd_grid((int64_t)p1.tiles_i * p1.tiles_j * S1);
+  constexpr size_t lds = (size_t)4 * TN_KS * 128;
+  static bool lds_raised = false;
+  if (lds > 48 * 1024 && !lds_raised) {
+    (void)hipFuncSetAttribute((const void*)rx_gemm_tn_pair_kernel<TN_KS, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)rx_gemm_tn_pair_kernel<TN_KS, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    lds_raised = true;
+  }
+  if (drop0) hipLaunchKernelGGL((rx_gemm_tn_pair_kernel<TN_KS, true, false>), dim3(n0 + n1), dim3(256), lds, stream, p0, p1, n0);
+  else hipLaunchKernelGGL((rx_gemm_tn_pair_kernel<TN_KS, false, false>), dim3(n0 + n1), dim3(256), lds, stream, p0, p1, n0);
+  B4R_CHECK_LAUNCH("b4r_gemm_tn_f32 pair (bf16x3)");
+  int rc = b4r_launch_slab_reduce_full(p0.slab, S0, d0->Mo, d0->No, d0->out, d0->ldo, d0->accumulate, p0.colsum_slab, d0->colsum,
+                                       p0.colsum_a_slab, d0->colsum_a, stream);
+  if (rc) return rc;
+  return b4r_launch_slab_reduce_full(p1.slab, S1, d1->Mo, d1->No, d1->out, d1->ldo, d1->accumulate, p1.colsum_slab, d1->colsum,
+                                     p1.colsum_a_slab, d1->colsum_a, stream);
 }

@@ -35,6 +35,7 @@ int b4r_head_rx_fwd_launch(const float* T, const float* E, const float* bias, co
 int b4r_head_rx_dE_launch(const float* T, const float* E, const float* bias, const float* lse, const int32_t* ylab, int M, int V,
                           int H, float* scratch, float* dE, float* db, hipStream_t stream);
 int b4r_ffn_block_bwd_marked(const b4r_ffn_desc* d, hipStream_t stream, hipEvent_t after_dx);
+int b4r_gemm_tn_pair(const b4r_gemm_tn_desc* d0, float* scratch0, const b4r_gemm_tn_desc* d1, float* scratch1, hipStream_t stream);
 int b4r_ce_finalize_launch(const float* row_scratch, int M, b4r_train_state* state, int overwrite, hipStream_t stream);
 int b4r_attn_bwd_streams(const float* qkv, const int64_t* input_mask, const float* ctx, const float* lse, const float* dctx,
                          int32_t B, int32_t L, int32_t heads, float qscale, float* dqkv, const uint32_t* rng,
@@ -422,6 +423,14 @@ int order_after(hipStream_t from, hipStream_t to) {
   return B4R_OK;
 }
 
+b4r_gemm_tn_desc tn_desc(const float* A, int lda, const float* Bm, int ldb, float* out, int ldo, int R, int Mo, int No, float* colsum,
+                         const uint32_t* rng, uint32_t stream_id, float rate, int b_dropout) {
+  b4r_gemm_tn_desc d{};
+  d.A = A; d.lda = lda; d.B = Bm; d.ldb = ldb; d.out = out; d.ldo = ldo; d.R = R; d.Mo = Mo; d.No = No;
+  d.colsum = colsum; d.rng = rng; d.drop_stream = stream_id; d.drop_rate = rate; d.b_dropout = b_dropout; d.accumulate = 0;
+  return d;
+}
+
 hipEvent_t side_event() { return g_side.ev[(g_side.next++) & 63]; }
 int side_mark(hipStream_t on, hipEvent_t* e) {
   *e = side_event();
@@ -469,11 +478,12 @@ extern "C" int b4r_encoder_layer_bwd(const b4r_ffn_desc* ffn, const b4r_attn_blo
   const int N = ffn->N, H = ffn->H;
   hipStream_t s = (hipStream_t)stream;
   RC(b4r_ffn_block_bwd(ffn, stream));
-  RC(gemm_tn(attn->ctx, H, attn->dz1, H, dWo, H, N, H, H, dbo, nullptr, attn->out_rate > 0.f ? attn->rng : nullptr, attn->out_stream,
-             attn->out_rate, 1, tn_scratch, s));
   RC(b4r_attn_block_bwd(attn, stream));
-  return gemm_tn(attn->x, H, attn->dqkv, 3 * H, dWqkv, 3 * H, N, H, 3 * H, dbqkv, nullptr, nullptr, 0, 0.f, 0,
-                 tn_scratch + b4r_gemm_tn_scratch_floats(N, H, H), s);
+  // dWo = ctx^T . dropmask(dz1) and dWqkv = x^T . dqkv (+ their bias gradients): one launch
+  const b4r_gemm_tn_desc d_wo = tn_desc(attn->ctx, H, attn->dz1, H, dWo, H, N, H, H, dbo, attn->out_rate > 0.f ? attn->rng : nullptr,
+                                        attn->out_stream, attn->out_rate, 1);
+  const b4r_gemm_tn_desc d_wqkv = tn_desc(attn->x, H, attn->dqkv, 3 * H, dWqkv, 3 * H, N, H, 3 * H, dbqkv, nullptr, 0, 0.f, 0);
+  return b4r_gemm_tn_pair(&d_wo, tn_scratch, &d_wqkv, tn_scratch + b4r_gemm_tn_scratch_floats(N, H, H), s);
 }
 
 // ===============================================================================================================
@@ -791,6 +801,7 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
     const float* x_in = (i == 0) ? ws + w.x0 : ws + w.x2[i - 1];
     RC(order_after(s_tn, s));   // the branches of the previous layer still read da / df / db / dqkv, which this layer rewrites
     if (side4) RC(side_wait(s, ev_wo));   // dWo of the layer above reads db, which this layer's feed-forward backward rewrites
+    float* wo_scratch_of_layer = nullptr;
     // output LayerNorm (for every layer but the last its backward rode on the QKV input-gradient product of layer i + 1)
     const bool rows_here = head_rows && i == cfg->num_layers - 1;
     if (i == cfg->num_layers - 1 && !rows_here)
@@ -850,10 +861,11 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
     if (attn_bwd_fused(cfg, L)) {
       // dWo = ctx^T . dropmask(dz1) (+ bias gradient); then the attention block's backward in one launch: dqkv and, through the
       // LayerNorm in front of this layer, da (for layer 0: through the embedding stage's dropout and LayerNorm)
-      if (side4) RC(side_wait(s2, ev_dx));   // next to the feed-forward weight-gradient kernel, which leaves room on every CU
-      RC(gemm_tn(ws + w.ctx[i], H, ws + w.db, H, grads + pl.wo[i], H, N, H, H, grads + pl.bo[i], nullptr, rng, B4R_STREAM_ATTN_OUT(i),
-                 od, 1, take(b4r_gemm_tn_scratch_floats(N, H, H)), side4 ? s2 : s));
+      float* wo_scratch = wo_scratch_of_layer = take(b4r_gemm_tn_scratch_floats(N, H, H));
       if (side4) {
+        RC(side_wait(s2, ev_dx));   // next to the feed-forward weight-gradient kernel, which leaves room on every CU
+        RC(gemm_tn(ws + w.ctx[i], H, ws + w.db, H, grads + pl.wo[i], H, N, H, H, grads + pl.bo[i], nullptr, rng, B4R_STREAM_ATTN_OUT(i),
+                   od, 1, wo_scratch, s2));
         RC(side_mark(s2, &ev_wo));
         RC(side_wait(s, ev_wqkv));   // dWqkv of the layer above reads dqkv, which this launch rewrites
       }
@@ -910,6 +922,14 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
       RC(dgrad_ln_bwd(ws + w.dqkv, 3 * H, params + pl.wqkv[i], 3 * H, ws + w.db, ws + w.da, N, H, nullptr, ws + w.mean0, ws + w.rstd0,
                       params + pl.emb_ln_g, grads + pl.emb_ln_g, grads + pl.emb_ln_b, take(ln_scratch), s, batch->input_word_ids,
                       params + pl.word_emb, params + pl.pos_emb, L, V, rng, B4R_STREAM_EMB, od));
+    }
+    if (!side4 && attn_bwd_fused(cfg, L)) {   // dWo (inputs ready since the feed-forward backward) and dWqkv: one launch
+      const b4r_gemm_tn_desc d_wo = tn_desc(ws + w.ctx[i], H, ws + w.db, H, grads + pl.wo[i], H, N, H, H, grads + pl.bo[i], rng,
+                                            B4R_STREAM_ATTN_OUT(i), od, 1);
+      const b4r_gemm_tn_desc d_wqkv = tn_desc(x_in, H, ws + w.dqkv, 3 * H, grads + pl.wqkv[i], 3 * H, N, H, 3 * H, grads + pl.bqkv[i],
+                                              nullptr, 0, 0.f, 0);
+      RC(b4r_gemm_tn_pair(&d_wo, wo_scratch_of_layer, &d_wqkv, take(b4r_gemm_tn_scratch_floats(N, H, 3 * H)), s));
+      continue;
     }
     if (side4 && attn_bwd_fused(cfg, L)) {   // next to the feed-forward backward of the layer below
       RC(order_after(s, s2));

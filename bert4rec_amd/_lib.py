@@ -94,7 +94,7 @@ ST_LOSS_SUM, ST_VALID, ST_CORRECT_MASKED, ST_CORRECT_ALL, ST_SLOTS_ALL, ST_SQNOR
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_QSCALE, EPI_BIAS_GELU, EPI_BIAS_DROP_RES, EPI_GELU_BWD, EPI_ADD_RES, EPI_BIAS_TANH = range(8)
 EPI_BIAS_DROP_RES_LN, EPI_ADD_RES_LN_BWD, EPI_BIAS_GELU_LN = 8, 9, 10
-FLAG_TRAINING, FLAG_POOLER, FLAG_FUSED_HEAD, FLAG_GRAD_TAIL, FLAG_HEAD_ROWS_ONLY = 1, 2, 4, 8, 16
+FLAG_TRAINING, FLAG_POOLER, FLAG_FUSED_HEAD, FLAG_GRAD_TAIL, FLAG_HEAD_ROWS_ONLY, FLAG_LOSS_SUMS = 1, 2, 4, 8, 16, 32
 LOSS_FUSED_HEAD = 2
 GEMM_F32, GEMM_BF16X3 = 0, 1
 

@@ -41,7 +41,8 @@ int b4r_attn_bwd_streams(const float* qkv, const int64_t* input_mask, const floa
                          int32_t B, int32_t L, int32_t heads, float qscale, float* dqkv, const uint32_t* rng,
                          uint32_t drop_stream, float drop_rate, const uint32_t* keep_bits, hipStream_t stream,
                          hipStream_t stream_dkv);
-int b4r_zero2(float* a, int64_t na, float* b, int64_t nb, hipStream_t stream, float* tail = nullptr, const b4r_train_state* state = nullptr);
+int b4r_zero2(float* a, int64_t na, float* b, int64_t nb, hipStream_t stream, float* tail = nullptr, b4r_train_state* state = nullptr,
+              const float* fin_rows = nullptr, int fin_M = 0);
 int b4r_optimizer_fused(const b4r_adamw_config* hp, float* params, const float* grads, float* adam_m, float* adam_v, int64_t n,
                         int64_t n_decay, float* scratch, b4r_train_state* state, hipStream_t stream, int sums_from_tail = 0);
 
@@ -734,8 +735,11 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
   // carry no gradient); with B4R_FLAG_GRAD_TAIL also the step's sums behind the gradients
   B4R_CHECK_ARG(!(flags & B4R_FLAG_GRAD_TAIL) || state, B4R_E_BADARG, "b4r_backward: B4R_FLAG_GRAD_TAIL needs the state");
   const bool head_rows = (flags & B4R_FLAG_HEAD_ROWS_ONLY) && head_rows_ok(cfg, batch);
+  const bool loss_sums = (flags & B4R_FLAG_LOSS_SUMS) != 0;
+  B4R_CHECK_ARG(!loss_sums || ((flags & B4R_FLAG_FUSED_HEAD) && state && batch->masked_lm_ids), B4R_E_BADARG,
+                "b4r_backward: B4R_FLAG_LOSS_SUMS needs B4R_FLAG_FUSED_HEAD, the state and masked_lm_ids");
   RC(b4r_zero2(grads, pl.total, ws + (head_rows ? w.hot : w.dx), head_rows ? w.da - w.hot : w.db - w.dx, s,
-               (flags & B4R_FLAG_GRAD_TAIL) ? grads + pl.total : nullptr, state));
+               (flags & B4R_FLAG_GRAD_TAIL) ? grads + pl.total : nullptr, state, loss_sums ? ws + w.rowsc : nullptr, (int)w.M));
 
   // ---- masked-LM head (logits buffer holds d loss_sum / d logits, pad columns zero) --------------------------------
   // s2: independent branches (see SideStream); it is ordered after the memsets here, joined before every reuse of a buffer
@@ -991,9 +995,10 @@ extern "C" int b4r_train_step(const b4r_model_config* cfg, const b4r_adamw_confi
   // head gathers only (B4R_FLAG_HEAD_ROWS_ONLY; the same flag goes to forward and backward)
   RC(b4r_forward(cfg, batch, params, nullptr, workspace, workspace_bytes, state,
                  B4R_FLAG_TRAINING | B4R_FLAG_HEAD_ROWS_ONLY | (fused ? B4R_FLAG_FUSED_HEAD : 0), stream));
-  RC(b4r_loss(cfg, batch, workspace, workspace_bytes, state, 1 | B4R_LOSS_OVERWRITE | (fused ? B4R_LOSS_FUSED_HEAD : 0), stream));
+  // with the logits-free head the loss sums are formed inside the backward's first launch (B4R_FLAG_LOSS_SUMS), else by b4r_loss
+  if (!fused) RC(b4r_loss(cfg, batch, workspace, workspace_bytes, state, 1 | B4R_LOSS_OVERWRITE, stream));
   RC(b4r_backward(cfg, batch, params, grads, workspace, workspace_bytes, state,
-                  B4R_FLAG_TRAINING | B4R_FLAG_HEAD_ROWS_ONLY | (fused ? B4R_FLAG_FUSED_HEAD : 0), stream));
+                  B4R_FLAG_TRAINING | B4R_FLAG_HEAD_ROWS_ONLY | (fused ? B4R_FLAG_FUSED_HEAD | B4R_FLAG_LOSS_SUMS : 0), stream));
   RC(b4r_optimizer_step(cfg, hp, params, grads, adam_m, adam_v, workspace, workspace_bytes, state, stream));
   return B4R_OK;
 }

@@ -744,22 +744,58 @@ extern "C" int b4r_softmax_ce(float* logits, int32_t M, int32_t V, int32_t ld, c
 // (memset nodes of a replayed graph were observed to leave the regions untouched from the second replay on).
 // tail (optional): the 8 floats behind the gradient buffer receive the step's five sums from the state (loss_sum, valid_count,
 // correct_masked, correct_all, slots_all), so that ONE all-reduce of [gradients | tail] carries them
-__global__ __launch_bounds__(256) void zero2_kernel(float* a, int64_t na4, float* b, int64_t nb4, float* tail, const float* state_f) {
+// fin_rows (optional): the LAST workgroup also does what ce_finalize_kernel does in overwrite mode -- the ordered sum of the fused
+// head's per-row scalars into the state, in exactly that kernel's summation order (a thread stands in for four of its 1024) --
+// before the tail copy, so that b4r_backward needs no b4r_loss launch in front of it (B4R_FLAG_LOSS_SUMS)
+__global__ __launch_bounds__(256) void zero2_kernel(float* a, int64_t na4, float* b, int64_t nb4, float* tail, float* state_f,
+                                                    const float* fin_rows, int fin_M) {
+  __shared__ float s[4][1024];
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-  if (tail != nullptr && blockIdx.x == 0 && threadIdx.x < 8) tail[threadIdx.x] = threadIdx.x < 5 ? state_f[4 + threadIdx.x] : 0.f;
+  const bool fin = fin_rows != nullptr && blockIdx.x == gridDim.x - 1;
+  if (fin) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int m = tid + 256 * v; m < fin_M; m += 1024) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] += fin_rows[4 * (int64_t)m + q];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s[q][tid + 256 * v] = acc[q];
+    }
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+      for (int t = tid; t < o; t += 256) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s[q][t] += s[q][t + o];
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {   // b4r_train_state floats: [4] loss_sum [5] valid_count [6] correct_masked [7] correct_all [8] slots_all [9] [10]
+      state_f[4] = 0.f + s[0][0]; state_f[5] = 0.f + s[1][0]; state_f[6] = 0.f + s[2][0]; state_f[7] = 0.f + s[3][0];
+      state_f[8] = 0.f + (float)fin_M; state_f[9] = 0.f; state_f[10] = 0.f;
+    }
+    __syncthreads();
+  }
+  if (tail != nullptr && (fin_rows != nullptr ? fin : blockIdx.x == 0) && threadIdx.x < 8)
+    tail[threadIdx.x] = threadIdx.x < 5 ? state_f[4 + threadIdx.x] : 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < na4 + nb4; i += (int64_t)gridDim.x * 256) {
     if (i < na4) *reinterpret_cast<f32x4*>(a + 4 * i) = z;
     else *reinterpret_cast<f32x4*>(b + 4 * (i - na4)) = z;
   }
 }
-int b4r_zero2(float* a, int64_t na, float* b, int64_t nb, hipStream_t stream, float* tail, const b4r_train_state* state) {
+int b4r_zero2(float* a, int64_t na, float* b, int64_t nb, hipStream_t stream, float* tail, b4r_train_state* state,
+              const float* fin_rows, int fin_M) {
   B4R_CHECK_ARG(na % 4 == 0 && nb % 4 == 0 && b4r_aligned16(a) && b4r_aligned16(b), B4R_E_ALIGN, "zero2: regions must be 16-byte granular");
+  B4R_CHECK_ARG(fin_rows == nullptr || (state != nullptr && fin_M > 0), B4R_E_BADARG, "zero2: the loss sums need the state");
   int64_t n4 = (na + nb) / 4;
   int grid = (int)((n4 + 255) / 256);
   if (grid > 2048) grid = 2048;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(zero2_kernel, dim3(grid), dim3(256), 0, stream, a, na / 4, b, nb / 4, tail, reinterpret_cast<const float*>(state));
-  B4R_CHECK_LAUNCH("zero fill");
+  hipLaunchKernelGGL(zero2_kernel, dim3(grid), dim3(256), 0, stream, a, na / 4, b, nb / 4, tail, reinterpret_cast<float*>(state), fin_rows,
+                     fin_M);
+  B4R_CHECK_LAUNCH(fin_rows ? "zero fill + loss sums" : "zero fill");
   return B4R_OK;
 }
 

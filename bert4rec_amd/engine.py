@@ -328,13 +328,15 @@ class Engine:
                                      _stream(self.device)), "b4r_loss")
 
     def backward(self, cb: Batch, training: bool = True, fused_head: bool = False, grad_tail: bool = False,
-                 head_rows_only: bool = False) -> None:
+                 head_rows_only: bool = False, loss_sums: bool = False) -> None:
         """grad_tail: also write the step's sums behind the gradients (data-parallel steps all-reduce grad_ext as one buffer);
-        head_rows_only: as given to the forward of the same step"""
+        head_rows_only: as given to the forward of the same step; loss_sums (fused head only): the call also sets the state's loss /
+        metric sums (B4R_FLAG_LOSS_SUMS: no begin_step() / loss() calls in front of it)"""
         self.ensure_training_buffers()
         ws = self.workspace(cb.B, cb.L, cb.P)
         flags = (_lib.FLAG_TRAINING if training else 0) | (_lib.FLAG_FUSED_HEAD if fused_head else 0) | \
-                (_lib.FLAG_GRAD_TAIL if grad_tail else 0) | (_lib.FLAG_HEAD_ROWS_ONLY if head_rows_only else 0)
+                (_lib.FLAG_GRAD_TAIL if grad_tail else 0) | (_lib.FLAG_HEAD_ROWS_ONLY if head_rows_only else 0) | \
+                (_lib.FLAG_LOSS_SUMS if loss_sums else 0)
         _lib.check(self.lib.b4r_backward(C.byref(self.cfg), C.byref(cb), _ptr(self.params), _ptr(self.grads), _ptr(ws),
                                          ws.numel() * 4, _ptr(self.state), flags, _stream(self.device)), "b4r_backward")
 
@@ -400,10 +402,12 @@ class Engine:
             self._pin_workspace(cb.B, cb.L, cb.P)
             g_pre, g_post = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_pre, capture_error_mode=_CAPTURE_MODE):
-                self.begin_step()
+                if not fused:
+                    self.begin_step()
                 self.forward(cb, training=True, pooler=False, fused_head=fused, head_rows_only=True)
-                self.loss(cb, want_grad=True, fused_head=fused)
-                self.backward(cb, training=True, fused_head=fused, grad_tail=True, head_rows_only=True)
+                if not fused:
+                    self.loss(cb, want_grad=True, fused_head=False)
+                self.backward(cb, training=True, fused_head=fused, grad_tail=True, head_rows_only=True, loss_sums=fused)
             with torch.cuda.graph(g_post, capture_error_mode=_CAPTURE_MODE):
                 self.optimizer_step(hp, cb, reduced=True)
             pair = graphs[key] = (g_pre, g_post)
@@ -417,10 +421,12 @@ class Engine:
         from .distributed import allreduce_step
         self.ensure_training_buffers()
         fused = self.fused_head_supported()
-        self.begin_step()
+        if not fused:
+            self.begin_step()
         self.forward(cb, training=True, pooler=False, fused_head=fused, head_rows_only=True)
-        self.loss(cb, want_grad=True, fused_head=fused)
-        self.backward(cb, training=True, fused_head=fused, grad_tail=True, head_rows_only=True)
+        if not fused:
+            self.loss(cb, want_grad=True, fused_head=False)
+        self.backward(cb, training=True, fused_head=fused, grad_tail=True, head_rows_only=True, loss_sums=fused)
         allreduce_step(self.grad_ext, group, self.rehearse_collectives)
         self.optimizer_step(hp, cb, reduced=True)
 

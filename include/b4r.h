@@ -146,6 +146,11 @@ int b4r_workspace_region(const b4r_model_config* cfg, int32_t B, int32_t L, int3
  * "sequence_output" / "encoder_output_<last>" are then only defined on those rows, which is why the forward / evaluation API never sets
  * the flag.  b4r_train_step uses it; ignored where the fused feed-forward block does not apply. */
 #define B4R_FLAG_HEAD_ROWS_ONLY 16
+/* b4r_backward only, with B4R_FLAG_FUSED_HEAD: the call begins by SETTING the state's sums (loss_sum, valid_count, correct_masked,
+ * correct_all, slots_all; gradient norms to 0) from the loss rows the logits-free head left in the workspace -- what
+ * b4r_loss(..., want_grad | B4R_LOSS_FUSED_HEAD | B4R_LOSS_OVERWRITE) does, inside the launch that clears the gradients (the same
+ * summation order, bit for bit).  No b4r_state_begin_step / b4r_loss call is then needed between forward and backward. */
+#define B4R_FLAG_LOSS_SUMS 32
 #define B4R_LOSS_FUSED_HEAD 2
 #define B4R_LOSS_OVERWRITE 4 /* b4r_loss: set the state's sums instead of adding to them (= b4r_state_begin_step first) */
 int32_t b4r_fused_head_supported(const b4r_model_config* cfg);

@@ -222,3 +222,30 @@ def test_graph_replayed_steps_equal_eager_steps():
     for (s0, a, lra), (s1, b, lrb) in zip(l0, l1):
         assert abs(a - b) <= 1e-4 * abs(a) and lra == lrb
     assert float((p0 - p1).abs().max()) < 1e-6
+
+
+def test_backward_can_form_the_loss_sums_itself_bit_for_bit():
+    """B4R_FLAG_LOSS_SUMS: b4r_backward sets the state's loss / metric sums inside its first launch, in b4r_loss's summation order:
+    the same bits as begin_step + b4r_loss(fused head) + b4r_backward, gradients included (what b4r_train_step and the
+    data-parallel step run)."""
+    cfg_o, shp = CONFIGS["ml1m_slice"]
+    eng, _ = build(cfg_o)
+    if not eng.fused_head_supported():
+        pytest.skip("the logits-free head needs the bf16x3 mode")
+    batch = orc.synthetic_batch(shp["B"], shp["L"], shp["P"], cfg_o.vocab_size, seed=4, ragged=True)
+    st_a, g_a = run_loss_and_grads(eng, batch, training=True, seed=5, step=2, fused_head=True)
+    cb, keep = eng.prepare_batch(batch)
+    eng.set_seed(5)
+    eng.set_step(2)
+    eng.state[4:11] = 12345           # stale sums: the flag overwrites, it does not add
+    eng.forward(cb, training=True, pooler=False, fused_head=True, head_rows_only=True)
+    eng.backward(cb, training=True, fused_head=True, head_rows_only=True, loss_sums=True, grad_tail=True)
+    torch.cuda.synchronize()
+    st_b, g_b = eng.read_state(), eng.export_named(eng.grads)
+    for k in ("loss_sum", "valid_count", "correct_masked", "correct_all", "slots_all"):
+        assert st_a[k] == st_b[k], k
+    for n in g_a:
+        if n != "word_embeddings/embeddings":      # summed with float atomics
+            assert torch.equal(g_a[n], g_b[n]), n
+    tail = eng.grad_ext[eng.n_params:eng.n_params + 5].cpu().tolist()
+    assert tail == [st_b[k] for k in ("loss_sum", "valid_count", "correct_masked", "correct_all", "slots_all")]

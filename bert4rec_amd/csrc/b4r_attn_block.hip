@@ -19,40 +19,9 @@
 //   3. per head the body of attn_rx_fwd_kernel (b4r_attn_rx.hip): S^T = K.Q^T in registers, softmax, dropout bits, O^T = V^T.P^T.
 //   4. y^T = Wo^T.ctx^T straight from the two heads' accumulators, bias, dropout, residual, LayerNorm (two 4-lane shuffles).
 // LDS: Wo image 16 KB + max(Wqkv image 48 KB, K / V images of both heads: 8 KB per 16 tokens) + the key mask.
-#include "b4r_rx_tiles.h"
+#include "b4r_block_tiles.h"
 
 namespace {
-
-constexpr int SUB = 1024;     // bytes of one 16 x 32 bf16 sub-tile
-constexpr int HID = 64;
-
-__device__ __forceinline__ int sub_off(int r16, int ch) { return r16 * 64 + 16 * (ch ^ ((0 - (r16 >> 2)) & 3)); }
-__device__ __forceinline__ int sub_base(int rt, int cb, int ncb) { return ((rt * ncb + cb) * 2) * SUB; }
-
-typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
-__device__ __forceinline__ bf16x8 tr_pair(const char* a, const char* b) {
-  const s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)a);
-  const s16x4 y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)b);
-  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7));
-}
-
-// W [R][C] fp32 row-major -> natural hi / lo image in 16 x 32 sub-tiles, all `nthreads` threads of the workgroup
-__device__ __forceinline__ void stage_weight(char* img, const float* W, int R, int C, int nthreads) {
-  // one float4 per thread and turn, sub-tile by sub-tile: the 64 lanes of a wave-instruction fill 8 whole rows (512 bytes) of one
-  // sub-tile, so the 8-byte LDS stores are conflict-free (row-major order put a wave across 8 sub-tiles 2 KB apart: 8-way)
-  const int ncb = C >> 5, nf4 = (R * C) >> 2;
-  for (int f = threadIdx.x; f < nf4; f += nthreads) {
-    const int st = f >> 7, u = f & 127;
-    const int rt = st / ncb, cb = st - rt * ncb;
-    const int r16 = u >> 3, q4 = u & 7;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(W + (int64_t)(16 * rt + r16) * C + 32 * cb + 4 * q4);
-    bf16x4 h, l;
-    b4r_split4(v, h, l);
-    char* dst = img + sub_base(rt, cb, ncb) + sub_off(r16, q4 >> 1) + 8 * (q4 & 1);
-    *reinterpret_cast<bf16x4*>(dst) = h;
-    *reinterpret_cast<bf16x4*>(dst + SUB) = l;
-  }
-}
 
 struct AbP {
   const float* x; const int64_t* mask;
@@ -64,12 +33,6 @@ struct AbP {
   DropArgs drop_p, drop_o;
 };
 
-__device__ __forceinline__ float sum4(const f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
-__device__ __forceinline__ float quad_sum(float s) {
-  s += __shfl_xor(s, 16, 64);
-  s += __shfl_xor(s, 32, 64);
-  return s;
-}
 __device__ __forceinline__ f32x4 lo4(const f32x8 v) { return (f32x4){v[0], v[1], v[2], v[3]}; }
 __device__ __forceinline__ f32x4 hi4(const f32x8 v) { return (f32x4){v[4], v[5], v[6], v[7]}; }
 
@@ -375,15 +338,6 @@ __device__ __forceinline__ bf16x4 tr_one(const char* a) {
   return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)a));
 }
 __device__ __forceinline__ bf16x8 row16(const char* a) { return *reinterpret_cast<const bf16x8*>(a); }
-// sum over the 16 lanes of a DPP row, valid in lane 15 of the row (four v_add_f32 with a row_shr modifier: a __shfl_xor butterfly
-// compiles to ds_bpermute_b32 and cost 5 us here)
-__device__ __forceinline__ float row_sum15(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));   // row_shr:1
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));   // row_shr:2
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));   // row_shr:4
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));   // row_shr:8
-  return v;
-}
 
 template <bool EMBED>
 __global__ __launch_bounds__(1024) void attn_block_bwd_kernel(AbBwdP p) {

@@ -32,81 +32,15 @@
 // (g, j) is then inner column 8g + j -- the natural order a row fragment delivers.  (An earlier layout with contiguous
 // tiles needed two 8-byte reads per fragment; hipcc fused the hi / lo pair into ds_read2st64_b64, which banks modulo 32 and
 // ran the input-gradient kernel at 72 % LDS bank-conflict cycles.)
-#include "b4r_rx_tiles.h"
+#include "b4r_block_tiles.h"
 
 namespace {
 
 constexpr int FW = 16;        // waves per workgroup (1024 threads, one workgroup per CU: 129 KB of weight images)
-constexpr int SUB = 1024;     // bytes of one 16 x 32 bf16 sub-tile
-constexpr int HID = 64, INNER = 256;
-constexpr int W_IMG = HID * INNER * 4;   // hi + lo image of one weight matrix: 64 KB
-// unroll factors of the inner-dimension loops: what hipcc allocates without spilling into the loop at 128 VGPRs (16 waves)
-#ifndef FFN_FWD_UNROLL
-#define FFN_FWD_UNROLL 4
-#endif
+// unroll factor of the input-gradient kernel's inner-dimension loop: what hipcc allocates without spilling at 128 VGPRs (16 waves)
 #ifndef FFN_DX_UNROLL
 #define FFN_DX_UNROLL 1
 #endif
-// timing experiments only (tools/build_variant.sh): 1 = no weight staging, 2 = no GELU arithmetic, 4 = no output stores
-#ifndef FFN_EXP
-#define FFN_EXP 0
-#endif
-
-__device__ __forceinline__ int sub_off(int r16, int ch) { return r16 * 64 + 16 * (ch ^ ((0 - (r16 >> 2)) & 3)); }
-// hi sub-tile (row tile rt, column block cb) of an image with ncb column blocks; the lo sub-tile follows it
-__device__ __forceinline__ int sub_base(int rt, int cb, int ncb) { return ((rt * ncb + cb) * 2) * SUB; }
-
-struct LaneK {
-  int tr[2];      // transposed fragment, rows = two stacked 16-row tiles (dw kernel): rows 4g .. 4g+3, column 16 db + i
-  int trk[2][2];  // transposed fragment whose rows are a 32-deep k block in natural order: [db][s] = rows 8g + 4s .. +3 of the
-                  // block (row tile g >> 1 of the pair: + (g >> 1) * row-tile stride, added by the caller), column 16 db + i
-  int trw[2][2];  // the same rows, columns interleaved: [a][s] = rows 8g + 4s .., column 8p + 4a + e for lane i = 4p + e
-  int row;        // row fragment: row i, columns 8g .. 8g+7
-  int hi_tile;    // g >> 1: which row tile of a 32-row pair the lane's k rows are in
-};
-__device__ __forceinline__ LaneK lane_consts(int lane) {
-  const int i = lane & 15, g = lane >> 4, qq = i >> 2, pp = i & 3;
-  LaneK k;
-#pragma unroll
-  for (int db = 0; db < 2; ++db) {
-    k.tr[db] = sub_off(4 * g + qq, 2 * db + (pp >> 1)) + 8 * (pp & 1);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      k.trk[db][s] = sub_off(8 * (g & 1) + 4 * s + qq, 2 * db + (pp >> 1)) + 8 * (pp & 1);
-      k.trw[db][s] = sub_off(8 * (g & 1) + 4 * s + qq, pp) + 8 * db;
-    }
-  }
-  k.row = sub_off(i, g);
-  k.hi_tile = g >> 1;
-  return k;
-}
-
-typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
-__device__ __forceinline__ bf16x8 tr_pair(const char* a, const char* b) {
-  const s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)a);
-  const s16x4 y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)b);
-  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7));
-}
-__device__ __forceinline__ bf16x8 row_at(const char* a) { return *reinterpret_cast<const bf16x8*>(a); }
-
-// W [R][C] fp32 row-major -> natural hi / lo image (R % 16 == 0, C % 32 == 0), all threads of the workgroup
-__device__ __forceinline__ void stage_weight(char* img, const float* W, int R, int C) {
-  // one float4 per thread and turn, sub-tile by sub-tile: the 64 lanes of a wave-instruction fill 8 whole rows (512 bytes) of one
-  // sub-tile, so the 8-byte LDS stores are conflict-free (row-major order put a wave across 8 sub-tiles 2 KB apart: 8-way)
-  const int ncb = C >> 5, nf4 = (R * C) >> 2;
-  for (int f = threadIdx.x; f < nf4; f += 64 * FW) {
-    const int st = f >> 7, u = f & 127;
-    const int rt = st / ncb, cb = st - rt * ncb;
-    const int r16 = u >> 3, q4 = u & 7;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(W + (int64_t)(16 * rt + r16) * C + 32 * cb + 4 * q4);
-    bf16x4 h, l;
-    b4r_split4(v, h, l);
-    char* dst = img + sub_base(rt, cb, ncb) + sub_off(r16, q4 >> 1) + 8 * (q4 & 1);
-    *reinterpret_cast<bf16x4*>(dst) = h;
-    *reinterpret_cast<bf16x4*>(dst + SUB) = l;
-  }
-}
-
 // gelu(x) and gelu'(x) from one erf / exp evaluation (b4r_erf_as)
 __device__ __forceinline__ void gelu_both(float x, float& gl, float& gr) {
   float e;
@@ -155,42 +89,6 @@ __device__ __forceinline__ int ffn_row(const FfnP& p, int j) {
 __device__ __forceinline__ bool ffn_listed(const FfnP& p) { return p.rows != nullptr || p.spos != nullptr; }
 __device__ __forceinline__ int ffn_slot(const FfnP& p, int j) { return p.spos ? (p.sids[j] != 0 ? j : -1) : p.slotof[j]; }
 
-__device__ __forceinline__ float sum4(const f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
-__device__ __forceinline__ float quad_sum(float s) {   // over the four lanes i, i+16, i+32, i+48 that share a token
-  s += __shfl_xor(s, 16, 64);
-  s += __shfl_xor(s, 32, 64);
-  return s;
-}
-
-// sum over the 16 lanes of a DPP row (the 16 tokens of a lane group), valid in lane 15 of the row: four v_add_f32 with a row_shr
-// modifier, no LDS crossbar traffic (a __shfl_xor butterfly compiles to ds_bpermute_b32)
-__device__ __forceinline__ float row_sum15(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));   // row_shr:1
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));   // row_shr:2
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));   // row_shr:4
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));   // row_shr:8
-  return v;
-}
-
-// fpre^T tile `a` of inner block kt (rows 4p + e = inner columns 32 kt + 8p + 4a + e, the wave's 16 tokens on the columns),
-// accumulator preset to the bias `c` (sb1[32 kt + 8g + 4a ..], read by the caller an iteration ahead: a wait on it would
-// otherwise drain every LDS read in flight in front of each product); xh / xl: the tokens' x1 rows as B operands, k-slot (g, j) = hidden column 32 ks + 8g + j
-__device__ __forceinline__ f32x4 fpre_tile(const char* w1img, f32x4 c, const LaneK& lk, int kt, int a,
-                                           const bf16x8 (&xh)[2], const bf16x8 (&xl)[2]) {
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    const char* t = w1img + sub_base(2 * ks + lk.hi_tile, kt, 8);
-    c = mfma3(tr_pair(t + lk.trw[a][0], t + lk.trw[a][1]), tr_pair(t + SUB + lk.trw[a][0], t + SUB + lk.trw[a][1]), xh[ks], xl[ks], c);
-  }
-  return c;
-}
-
-// the wave's 16 rows of a [N, 64] matrix as B operands of products that sum over the hidden index
-__device__ __forceinline__ void load_rows(const float* src, int tokc, int g, f32x8 (&v)[2]) {
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) v[ks] = load8(src + (int64_t)tokc * HID + 32 * ks + 8 * g);
-}
-
 // -----------------------------------------------------------------------------------------------------------
 // forward.  LDS: [W1 image 64 KB | W2 image 64 KB | b1]
 // -----------------------------------------------------------------------------------------------------------
@@ -201,8 +99,8 @@ __global__ __launch_bounds__(64 * FW) void ffn_fwd_kernel(FfnP p) {
   char* w2img = smem_ffn + W_IMG;
   float* sb1 = reinterpret_cast<float*>(smem_ffn + 2 * W_IMG);
   if (!(FFN_EXP & 1)) {
-  stage_weight(w1img, p.W1, HID, INNER);
-  stage_weight(w2img, p.W2, INNER, HID);
+  stage_weight(w1img, p.W1, HID, INNER, 64 * FW);
+  stage_weight(w2img, p.W2, INNER, HID, 64 * FW);
   }
   if (threadIdx.x < INNER) sb1[threadIdx.x] = p.b1[threadIdx.x];
   FF_MARK(1);
@@ -214,84 +112,12 @@ __global__ __launch_bounds__(64 * FW) void ffn_fwd_kernel(FfnP p) {
   const DropCtx dctx = b4r_drop_ctx(p.drop);
   const int Nn = ffn_rows(p);
   const int ntiles = (Nn + 15) >> 4;
+  const FfnTileP tp{p.x1, p.b2, p.g2, p.be2, p.z2, p.x2, p.mean2, p.rstd2, p.eps};
   for (int t = blockIdx.x + gridDim.x * wave; t < ntiles; t += gridDim.x * FW) {   // wave-uniform: EXEC stays full
     const int j = 16 * t + i;
-    const int tok = ffn_row(p, min(j, Nn - 1)), tokc = tok;   // tok: the row in the [N, 64] tensors; pad lanes repeat the last row
-    bf16x8 xh[2], xl[2];
-    {
-      f32x8 xv[2];
-      load_rows(p.x1, tokc, g, xv);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) split8(xv[ks], xh[ks], xl[ks]);
-    }
+    const int tok = ffn_row(p, min(j, Nn - 1));   // the row in the [N, 64] tensors; pad lanes repeat the last row
     FF_MARK(3);
-    f32x4 acc[4];
-#pragma unroll
-    for (int hb = 0; hb < 4; ++hb) acc[hb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x8 bnext = load8(&sb1[8 * g]);
-#pragma unroll FFN_FWD_UNROLL
-    for (int kt = 0; kt < INNER / 32; ++kt) {
-      const f32x8 bias = bnext;
-      bnext = load8(&sb1[32 * min(kt + 1, INNER / 32 - 1) + 8 * g]);
-      f32x4 f[2];
-#pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        const f32x4 c = fpre_tile(w1img, a ? (f32x4){bias[4], bias[5], bias[6], bias[7]} : (f32x4){bias[0], bias[1], bias[2], bias[3]},
-                                  lk, kt, a, xh, xl);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) f[a][r] = (FFN_EXP & 2) ? c[r] : b4r_gelu_fast(c[r]);
-      }
-      bf16x8 fh, fl;
-      split8(cat(f[0], f[1]), fh, fl);   // k-slot (g, j) = inner column 32 kt + 8g + j
-      const char* t = w2img + sub_base(2 * kt + lk.hi_tile, 0, 2);
-#pragma unroll
-      for (int hb = 0; hb < 4; ++hb) {   // G^T[16 hb + ..][token] += W2^T[.., inner block kt] . f^T
-        const char* th = t + (hb >> 1) * 2 * SUB;
-        const int db = hb & 1;
-        acc[hb] = mfma3(tr_pair(th + lk.trk[db][0], th + lk.trk[db][1]), tr_pair(th + SUB + lk.trk[db][0], th + SUB + lk.trk[db][1]),
-                        fh, fl, acc[hb]);
-      }
-    }
-    FF_MARK(4);
-    // bias + dropout + residual + LayerNorm: lane (i, g) holds columns 16 hb + 4g .. +3 of token i
-    f32x4 z[4];
-    float s = 0.f;
-#pragma unroll
-    for (int hb = 0; hb < 4; ++hb) {
-      const f32x4 y = acc[hb] + *reinterpret_cast<const f32x4*>(p.b2 + 16 * hb + 4 * g);
-      const f32x4 res = *reinterpret_cast<const f32x4*>(p.x1 + (int64_t)tokc * HID + 16 * hb + 4 * g);
-      z[hb] = res + b4r_drop4(dctx, y, (uint64_t)tok * HID + (uint64_t)(16 * hb + 4 * g));
-      s += sum4(z[hb]);
-    }
-    const float mean = quad_sum(s) * (1.0f / HID);
-    float q = 0.f;
-#pragma unroll
-    for (int hb = 0; hb < 4; ++hb) {
-      const f32x4 d = z[hb] - mean;
-      q += sum4(d * d);
-    }
-    const float rstd = rsqrtf(quad_sum(q) * (1.0f / HID) + p.eps);
-    FF_MARK(5);
-    if (j < Nn && (!(FFN_EXP & 4) || rstd == 12345.f)) {
-#pragma unroll
-      for (int hb = 0; hb < 4; ++hb) {
-        const int64_t o = (int64_t)tok * HID + 16 * hb + 4 * g;
-        const f32x4 gm = *reinterpret_cast<const f32x4*>(p.g2 + 16 * hb + 4 * g);
-        const f32x4 be = *reinterpret_cast<const f32x4*>(p.be2 + 16 * hb + 4 * g);
-        f32x4 y;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float inv = rstd * gm[e];
-          y[e] = z[hb][e] * inv + (be[e] - mean * inv);
-        }
-        if (p.z2) *reinterpret_cast<f32x4*>(p.z2 + o) = z[hb];
-        *reinterpret_cast<f32x4*>(p.x2 + o) = y;
-      }
-      if (g == 0) {
-        if (p.mean2) p.mean2[tok] = mean;
-        if (p.rstd2) p.rstd2[tok] = rstd;
-      }
-    }
+    ffn_fwd_tile(tp, w1img, w2img, sb1, lk, dctx, tok, j < Nn, g);
     FF_MARK(6);
   }
   FF_MARK(7);
@@ -307,8 +133,8 @@ __global__ __launch_bounds__(64 * FW) void ffn_bwd_dx_kernel(FfnP p) {
   char* w2img = smem_ffn + W_IMG;
   float* sb1 = reinterpret_cast<float*>(smem_ffn + 2 * W_IMG);
   float* sred = sb1 + INNER;   // [FW][128], then [FW][128] for the output LayerNorm (row-list mode)
-  stage_weight(w1img, p.W1, HID, INNER);
-  stage_weight(w2img, p.W2, INNER, HID);
+  stage_weight(w1img, p.W1, HID, INNER, 64 * FW);
+  stage_weight(w2img, p.W2, INNER, HID, 64 * FW);
   if (threadIdx.x < INNER) sb1[threadIdx.x] = p.b1[threadIdx.x];
   __syncthreads();
 

@@ -468,6 +468,8 @@ extern "C" int b4r_encoder_layer_fwd(const b4r_attn_block_desc* attn, const b4r_
   B4R_CHECK_ARG(attn && ffn, B4R_E_BADARG, "b4r_encoder_layer_fwd: null descriptor");
   B4R_CHECK_ARG(attn->x1 != nullptr && attn->x1 == ffn->x1 && (int64_t)attn->B * attn->L == ffn->N && attn->H == ffn->H, B4R_E_BADARG,
                 "b4r_encoder_layer_fwd: the attention half's x1 [B*L,H] must be the feed-forward half's input");
+  // (both halves behind each other in ONE launch were measured: 68 us against 39 + 25 us -- the feed-forward phase has to wait
+  // for the attention half's stores at the barrier that frees the LDS, DESIGN.md section 4.1 -- and not kept)
   RC(b4r_attn_block_fwd(attn, stream));
   return b4r_ffn_block_fwd(ffn, stream);
 }
@@ -585,8 +587,10 @@ extern "C" int b4r_forward(const b4r_model_config* cfg, const b4r_batch* batch, 
   const bool head_rows = (flags & B4R_FLAG_HEAD_ROWS_ONLY) && head_rows_ok(cfg, batch);
   const float* x = ws + w.x0;
   for (int i = 0; i < cfg->num_layers; ++i) {
+    const bool layer_fused = attn_fused(cfg, L) && ffn_fused(cfg);
+    b4r_attn_block_desc ad{};
+    b4r_ffn_desc fd{};
     if (attn_fused(cfg, L)) {
-      b4r_attn_block_desc ad{};
       ad.B = B; ad.L = L; ad.H = H; ad.heads = cfg->num_heads; ad.x = x; ad.input_mask = batch->input_mask;
       ad.Wqkv = params + pl.wqkv[i]; ad.bqkv = params + pl.bqkv[i]; ad.Wo = params + pl.wo[i]; ad.bo = params + pl.bo[i];
       ad.ln_gamma = params + pl.ln1_g[i]; ad.ln_beta = params + pl.ln1_b[i]; ad.ln_eps = cfg->ln_eps;
@@ -595,7 +599,7 @@ extern "C" int b4r_forward(const b4r_model_config* cfg, const b4r_batch* batch, 
       ad.qkv = attn_bwd_fused(cfg, L) ? nullptr : ws + w.qkv[i];   // only round 1's backward kernels read it
       ad.ctx = ws + w.ctx[i]; ad.lse = ws + w.lse[i]; ad.keep_bits = reinterpret_cast<uint32_t*>(ws + w.keep[i]);
       ad.z1 = ws + w.z1[i]; ad.x1 = ws + w.x1[i]; ad.mean1 = ws + w.mean1[i]; ad.rstd1 = ws + w.rstd1[i];
-      RC(b4r_attn_block_fwd(&ad, stream));
+      if (!layer_fused) RC(b4r_attn_block_fwd(&ad, stream));
     } else {
     RC(gemm(x, H, params + pl.wqkv[i], 3 * H, ws + w.qkv[i], 3 * H, N, 3 * H, H, 0, B4R_EPI_BIAS_QSCALE, params + pl.bqkv[i],
             nullptr, 0, nullptr, 0, qscale, H, nullptr, 0, 0.f, 0, s));
@@ -606,7 +610,6 @@ extern "C" int b4r_forward(const b4r_model_config* cfg, const b4r_batch* batch, 
                     od, s));
     }
     if (ffn_fused(cfg)) {
-      b4r_ffn_desc fd{};
       fd.N = N; fd.H = H; fd.I = I; fd.x1 = ws + w.x1[i];
       fd.W1 = params + pl.w1[i]; fd.b1 = params + pl.b1[i]; fd.W2 = params + pl.w2[i]; fd.b2 = params + pl.b2[i];
       fd.ln_gamma = params + pl.ln2_g[i]; fd.ln_beta = params + pl.ln2_b[i]; fd.ln_eps = cfg->ln_eps;
@@ -616,7 +619,8 @@ extern "C" int b4r_forward(const b4r_model_config* cfg, const b4r_batch* batch, 
         fd.slot_positions = batch->masked_lm_positions; fd.slot_ids = batch->masked_lm_ids; fd.slots_per_seq = batch->P; fd.seq_len = L;
         fd.max_rows = (int32_t)w.maxrows;
       }
-      RC(b4r_ffn_block_fwd(&fd, stream));
+      if (layer_fused) RC(b4r_encoder_layer_fwd(&ad, &fd, stream));
+      else RC(b4r_ffn_block_fwd(&fd, stream));
     } else {
     RC(gemm(ws + w.x1[i], H, params + pl.w1[i], I, ws + w.f[i], I, N, I, H, 0, B4R_EPI_BIAS_GELU, params + pl.b1[i],
             ws + w.fpre[i], I, nullptr, 0, 1.f, 0, nullptr, 0, 0.f, 0, s));

@@ -754,16 +754,30 @@ __global__ __launch_bounds__(256) void zero2_kernel(float* a, int64_t na4, float
   const bool fin = fin_rows != nullptr && blockIdx.x == gridDim.x - 1;
   if (fin) {
     const int tid = threadIdx.x;
+    // a thread stands in for threads tid, tid + 256, tid + 512, tid + 768 of ce_finalize_kernel: four independent chains, each
+    // adding its rows m, m + 1024, ... in order; the loads of 8 steps of all four chains are in flight together
+    f32x4 acc[4];
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      float acc[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int m = tid + 256 * v; m < fin_M; m += 1024) {
+    for (int v = 0; v < 4; ++v) acc[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int m0 = tid; m0 < fin_M; m0 += 8 * 1024) {
+      f32x4 r[8][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] += fin_rows[4 * (int64_t)m + q];
-      }
+      for (int u = 0; u < 8; ++u)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) s[q][tid + 256 * v] = acc[q];
+        for (int v = 0; v < 4; ++v) {
+          const int m = m0 + 1024 * u + 256 * v;
+          r[u][v] = m < fin_M ? *reinterpret_cast<const f32x4*>(fin_rows + 4 * (int64_t)m) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          if (m0 + 1024 * u + 256 * v < fin_M) acc[v] += r[u][v];
     }
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) s[q][tid + 256 * v] = acc[v][q];
     __syncthreads();
     for (int o = 512; o > 0; o >>= 1) {
       for (int t = tid; t < o; t += 256) {

@@ -58,13 +58,29 @@ if hasattr(lib, "b4r_debug_ab_prof"):   # a -DAB_PROF build: phase stamps of wor
     for k in sorted(names, key=lambda k: t[k]):
         print("%-32s +%7d cycles  (total %8d)" % (names[k], t[k] - prev, t[k] - t[0]))
         prev = t[k]
+# the whole layer forward (attention half + feed-forward half in one launch)
+I = 256
+W1, b1, W2, b2 = r(H, I, sc=0.1), r(I, sc=0.1), r(I, H, sc=0.1), r(H, sc=0.1)
+g2, be2 = 1 + r(H, sc=0.1), r(H, sc=0.1)
+z2, x2 = torch.empty(N, H, device="cuda"), torch.empty(N, H, device="cuda")
+mean1, rstd1, mean2, rstd2 = (torch.empty(N, device="cuda") for _ in range(4))
+fd.mean1, fd.rstd1 = P(mean1), P(rstd1)
+ff = _lib.FfnDesc()
+ff.N, ff.H, ff.I = N, H, I
+ff.x1, ff.W1, ff.b1, ff.W2, ff.b2 = P(x1), P(W1), P(b1), P(W2), P(b2)
+ff.ln_gamma, ff.ln_beta, ff.ln_eps = P(g2), P(be2), 1e-12
+ff.rng, ff.drop_stream, ff.drop_rate = rng, 3, rate
+ff.z2, ff.x2, ff.mean2, ff.rstd2 = P(z2), P(x2), P(mean2), P(rstd2)
+layer = lambda: _lib.check(lib.b4r_encoder_layer_fwd(C.byref(fd), C.byref(ff), st), "layer fwd")
+ffn_only = lambda: _lib.check(lib.b4r_ffn_block_fwd(C.byref(ff), st), "ffn fwd")
+print("whole layer forward %.1f us   (attention half alone %.1f us, feed-forward half alone %.1f us)" % (timeit(layer), timeit(fwd), timeit(ffn_only)))
 if hasattr(lib, "b4r_debug_af_prof"):
-    fwd(); torch.cuda.synchronize()
+    layer(); torch.cuda.synchronize()
     buf = (C.c_longlong * 16)()
     lib.b4r_debug_af_prof.argtypes = [C.c_void_p]
     assert lib.b4r_debug_af_prof(buf) == 0
     t = list(buf)
     names = ["start", "x loaded, weights staged", "barrier", "qkv computed", "barrier", "K/V images written", "barrier", "head 0 start", "head 1 start",
-             "attention done", "ctx stored, out-proj done", "residual + LN stats", "end"]
+             "attention done", "ctx stored, out-proj done", "residual + LN stats"]
     for k in range(1, 13):
         print("fwd %-28s +%7d cycles  (total %8d)" % (names[k], t[k] - t[k - 1], t[k] - t[0]))

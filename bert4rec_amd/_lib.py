@@ -61,7 +61,10 @@ class AttnBlockDesc(C.Structure):
                 ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float), ("rng", C.c_void_p),
                 ("probs_stream", C.c_uint32), ("probs_rate", C.c_float), ("out_stream", C.c_uint32), ("out_rate", C.c_float),
                 ("qkv", C.c_void_p), ("ctx", C.c_void_p), ("lse", C.c_void_p), ("keep_bits", C.c_void_p), ("z1", C.c_void_p),
-                ("x1", C.c_void_p), ("mean1", C.c_void_p), ("rstd1", C.c_void_p)]
+                ("x1", C.c_void_p), ("mean1", C.c_void_p), ("rstd1", C.c_void_p),
+                ("emb_ids", C.c_void_p), ("emb_table", C.c_void_p), ("emb_pos", C.c_void_p), ("emb_gamma", C.c_void_p),
+                ("emb_beta", C.c_void_p), ("emb_vocab", C.c_int32), ("emb_eps", C.c_float), ("emb_stream", C.c_uint32),
+                ("emb_rate", C.c_float), ("emb_x", C.c_void_p), ("emb_mean", C.c_void_p), ("emb_rstd", C.c_void_p)]
 
 
 class AttnBlockBwdDesc(C.Structure):

@@ -31,6 +31,12 @@ struct AbP {
   int B, L, KT;
   float qscale, eps;
   DropArgs drop_p, drop_o;
+  // first layer (ids != NULL): the block input is formed here, x = dropout(LayerNorm(table[id] + pos[position])) (the embedding
+  // stage, bert4rec_encoder.py:198-214), and written to x_out with its statistics
+  const int64_t* ids; const float* table; const float* pos; const float* g0; const float* be0;
+  float* x_out; float* mean0; float* rstd0;
+  int V; float eps0;
+  DropArgs drop_e;
 };
 
 __device__ __forceinline__ f32x4 lo4(const f32x8 v) { return (f32x4){v[0], v[1], v[2], v[3]}; }
@@ -68,8 +74,52 @@ __global__ __launch_bounds__(1024) void attn_block_fwd_kernel(AbP p) {
   const int tok = 16 * wave + i, tokc = min(tok, L - 1);
   const float amax = b4r_seq_amax(p.mask + row0, L);
   f32x8 xv[2];
+  const float* xsrc = p.x;   // the residual of the epilogue is read from here
+  if (p.ids != nullptr) {   // block-uniform: the embedding stage for this wave's tokens (position = token index in the sequence)
+    int64_t id = p.ids[row0 + tokc];
+    if (id < 0 || id >= p.V) id = 0;   // out-of-range ids read the PAD row, as b4r_embed_ln_fwd does
+    float s0 = 0.f;
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) xv[ks] = load8(p.x + (row0 + tokc) * HID + 32 * ks + 8 * g);   // in flight during the staging
+    for (int ks = 0; ks < 2; ++ks) {
+      xv[ks] = load8(p.table + id * HID + 32 * ks + 8 * g) + load8(p.pos + (int64_t)tokc * HID + 32 * ks + 8 * g);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s0 += xv[ks][e];
+    }
+    const float mean = quad_sum(s0) * (1.0f / HID);
+    float q0 = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = xv[ks][e] - mean; q0 += d * d; }
+    const float rstd = rsqrtf(quad_sum(q0) * (1.0f / HID) + p.eps0);
+    const DropCtx dce = b4r_drop_ctx(p.drop_e);
+    const bool live0 = tok < L;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const f32x8 gm = load8(p.g0 + 32 * ks + 8 * g), be = load8(p.be0 + 32 * ks + 8 * g);
+      f32x8 y;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float inv = rstd * gm[e];
+        y[e] = xv[ks][e] * inv + (be[e] - mean * inv);
+      }
+      const uint64_t e0 = (uint64_t)(row0 + tok) * HID + (uint64_t)(32 * ks + 8 * g);
+      const f32x4 lo = b4r_drop4(dce, (f32x4){y[0], y[1], y[2], y[3]}, e0), hi = b4r_drop4(dce, (f32x4){y[4], y[5], y[6], y[7]}, e0 + 4);
+      xv[ks] = cat(lo, hi);
+      if (live0) {
+        *reinterpret_cast<f32x4*>(p.x_out + (row0 + tok) * HID + 32 * ks + 8 * g) = lo;
+        *reinterpret_cast<f32x4*>(p.x_out + (row0 + tok) * HID + 32 * ks + 8 * g + 4) = hi;
+      }
+    }
+    if (g == 0 && live0) {
+      if (p.mean0) p.mean0[row0 + tok] = mean;
+      if (p.rstd0) p.rstd0[row0 + tok] = rstd;
+    }
+    xsrc = p.x_out;
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) xv[ks] = load8(p.x + (row0 + tokc) * HID + 32 * ks + 8 * g);   // in flight during the staging
+  }
   stage_weight(big, p.Wqkv, HID, 3 * HID, nthreads);
   stage_weight(woimg, p.Wo, HID, HID, nthreads);
   for (int k = threadIdx.x; k < KTE * 16; k += nthreads)
@@ -249,7 +299,7 @@ __global__ __launch_bounds__(1024) void attn_block_fwd_kernel(AbP p) {
 #pragma unroll
   for (int hb = 0; hb < 4; ++hb) {
     const f32x4 v = y[hb] + *reinterpret_cast<const f32x4*>(p.bo + 16 * hb + 4 * g);
-    const f32x4 res = *reinterpret_cast<const f32x4*>(p.x + (row0 + tokc) * HID + 16 * hb + 4 * g);
+    const f32x4 res = *reinterpret_cast<const f32x4*>(xsrc + (row0 + tokc) * HID + 16 * hb + 4 * g);
     z[hb] = res + b4r_drop4(dco, v, (uint64_t)(row0 + tok) * HID + (uint64_t)(16 * hb + 4 * g));
     s += sum4(z[hb]);
   }
@@ -718,8 +768,13 @@ extern "C" int b4r_attn_block_fwd(const b4r_attn_block_desc* d, b4r_stream_t str
   B4R_CHECK_ARG(b4r_attn_block_supported(d->H, d->heads, d->L), B4R_E_SHAPE,
                 "b4r_attn_block_fwd: needs hidden size 64, 2 heads, L <= 256 and the bf16x3 mode (H=%d heads=%d L=%d)", d->H, d->heads,
                 d->L);
-  B4R_CHECK_ARG(d->B > 0 && d->x && d->input_mask && d->Wqkv && d->bqkv && d->Wo && d->bo && d->ln_gamma && d->ln_beta && d->x1,
+  const bool embed = d->emb_ids != nullptr;
+  B4R_CHECK_ARG(d->B > 0 && (d->x || embed) && d->input_mask && d->Wqkv && d->bqkv && d->Wo && d->bo && d->ln_gamma && d->ln_beta && d->x1,
                 B4R_E_BADARG, "b4r_attn_block_fwd: null argument");
+  B4R_CHECK_ARG(!embed || (d->emb_table && d->emb_pos && d->emb_gamma && d->emb_beta && d->emb_x && d->emb_vocab > 0 &&
+                           al16(d->emb_table) && al16(d->emb_pos) && al16(d->emb_gamma) && al16(d->emb_beta) && al16(d->emb_x)),
+                B4R_E_BADARG, "b4r_attn_block_fwd: the embedding mode needs emb_table, emb_pos, emb_gamma, emb_beta, emb_x (16-byte "
+                "aligned) and emb_vocab");
   B4R_CHECK_ARG(al16(d->x) && al16(d->Wqkv) && al16(d->Wo) && al16(d->bo) && al16(d->ln_gamma) && al16(d->ln_beta) && al16(d->qkv) &&
                     al16(d->ctx) && al16(d->z1) && al16(d->x1) && al16(d->keep_bits),
                 B4R_E_ALIGN, "b4r_attn_block_fwd: operands must be 16-byte aligned");
@@ -732,6 +787,11 @@ extern "C" int b4r_attn_block_fwd(const b4r_attn_block_desc* d, b4r_stream_t str
   p.drop_p = b4r_make_drop(d->rng, d->probs_stream, d->probs_rate, d->rng != nullptr);
   p.drop_o = b4r_make_drop(d->rng, d->out_stream, d->out_rate, d->rng != nullptr);
   B4R_CHECK_ARG(!p.drop_p.rng || d->keep_bits, B4R_E_BADARG, "b4r_attn_block_fwd: attention dropout needs keep_bits");
+  if (embed) {
+    p.ids = d->emb_ids; p.table = d->emb_table; p.pos = d->emb_pos; p.g0 = d->emb_gamma; p.be0 = d->emb_beta; p.V = d->emb_vocab;
+    p.x_out = d->emb_x; p.mean0 = d->emb_mean; p.rstd0 = d->emb_rstd; p.eps0 = d->emb_eps;
+    p.drop_e = b4r_make_drop(d->rng, d->emb_stream, d->emb_rate, d->rng != nullptr);
+  }
   const int KTt = p.KT <= 4 ? 4 : p.KT <= 8 ? 8 : p.KT <= 13 ? 13 : 16;
   const dim3 grid((unsigned)d->B), block((unsigned)(64 * p.KT));
   hipStream_t s = (hipStream_t)stream;

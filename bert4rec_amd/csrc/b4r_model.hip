@@ -582,8 +582,12 @@ extern "C" int b4r_forward(const b4r_model_config* cfg, const b4r_batch* batch, 
   const int H = cfg->hidden_size, I = cfg->inner_dim, V = cfg->vocab_size, N = B * L, M = B * P;
   const float qscale = 1.0f / sqrtf(32.0f);
 
-  RC(b4r_embed_ln_fwd(batch->input_word_ids, B, L, params + pl.word_emb, V, params + pl.pos_emb, params + pl.emb_ln_g,
-                      params + pl.emb_ln_b, H, cfg->ln_eps, ws + w.x0, ws + w.mean0, ws + w.rstd0, rng, od, stream));
+  // the embedding stage: inside the first layer's attention block where that runs fused, else a launch of its own
+  static const bool emb_in_block = !(getenv("B4R_EMB_FUSED") && atoi(getenv("B4R_EMB_FUSED")) == 0);
+  const bool emb_fused = emb_in_block && attn_fused(cfg, L) && cfg->num_layers > 0;
+  if (!emb_fused)
+    RC(b4r_embed_ln_fwd(batch->input_word_ids, B, L, params + pl.word_emb, V, params + pl.pos_emb, params + pl.emb_ln_g,
+                        params + pl.emb_ln_b, H, cfg->ln_eps, ws + w.x0, ws + w.mean0, ws + w.rstd0, rng, od, stream));
   const bool head_rows = (flags & B4R_FLAG_HEAD_ROWS_ONLY) && head_rows_ok(cfg, batch);
   const float* x = ws + w.x0;
   for (int i = 0; i < cfg->num_layers; ++i) {
@@ -599,6 +603,12 @@ extern "C" int b4r_forward(const b4r_model_config* cfg, const b4r_batch* batch, 
       ad.qkv = attn_bwd_fused(cfg, L) ? nullptr : ws + w.qkv[i];   // only round 1's backward kernels read it
       ad.ctx = ws + w.ctx[i]; ad.lse = ws + w.lse[i]; ad.keep_bits = reinterpret_cast<uint32_t*>(ws + w.keep[i]);
       ad.z1 = ws + w.z1[i]; ad.x1 = ws + w.x1[i]; ad.mean1 = ws + w.mean1[i]; ad.rstd1 = ws + w.rstd1[i];
+      if (i == 0 && emb_fused) {
+        ad.emb_ids = batch->input_word_ids; ad.emb_table = params + pl.word_emb; ad.emb_pos = params + pl.pos_emb; ad.emb_vocab = V;
+        ad.emb_gamma = params + pl.emb_ln_g; ad.emb_beta = params + pl.emb_ln_b; ad.emb_eps = cfg->ln_eps;
+        ad.emb_stream = B4R_STREAM_EMB; ad.emb_rate = od; if (od > 0.f) ad.rng = rng;
+        ad.emb_x = ws + w.x0; ad.emb_mean = ws + w.mean0; ad.emb_rstd = ws + w.rstd0;
+      }
       if (!layer_fused) RC(b4r_attn_block_fwd(&ad, stream));
     } else {
     RC(gemm(x, H, params + pl.wqkv[i], 3 * H, ws + w.qkv[i], 3 * H, N, 3 * H, H, 0, B4R_EPI_BIAS_QSCALE, params + pl.bqkv[i],

@@ -390,34 +390,48 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(float* logits, int V, i
   }
 }
 
-// ordered reduction of the per-row scalars into the state (single workgroup => fixed summation order)
-__global__ __launch_bounds__(1024) void ce_finalize_kernel(const float* row_out, int M, b4r_train_state* st, int overwrite) {
-  __shared__ float s[4][1024];
+// Ordered sum of the per-row scalars [M][4] (loss term, valid flag, correct-masked, correct-all) by ONE workgroup of 256 threads
+// (fixed summation order => bitwise reproducible): thread t adds its rows t, t + 256, ... in order (the loads of 8 rows in
+// flight), then threads 0..3 add the 256 partial sums of one component each in thread order.  s: [4][256] floats of LDS.
+__device__ __forceinline__ void loss_rows_reduce(const float* rows, int M, float (*s)[256], float (&out)[4]) {
   const int tid = threadIdx.x;
-  float a[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int m = tid; m < M; m += 1024) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int m0 = tid; m0 < M; m0 += 8 * 256) {
+    f32x4 r[8];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) a[q] += row_out[4 * (int64_t)m + q];
+    for (int u = 0; u < 8; ++u)
+      r[u] = m0 + 256 * u < M ? *reinterpret_cast<const f32x4*>(rows + 4 * (int64_t)(m0 + 256 * u)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (m0 + 256 * u < M) acc += r[u];
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q) s[q][tid] = a[q];
+  for (int q = 0; q < 4; ++q) s[q][tid] = acc[q];
   __syncthreads();
-  for (int o = 512; o > 0; o >>= 1) {
-    if (tid < o) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) s[q][tid] += s[q][tid + o];
-    }
-    __syncthreads();
+  if (tid < 4) {
+    float r = 0.f;
+    for (int t = 0; t < 256; ++t) r += s[tid][t];
+    s[tid][0] = r;
   }
-  if (tid == 0) {
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) out[q] = s[q][0];
+}
+
+// the sums into the state: b4r_loss's last launch (the logits-free head's rows or softmax_ce_kernel's)
+__global__ __launch_bounds__(256) void ce_finalize_kernel(const float* row_out, int M, b4r_train_state* st, int overwrite) {
+  __shared__ float s[4][256];
+  float r[4];
+  loss_rows_reduce(row_out, M, s, r);
+  if (threadIdx.x == 0) {
     if (overwrite) {   // what b4r_state_begin_step + accumulation would leave (b4r_train_step saves that launch)
       st->loss_sum = 0.f; st->valid_count = 0.f; st->correct_masked = 0.f; st->correct_all = 0.f; st->slots_all = 0.f;
       st->grad_sqnorm = 0.f; st->grad_norm = 0.f;
     }
-    st->loss_sum += s[0][0];
-    st->valid_count += s[1][0];
-    st->correct_masked += s[2][0];
-    st->correct_all += s[3][0];
+    st->loss_sum += r[0];
+    st->valid_count += r[1];
+    st->correct_masked += r[2];
+    st->correct_all += r[3];
     st->slots_all += (float)M;
   }
 }
@@ -734,7 +748,7 @@ extern "C" int b4r_softmax_ce(float* logits, int32_t M, int32_t V, int32_t ld, c
   hipLaunchKernelGGL(softmax_ce_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, logits, V, ld, y_true, row_scratch,
                      want_grad & 1);
   B4R_CHECK_LAUNCH("b4r_softmax_ce");
-  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, row_scratch, M, state, (want_grad >> 2) & 1);
+  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, row_scratch, M, state, (want_grad >> 2) & 1);
   B4R_CHECK_LAUNCH("b4r_softmax_ce finalize");
   return B4R_OK;
 }
@@ -745,50 +759,19 @@ extern "C" int b4r_softmax_ce(float* logits, int32_t M, int32_t V, int32_t ld, c
 // tail (optional): the 8 floats behind the gradient buffer receive the step's five sums from the state (loss_sum, valid_count,
 // correct_masked, correct_all, slots_all), so that ONE all-reduce of [gradients | tail] carries them
 // fin_rows (optional): the LAST workgroup also does what ce_finalize_kernel does in overwrite mode -- the ordered sum of the fused
-// head's per-row scalars into the state, in exactly that kernel's summation order (a thread stands in for four of its 1024) --
-// before the tail copy, so that b4r_backward needs no b4r_loss launch in front of it (B4R_FLAG_LOSS_SUMS)
+// head's per-row scalars into the state (loss_rows_reduce: the same summation order, bit for bit) -- before the tail copy, so that
+// b4r_backward needs no b4r_loss launch in front of it (B4R_FLAG_LOSS_SUMS)
 __global__ __launch_bounds__(256) void zero2_kernel(float* a, int64_t na4, float* b, int64_t nb4, float* tail, float* state_f,
                                                     const float* fin_rows, int fin_M) {
-  __shared__ float s[4][1024];
+  __shared__ float s[4][256];
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
   const bool fin = fin_rows != nullptr && blockIdx.x == gridDim.x - 1;
   if (fin) {
-    const int tid = threadIdx.x;
-    // a thread stands in for threads tid, tid + 256, tid + 512, tid + 768 of ce_finalize_kernel: four independent chains, each
-    // adding its rows m, m + 1024, ... in order; the loads of 8 steps of all four chains are in flight together
-    f32x4 acc[4];
-#pragma unroll
-    for (int v = 0; v < 4; ++v) acc[v] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int m0 = tid; m0 < fin_M; m0 += 8 * 1024) {
-      f32x4 r[8][4];
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const int m = m0 + 1024 * u + 256 * v;
-          r[u][v] = m < fin_M ? *reinterpret_cast<const f32x4*>(fin_rows + 4 * (int64_t)m) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-#pragma unroll
-        for (int v = 0; v < 4; ++v)
-          if (m0 + 1024 * u + 256 * v < fin_M) acc[v] += r[u][v];
-    }
-#pragma unroll
-    for (int v = 0; v < 4; ++v)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) s[q][tid + 256 * v] = acc[v][q];
-    __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
-      for (int t = tid; t < o; t += 256) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) s[q][t] += s[q][t + o];
-      }
-      __syncthreads();
-    }
-    if (tid == 0) {   // b4r_train_state floats: [4] loss_sum [5] valid_count [6] correct_masked [7] correct_all [8] slots_all [9] [10]
-      state_f[4] = 0.f + s[0][0]; state_f[5] = 0.f + s[1][0]; state_f[6] = 0.f + s[2][0]; state_f[7] = 0.f + s[3][0];
-      state_f[8] = 0.f + (float)fin_M; state_f[9] = 0.f; state_f[10] = 0.f;
+    float r[4];
+    loss_rows_reduce(fin_rows, fin_M, s, r);
+    if (threadIdx.x == 0) {   // b4r_train_state floats: [4] loss_sum [5] valid_count [6] correct_masked [7] correct_all [8] slots_all [9] [10]
+      state_f[4] = r[0]; state_f[5] = r[1]; state_f[6] = r[2]; state_f[7] = r[3];
+      state_f[8] = (float)fin_M; state_f[9] = 0.f; state_f[10] = 0.f;
     }
     __syncthreads();
   }
@@ -815,7 +798,7 @@ int b4r_zero2(float* a, int64_t na, float* b, int64_t nb, hipStream_t stream, fl
 
 int b4r_ce_finalize_launch(const float* row_scratch, int M, b4r_train_state* state, int overwrite, hipStream_t stream) {
   B4R_CHECK_ARG(row_scratch && state && M > 0, B4R_E_BADARG, "ce_finalize: bad argument");
-  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(1024), 0, stream, row_scratch, M, state, overwrite);
+  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(256), 0, stream, row_scratch, M, state, overwrite);
   B4R_CHECK_LAUNCH("b4r_loss finalize");
   return B4R_OK;
 }

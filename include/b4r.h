@@ -391,6 +391,14 @@ typedef struct b4r_attn_block_desc {
   const uint32_t* rng; uint32_t probs_stream; float probs_rate; uint32_t out_stream; float out_rate;
   float* qkv; float* ctx; float* lse; uint32_t* keep_bits;
   float* z1; float* x1; float* mean1; float* rstd1;   /* z1 / mean1 / rstd1 may be NULL */
+  /* FIRST LAYER, optional (emb_ids != NULL; x is then ignored): the block forms its own input, the embedding stage of
+   * bert4rec_encoder.py:198-214, x = dropout(LayerNorm(emb_table[id] + emb_pos[position]) * emb_gamma + emb_beta), and writes it to
+   * emb_x [B*L,H] with the statistics emb_mean / emb_rstd [B*L] (may be NULL) -- what b4r_embed_ln_fwd does in a launch of its own.
+   * emb_ids [B,L] int64 (out-of-range ids read row 0), emb_table [emb_vocab,H], emb_pos [>= L,H]; dropout site emb_stream at rate
+   * emb_rate, element index row*64 + col (rng == NULL: off). */
+  const int64_t* emb_ids; const float* emb_table; const float* emb_pos; const float* emb_gamma; const float* emb_beta;
+  int32_t emb_vocab; float emb_eps; uint32_t emb_stream; float emb_rate;
+  float* emb_x; float* emb_mean; float* emb_rstd;
 } b4r_attn_block_desc;
 int32_t b4r_attn_block_supported(int32_t hidden_size, int32_t num_heads, int32_t L);
 int b4r_attn_block_fwd(const b4r_attn_block_desc* d, b4r_stream_t stream);

@@ -404,3 +404,48 @@ def test_encoder_layer_is_the_two_halves_plus_the_two_weight_gradient_products(B
     for got, want, what in ((whole["dWo"], ctx.T @ dz1, "dWo"), (whole["dbo"], dz1.sum(0), "dbo"), (whole["dWqkv"], x.T @ dqkv, "dWqkv"),
                             (whole["dbqkv"], dqkv.sum(0), "dbqkv")):
         assert T.maxdiff(got, want) < 3e-5 * max(1.0, float(want.abs().max())), what
+
+
+@pytest.mark.parametrize("B,L,rate", [(4, 200, 0.2), (3, 37, 0.0)])
+def test_attention_block_can_form_its_input_from_the_embedding_tables(B, L, rate):
+    """First layer: b4r_attn_block_fwd with emb_ids runs the embedding stage (bert4rec_encoder.py:198-214: item row + position row ->
+    LayerNorm -> dropout) itself.  Against b4r_embed_ln_fwd followed by the plain block: same dropout decisions, x / statistics and
+    every block output to rounding (the two kernels sum the 64 columns of a row in different orders)."""
+    lib = _lib.load()
+    _lib.check(lib.b4r_set_gemm_mode(_lib.GEMM_BF16X3))
+    N, V, seed, step = B * L, 211, 19, 4
+    t, mask = attn_inputs(B, L, seed=L + 3)
+    g = {k: v.to(DEV) for k, v in t.items()}
+    ids = torch.randint(-2, V + 2, (B, L), generator=torch.Generator().manual_seed(3)).to(DEV)   # a few out-of-range ids: row 0
+    table, pos = rnd(V, 64, seed=8).to(DEV), (0.3 * rnd(L, 64, seed=9)).to(DEV)
+    g0, be0 = (1.0 + 0.2 * rnd(64, seed=10)).to(DEV), (0.1 * rnd(64, seed=11)).to(DEV)
+    st = T.new_state(seed, step) if rate > 0 else None
+    maskd = mask.to(DEV)
+
+    def run(embed):
+        o = {k: torch.full(s_, float("nan"), dtype=torch.float32, device=DEV) for k, s_ in
+             dict(x0=(N, 64), m0=(N,), r0=(N,), ctx=(N, 64), lse=(B, 2, L), z1=(N, 64), x1=(N, 64)).items()}
+        bits = torch.zeros(lib.b4r_attn_keep_words(B, L, 2), dtype=torch.int32, device=DEV)
+        d = _lib.AttnBlockDesc()
+        d.B, d.L, d.H, d.heads, d.input_mask = B, L, 64, 2, P(maskd)
+        d.Wqkv, d.bqkv, d.Wo, d.bo = P(g["Wqkv"]), P(g["bqkv"]), P(g["Wo"]), P(g["bo"])
+        d.ln_gamma, d.ln_beta, d.ln_eps = P(g["g1"]), P(g["be1"]), 1e-12
+        d.rng, d.probs_stream, d.probs_rate, d.out_stream, d.out_rate = P(st), 1, rate, 2, rate
+        d.ctx, d.lse, d.keep_bits, d.z1, d.x1 = P(o["ctx"]), P(o["lse"]), P(bits), P(o["z1"]), P(o["x1"])
+        if embed:
+            d.emb_ids, d.emb_table, d.emb_pos, d.emb_gamma, d.emb_beta = P(ids), P(table), P(pos), P(g0), P(be0)
+            d.emb_vocab, d.emb_eps, d.emb_stream, d.emb_rate = V, 1e-12, 0, rate
+            d.emb_x, d.emb_mean, d.emb_rstd = P(o["x0"]), P(o["m0"]), P(o["r0"])
+        else:
+            _lib.check(lib.b4r_embed_ln_fwd(P(ids), B, L, P(table), V, P(pos), P(g0), P(be0), 64, 1e-12, P(o["x0"]), P(o["m0"]), P(o["r0"]),
+                                            P(st), rate, stream()), "b4r_embed_ln_fwd")
+            d.x = P(o["x0"])
+        _lib.check(lib.b4r_attn_block_fwd(C.byref(d), stream()), "b4r_attn_block_fwd")
+        torch.cuda.synchronize()
+        return o, bits
+
+    (a, bits_a), (b, bits_b) = run(True), run(False)
+    assert torch.equal(a["x0"] == 0, b["x0"] == 0) and torch.equal(bits_a, bits_b)      # the same dropout decisions
+    for k, tol in (("x0", 2e-6), ("m0", 1e-6), ("ctx", 2e-5), ("z1", 2e-5), ("x1", 2e-5), ("lse", 2e-5)):
+        assert T.maxdiff(a[k], b[k].cpu()) < tol * max(1.0, float(b[k].abs().max())), k
+    assert T.maxdiff(a["r0"] / b["r0"], torch.ones(N)) < 1e-5

@@ -35,6 +35,8 @@ int b4r_head_rx_fwd_launch(const float* T, const float* E, const float* bias, co
 int b4r_head_rx_dE_launch(const float* T, const float* E, const float* bias, const float* lse, const int32_t* ylab, int M, int V,
                           int H, float* scratch, float* dE, float* db, hipStream_t stream);
 int b4r_ffn_block_bwd_marked(const b4r_ffn_desc* d, hipStream_t stream, hipEvent_t after_dx);
+int b4r_embed_grads(const float* x, const int64_t* ids, int B, int L, int H, float* table_grad, int64_t V, int hot_rows,
+                    float* hot_scratch, float* dpos, float* colsum_scratch, hipStream_t stream);
 int b4r_gemm_tn_pair(const b4r_gemm_tn_desc* d0, float* scratch0, const b4r_gemm_tn_desc* d1, float* scratch1, hipStream_t stream);
 int b4r_ce_finalize_launch(const float* row_scratch, int M, b4r_train_state* state, int overwrite, hipStream_t stream);
 int b4r_attn_bwd_streams(const float* qkv, const int64_t* input_mask, const float* ctx, const float* lse, const float* dctx,
@@ -968,9 +970,8 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
   RC(b4r_reduce_queue_flush(s));
   B4rReduceQueue tail_queue;
   b4r_reduce_queue_begin(&tail_queue);   // the two small reductions below share one launch as well
-  RC(b4r_scatter_add_rows_impl(ws + w.da, batch->input_word_ids, 0, 1, N, H, grads + pl.word_emb, H, nullptr, V, 3,
-                               ws + w.hot, s));   // slots zeroed by the memset at the top
-  RC(b4r_batch_colsum(ws + w.da, B, L, H, grads + pl.pos_emb, take((int64_t)b4r_cdiv(B, 16) * L * H), s));
+  RC(b4r_embed_grads(ws + w.da, batch->input_word_ids, B, L, H, grads + pl.word_emb, V, 3, ws + w.hot /* zeroed at the top */,
+                     grads + pl.pos_emb, take((int64_t)b4r_cdiv(B, 16) * L * H), s));
   RC(b4r_reduce_queue_flush(s));
   B4R_CHECK_ARG(scratch_used <= w.scratch_floats, B4R_E_NOMEM, "b4r_backward: internal scratch overflow");
   return B4R_OK;

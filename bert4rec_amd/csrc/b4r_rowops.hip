@@ -270,10 +270,10 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* src, int 
 constexpr int HOT_SLOTS = 64;
 // one lane per float: a wave-instruction adds 64 consecutive dwords (256 contiguous bytes of one or a few rows), the
 // shape at which global float atomics run at full rate (MI355X_MICROARCH.md 'Global float atomics')
-__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* src, const int64_t* idx, int64_t idx_add_per,
-                                                               int per, int n, int H, float* dst, int dst_ld,
-                                                               const int64_t* skip_if_zero, int64_t dst_rows,
-                                                               int hot_rows, float* hot_slab) {
+__device__ __forceinline__ void scatter_add_rows_body(const float* src, const int64_t* idx, int64_t idx_add_per,
+                                                      int per, int n, int H, float* dst, int dst_ld,
+                                                      const int64_t* skip_if_zero, int64_t dst_rows,
+                                                      int hot_rows, float* hot_slab, const int block, const int nblocks) {
   // hot_rows > 0: destination rows [0, hot_rows) (the special tokens PAD/MASK/UNK of the item table: [MASK] alone is
   // ~20 % of all tokens) are first summed in LDS and leave the workgroup once, instead of thousands of global atomics
   // queueing on the same 256 bytes.  Even one flush per workgroup is 1024 same-address atomics per float, which the L2
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* src,
   for (int k = threadIdx.x; k < hot_rows * H; k += 256) s_hot[k] = 0.f;
   if (hot_rows > 0) __syncthreads();
   const int64_t total = (int64_t)n * H;
-  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+  for (int64_t t = (int64_t)block * 256 + threadIdx.x; t < total; t += (int64_t)nblocks * 256) {
     const int i = (int)(t / H), c = (int)(t % H);
     if (skip_if_zero != nullptr && skip_if_zero[i] == 0) continue;
     int64_t pos = idx[i];
@@ -300,22 +300,46 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* src,
     for (int k = threadIdx.x; k < hot_rows * H; k += 256) {
       const float v = s_hot[k];
       if (v == 0.f) continue;
-      if (hot_slab) atomicAdd(hot_slab + (int64_t)(blockIdx.x % HOT_SLOTS) * hot_rows * H + k, v);
+      if (hot_slab) atomicAdd(hot_slab + (int64_t)(block % HOT_SLOTS) * hot_rows * H + k, v);
       else atomicAdd(dst + (int64_t)(k / H) * dst_ld + (k % H), v);
     }
   }
 }
 
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* src, const int64_t* idx, int64_t idx_add_per,
+                                                               int per, int n, int H, float* dst, int dst_ld,
+                                                               const int64_t* skip_if_zero, int64_t dst_rows,
+                                                               int hot_rows, float* hot_slab) {
+  scatter_add_rows_body(src, idx, idx_add_per, per, n, H, dst, dst_ld, skip_if_zero, dst_rows, hot_rows, hot_slab, (int)blockIdx.x,
+                        (int)gridDim.x);
+}
+
 // partial[s][l][c] = sum over b in slice s of x[(b*L + l)*H + c]
-__global__ __launch_bounds__(256) void batch_colsum_kernel(const float* x, int B, int L, int H, int bchunk, float* partial) {
+__device__ __forceinline__ void batch_colsum_body(const float* x, int B, int L, int H, int bchunk, float* partial, const int bx, const int by) {
   const int h4 = H / 4;
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t t = (int64_t)bx * 256 + threadIdx.x;
   if (t >= (int64_t)L * h4) return;
   const int l = (int)(t / h4), c = (int)(t % h4) * 4;
-  const int b0 = blockIdx.y * bchunk, b1 = min(B, b0 + bchunk);
+  const int b0 = by * bchunk, b1 = min(B, b0 + bchunk);
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   for (int b = b0; b < b1; ++b) s += *reinterpret_cast<const f32x4*>(x + ((int64_t)b * L + l) * H + c);
-  *reinterpret_cast<f32x4*>(partial + ((int64_t)blockIdx.y * L + l) * H + c) = s;
+  *reinterpret_cast<f32x4*>(partial + ((int64_t)by * L + l) * H + c) = s;
+}
+__global__ __launch_bounds__(256) void batch_colsum_kernel(const float* x, int B, int L, int H, int bchunk, float* partial) {
+  batch_colsum_body(x, B, L, H, bchunk, partial, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// the two gradients of the embedding stage from d(item row + position row) [B*L, H] in ONE launch: the item-table scatter-add
+// (workgroups [0, n_scatter)) and the batch sums of the position table (the rest, gx per batch slice): both only read x
+__global__ __launch_bounds__(256) void embed_grads_kernel(const float* x, const int64_t* ids, int n, int H, float* table_grad,
+                                                          int64_t table_rows, int hot_rows, float* hot_slab, int n_scatter, int B, int L,
+                                                          int bchunk, int gx, float* partial) {
+  if ((int)blockIdx.x < n_scatter) {
+    scatter_add_rows_body(x, ids, 0, 1, n, H, table_grad, H, nullptr, table_rows, hot_rows, hot_slab, (int)blockIdx.x, n_scatter);
+  } else {
+    const int k = (int)blockIdx.x - n_scatter;
+    batch_colsum_body(x, B, L, H, bchunk, partial, k % gx, k / gx);
+  }
 }
 
 // -----------------------------------------------------------------------------------------------------------
@@ -738,6 +762,25 @@ int b4r_batch_colsum(const float* x, int B, int L, int H, float* dpos, float* sc
   hipLaunchKernelGGL(batch_colsum_kernel, grid, dim3(256), 0, stream, x, B, L, H, bchunk, scratch);
   B4R_CHECK_LAUNCH("batch_colsum");
   return b4r_launch_slab_reduce_full(scratch, S, L, H, dpos, H, 0, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+// item-table and position-table gradients of the embedding stage in one launch (b4r_backward's tail); hot_scratch as in
+// b4r_scatter_add_rows_impl (zeroed by the caller), colsum_scratch >= ceil(B/16)*L*H floats
+int b4r_embed_grads(const float* x, const int64_t* ids, int B, int L, int H, float* table_grad, int64_t V, int hot_rows,
+                    float* hot_scratch, float* dpos, float* colsum_scratch, hipStream_t stream) {
+  const int n = B * L, bchunk = 16, S = b4r_cdiv(B, bchunk);
+  int n_scatter = b4r_cdiv((int64_t)n * H, 256);
+  if (n_scatter > 1024) n_scatter = 1024;
+  if (hot_rows <= 0) hot_scratch = nullptr;
+  const int gx = b4r_cdiv((int64_t)L * (H / 4), 256);
+  hipLaunchKernelGGL(embed_grads_kernel, dim3(n_scatter + gx * S), dim3(256), (size_t)(hot_rows > 0 ? hot_rows : 0) * H * sizeof(float),
+                     stream, x, ids, n, H, table_grad, V, hot_rows, hot_scratch, n_scatter, B, L, bchunk, gx, colsum_scratch);
+  B4R_CHECK_LAUNCH("embedding gradients (scatter-add + position sums)");
+  int rc = B4R_OK;
+  if (hot_scratch)
+    rc = b4r_launch_slab_reduce_full(hot_scratch, HOT_SLOTS, hot_rows, H, table_grad, H, 1, nullptr, nullptr, nullptr, nullptr, stream);
+  if (rc) return rc;
+  return b4r_launch_slab_reduce_full(colsum_scratch, S, L, H, dpos, H, 0, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int b4r_softmax_ce(float* logits, int32_t M, int32_t V, int32_t ld, const int64_t* y_true,

@@ -87,7 +87,8 @@ class FfnDesc(C.Structure):
                 ("dW2", C.c_void_p), ("db2", C.c_void_p), ("dln1_gamma", C.c_void_p), ("scratch", C.c_void_p),
                 ("rows", C.c_void_p), ("n_rows", C.c_void_p), ("max_rows", C.c_int32), ("row_slot", C.c_void_p),
                 ("slot_grad", C.c_void_p), ("dln_gamma", C.c_void_p), ("dz2_rows", C.c_void_p),
-                ("slot_positions", C.c_void_p), ("slot_ids", C.c_void_p), ("slots_per_seq", C.c_int32), ("seq_len", C.c_int32)]
+                ("slot_positions", C.c_void_p), ("slot_ids", C.c_void_p), ("slots_per_seq", C.c_int32), ("seq_len", C.c_int32),
+                ("ln1_beta", C.c_void_p)]
 
 
 # b4r_train_state: 16 x 32-bit words; word indices of the float fields

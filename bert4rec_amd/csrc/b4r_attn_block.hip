@@ -325,7 +325,7 @@ __global__ __launch_bounds__(1024) void attn_block_fwd_kernel(AbP p) {
         out[e] = z[hb][e] * inv + (be[e] - mean * inv);
       }
       if (p.z1) *reinterpret_cast<f32x4*>(p.z1 + off) = z[hb];
-      *reinterpret_cast<f32x4*>(p.x1 + off) = out;
+      if (p.x1) *reinterpret_cast<f32x4*>(p.x1 + off) = out;
     }
     if (g == 0) {
       if (p.mean1) p.mean1[row0 + tok] = mean;
@@ -769,8 +769,9 @@ extern "C" int b4r_attn_block_fwd(const b4r_attn_block_desc* d, b4r_stream_t str
                 "b4r_attn_block_fwd: needs hidden size 64, 2 heads, L <= 256 and the bf16x3 mode (H=%d heads=%d L=%d)", d->H, d->heads,
                 d->L);
   const bool embed = d->emb_ids != nullptr;
-  B4R_CHECK_ARG(d->B > 0 && (d->x || embed) && d->input_mask && d->Wqkv && d->bqkv && d->Wo && d->bo && d->ln_gamma && d->ln_beta && d->x1,
-                B4R_E_BADARG, "b4r_attn_block_fwd: null argument");
+  B4R_CHECK_ARG(d->B > 0 && (d->x || embed) && d->input_mask && d->Wqkv && d->bqkv && d->Wo && d->bo && d->ln_gamma && d->ln_beta &&
+                    (d->x1 || (d->z1 && d->mean1 && d->rstd1)),
+                B4R_E_BADARG, "b4r_attn_block_fwd: null argument (outputs: x1, or z1 + mean1 + rstd1)");
   B4R_CHECK_ARG(!embed || (d->emb_table && d->emb_pos && d->emb_gamma && d->emb_beta && d->emb_x && d->emb_vocab > 0 &&
                            al16(d->emb_table) && al16(d->emb_pos) && al16(d->emb_gamma) && al16(d->emb_beta) && al16(d->emb_x)),
                 B4R_E_BADARG, "b4r_attn_block_fwd: the embedding mode needs emb_table, emb_pos, emb_gamma, emb_beta, emb_x (16-byte "

@@ -109,9 +109,47 @@ __device__ __forceinline__ void load_rows(const float* src, int tokc, int g, f32
   for (int ks = 0; ks < 2; ++ks) v[ks] = load8(src + (int64_t)tokc * HID + 32 * ks + 8 * g);
 }
 
+// The feed-forward half's input x1 = LayerNorm(z1) * g1 + be1 is either given ([N, 64]) or formed on load from the attention half's
+// pre-LayerNorm sum z1 and its statistics (x1 == NULL: then the attention block need not store x1 at all -- 13 MB less written per
+// layer at ML-1M -- and the kernels that read both z1 and x1 read one tensor).  The formula is the attention epilogue's.
+struct X1Src {
+  const float* x1; const float* z1; const float* mean1; const float* rstd1; const float* g1; const float* be1;
+};
+// 8 (or 4) consecutive columns col.. of row `tok`
+__device__ __forceinline__ f32x8 x1_load8(const X1Src& s, int64_t tok, int col) {
+  if (s.x1 != nullptr) return load8(s.x1 + tok * HID + col);
+  const f32x8 z = load8(s.z1 + tok * HID + col), gm = load8(s.g1 + col), be = load8(s.be1 + col);
+  const float mean = s.mean1[tok], rstd = s.rstd1[tok];
+  f32x8 y;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float inv = rstd * gm[e];
+    y[e] = z[e] * inv + (be[e] - mean * inv);
+  }
+  return y;
+}
+__device__ __forceinline__ f32x4 x1_load4(const X1Src& s, int64_t tok, int col) {
+  if (s.x1 != nullptr) return *reinterpret_cast<const f32x4*>(s.x1 + tok * HID + col);
+  const f32x4 z = *reinterpret_cast<const f32x4*>(s.z1 + tok * HID + col), gm = *reinterpret_cast<const f32x4*>(s.g1 + col),
+              be = *reinterpret_cast<const f32x4*>(s.be1 + col);
+  const float mean = s.mean1[tok], rstd = s.rstd1[tok];
+  f32x4 y;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float inv = rstd * gm[e];
+    y[e] = z[e] * inv + (be[e] - mean * inv);
+  }
+  return y;
+}
+// the wave's 16 rows of x1 as B operands of products that sum over the hidden index
+__device__ __forceinline__ void load_x1_rows(const X1Src& s, int tok, int g, f32x8 (&v)[2]) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) v[ks] = x1_load8(s, tok, 32 * ks + 8 * g);
+}
+
 // what the forward pass of one tile reads and writes besides the weight images
 struct FfnTileP {
-  const float* x1; const float* b2; const float* g2; const float* be2;
+  X1Src x1; const float* b2; const float* g2; const float* be2;
   float* z2; float* x2; float* mean2; float* rstd2;
   float eps;
 };
@@ -123,7 +161,7 @@ __device__ __forceinline__ void ffn_fwd_tile(const FfnTileP& p, const char* w1im
   bf16x8 xh[2], xl[2];
   {
     f32x8 xv[2];
-    load_rows(p.x1, tok, g, xv);
+    load_x1_rows(p.x1, tok, g, xv);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) split8(xv[ks], xh[ks], xl[ks]);
   }
@@ -160,7 +198,7 @@ __device__ __forceinline__ void ffn_fwd_tile(const FfnTileP& p, const char* w1im
 #pragma unroll
   for (int hb = 0; hb < 4; ++hb) {
     const f32x4 y = acc[hb] + *reinterpret_cast<const f32x4*>(p.b2 + 16 * hb + 4 * g);
-    const f32x4 res = *reinterpret_cast<const f32x4*>(p.x1 + (int64_t)tok * HID + 16 * hb + 4 * g);
+    const f32x4 res = x1_load4(p.x1, tok, 16 * hb + 4 * g);
     z[hb] = res + b4r_drop4(dctx, y, (uint64_t)tok * HID + (uint64_t)(16 * hb + 4 * g));
     s += sum4(z[hb]);
   }

@@ -60,6 +60,7 @@ __device__ long long g_ff_prof[64];
 struct FfnP {
   const float* x1; const float* W1; const float* b1; const float* W2; const float* b2;
   const float* g2; const float* be2;
+  const float* be1;   // with x1 == NULL the input is formed from z1, mean1, rstd1, g1, be1 (X1Src)
   float* z2; float* x2; float* mean2; float* rstd2;
   const float* dz2; const float* z1; const float* mean1; const float* rstd1; const float* g1;
   float* dz1; float* ln_part;
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(64 * FW) void ffn_fwd_kernel(FfnP p) {
   const DropCtx dctx = b4r_drop_ctx(p.drop);
   const int Nn = ffn_rows(p);
   const int ntiles = (Nn + 15) >> 4;
-  const FfnTileP tp{p.x1, p.b2, p.g2, p.be2, p.z2, p.x2, p.mean2, p.rstd2, p.eps};
+  const FfnTileP tp{X1Src{p.x1, p.z1, p.mean1, p.rstd1, p.g1, p.be1}, p.b2, p.g2, p.be2, p.z2, p.x2, p.mean2, p.rstd2, p.eps};
   for (int t = blockIdx.x + gridDim.x * wave; t < ntiles; t += gridDim.x * FW) {   // wave-uniform: EXEC stays full
     const int j = 16 * t + i;
     const int tok = ffn_row(p, min(j, Nn - 1));   // the row in the [N, 64] tensors; pad lanes repeat the last row
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(64 * FW) void ffn_bwd_dx_kernel(FfnP p) {
     bf16x8 xh[2], xl[2], gh[2], gl[2];
     {
       f32x8 xv[2], dg[2];
-      load_rows(p.x1, tokc, g, xv);
+      load_x1_rows(X1Src{p.x1, p.z1, p.mean1, p.rstd1, p.g1, p.be1}, tokc, g, xv);
       if (rowmode) {
         ln2_mean = p.mean2[tokc]; ln2_rstd = p.rstd2[tokc];
         f32x8 zz[2], gm[2];
@@ -354,7 +355,8 @@ __global__ __launch_bounds__(64 * FW) void ffn_bwd_dw_kernel(FfnP p) {
     const int j = min(CH_TOK * c + stok, Nn - 1);
     srow = ffn_row(p, j);
     const int64_t src_row = (is_dz && rowmode) ? j : srow;   // the compact dz2 is indexed by j
-    sv = *reinterpret_cast<const f32x4*>(ssrc + src_row * HID + 4 * sc4);
+    sv = (is_dz || p.x1 != nullptr) ? *reinterpret_cast<const f32x4*>(ssrc + src_row * HID + 4 * sc4)
+                                    : x1_load4(X1Src{nullptr, p.z1, p.mean1, p.rstd1, p.g1, p.be1}, srow, 4 * sc4);
   };
   auto put = [&](int c, int stage) {
     const int j = CH_TOK * c + stok;
@@ -463,6 +465,7 @@ constexpr size_t DX_LDS = FWD_LDS + 2 * FW * 128 * sizeof(float);
 FfnP make_p(const b4r_ffn_desc* d) {
   FfnP p{};
   p.x1 = d->x1; p.W1 = d->W1; p.b1 = d->b1; p.W2 = d->W2; p.b2 = d->b2; p.g2 = d->ln_gamma; p.be2 = d->ln_beta;
+  p.be1 = d->ln1_beta;
   p.z2 = d->z2; p.x2 = d->x2; p.mean2 = d->mean2; p.rstd2 = d->rstd2;
   p.dz2 = d->dz2; p.z1 = d->z1; p.mean1 = d->mean1; p.rstd1 = d->rstd1; p.g1 = d->ln1_gamma; p.dz1 = d->dz1;
   p.N = d->N; p.eps = d->ln_eps;
@@ -473,6 +476,11 @@ FfnP make_p(const b4r_ffn_desc* d) {
 }
 
 bool al16(const void* q) { return q == nullptr || b4r_aligned16(q); }
+// the block input: x1 itself, or everything needed to form it from the attention half's pre-LayerNorm sum
+bool x1_given(const b4r_ffn_desc* d) {
+  return d->x1 != nullptr || (d->z1 && d->mean1 && d->rstd1 && d->ln1_gamma && d->ln1_beta && b4r_aligned16(d->z1) &&
+                              b4r_aligned16(d->ln1_gamma) && b4r_aligned16(d->ln1_beta));
+}
 
 // slot mode: all of its fields or none, never together with an explicit list, the rows it names inside [0, N)
 bool slot_mode_ok(const b4r_ffn_desc* d) {
@@ -503,8 +511,8 @@ extern "C" int b4r_ffn_block_fwd(const b4r_ffn_desc* d, b4r_stream_t stream) {
   B4R_CHECK_ARG(d != nullptr, B4R_E_BADARG, "b4r_ffn_block_fwd: null descriptor");
   B4R_CHECK_ARG(b4r_ffn_block_supported(d->H, d->I), B4R_E_SHAPE,
                 "b4r_ffn_block_fwd: needs hidden size 64, inner size 256 and the bf16x3 mode (H=%d I=%d)", d->H, d->I);
-  B4R_CHECK_ARG(d->N > 0 && d->x1 && d->W1 && d->b1 && d->W2 && d->b2 && d->ln_gamma && d->ln_beta && d->x2, B4R_E_BADARG,
-                "b4r_ffn_block_fwd: null argument");
+  B4R_CHECK_ARG(d->N > 0 && x1_given(d) && d->W1 && d->b1 && d->W2 && d->b2 && d->ln_gamma && d->ln_beta && d->x2, B4R_E_BADARG,
+                "b4r_ffn_block_fwd: null argument (the input is x1, or z1 + mean1 + rstd1 + ln1_gamma + ln1_beta)");
   B4R_CHECK_ARG(al16(d->x1) && al16(d->W1) && al16(d->W2) && al16(d->b2) && al16(d->ln_gamma) && al16(d->ln_beta) && al16(d->z2) &&
                     al16(d->x2),
                 B4R_E_ALIGN, "b4r_ffn_block_fwd: operands must be 16-byte aligned");
@@ -537,7 +545,7 @@ int b4r_ffn_block_bwd_marked(const b4r_ffn_desc* d, hipStream_t stream, hipEvent
   const bool rowmode = d->rows != nullptr || slotmode;
   B4R_CHECK_ARG(slot_mode_ok(d), B4R_E_BADARG,
                 "b4r_ffn_block_bwd: the slot mode needs slot_positions, slot_ids, slots_per_seq, seq_len, max_rows and no explicit list");
-  B4R_CHECK_ARG(d->N > 0 && d->x1 && d->W1 && d->b1 && d->W2 && (d->dz2 || rowmode) && d->z1 && d->mean1 && d->rstd1 && d->ln1_gamma &&
+  B4R_CHECK_ARG(d->N > 0 && x1_given(d) && d->W1 && d->b1 && d->W2 && (d->dz2 || rowmode) && d->z1 && d->mean1 && d->rstd1 && d->ln1_gamma &&
                     d->dz1 && d->dW1 && d->db1 && d->dW2 && d->db2 && d->dln1_gamma && d->scratch,
                 B4R_E_BADARG, "b4r_ffn_block_bwd: null argument");
   B4R_CHECK_ARG(!rowmode || ((slotmode || (d->n_rows && d->row_slot)) && d->max_rows > 0 && d->slot_grad && d->z2 && d->mean2 && d->rstd2 && d->ln_gamma &&

@@ -371,6 +371,13 @@ bool attn_bwd_fused(const b4r_model_config* c, int L) {
   return on && attn_fused(c, L) && b4r_attn_block_bwd_supported(c->hidden_size, c->num_heads, L) != 0;
 }
 
+// x1 = LayerNorm(z1) is not stored between the two fused halves of a layer: the feed-forward kernels form it on load (B4R_X1_ON_LOAD=0:
+// the attention block writes it as before)
+bool x1_on_load() {
+  static const bool on = !(getenv("B4R_X1_ON_LOAD") && atoi(getenv("B4R_X1_ON_LOAD")) == 0);
+  return on;
+}
+
 // B4R_FLAG_HEAD_ROWS_ONLY is honoured where the last layer's feed-forward half runs as the fused block and the row list fits
 bool head_rows_ok(const b4r_model_config* c, const b4r_batch* b) {
   static const bool on = !(getenv("B4R_HEAD_ROWS") && atoi(getenv("B4R_HEAD_ROWS")) == 0);
@@ -468,8 +475,10 @@ extern "C" int64_t b4r_encoder_layer_bwd_scratch_floats(int32_t N) {
 }
 extern "C" int b4r_encoder_layer_fwd(const b4r_attn_block_desc* attn, const b4r_ffn_desc* ffn, b4r_stream_t stream) {
   B4R_CHECK_ARG(attn && ffn, B4R_E_BADARG, "b4r_encoder_layer_fwd: null descriptor");
-  B4R_CHECK_ARG(attn->x1 != nullptr && attn->x1 == ffn->x1 && (int64_t)attn->B * attn->L == ffn->N && attn->H == ffn->H, B4R_E_BADARG,
-                "b4r_encoder_layer_fwd: the attention half's x1 [B*L,H] must be the feed-forward half's input");
+  B4R_CHECK_ARG(((attn->x1 != nullptr && attn->x1 == ffn->x1) || (ffn->x1 == nullptr && attn->z1 != nullptr && attn->z1 == ffn->z1)) &&
+                    (int64_t)attn->B * attn->L == ffn->N && attn->H == ffn->H,
+                B4R_E_BADARG, "b4r_encoder_layer_fwd: the attention half's x1 (or, with x1 == NULL, its z1) [B*L,H] must be the "
+                "feed-forward half's input");
   // (both halves behind each other in ONE launch were measured: 68 us against 39 + 25 us -- the feed-forward phase has to wait
   // for the attention half's stores at the barrier that frees the LDS, DESIGN.md section 4.1 -- and not kept)
   RC(b4r_attn_block_fwd(attn, stream));
@@ -604,7 +613,8 @@ extern "C" int b4r_forward(const b4r_model_config* cfg, const b4r_batch* batch, 
       ad.probs_stream = B4R_STREAM_ATTN_PROBS(i); ad.probs_rate = adp; ad.out_stream = B4R_STREAM_ATTN_OUT(i); ad.out_rate = od;
       ad.qkv = attn_bwd_fused(cfg, L) ? nullptr : ws + w.qkv[i];   // only round 1's backward kernels read it
       ad.ctx = ws + w.ctx[i]; ad.lse = ws + w.lse[i]; ad.keep_bits = reinterpret_cast<uint32_t*>(ws + w.keep[i]);
-      ad.z1 = ws + w.z1[i]; ad.x1 = ws + w.x1[i]; ad.mean1 = ws + w.mean1[i]; ad.rstd1 = ws + w.rstd1[i];
+      ad.z1 = ws + w.z1[i]; ad.mean1 = ws + w.mean1[i]; ad.rstd1 = ws + w.rstd1[i];
+      ad.x1 = (layer_fused && x1_on_load()) ? nullptr : ws + w.x1[i];   // the fused feed-forward half forms x1 from z1 itself
       if (i == 0 && emb_fused) {
         ad.emb_ids = batch->input_word_ids; ad.emb_table = params + pl.word_emb; ad.emb_pos = params + pl.pos_emb; ad.emb_vocab = V;
         ad.emb_gamma = params + pl.emb_ln_g; ad.emb_beta = params + pl.emb_ln_b; ad.emb_eps = cfg->ln_eps;
@@ -622,7 +632,9 @@ extern "C" int b4r_forward(const b4r_model_config* cfg, const b4r_batch* batch, 
                     od, s));
     }
     if (ffn_fused(cfg)) {
-      fd.N = N; fd.H = H; fd.I = I; fd.x1 = ws + w.x1[i];
+      fd.N = N; fd.H = H; fd.I = I; fd.x1 = (layer_fused && x1_on_load()) ? nullptr : ws + w.x1[i];
+      fd.z1 = ws + w.z1[i]; fd.mean1 = ws + w.mean1[i]; fd.rstd1 = ws + w.rstd1[i];
+      fd.ln1_gamma = params + pl.ln1_g[i]; fd.ln1_beta = params + pl.ln1_b[i];
       fd.W1 = params + pl.w1[i]; fd.b1 = params + pl.b1[i]; fd.W2 = params + pl.w2[i]; fd.b2 = params + pl.b2[i];
       fd.ln_gamma = params + pl.ln2_g[i]; fd.ln_beta = params + pl.ln2_b[i]; fd.ln_eps = cfg->ln_eps;
       fd.rng = od > 0.f ? rng : nullptr; fd.drop_stream = B4R_STREAM_FFN_OUT(i); fd.drop_rate = od;
@@ -831,11 +843,12 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
       // feed-forward block: dz1 (-> db), dW1 / db1 / dW2 / db2 and the attention LayerNorm's gamma / beta gradients from dz2 (da);
       // the [N, inner] pre-activation is recomputed from x1 inside the two kernels
       b4r_ffn_desc fd{};
-      fd.N = N; fd.H = H; fd.I = I; fd.x1 = ws + w.x1[i];
+      fd.N = N; fd.H = H; fd.I = I;
+      fd.x1 = (attn_fused(cfg, L) && x1_on_load()) ? nullptr : ws + w.x1[i];   // as the forward of this step left it
       fd.W1 = params + pl.w1[i]; fd.b1 = params + pl.b1[i]; fd.W2 = params + pl.w2[i]; fd.b2 = params + pl.b2[i];
       fd.rng = od > 0.f ? rng : nullptr; fd.drop_stream = B4R_STREAM_FFN_OUT(i); fd.drop_rate = od;
       fd.dz2 = ws + w.da; fd.z1 = ws + w.z1[i]; fd.mean1 = ws + w.mean1[i]; fd.rstd1 = ws + w.rstd1[i];
-      fd.ln1_gamma = params + pl.ln1_g[i]; fd.dz1 = ws + w.db;
+      fd.ln1_gamma = params + pl.ln1_g[i]; fd.ln1_beta = params + pl.ln1_b[i]; fd.dz1 = ws + w.db;
       fd.dW1 = grads + pl.w1[i]; fd.db1 = grads + pl.b1[i]; fd.dW2 = grads + pl.w2[i]; fd.db2 = grads + pl.b2[i];
       fd.dln1_gamma = grads + pl.ln1_g[i];
       fd.scratch = take(b4r_ffn_block_bwd_scratch_floats(N));

@@ -390,7 +390,8 @@ typedef struct b4r_attn_block_desc {
   const float* ln_gamma; const float* ln_beta; float ln_eps;   /* self_attention_layer_norm */
   const uint32_t* rng; uint32_t probs_stream; float probs_rate; uint32_t out_stream; float out_rate;
   float* qkv; float* ctx; float* lse; uint32_t* keep_bits;
-  float* z1; float* x1; float* mean1; float* rstd1;   /* z1 / mean1 / rstd1 may be NULL */
+  float* z1; float* x1; float* mean1; float* rstd1;   /* z1 / mean1 / rstd1 may be NULL; x1 too when z1, mean1, rstd1 are given (the
+                                                       * feed-forward block then forms x1 on load, b4r_ffn_desc.ln1_beta) */
   /* FIRST LAYER, optional (emb_ids != NULL; x is then ignored): the block forms its own input, the embedding stage of
    * bert4rec_encoder.py:198-214, x = dropout(LayerNorm(emb_table[id] + emb_pos[position]) * emb_gamma + emb_beta), and writes it to
    * emb_x [B*L,H] with the statistics emb_mean / emb_rstd [B*L] (may be NULL) -- what b4r_embed_ln_fwd does in a launch of its own.
@@ -456,6 +457,9 @@ typedef struct b4r_ffn_desc {
    * max_rows = B*P, rows[j] = (j / slots_per_seq) * seq_len + clamp(slot_positions[j]), row_slot[j] = j where slot_ids[j] != 0,
    * else -1.  rows / n_rows / row_slot stay NULL. */
   const int64_t* slot_positions; const int64_t* slot_ids; int32_t slots_per_seq, seq_len;
+  /* x1 == NULL: the block input is formed on load, x1 = LayerNorm(z1) * ln1_gamma + ln1_beta from z1 / mean1 / rstd1 (inputs of the
+   * forward too, then) -- the attention block need not store x1 at all (b4r_attn_block_desc.x1 = NULL). */
+  const float* ln1_beta;
 } b4r_ffn_desc;
 /* The rows of the sequence output that the masked-LM head of this batch reads, one entry per masked-LM slot m = b*P + p:
  * rows[m] = b*L + clamp(position[m]) (padded slots gather position 0, as tfm MaskedLM does: their entries repeat a row, which the

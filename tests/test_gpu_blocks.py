@@ -350,7 +350,7 @@ def test_encoder_layer_is_the_two_halves_plus_the_two_weight_gradient_products(B
                   rstd2=(N,), dz1=(N, 64), dW1=(64, 256), db1=(256,), dW2=(256, 64), db2=(64,), dln1=(128,), dqkv=(N, 192),
                   da=(N, 64), dlnp=(128,), dWo=(64, 64), dbo=(64,), dWqkv=(64, 192), dbqkv=(192,))
 
-    def run(layer_calls):
+    def run(layer_calls, store_x1=True):
         o = {k: torch.full(s_, float("nan"), dtype=torch.float32, device=DEV) for k, s_ in shapes.items()}
         bits.zero_()
         ad = _lib.AttnBlockDesc()
@@ -360,10 +360,11 @@ def test_encoder_layer_is_the_two_halves_plus_the_two_weight_gradient_products(B
         ad.ln_gamma, ad.ln_beta, ad.ln_eps = P(g["g1"]), P(g["be1"]), 1e-12
         ad.rng, ad.probs_stream, ad.probs_rate, ad.out_stream, ad.out_rate = P(st), 1, rate, 2, rate
         ad.ctx, ad.lse, ad.keep_bits = P(o["ctx"]), P(o["lse"]), P(bits)
-        ad.z1, ad.x1, ad.mean1, ad.rstd1 = P(o["z1"]), P(o["x1"]), P(o["mean1"]), P(o["rstd1"])
+        ad.z1, ad.x1, ad.mean1, ad.rstd1 = P(o["z1"]), (P(o["x1"]) if store_x1 else None), P(o["mean1"]), P(o["rstd1"])
         fd = _lib.FfnDesc()
         fd.N, fd.H, fd.I = N, 64, 256
-        fd.x1, fd.W1, fd.b1, fd.W2, fd.b2 = P(o["x1"]), P(g["W1"]), P(g["b1"]), P(g["W2"]), P(g["b2"])
+        fd.x1, fd.W1, fd.b1, fd.W2, fd.b2 = (P(o["x1"]) if store_x1 else None), P(g["W1"]), P(g["b1"]), P(g["W2"]), P(g["b2"])
+        fd.ln1_beta = P(g["be1"])
         fd.ln_gamma, fd.ln_beta, fd.ln_eps = P(g["g2"]), P(g["be2"]), 1e-12
         fd.rng, fd.drop_stream, fd.drop_rate = P(st), 3, rate
         fd.z2, fd.x2, fd.mean2, fd.rstd2 = P(o["z2"]), P(o["x2"]), P(o["mean2"]), P(o["rstd2"])
@@ -393,6 +394,12 @@ def test_encoder_layer_is_the_two_halves_plus_the_two_weight_gradient_products(B
         return o
 
     whole, halves = run(True), run(False)
+    # x1 not stored at all: the feed-forward kernels form it from z1 and the statistics (the attention epilogue's formula)
+    lean = run(True, store_x1=False)
+    for k in shapes:
+        if k != "x1":
+            assert T.maxdiff(lean[k], whole[k].cpu()) < 2e-6 * max(1.0, float(whole[k].abs().max())), k
+    assert bool(torch.isnan(lean["x1"]).all())
     for k in shapes:
         if k not in ("dWo", "dbo", "dWqkv", "dbqkv"):
             assert torch.equal(whole[k], halves[k]), k

@@ -20,7 +20,8 @@ def _newer(target: str, deps) -> bool:
 
 def build_library(force: bool = False, verbose: bool = True) -> str:
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "b4r_common.h"), os.path.join(CSRC, "b4r_rx_tiles.h"), os.path.join(os.path.dirname(HERE), "include", "b4r.h")]
+    headers = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h")]   # every translation unit is rebuilt
+    deps = srcs + headers + [os.path.join(os.path.dirname(HERE), "include", "b4r.h")]
     if not force and _newer(OUT, deps):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -72,7 +72,9 @@ __global__ __launch_bounds__(1024) void attn_block_fwd_kernel(AbP p) {
   // ---- phase 0: weights and the key mask ------------------------------------------------------------------------------
   AF_MARK(0);
   const int tok = 16 * wave + i, tokc = min(tok, L - 1);
-  const float amax = b4r_seq_amax(p.mask + row0, L);
+  // b4r_seq_amax, its barrier folded into the one behind the weight staging
+  int any_key = 0;
+  for (int k = threadIdx.x; k < L; k += blockDim.x) any_key |= (p.mask[row0 + k] != 0) ? 1 : 0;
   f32x8 xv[2];
   const float* xsrc = p.x;   // the residual of the epilogue is read from here
   if (p.ids != nullptr) {   // block-uniform: the embedding stage for this wave's tokens (position = token index in the sequence)
@@ -120,8 +122,7 @@ __global__ __launch_bounds__(1024) void attn_block_fwd_kernel(AbP p) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) xv[ks] = load8(p.x + (row0 + tokc) * HID + 32 * ks + 8 * g);   // in flight during the staging
   }
-  stage_weight(big, p.Wqkv, HID, 3 * HID, nthreads);
-  stage_weight(woimg, p.Wo, HID, HID, nthreads);
+  stage_weight_pair(big, p.Wqkv, HID, 3 * HID, woimg, p.Wo, HID, HID, nthreads);
   for (int k = threadIdx.x; k < KTE * 16; k += nthreads)
     sAdd[k] = k < L ? (1.0f - (float)p.mask[row0 + k]) * -1e9f : -INFINITY;
   for (int k = threadIdx.x; k < 3 * HID; k += nthreads) sbq[k] = p.bqkv[k];
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(1024) void attn_block_fwd_kernel(AbP p) {
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) split8(xv[ks], xh[ks], xl[ks]);
   AF_MARK(1);
-  __syncthreads();
+  const float amax = __syncthreads_or(any_key) ? 0.0f : -1e9f;
   AF_MARK(2);
 
   // ---- phase 1: q, k, v of this wave's 16 tokens.  Tile a of feature block fb holds features 32 fb + 8p + 4a + e on its
@@ -408,7 +409,10 @@ __global__ __launch_bounds__(1024) void attn_block_bwd_kernel(AbBwdP p) {
   const bool live = tok < L;
   char* scratch = scratch_all + wave * 2048;
   char* woimg = R + 48 * 1024;
-  const float amax = b4r_seq_amax(p.mask + row0, L);
+  // b4r_seq_amax, its barrier folded into the first one of the head loop
+  int any_key = 0;
+  for (int k = threadIdx.x; k < L; k += blockDim.x) any_key |= (p.mask[row0 + k] != 0) ? 1 : 0;
+  float amax = 0.0f;
 
   for (int k = threadIdx.x; k < KT * 16; k += nthreads) sAdd[k] = k < L ? (1.0f - (float)p.mask[row0 + k]) * -1e9f : -INFINITY;
   for (int k = threadIdx.x; k < 3 * HID; k += nthreads) sbq[k] = p.bqkv[k];
@@ -429,11 +433,13 @@ __global__ __launch_bounds__(1024) void attn_block_bwd_kernel(AbBwdP p) {
 
   AB_MARK(0);
   for (int hd = 0; hd <= 2; ++hd) {
-    __syncthreads();   // the tile region is free (previous head done; first pass: sAdd / sbq written)
+    // the tile region is free (previous head done; first pass: sAdd / sbq written)
+    if (hd == 0) amax = __syncthreads_or(any_key) ? 0.0f : -1e9f;
+    else __syncthreads();
     AB_MARK(1 + 10 * hd);
     if (!(AB_EXP & 8) || hd == 0) {
-    stage_weight(R, p.Wqkv, HID, 3 * HID, nthreads);
-    if (hd < 2) stage_weight(woimg, p.Wo, HID, HID, nthreads);
+    if (hd < 2) stage_weight_pair(R, p.Wqkv, HID, 3 * HID, woimg, p.Wo, HID, HID, nthreads);
+    else stage_weight(R, p.Wqkv, HID, 3 * HID, nthreads);
     }
     __syncthreads();
     AB_MARK(2 + 10 * hd);

@@ -31,22 +31,50 @@ __device__ __forceinline__ bf16x8 tr_pair(const char* a, const char* b) {
 }
 __device__ __forceinline__ bf16x8 row_at(const char* a) { return *reinterpret_cast<const bf16x8*>(a); }
 
-// W [R][C] fp32 row-major -> natural hi / lo image (R % 16 == 0, C % 32 == 0), all `nthreads` threads of the workgroup
-__device__ __forceinline__ void stage_weight(char* img, const float* W, int R, int C, int nthreads) {
-  // one float4 per thread and turn, sub-tile by sub-tile: the 64 lanes of a wave-instruction fill 8 whole rows (512 bytes) of one
-  // sub-tile, so the 8-byte LDS stores are conflict-free (row-major order put a wave across 8 sub-tiles 2 KB apart: 8-way)
+// W [R][C] fp32 row-major -> natural hi / lo image (R % 16 == 0, C % 32 == 0), all `nthreads` threads of the workgroup.
+// One float4 per thread and turn, sub-tile by sub-tile: the 64 lanes of a wave-instruction fill 8 whole rows (512 bytes) of one
+// sub-tile, so the 8-byte LDS stores are conflict-free (row-major order put a wave across 8 sub-tiles 2 KB apart: 8-way).
+// Four turns are requested before the first is converted: one load latency per four turns instead of one per turn (the in-kernel
+// stamps showed 900 cycles per turn, i.e. the loop waited for every load: 3.5 us for the two feed-forward matrices).
+constexpr int STAGE_U = 4;
+struct StageTurns { f32x4 v[STAGE_U]; int off[STAGE_U]; };
+__device__ __forceinline__ void stage_request(StageTurns& t, const float* W, int R, int C, int f0, int nthreads) {
   const int ncb = C >> 5, nf4 = (R * C) >> 2;
-  for (int f = threadIdx.x; f < nf4; f += nthreads) {
-    const int st = f >> 7, u = f & 127;
+#pragma unroll
+  for (int u = 0; u < STAGE_U; ++u) {
+    const int f = min(f0 + u * nthreads, nf4 - 1);   // clamped: every load unconditional
+    const int st = f >> 7, w = f & 127;
     const int rt = st / ncb, cb = st - rt * ncb;
-    const int r16 = u >> 3, q4 = u & 7;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(W + (int64_t)(16 * rt + r16) * C + 32 * cb + 4 * q4);
-    bf16x4 h, l;
-    b4r_split4(v, h, l);
-    char* dst = img + sub_base(rt, cb, ncb) + sub_off(r16, q4 >> 1) + 8 * (q4 & 1);
-    *reinterpret_cast<bf16x4*>(dst) = h;
-    *reinterpret_cast<bf16x4*>(dst + SUB) = l;
+    const int r16 = w >> 3, q4 = w & 7;
+    t.v[u] = *reinterpret_cast<const f32x4*>(W + (int64_t)(16 * rt + r16) * C + 32 * cb + 4 * q4);
+    t.off[u] = sub_base(rt, cb, ncb) + sub_off(r16, q4 >> 1) + 8 * (q4 & 1);
   }
+}
+__device__ __forceinline__ void stage_commit(const StageTurns& t, char* img, int R, int C, int f0, int nthreads) {
+  const int nf4 = (R * C) >> 2;
+#pragma unroll
+  for (int u = 0; u < STAGE_U; ++u) {
+    if (f0 + u * nthreads < nf4) {
+      bf16x4 h, l;
+      b4r_split4(t.v[u], h, l);
+      *reinterpret_cast<bf16x4*>(img + t.off[u]) = h;
+      *reinterpret_cast<bf16x4*>(img + t.off[u] + SUB) = l;
+    }
+  }
+}
+__device__ __forceinline__ void stage_weight(char* img, const float* W, int R, int C, int nthreads) {
+  const int nf4 = (R * C) >> 2;
+  for (int f0 = threadIdx.x; f0 < nf4; f0 += STAGE_U * nthreads) {
+    StageTurns t;
+    stage_request(t, W, R, C, f0, nthreads);
+    stage_commit(t, img, R, C, f0, nthreads);
+  }
+}
+// two matrices: one after the other (requesting the turns of both together was measured: 3 us per step SLOWER)
+__device__ __forceinline__ void stage_weight_pair(char* img_a, const float* Wa, int Ra, int Ca, char* img_b, const float* Wb, int Rb, int Cb,
+                                                  int nthreads) {
+  stage_weight(img_a, Wa, Ra, Ca, nthreads);
+  stage_weight(img_b, Wb, Rb, Cb, nthreads);
 }
 
 __device__ __forceinline__ float sum4(const f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }

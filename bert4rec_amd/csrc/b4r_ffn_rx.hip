@@ -100,8 +100,7 @@ __global__ __launch_bounds__(64 * FW) void ffn_fwd_kernel(FfnP p) {
   char* w2img = smem_ffn + W_IMG;
   float* sb1 = reinterpret_cast<float*>(smem_ffn + 2 * W_IMG);
   if (!(FFN_EXP & 1)) {
-  stage_weight(w1img, p.W1, HID, INNER, 64 * FW);
-  stage_weight(w2img, p.W2, INNER, HID, 64 * FW);
+  stage_weight_pair(w1img, p.W1, HID, INNER, w2img, p.W2, INNER, HID, 64 * FW);
   }
   if (threadIdx.x < INNER) sb1[threadIdx.x] = p.b1[threadIdx.x];
   FF_MARK(1);
@@ -134,8 +133,7 @@ __global__ __launch_bounds__(64 * FW) void ffn_bwd_dx_kernel(FfnP p) {
   char* w2img = smem_ffn + W_IMG;
   float* sb1 = reinterpret_cast<float*>(smem_ffn + 2 * W_IMG);
   float* sred = sb1 + INNER;   // [FW][128], then [FW][128] for the output LayerNorm (row-list mode)
-  stage_weight(w1img, p.W1, HID, INNER, 64 * FW);
-  stage_weight(w2img, p.W2, INNER, HID, 64 * FW);
+  stage_weight_pair(w1img, p.W1, HID, INNER, w2img, p.W2, INNER, HID, 64 * FW);
   if (threadIdx.x < INNER) sb1[threadIdx.x] = p.b1[threadIdx.x];
   __syncthreads();
 

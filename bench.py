@@ -130,7 +130,7 @@ def algorithmic_work(label, V, H, NL, NH, I, L, P, B):
     N, M = B * L, B * P
     act = N * H * 4                                         # one [N, H] fp32 activation
     if label.startswith("b4r_ffn_block_fwd"):
-        return "hbm", 3 * act + 2 * N * 4 + 2 * H * I * 4, "x1 in; z2, x2, statistics out; W1, W2"
+        return "hbm", 3 * act + 4 * N * 4 + 2 * H * I * 4, "z1 (-> x1) in; z2, x2, statistics out; W1, W2"
     if label.startswith("b4r_ffn_block_bwd (dx)"):
         return "hbm", 4 * act + 2 * N * 4 + 2 * H * I * 4, "x1, dz2, z1 in; dz1 out; statistics; W1, W2"
     if label.startswith("b4r_ffn_block_bwd (dw)"):
@@ -141,7 +141,7 @@ def algorithmic_work(label, V, H, NL, NH, I, L, P, B):
     # 312 FLOP/byte even counting the split products -> the HBM roof is the binding one
     small = B * NH * L * 4 + 2 * N * 4 + (B * NH * ((L + 15) // 16) * 2 * 64) * 4    # lse, mean / rstd, keep bits
     if label.startswith("b4r_attn_block_fwd"):
-        return "hbm", 4 * act + small, "x in; ctx, z1, x1 out; lse, statistics, dropout bits"
+        return "hbm", 3 * act + small, "x in; ctx, z1 out (x1 is formed on load by the feed-forward kernels); lse, statistics, dropout bits"
     if label.startswith("b4r_attn_block_bwd"):
         return "hbm", 4 * act + 3 * act + act + small, "x, dz1, ctx, previous z in; dqkv [N,3H], dx_prev out; lse, statistics, dropout bits"
     if label.startswith("b4r_attn_fwd"):

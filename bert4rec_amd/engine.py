@@ -441,9 +441,11 @@ class Engine:
                                  random_token_rate, finetune, seed, rows, row_finetune, self.device)
 
     def sample_candidates(self, logp: torch.Tensor, exclude: torch.Tensor, gt: torch.Tensor, n_samples: int,
-                          seed: int) -> torch.Tensor:
+                          seed: int, short_flag: Optional[torch.Tensor] = None) -> torch.Tensor:
         """b4r_sample_candidates: exclude [R,E] int64 (-1 padded), gt [R] int64 -> cand [R, n_samples+1] int64 (device);
-        raises ValueError when a row has fewer than n_samples drawable items (popular_random_sampler.py:56-58)."""
+        raises ValueError when a row has fewer than n_samples drawable items (popular_random_sampler.py:56-58).
+        short_flag: a device bool tensor [1] -- that condition is OR-ed into it instead of being read back here (the caller checks it
+        once, e.g. at the end of an evaluation: no host synchronisation per batch)."""
         logp = logp.to(device=self.device, dtype=torch.float32).contiguous()
         exclude = exclude.to(device=self.device, dtype=torch.int64).contiguous()
         gt = gt.to(device=self.device, dtype=torch.int64).contiguous()
@@ -452,7 +454,10 @@ class Engine:
         _lib.check(self.lib.b4r_sample_candidates(_ptr(logp), logp.numel(), _ptr(exclude), E, _ptr(gt), R, n_samples,
                                                   int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(cand), _stream(self.device)),
                    "b4r_sample_candidates")
-        if bool((cand[:, :n_samples] < 0).any()):
+        short = (cand[:, :n_samples] < 0).any()
+        if short_flag is not None:
+            short_flag |= short
+        elif bool(short):
             raise ValueError(f"The exclusion lists reduce the vocab too much to take a sample of size {n_samples} "
                              f"(since no duplicates are allowed).")
         return cand

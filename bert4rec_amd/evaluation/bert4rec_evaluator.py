@@ -33,6 +33,8 @@ class BERT4RecEvaluator(BaseEvaluator):
         self._seed = int(seed)
         self._draws = 0
         self._logp = None
+        self._short = None   # device flag: some row had fewer drawable items than the sample size (checked once per evaluation)
+        self._slots = None
         if metrics is None:
             metrics = default_metrics()
         if isinstance(sampler, str):
@@ -73,6 +75,10 @@ class BERT4RecEvaluator(BaseEvaluator):
         if self._dev is None:
             return
         _, sums, users = self._dev
+        if getattr(self, "_short", None) is not None and bool(self._short.cpu()[0]):   # checked once, not per batch
+            self._short.zero_()
+            raise ValueError(f"The exclusion lists reduce the vocab too much to take a sample of size {self.sampler.sample_size} "
+                             f"(since no duplicates are allowed).")
         sums_h, users_h = sums.cpu().tolist(), int(users.cpu()[0])
         for m, g in zip(self._metrics, sums_h):
             m.absorb(g, users_h)
@@ -129,28 +135,33 @@ class BERT4RecEvaluator(BaseEvaluator):
         w = torch.as_tensor(test_batch["masked_lm_weights"]).to(dev) != 0
         ids_t = torch.as_tensor(test_batch["masked_lm_ids"]).to(dev)
         labels = torch.as_tensor(test_batch["labels"]).to(dev)
-        b_idx, p_idx = torch.nonzero(w, as_tuple=True)          # row-major: batch order, then slot order
+        b_idx, p_idx = torch.nonzero(w, as_tuple=True)          # row-major: batch order, then slot order (the one read-back per batch)
+        self._slots = b_idx * w.shape[1] + p_idx                # handed to rank_items_tensor: it need not look for them again
         if b_idx.numel() == 0:
             return torch.empty((0, self.sampler.sample_size + 1), dtype=torch.int64), torch.empty((0,), dtype=torch.int64)
         gt = ids_t[b_idx, p_idx].to(torch.int64)
         exclude = labels[b_idx].to(torch.int64)                 # the user's whole sequence (bert4rec_evaluator.py:86-95)
         self._draws += 1
+        if self._short is None or self._short.device != dev:
+            self._short = torch.zeros(1, dtype=torch.bool, device=dev)
         cand = eng.sample_candidates(self._logp, exclude, gt, self.sampler.sample_size,
-                                     seed=(self._seed << 32) ^ self._draws)
+                                     seed=(self._seed << 32) ^ self._draws, short_flag=self._short)
         return cand, gt
 
     def evaluate_batch(self, model, test_batch: dict, candidates=None, ground_truth=None):
         """bert4rec_evaluator.py:60-120 for one batch.  Returns the ground-truth ranks: a device int32 tensor when the metric
         sums are accumulated on the GPU (flushed by evaluate() / get_metrics_results()), else a numpy array."""
+        slots = None
         if candidates is None:
             if self._device_sampler_ready(model):
                 candidates, ground_truth = self.sample_candidates_device(model, test_batch)
+                slots = self._slots
             else:
                 candidates, ground_truth = self.sample_candidates(test_batch)
         if len(candidates) == 0:
             return []
         _, gt_rank, _, _ = model.rank_items_tensor(test_batch, torch.as_tensor(candidates), torch.as_tensor(ground_truth),
-                                                   want_ranking=False)
+                                                   want_ranking=False, slots=slots)
         engine = getattr(model, "engine", None)
         if engine is not None and gt_rank.is_cuda and len(self._metrics) <= 32:
             _, sums, users = self._device_sums(engine)

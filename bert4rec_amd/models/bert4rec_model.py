@@ -233,22 +233,25 @@ class BERT4RecModel:
         return history
 
     # ---- ranking ----------------------------------------------------------------------------------------------------------
-    def _ranked_slot_hidden(self, encoder_input: Dict[str, torch.Tensor]):
+    def _ranked_slot_hidden(self, encoder_input: Dict[str, torch.Tensor], slots: Optional[torch.Tensor] = None):
         """Encoder forward (no logits, no head on the slots nobody ranks), then tfm MaskedLM's transform on the R slots with
         masked_lm_weights == 1 only (all slots when the key is absent).  The reference computes all [B, P, V] logits and
         keeps the valid slots afterwards (bert4rec_model.py:215-220).  Returns (hidden [R,H], slot index [R] = b*P+p,
-        valid slots per batch row)."""
+        valid slots per batch row).  slots: the caller already has the slot indices (the evaluator, from sampling the candidates):
+        nothing is read back to the host here, and the per-row counts are not formed (None)."""
         cb, keep = self.engine.prepare_batch(encoder_input)
         if cb.P == 0:
             raise ValueError("rank_items needs masked_lm_positions")
         B, L, P = cb.B, cb.L, cb.P
         self.engine.encoder_forward(cb, training=False)
-        if "masked_lm_weights" in encoder_input and encoder_input["masked_lm_weights"] is not None:
-            w = torch.as_tensor(encoder_input["masked_lm_weights"]).to(self.device).reshape(B, P) != 0
-        else:
-            w = torch.ones((B, P), dtype=torch.bool, device=self.device)
-        slots = torch.nonzero(w.reshape(-1), as_tuple=False).reshape(-1)  # row-major => batch order, then slot order
-        counts = w.sum(dim=1).tolist()
+        counts = None
+        if slots is None:
+            if "masked_lm_weights" in encoder_input and encoder_input["masked_lm_weights"] is not None:
+                w = torch.as_tensor(encoder_input["masked_lm_weights"]).to(self.device).reshape(B, P) != 0
+            else:
+                w = torch.ones((B, P), dtype=torch.bool, device=self.device)
+            slots = torch.nonzero(w.reshape(-1), as_tuple=False).reshape(-1)  # row-major => batch order, then slot order
+            counts = w.sum(dim=1).tolist()
         if slots.numel() == 0:
             return None, slots, counts
         pos = keep["masked_lm_positions"].reshape(-1)[slots].clamp(0, L - 1)   # tfm MaskedLM gathers position + b*L
@@ -257,11 +260,13 @@ class BERT4RecModel:
         return self.engine.mlm_transform_rows(seq, rows), slots, counts
 
     def rank_items_tensor(self, encoder_input: Dict[str, torch.Tensor], candidates: Optional[torch.Tensor] = None,
-                          ground_truth: Optional[torch.Tensor] = None, want_ranking: bool = True):
+                          ground_truth: Optional[torch.Tensor] = None, want_ranking: bool = True,
+                          slots: Optional[torch.Tensor] = None):
         """Device-side core of rank_items: b4r_rank_candidates on every slot with masked_lm_weights == 1.  candidates:
         [R, C] int64 or None (whole vocabulary, ranked without materialising an [R, V] candidate list).
-        Returns (ranking [R,C] int64, gt_rank [R] int32 or None, slot_index [R] int64 (b*P+p), rows_per_batch_entry)."""
-        hidden, slots, counts = self._ranked_slot_hidden(encoder_input)
+        Returns (ranking [R,C] int64, gt_rank [R] int32 or None, slot_index [R] int64 (b*P+p), rows_per_batch_entry (None when the
+        caller passed `slots`))."""
+        hidden, slots, counts = self._ranked_slot_hidden(encoder_input, slots)
         R = int(slots.numel())
         if R == 0:
             return None, None, slots, counts

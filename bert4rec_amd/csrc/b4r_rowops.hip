@@ -1033,12 +1033,44 @@ extern "C" int b4r_mlm_rows(const int64_t* masked_lm_positions, const int64_t* m
 // items draws: successive picks proportional to p among what is left) as Gumbel top-k: key_v = log p_v + G_v with
 // G_v = -log(-log u_v); the C largest keys, in descending order, are the sample in draw order.  u_v comes from a counter
 // hash of (seed, row, v) with 24 bits, so it lies strictly inside (0, 1).
+// (value, index) of the larger key; equal keys: the lower index (np.random.choice's order of draws is not affected: ties of 24-bit
+// Gumbel keys are broken the same way everywhere in this kernel)
+__device__ __forceinline__ void keep_larger(float& best, int& bidx, float ov, int oi) {
+  if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+}
+template <int CTRL>
+__device__ __forceinline__ void argmax_dpp(float& best, int& bidx) {
+  const float ov = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, best), CTRL, 0xf, 0xf, false));
+  const int oi = __builtin_amdgcn_update_dpp(0, bidx, CTRL, 0xf, 0xf, false);
+  keep_larger(best, bidx, ov, oi);
+}
+// argmax over the 64 lanes of a wave, result in every lane: rotations inside the 16-lane rows (DPP), then the rows (permlane swaps);
+// no LDS crossbar traffic (__shfl_xor compiles to ds_bpermute_b32: 12 of them per draw were most of this kernel's 173 us)
+__device__ __forceinline__ void wave_argmax(float& best, int& bidx) {
+  argmax_dpp<0x121>(best, bidx);   // row_ror:1
+  argmax_dpp<0x122>(best, bidx);   // row_ror:2
+  argmax_dpp<0x124>(best, bidx);   // row_ror:4
+  argmax_dpp<0x128>(best, bidx);   // row_ror:8
+  {
+    const auto v = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, best), __builtin_bit_cast(unsigned, best), false, false);
+    const auto i = __builtin_amdgcn_permlane16_swap((unsigned)bidx, (unsigned)bidx, false, false);
+    const bool odd = (threadIdx.x & 16) != 0;   // the neighbour row's value: new vdst in odd rows, new vsrc in even rows
+    keep_larger(best, bidx, __builtin_bit_cast(float, odd ? v[0] : v[1]), (int)(odd ? i[0] : i[1]));
+  }
+  {
+    const auto v = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, best), __builtin_bit_cast(unsigned, best), false, false);
+    const auto i = __builtin_amdgcn_permlane32_swap((unsigned)bidx, (unsigned)bidx, false, false);
+    const bool upper = (threadIdx.x & 32) != 0;
+    keep_larger(best, bidx, __builtin_bit_cast(float, upper ? v[0] : v[1]), (int)(upper ? i[0] : i[1]));
+  }
+}
+
 __global__ __launch_bounds__(256) void sample_candidates_kernel(const float* logp, int V, const int64_t* exclude, int E,
                                                                 const int64_t* gt, int C, uint32_t seed_lo,
                                                                 uint32_t seed_hi, int64_t* cand) {
   extern __shared__ float s_key[];            // [V]
-  __shared__ float s_v[4];
-  __shared__ int s_i[4];
+  __shared__ float s_v[2][4];
+  __shared__ int s_i[2][4];
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t rk = b4r_hash32((uint32_t)row * 0x9E3779B9u + seed_hi);
   for (int v = tid; v < V; v += 256) {
@@ -1056,30 +1088,32 @@ __global__ __launch_bounds__(256) void sample_candidates_kernel(const float* log
   if (tid == 0 && g >= 0 && g < V) s_key[g] = -INFINITY;
   __syncthreads();
   int64_t* out = cand + (int64_t)row * (C + 1);
-  for (int c = 0; c < C; ++c) {
-    float best = -INFINITY; int bidx = 0x7fffffff;
+  // a tournament: every thread keeps the best of ITS keys (v = tid, tid + 256, ...); a draw is the best of the 256 thread-bests, and
+  // only the thread that owned the drawn key looks through its keys again
+  auto own_best = [&](float& best, int& bidx) {
+    best = -INFINITY; bidx = 0x7fffffff;
     for (int v = tid; v < V; v += 256) {
       const float k = s_key[v];
       if (k > best) { best = k; bidx = v; }    // increasing v per thread: the lowest index wins ties
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(best, o, 64);
-      const int oi = __shfl_xor(bidx, o, 64);
-      if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
-    }
-    if (lane == 0) { s_v[wave] = best; s_i[wave] = bidx; }
+  };
+  float my_best; int my_idx;
+  own_best(my_best, my_idx);
+  for (int c = 0; c < C; ++c) {
+    float best = my_best; int bidx = my_idx;
+    wave_argmax(best, bidx);
+    const int buf = c & 1;   // two sets of slots: the next draw's writes cannot overtake this draw's reads
+    if (lane == 0) { s_v[buf][wave] = best; s_i[buf][wave] = bidx; }
     __syncthreads();
-    if (tid == 0) {
-      best = s_v[0]; bidx = s_i[0];
+    best = s_v[buf][0]; bidx = s_i[buf][0];
 #pragma unroll
-      for (int w = 1; w < 4; ++w)
-        if (s_v[w] > best || (s_v[w] == best && s_i[w] < bidx)) { best = s_v[w]; bidx = s_i[w]; }
-      const bool ok = best > -INFINITY;
-      out[c] = ok ? (int64_t)bidx : -1;        // -1: fewer than C items with non-zero probability are left
-      if (ok) s_key[bidx] = -INFINITY;
+    for (int w = 1; w < 4; ++w) keep_larger(best, bidx, s_v[buf][w], s_i[buf][w]);
+    const bool ok = best > -INFINITY;
+    if (tid == 0) out[c] = ok ? (int64_t)bidx : -1;        // -1: fewer than C items with non-zero probability are left
+    if (ok && (bidx & 255) == tid) {   // this thread owned the drawn key
+      s_key[bidx] = -INFINITY;
+      own_best(my_best, my_idx);
     }
-    __syncthreads();
   }
   if (tid == 0) out[C] = g;
 }

@@ -815,3 +815,39 @@ def test_mlm_rows_lists_the_rows_the_head_gathers(B, L, P):
     torch.cuda.synchronize()
     assert int(n.cpu()[0]) == B * P
     assert rows.cpu().tolist() == want_rows and slot.cpu().tolist() == want_slot
+
+
+def test_sample_candidates_takes_the_largest_gumbel_keys_in_order():
+    """The sampler kernel's selection at an ML-1M-sized vocabulary (keys spread over all 256 threads of the workgroup: thread-local
+    bests, wave argmax, cross-wave merge, owner rescan): with the keys restated on the host (key_v = log p_v - log(-log u_v), u_v from
+    the counter hash of (seed, row, v)) the draws are the C largest keys among the allowed items, in descending order."""
+    lib = _lib.load()
+    V, C, R, E, seed = 3709, 100, 48, 200, (77 << 32) | 991
+    g = torch.Generator().manual_seed(5)
+    p = torch.rand(V, generator=g).double() ** 3
+    p[:3] = 0.0
+    p[torch.randint(3, V, (300,), generator=g)] = 0.0               # unseen items: never drawn
+    logp32 = torch.log(p).float()
+    ex = torch.randint(-1, V + 5, (R, E), generator=g)
+    gt = torch.randint(3, V, (R,), generator=g)
+    cand = torch.empty((R, C + 1), dtype=torch.int64, device=DEV)
+    logpd, exd, gtd = logp32.to(DEV), ex.to(DEV), gt.to(DEV)
+    _lib.check(lib.b4r_sample_candidates(P(logpd), V, P(exd), E, P(gtd), R, C, seed, P(cand), stream()))
+    c = cand.cpu()
+    assert torch.equal(c[:, C], gt)
+    v = torch.arange(V, dtype=torch.int64)
+    seed_lo, seed_hi = seed & 0xFFFFFFFF, seed >> 32
+    for r in range(R):
+        rk = orc._hash32_int((r * 0x9E3779B9 + seed_hi) & 0xFFFFFFFF)
+        h = orc._hash32((orc._hash32(v ^ seed_lo) + rk) & 0xFFFFFFFF)
+        u = ((h >> 8).double() + 0.5) / 16777216.0
+        key = logp32.double() - torch.log(-torch.log(u))
+        banned = set(int(x) for x in ex[r].tolist() if 0 <= x < V) | {int(gt[r])}
+        key[list(banned)] = -float("inf")
+        drawn = c[r, :C]
+        assert len(set(drawn.tolist())) == C and not (set(drawn.tolist()) & banned) and bool((p[drawn] > 0).all())
+        kd = key[drawn]
+        assert bool((kd[:-1] >= kd[1:] - 1e-4).all()), r            # descending (the device uses fast logarithms: 1e-4 slack)
+        rest = key.clone()
+        rest[drawn] = -float("inf")
+        assert float(kd.min()) >= float(rest.max()) - 1e-4, r      # nothing larger was left behind

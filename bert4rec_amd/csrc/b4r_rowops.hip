@@ -1068,7 +1068,8 @@ __device__ __forceinline__ void wave_argmax(float& best, int& bidx) {
 __global__ __launch_bounds__(256) void sample_candidates_kernel(const float* logp, int V, const int64_t* exclude, int E,
                                                                 const int64_t* gt, int C, uint32_t seed_lo,
                                                                 uint32_t seed_hi, int64_t* cand) {
-  extern __shared__ float s_key[];            // [V]
+  extern __shared__ float s_key[];            // [V] keys, then [C] drawn items
+  int* s_out = reinterpret_cast<int*>(s_key + V);
   __shared__ float s_v[2][4];
   __shared__ int s_i[2][4];
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1092,9 +1093,13 @@ __global__ __launch_bounds__(256) void sample_candidates_kernel(const float* log
   // only the thread that owned the drawn key looks through its keys again
   auto own_best = [&](float& best, int& bidx) {
     best = -INFINITY; bidx = 0x7fffffff;
-    for (int v = tid; v < V; v += 256) {
-      const float k = s_key[v];
-      if (k > best) { best = k; bidx = v; }    // increasing v per thread: the lowest index wins ties
+    for (int v0 = tid; v0 < V; v0 += 8 * 256) {   // eight LDS reads in flight, then the comparisons (one read at a time cost ~1 us per draw)
+      float k[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) k[u] = v0 + 256 * u < V ? s_key[v0 + 256 * u] : -INFINITY;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (k[u] > best) { best = k[u]; bidx = v0 + 256 * u; }    // increasing v per thread: the lowest index wins ties
     }
   };
   float my_best; int my_idx;
@@ -1109,12 +1114,16 @@ __global__ __launch_bounds__(256) void sample_candidates_kernel(const float* log
 #pragma unroll
     for (int w = 1; w < 4; ++w) keep_larger(best, bidx, s_v[buf][w], s_i[buf][w]);
     const bool ok = best > -INFINITY;
-    if (tid == 0) out[c] = ok ? (int64_t)bidx : -1;        // -1: fewer than C items with non-zero probability are left
+    // -1: fewer than C items with non-zero probability are left.  Kept in LDS until the end: a global store per draw would put a
+    // store acknowledgement (the barrier waits for it) on every draw's critical path
+    if (tid == 0) s_out[c] = ok ? bidx : -1;
     if (ok && (bidx & 255) == tid) {   // this thread owned the drawn key
       s_key[bidx] = -INFINITY;
       own_best(my_best, my_idx);
     }
   }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) out[c] = (int64_t)s_out[c];
   if (tid == 0) out[C] = g;
 }
 
@@ -1122,8 +1131,9 @@ extern "C" int b4r_sample_candidates(const float* logp, int32_t V, const int64_t
                                      int32_t R, int32_t C, uint64_t seed, int64_t* cand, b4r_stream_t stream) {
   B4R_CHECK_ARG(logp && cand && (exclude || E == 0), B4R_E_BADARG, "b4r_sample_candidates: null argument");
   B4R_CHECK_ARG(V > 0 && R > 0 && C > 0 && E >= 0 && C <= V, B4R_E_SHAPE, "b4r_sample_candidates: bad shape");
-  const size_t lds = (size_t)V * sizeof(float);
-  B4R_CHECK_ARG(lds <= 150 * 1024, B4R_E_SHAPE, "b4r_sample_candidates: vocabulary %d does not fit the 160 KB of LDS", V);
+  const size_t lds = ((size_t)V + (size_t)C) * sizeof(float);
+  B4R_CHECK_ARG((size_t)V * sizeof(float) <= 150 * 1024 && lds <= 158 * 1024, B4R_E_SHAPE,
+                "b4r_sample_candidates: vocabulary %d (+ %d draws) does not fit the 160 KB of LDS", V, C);
   { int rc = b4r_raise_lds((const void*)sample_candidates_kernel, lds, "b4r_sample_candidates"); if (rc) return rc; }
   hipLaunchKernelGGL(sample_candidates_kernel, dim3(R), dim3(256), lds, (hipStream_t)stream, logp, V, exclude, E, gt, C,
                      (uint32_t)seed, (uint32_t)(seed >> 32), cand);

@@ -446,6 +446,17 @@ __global__ __launch_bounds__(1024) void attn_block_bwd_kernel(AbBwdP p) {
     if (hd > 0) {
       // dX^T[16 hb + ..][token] += Wqkv[.., features of head hd-1] . dqkv^T: A = rows of the Wqkv image (natural k order)
       const int ph = hd - 1;
+      // dqkv of that head leaves here, BEHIND the two barriers of the staging: a barrier waits for the wave's outstanding stores, and
+      // right after the sweep that put 2.7 us of store acknowledgements on the critical path of every head
+      if (live) {   // (keeping the last head's until the very end of the kernel was tried: 52 spilled registers, slower)
+        float* dst = p.dqkv + (row0 + tok) * (3 * HID) + 32 * ph + 8 * g;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          *reinterpret_cast<f32x4*>(dst + 4 * a) = gq[a];
+          *reinterpret_cast<f32x4*>(dst + HID + 4 * a) = gk[a];
+          *reinterpret_cast<f32x4*>(dst + 2 * HID + 4 * a) = gv[a];
+        }
+      }
       bf16x8 bh_[3], bl_[3];
       split8(cat(gq[0], gq[1]), bh_[0], bl_[0]);
       split8(cat(gk[0], gk[1]), bh_[1], bl_[1]);
@@ -617,15 +628,6 @@ __global__ __launch_bounds__(1024) void attn_block_bwd_kernel(AbBwdP p) {
       gk[a] = *reinterpret_cast<const f32x4*>(mytile + BX + a * 1024 + lane * 16);
       gv[a] = *reinterpret_cast<const f32x4*>(mytile + BX + (2 + a) * 1024 + lane * 16);
     }
-    if (live) {
-      float* dst = p.dqkv + (row0 + tok) * (3 * HID) + 32 * hd + 8 * g;
-#pragma unroll
-      for (int a = 0; a < 2; ++a) {
-        *reinterpret_cast<f32x4*>(dst + 4 * a) = gq[a];
-        *reinterpret_cast<f32x4*>(dst + HID + 4 * a) = gk[a];
-        *reinterpret_cast<f32x4*>(dst + 2 * HID + 4 * a) = gv[a];
-      }
-    }
   }
 
   AB_MARK(30);
@@ -658,16 +660,6 @@ __global__ __launch_bounds__(1024) void attn_block_bwd_kernel(AbBwdP p) {
   }
   const float c1 = quad_sum(s1) * (1.0f / HID), c2 = quad_sum(s2) * (1.0f / HID);
   AB_MARK(32);
-  if (live) {
-#pragma unroll
-    for (int hb = 0; hb < 4; ++hb) {
-      f32x4 dz;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) dz[e] = rstd * (ge[hb][e] - c1 - xhat[hb][e] * c2);
-      *reinterpret_cast<f32x4*>(p.da + (row0 + tok) * HID + 16 * hb + 4 * g) = dz;
-    }
-  }
-  AB_MARK(33);
 #pragma unroll
   for (int hb = 0; hb < 4; ++hb) {   // column sums over the wave's 16 tokens
 #pragma unroll
@@ -678,13 +670,23 @@ __global__ __launch_bounds__(1024) void attn_block_bwd_kernel(AbBwdP p) {
     }
   }
   AB_MARK(34);
-  __syncthreads();
+  __syncthreads();   // before the wave's big stores: a barrier behind them would wait for their acknowledgements
   AB_MARK(35);
   for (int k = threadIdx.x; k < 128; k += nthreads) {   // a workgroup may be a single wave (L <= 16)
     float r = 0.f;
     for (int w = 0; w < KT; ++w) r += sred[w * 128 + k];
     p.ln_part[(int64_t)b * 128 + k] = r;
   }
+  if (live) {
+#pragma unroll
+    for (int hb = 0; hb < 4; ++hb) {
+      f32x4 dz;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dz[e] = rstd * (ge[hb][e] - c1 - xhat[hb][e] * c2);
+      *reinterpret_cast<f32x4*>(p.da + (row0 + tok) * HID + 16 * hb + 4 * g) = dz;
+    }
+  }
+  AB_MARK(33);
   AB_MARK(31);
 }
 

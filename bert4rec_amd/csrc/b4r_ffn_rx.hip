@@ -421,8 +421,19 @@ __global__ __launch_bounds__(64 * FW) void ffn_bwd_dw_kernel(FfnP p) {
   }
   FF_MARK(41);
 
-  // partial results of this workgroup -> slabs (summed over the workgroups in slab order by the deferred reduction)
+  // db2[h] = sum over tokens of dropmask(dz2): per-thread sums over chunks, then over the 32 token slots of the staging layout.
+  // This reduction (one barrier) comes BEFORE the 131 KB of slab stores: behind them the barrier would wait for their acknowledgements.
   const int64_t wg = blockIdx.x;
+  float* red = reinterpret_cast<float*>(smem_dw);   // [32][64]; the loop's last barrier has passed
+  if (is_dz) *reinterpret_cast<f32x4*>(&red[stok * HID + 4 * sc4]) = db2;
+  __syncthreads();
+  if (threadIdx.x < HID) {
+    float r = 0.f;
+#pragma unroll
+    for (int s = 0; s < CH_TOK; ++s) r += red[s * HID + threadIdx.x];
+    p.slab_b2[wg * HID + threadIdx.x] = r;
+  }
+  // partial results of this workgroup -> slabs (summed over the workgroups in slab order by the deferred reduction)
   float* sw1 = p.slab_w1 + wg * (HID * INNER);
   float* sw2 = p.slab_w2 + wg * (HID * INNER);
 #pragma unroll
@@ -433,16 +444,6 @@ __global__ __launch_bounds__(64 * FW) void ffn_bwd_dw_kernel(FfnP p) {
   }
   db1 = quad_sum(db1);
   if (g == 0) p.slab_b1[wg * INNER + 16 * ib + i] = db1;
-  // db2[h] = sum over tokens of dropmask(dz2): per-thread sums over chunks, then over the 32 token slots of the staging layout
-  float* red = reinterpret_cast<float*>(smem_dw);   // [32][64]; the loop's last barrier has passed
-  if (is_dz) *reinterpret_cast<f32x4*>(&red[stok * HID + 4 * sc4]) = db2;
-  __syncthreads();
-  if (threadIdx.x < HID) {
-    float r = 0.f;
-#pragma unroll
-    for (int s = 0; s < CH_TOK; ++s) r += red[s * HID + threadIdx.x];
-    p.slab_b2[wg * HID + threadIdx.x] = r;
-  }
   FF_MARK(42);
 }
 

@@ -1094,13 +1094,8 @@ __device__ __forceinline__ void rx_gemm_tn_body(const RxTnP& p, const int block)
     if (DGRAD) dgrad(k0 + KS);
   }
 
-  float* slab = p.slab + (int64_t)z * p.Mo * p.No;
-  const int col = j0 + 32 * wn + r;
-#pragma unroll
-  for (int reg = 0; reg < 16; ++reg) {
-    const int row = i0 + 32 * wm + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-    if (row < p.Mo && col < p.No) slab[(int64_t)row * p.No + col] = acc[reg];
-  }
+  // the column sums first (two barriers), the tile's 16 KB of slab stores last: behind the stores the barriers would wait for
+  // their acknowledgements
   if (do_cs || do_csa) {             // 16 row groups per column quad, summed in a fixed order
     __syncthreads();
     float* red = reinterpret_cast<float*>(s_tn);   // [2][16 row groups][64 columns]
@@ -1115,6 +1110,13 @@ __device__ __forceinline__ void rx_gemm_tn_body(const RxTnP& p, const int block)
       if (which == 0 && do_cs && j0 + c < p.No) p.colsum_slab[(int64_t)z * p.No + j0 + c] = sum;
       if (which == 1 && do_csa && i0 + c < p.Mo) p.colsum_a_slab[(int64_t)z * p.Mo + i0 + c] = sum;
     }
+  }
+  float* slab = p.slab + (int64_t)z * p.Mo * p.No;
+  const int col = j0 + 32 * wn + r;
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) {
+    const int row = i0 + 32 * wm + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    if (row < p.Mo && col < p.No) slab[(int64_t)row * p.No + col] = acc[reg];
   }
 }
 

@@ -224,7 +224,7 @@ class Engine:
         host = self.state.cpu()
         f = host.view(torch.float32)
         step = int(host[_lib.ST_STEP:_lib.ST_STEP + 2].view(torch.int64)[0])
-        return dict(step=step, loss_sum=float(f[_lib.ST_LOSS_SUM]), valid_count=float(f[_lib.ST_VALID]),
+        return dict(step=step, seed=int(host[_lib.ST_SEED]) & 0xFFFFFFFF, loss_sum=float(f[_lib.ST_LOSS_SUM]), valid_count=float(f[_lib.ST_VALID]),
                     correct_masked=float(f[_lib.ST_CORRECT_MASKED]), correct_all=float(f[_lib.ST_CORRECT_ALL]),
                     slots_all=float(f[_lib.ST_SLOTS_ALL]), grad_sqnorm=float(f[_lib.ST_SQNORM]),
                     grad_norm=float(f[_lib.ST_GRAD_NORM]), lr=float(f[_lib.ST_LR]))

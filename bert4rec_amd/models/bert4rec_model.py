@@ -208,9 +208,16 @@ class BERT4RecModel:
         for cb_ in callbacks:
             if hasattr(cb_, "set_model"):
                 cb_.set_model(self)
+        rank, world = _dp_rank_world()
+        if world > 1:   # data parallel: the ranks take the batches of an epoch in turn (same number each), with their own dropout masks
+            if not hasattr(x, "__len__"):
+                raise ValueError("data-parallel fit() needs a sized training set (every rank must take the same number of steps)")
+            if not getattr(self, "_dp_seeded", False):
+                self.engine.set_seed(self.engine.read_state()["seed"] + rank)
+                self._dp_seeded = True
         for epoch in range(epochs):
             self._train_log.reset()
-            for i, batch in enumerate(x):
+            for i, batch in enumerate(dp_shard(x, rank, world)):
                 if steps_per_epoch is not None and i >= steps_per_epoch:
                     break
                 cb, keep = self.engine.prepare_batch(batch)
@@ -342,3 +349,27 @@ class BERT4RecModel:
     @classmethod
     def from_config(cls, config, custom_object=None):
         return cls(**config)
+
+
+def _dp_rank_world():
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    except Exception:   # pragma: no cover
+        pass
+    return 0, 1
+
+
+def dp_shard(batches, rank: int, world: int):
+    """The batches rank `rank` of `world` trains on in one epoch: every world-th batch, and only whole rounds (the trailing
+    len % world batches are skipped so that all ranks meet in the same number of all-reduces).  world == 1: all of them."""
+    if world <= 1:
+        yield from batches
+        return
+    rounds = len(batches) // world
+    for i, b in enumerate(batches):
+        if i >= rounds * world:
+            break
+        if i % world == rank:
+            yield b

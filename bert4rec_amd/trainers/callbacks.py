@@ -53,9 +53,15 @@ class ModelCheckpoint(Callback):
             if not better:
                 return
             self.best = cur
-        f = self.weights_file()
-        f.parent.mkdir(parents=True, exist_ok=True)
-        self.model.save_weights(f)
+        # data-parallel runs: every rank holds the same weights and sees the same logs; rank 0 writes, the others wait for the file
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if not multi or dist.get_rank() == 0:
+            f = self.weights_file()
+            f.parent.mkdir(parents=True, exist_ok=True)
+            self.model.save_weights(f)
+        if multi:
+            dist.barrier()
 
 
 class EarlyStopping(Callback):

@@ -349,3 +349,14 @@ def test_length_bucketing_and_padding_trim_keep_the_rows_and_cut_only_padding():
     assert sorted(dev.order.tolist()) == list(range(len(dev_train)))
     assert dev.batch_columns == [du.trimmed_length(lens[dev.order[s:s + 16]].max(), 64) for s in range(0, len(dev_train), 16)]
     assert all(p in (4, 8) for p in dev.batch_slots) and min(dev.batch_slots) == 4
+
+
+def test_data_parallel_fit_takes_every_world_th_batch_in_whole_rounds():
+    """BERT4RecModel.fit with an initialised process group: rank r trains on batches r, r + world, ... and the trailing
+    len % world batches are left out, so every rank makes the same number of steps (= all-reduces)."""
+    from bert4rec_amd.models.bert4rec_model import dp_shard
+    data = list(range(11))
+    assert list(dp_shard(data, 0, 1)) == data
+    got = [list(dp_shard(data, r, 4)) for r in range(4)]
+    assert got == [[0, 4], [1, 5], [2, 6], [3, 7]]
+    assert all(len(g) == 2 for g in got)

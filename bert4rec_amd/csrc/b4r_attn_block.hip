@@ -73,8 +73,12 @@ __global__ __launch_bounds__(1024) void attn_block_fwd_kernel(AbP p) {
   AF_MARK(0);
   const int tok = 16 * wave + i, tokc = min(tok, L - 1);
   // b4r_seq_amax, its barrier folded into the one behind the weight staging
-  int any_key = 0;
-  for (int k = threadIdx.x; k < L; k += blockDim.x) any_key |= (p.mask[row0 + k] != 0) ? 1 : 0;
+  // the workgroup has at least 4 threads per token: one turn covers the key mask; it and the bias are requested here, ahead of the
+  // weight staging, and go to LDS behind it (three load latencies less in front of the first barrier)
+  const int64_t mval = (int)threadIdx.x < L ? p.mask[row0 + threadIdx.x] : 0;
+  const int any_key = mval != 0 ? 1 : 0;
+  const bool bias_one_turn = blockDim.x >= 3 * HID;
+  const float bq_val = (bias_one_turn && threadIdx.x < 3 * HID) ? p.bqkv[threadIdx.x] : 0.f;
   f32x8 xv[2];
   const float* xsrc = p.x;   // the residual of the epilogue is read from here
   if (p.ids != nullptr) {   // block-uniform: the embedding stage for this wave's tokens (position = token index in the sequence)
@@ -123,9 +127,9 @@ __global__ __launch_bounds__(1024) void attn_block_fwd_kernel(AbP p) {
     for (int ks = 0; ks < 2; ++ks) xv[ks] = load8(p.x + (row0 + tokc) * HID + 32 * ks + 8 * g);   // in flight during the staging
   }
   stage_weight_pair(big, p.Wqkv, HID, 3 * HID, woimg, p.Wo, HID, HID, nthreads);
-  for (int k = threadIdx.x; k < KTE * 16; k += nthreads)
-    sAdd[k] = k < L ? (1.0f - (float)p.mask[row0 + k]) * -1e9f : -INFINITY;
-  for (int k = threadIdx.x; k < 3 * HID; k += nthreads) sbq[k] = p.bqkv[k];
+  if ((int)threadIdx.x < KTE * 16) sAdd[threadIdx.x] = (int)threadIdx.x < L ? (1.0f - (float)mval) * -1e9f : -INFINITY;
+  if (bias_one_turn) { if (threadIdx.x < 3 * HID) sbq[threadIdx.x] = bq_val; }
+  else for (int k = threadIdx.x; k < 3 * HID; k += nthreads) sbq[k] = p.bqkv[k];
   bf16x8 xh[2], xl[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) split8(xv[ks], xh[ks], xl[ks]);
@@ -410,11 +414,11 @@ __global__ __launch_bounds__(1024) void attn_block_bwd_kernel(AbBwdP p) {
   char* scratch = scratch_all + wave * 2048;
   char* woimg = R + 48 * 1024;
   // b4r_seq_amax, its barrier folded into the first one of the head loop
-  int any_key = 0;
-  for (int k = threadIdx.x; k < L; k += blockDim.x) any_key |= (p.mask[row0 + k] != 0) ? 1 : 0;
+  const int64_t mval = (int)threadIdx.x < L ? p.mask[row0 + threadIdx.x] : 0;   // one turn: at least 4 threads per token
+  const int any_key = mval != 0 ? 1 : 0;
   float amax = 0.0f;
 
-  for (int k = threadIdx.x; k < KT * 16; k += nthreads) sAdd[k] = k < L ? (1.0f - (float)p.mask[row0 + k]) * -1e9f : -INFINITY;
+  if ((int)threadIdx.x < KT * 16) sAdd[threadIdx.x] = (int)threadIdx.x < L ? (1.0f - (float)mval) * -1e9f : -INFINITY;
   for (int k = threadIdx.x; k < 3 * HID; k += nthreads) sbq[k] = p.bqkv[k];
 
   // lane constants.  tr_w: transposed fragment whose 16 columns are the interleaved features 8p' + 4a + e (b4r_ffn_rx.hip);

@@ -132,11 +132,11 @@ def algorithmic_work(label, V, H, NL, NH, I, L, P, B):
     if label.startswith("b4r_ffn_block_fwd"):
         return "hbm", 3 * act + 4 * N * 4 + 2 * H * I * 4, "z1 (-> x1) in; z2, x2, statistics out; W1, W2"
     if label.startswith("b4r_ffn_block_bwd (dx)"):
-        return "hbm", 4 * act + 2 * N * 4 + 2 * H * I * 4, "x1, dz2, z1 in; dz1 out; statistics; W1, W2"
+        return "hbm", 3 * act + 2 * N * 4 + 2 * H * I * 4, "z1 (-> x1), dz2 in; dz1 out; statistics; W1, W2"
     if label.startswith("b4r_ffn_block_bwd (dw)"):
         chunks = -(-N // 32)
         slabs = -(-chunks // -(-chunks // 256))             # b4r_ffn_block_bwd: fewest workgroups with the same longest chunk run
-        return "hbm", 2 * act + slabs * (2 * H * I + I + H) * 4, f"x1, dz2 in; {slabs} partial slabs of dW1, dW2, db1, db2 out"
+        return "hbm", 2 * act + slabs * (2 * H * I + I + H) * 4, f"z1 (-> x1), dz2 in; {slabs} partial slabs of dW1, dW2, db1, db2 out"
     # the attention blocks: 9.5 GFLOP (fp32-equivalent, 3x that executed as bf16 MFMA) over ~110 MB = below the machine balance of
     # 312 FLOP/byte even counting the split products -> the HBM roof is the binding one
     small = B * NH * L * 4 + 2 * N * 4 + (B * NH * ((L + 15) // 16) * 2 * 64) * 4    # lse, mean / rstd, keep bits

@@ -562,6 +562,17 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamP a) {
 // advances the step -- the other workgroups have read the state by then.
 __global__ __launch_bounds__(256) void adamw_fused_kernel(AdamP a, const float* partial, int np, unsigned int* ticket) {
   __shared__ float s_red[256];
+  // the operands of this thread's first turn (normally its only one) and the state are requested before the norm is summed: the
+  // barriers of that sum would otherwise stand between their latency and their use
+  const int64_t n4 = a.n / 4;
+  const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t i0c = i0 < n4 ? i0 : 0;
+  f32x4 p0 = *reinterpret_cast<f32x4*>(a.p + 4 * i0c);
+  const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.g + 4 * i0c);
+  f32x4 m0 = *reinterpret_cast<f32x4*>(a.m + 4 * i0c);
+  f32x4 v0 = *reinterpret_cast<f32x4*>(a.v + 4 * i0c);
+  const int64_t step = a.st->step;
+  const float cnt = a.st->valid_count;
   float acc = 0.f;
   for (int i = threadIdx.x; i < np; i += 256) acc += partial[i];
   s_red[threadIdx.x] = acc;
@@ -571,8 +582,6 @@ __global__ __launch_bounds__(256) void adamw_fused_kernel(AdamP a, const float* 
     __syncthreads();
   }
   const float sqnorm = s_red[0];
-  const int64_t step = a.st->step;
-  const float cnt = a.st->valid_count;
   const float inv_cnt = cnt > 0.f ? 1.0f / cnt : 1.0f;
   const float gnorm = sqrtf(sqnorm) * inv_cnt;
   const float clip_scale = a.hp.clip_norm > 0.f ? a.hp.clip_norm / fmaxf(gnorm, a.hp.clip_norm) : 1.0f;
@@ -582,12 +591,15 @@ __global__ __launch_bounds__(256) void adamw_fused_kernel(AdamP a, const float* 
   const float alpha = lr_t * sqrtf(1.0f - b2p) / (1.0f - b1p);
   const float omb1 = 1.0f - a.hp.beta_1, omb2 = 1.0f - a.hp.beta_2;
   const float wd = a.hp.weight_decay_rate, eps = a.hp.epsilon;
-  const int64_t n4 = a.n / 4;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    f32x4 p = *reinterpret_cast<f32x4*>(a.p + 4 * i);
-    const f32x4 g = *reinterpret_cast<const f32x4*>(a.g + 4 * i);
-    f32x4 m = *reinterpret_cast<f32x4*>(a.m + 4 * i);
-    f32x4 v = *reinterpret_cast<f32x4*>(a.v + 4 * i);
+  for (int64_t i = i0; i < n4; i += (int64_t)gridDim.x * 256) {
+    f32x4 p, g, m, v;
+    if (i == i0) { p = p0; g = g0; m = m0; v = v0; }
+    else {
+      p = *reinterpret_cast<f32x4*>(a.p + 4 * i);
+      g = *reinterpret_cast<const f32x4*>(a.g + 4 * i);
+      m = *reinterpret_cast<f32x4*>(a.m + 4 * i);
+      v = *reinterpret_cast<f32x4*>(a.v + 4 * i);
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float ge = (g[e] * inv_cnt) * clip_scale;
@@ -602,7 +614,9 @@ __global__ __launch_bounds__(256) void adamw_fused_kernel(AdamP a, const float* 
     *reinterpret_cast<f32x4*>(a.m + 4 * i) = m;
     *reinterpret_cast<f32x4*>(a.v + 4 * i) = v;
   }
-  __syncthreads();
+  // every thread has USED the state values it loaded by now; the barrier only has to order those uses before the ticket, it need
+  // not wait for this workgroup's stores (s_barrier alone: __syncthreads would add s_waitcnt vmcnt(0))
+  __builtin_amdgcn_s_barrier();
   if (threadIdx.x == 0) {
     // no release fence: the other workgroups only READ the state, and those loads have completed (their values were used
     // above) before this relaxed device-scope atomic is issued; a fence here would write back each XCD's dirty L2 lines

@@ -81,6 +81,7 @@ __global__ __launch_bounds__(1024) void attn_block_fwd_kernel(AbP p) {
   const float bq_val = (bias_one_turn && threadIdx.x < 3 * HID) ? p.bqkv[threadIdx.x] : 0.f;
   f32x8 xv[2];
   const float* xsrc = p.x;   // the residual of the epilogue is read from here
+  float emb_mean = 0.f, emb_rstd = 0.f;
   if (p.ids != nullptr) {   // block-uniform: the embedding stage for this wave's tokens (position = token index in the sequence)
     int64_t id = p.ids[row0 + tokc];
     if (id < 0 || id >= p.V) id = 0;   // out-of-range ids read the PAD row, as b4r_embed_ln_fwd does
@@ -112,15 +113,8 @@ __global__ __launch_bounds__(1024) void attn_block_fwd_kernel(AbP p) {
       const uint64_t e0 = (uint64_t)(row0 + tok) * HID + (uint64_t)(32 * ks + 8 * g);
       const f32x4 lo = b4r_drop4(dce, (f32x4){y[0], y[1], y[2], y[3]}, e0), hi = b4r_drop4(dce, (f32x4){y[4], y[5], y[6], y[7]}, e0 + 4);
       xv[ks] = cat(lo, hi);
-      if (live0) {
-        *reinterpret_cast<f32x4*>(p.x_out + (row0 + tok) * HID + 32 * ks + 8 * g) = lo;
-        *reinterpret_cast<f32x4*>(p.x_out + (row0 + tok) * HID + 32 * ks + 8 * g + 4) = hi;
-      }
     }
-    if (g == 0 && live0) {
-      if (p.mean0) p.mean0[row0 + tok] = mean;
-      if (p.rstd0) p.rstd0[row0 + tok] = rstd;
-    }
+    emb_mean = mean; emb_rstd = rstd;   // x and its statistics are stored behind the staging barrier (which would wait for the stores)
     xsrc = p.x_out;
   } else {
 #pragma unroll
@@ -136,6 +130,17 @@ __global__ __launch_bounds__(1024) void attn_block_fwd_kernel(AbP p) {
   AF_MARK(1);
   const float amax = __syncthreads_or(any_key) ? 0.0f : -1e9f;
   AF_MARK(2);
+  if (p.ids != nullptr && tok < L) {   // the embedding stage's outputs (their acknowledgements arrive during the QKV phase)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      *reinterpret_cast<f32x4*>(p.x_out + (row0 + tok) * HID + 32 * ks + 8 * g) = (f32x4){xv[ks][0], xv[ks][1], xv[ks][2], xv[ks][3]};
+      *reinterpret_cast<f32x4*>(p.x_out + (row0 + tok) * HID + 32 * ks + 8 * g + 4) = (f32x4){xv[ks][4], xv[ks][5], xv[ks][6], xv[ks][7]};
+    }
+    if (g == 0) {
+      if (p.mean0) p.mean0[row0 + tok] = emb_mean;
+      if (p.rstd0) p.rstd0[row0 + tok] = emb_rstd;
+    }
+  }
 
   // ---- phase 1: q, k, v of this wave's 16 tokens.  Tile a of feature block fb holds features 32 fb + 8p + 4a + e on its
   // rows 4p + e, so that a stacked pair is a B operand in natural feature order (b4r_ffn_rx.hip) ---------------------------

@@ -433,3 +433,28 @@ def test_custom_weight_decay_selection_decays_exactly_the_selected_variables():
         else:
             assert float(d.abs().max()) < 1e-7, k     # (the item table's gradient is summed with float atomics: last-bit noise)
     assert n_ln >= 6
+
+
+def test_evaluation_on_trimmed_batches_gives_the_same_ranks():
+    """make_batches(trim_padding=True) on the test split: the evaluator's candidate draws depend on (seed, draw counter, row), the
+    ranking on the hidden state of each user's last position -- neither on the padding columns that are cut, so the ground-truth
+    ranks and every metric are those of the padded batches."""
+    ds = datasets.synthetic_dataset(n_users=96, n_items=300, min_len=4, max_len=70, seed=4)
+    dl = dataloaders.get_dataloader_factory("bert4rec").create_ml_1m_dataloader(data_source=ds, max_seq_len=64,
+                                                                               max_predictions_per_seq=12, input_duplication_factor=1)
+    _, _, test = dl.prepare_training(finetuning_split=0.1)
+    model = make_model(dl.tokenizer.get_vocab_size(), seed=2, L=64)
+    smp = dataloaders.samplers.get("pop_random", source=[t for e in test.examples for t in e["labels"].tolist() if t > 2],
+                                   vocab=list(range(dl.tokenizer.get_vocab_size())), sample_size=50, seed=3)
+    results, ranks = [], []
+    for trim in (False, True):
+        ev = evaluation.get(sampler=smp, device_sampling=True, seed=5)
+        bs = dataloaders.make_batches(test, batch_size=16, seed=1, bucket_by_length=6, trim_padding=trim)   # same composition both times
+        if trim:
+            assert min(b["input_word_ids"].shape[1] for b in bs) < 64 and all(b["masked_lm_ids"].shape[1] == 4 for b in bs)
+        ranks.append(torch.cat([ev.evaluate_batch(model, b).cpu() for b in bs]))
+        results.append(ev.get_metrics_results())
+    same = (ranks[0] == ranks[1]).float().mean().item()
+    assert same > 0.99, same                     # (a rank can move by one where two candidate scores agree to ~1e-6)
+    for k in results[0]:
+        assert abs(results[0][k] - results[1][k]) < 0.01 * max(1.0, abs(results[0][k])), k

@@ -102,3 +102,55 @@ def test_bench_runs_its_rccl_path_with_one_rank(graph):
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)
     assert res["n_gpus"] == 1 and res["value"] > 0 and 0 < res["final_loss"] < 12
+
+
+def _fit_model():
+    from bert4rec_amd import config, models
+    from bert4rec_amd.models.components import networks
+    from bert4rec_amd.trainers import optimizers
+    cfgd = {**config.get_encoder_config("ml-1m_64"), "max_sequence_length": L, "output_dropout": 0.0, "attention_dropout": 0.0}
+    model = models.BERT4RecModel(networks.Bert4RecEncoder(V, seed=4, **cfgd))
+    model.compile(optimizer=optimizers.get("adamw", init_lr=1e-3, num_warmup_steps=2, num_train_steps=50))
+    return model
+
+
+def _fit_batches():
+    from oracle import bert4rec_oracle as orc
+    from bert4rec_amd.dataloaders.dataloader_utils import BatchedDataset
+    return BatchedDataset([orc.synthetic_batch(B // 2, L, P, V, seed=90 + i, ragged=True) for i in range(5)])   # 5: one is left over
+
+
+def _fit_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    model = _fit_model()
+    hist = model.fit(_fit_batches(), epochs=2, verbose=0)
+    torch.cuda.synchronize()
+    torch.save({"weights": model.get_weights(), "loss": hist.history["loss"], "steps": model._trained_steps},
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_fit_shards_the_batches_and_equals_single_process_training_on_the_joined_batches():
+    """BERT4RecModel.fit under an initialised process group: rank r trains on batches r, r + 2, ... of every epoch (whole rounds
+    only), the gradients are summed over the ranks -- i.e. one step on the two batches joined.  Both ranks end with the same
+    weights, and those are the single-process weights after training on the joined batches."""
+    with tempfile.TemporaryDirectory() as tmp:
+        mp.spawn(_fit_worker, args=(2, _free_port(), tmp), nprocs=2, join=True)
+        r0, r1 = torch.load(os.path.join(tmp, "rank0.pt")), torch.load(os.path.join(tmp, "rank1.pt"))
+    assert r0["steps"] == r1["steps"] == 2 * 2                      # 5 batches -> 2 whole rounds per epoch, 2 epochs
+    for k in r0["weights"]:
+        assert torch.equal(r0["weights"][k], r1["weights"][k]), k   # identical updates on every rank
+    assert r0["loss"] == r1["loss"]                                 # the logged sums are the all-reduced ones
+    bs = _fit_batches().batches
+    joined = [{k: torch.cat([bs[2 * j][k], bs[2 * j + 1][k]]) for k in bs[0]} for j in range(2)]
+    from bert4rec_amd.dataloaders.dataloader_utils import BatchedDataset
+    single = _fit_model()
+    hist = single.fit(BatchedDataset(joined), epochs=2, verbose=0)
+    w = single.get_weights()
+    for k in w:
+        scale = max(1e-3, float(w[k].abs().max()))
+        assert float((w[k] - r0["weights"][k]).abs().max()) < 2e-5 * scale + 2e-6, k
+    assert max(abs(a - b) for a, b in zip(hist.history["loss"], r0["loss"])) < 1e-4

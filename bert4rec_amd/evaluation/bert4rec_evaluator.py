@@ -160,8 +160,9 @@ class BERT4RecEvaluator(BaseEvaluator):
                 candidates, ground_truth = self.sample_candidates(test_batch)
         if len(candidates) == 0:
             return []
+        extra = {} if slots is None else {"slots": slots}   # (models without the shortcut keep working)
         _, gt_rank, _, _ = model.rank_items_tensor(test_batch, torch.as_tensor(candidates), torch.as_tensor(ground_truth),
-                                                   want_ranking=False, slots=slots)
+                                                   want_ranking=False, **extra)
         engine = getattr(model, "engine", None)
         if engine is not None and gt_rank.is_cuda and len(self._metrics) <= 32:
             _, sums, users = self._device_sums(engine)

@@ -249,3 +249,40 @@ def test_backward_can_form_the_loss_sums_itself_bit_for_bit():
             assert torch.equal(g_a[n], g_b[n]), n
     tail = eng.grad_ext[eng.n_params:eng.n_params + 5].cpu().tolist()
     assert tail == [st_b[k] for k in ("loss_sum", "valid_count", "correct_masked", "correct_all", "slots_all")]
+
+
+def test_launch_timer_lists_the_launches_of_a_train_step_in_order():
+    """b4r_timing_begin / b4r_timing_end (what bench.py builds its per-step breakdown and its roofline block from): one entry per
+    launch in enqueue order, the same sequence for every step, positive durations that add up to about the step's GPU time."""
+    import ctypes as C
+    from bert4rec_amd import _lib
+    from bert4rec_amd.engine import make_adamw_config
+    cfg_o, shp = CONFIGS["ml1m_slice"]
+    eng, _ = build(cfg_o)
+    if not eng.fused_head_supported():
+        pytest.skip("counts the launches of the bf16x3 step")
+    lib = _lib.load()
+    hp = make_adamw_config()
+    cb, keep = eng.prepare_batch(orc.synthetic_batch(shp["B"], shp["L"], shp["P"], cfg_o.vocab_size, seed=3))
+    for _ in range(3):
+        eng.train_step(hp, cb)
+    torch.cuda.synchronize()
+    stream = torch.cuda.current_stream().cuda_stream
+    cap, stride, steps = 512, 128, 3
+    _lib.check(lib.b4r_timing_begin(stream, cap), "b4r_timing_begin")
+    for _ in range(steps):
+        eng.train_step(hp, cb)
+    n = C.c_int32(0)
+    us = (C.c_float * cap)()
+    names = C.create_string_buffer(cap * stride)
+    _lib.check(lib.b4r_timing_end(C.byref(n), us, names, stride, cap), "b4r_timing_end")
+    assert n.value % steps == 0 and 15 <= n.value // steps <= 40
+    per = n.value // steps
+    labels = [names.raw[j * stride:(j + 1) * stride].split(b"\\0", 1)[0].decode() for j in range(n.value)]
+    assert labels[:per] == labels[per:2 * per] == labels[2 * per:]
+    assert any(l.startswith("b4r_attn_block_bwd") for l in labels[:per]) and any("head" in l for l in labels[:per])
+    assert all(us[j] > 0.0 for j in range(n.value)) and 50.0 < sum(us[j] for j in range(per)) < 5000.0
+    # outside a begin / end pair nothing is recorded
+    eng.train_step(hp, cb)
+    n2 = C.c_int32(-1)
+    assert lib.b4r_timing_end(C.byref(n2), us, names, stride, cap) != 0 or n2.value == 0

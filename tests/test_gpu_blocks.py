@@ -171,7 +171,7 @@ def attn_reference(t, mask, B, L, p_rate, o_rate, seed, step, site_p, site_o, ep
 
 
 @pytest.mark.parametrize("B,L,p_rate,o_rate", [(3, 16, 0.0, 0.0), (5, 50, 0.0, 0.0), (4, 200, 0.2, 0.2), (6, 100, 0.0, 0.3),
-                                              (2, 256, 0.2, 0.0), (7, 37, 0.5, 0.5)])
+                                              (2, 256, 0.2, 0.0), (7, 37, 0.5, 0.5), (3, 160, 0.2, 0.2), (2, 150, 0.0, 0.0)])
 def test_attn_block_forward_matches_fp64(B, L, p_rate, o_rate):
     lib = _lib.load()
     _lib.check(lib.b4r_set_gemm_mode(_lib.GEMM_BF16X3))
@@ -254,7 +254,8 @@ def attn_bwd_reference(t, mask, B, L, p_rate, o_rate, e_rate, seed, step, site_p
 
 
 @pytest.mark.parametrize("B,L,p_rate,o_rate,embed", [(3, 16, 0.0, 0.0, False), (5, 50, 0.0, 0.0, False), (4, 200, 0.2, 0.2, False),
-                                                     (6, 100, 0.0, 0.3, True), (3, 208, 0.2, 0.0, False), (7, 37, 0.5, 0.5, True)])
+                                                     (6, 100, 0.0, 0.3, True), (3, 208, 0.2, 0.0, False), (7, 37, 0.5, 0.5, True),
+                                                     (3, 160, 0.2, 0.2, False), (2, 112, 0.0, 0.0, True)])
 def test_attn_block_backward_matches_fp64_autograd(B, L, p_rate, o_rate, embed):
     """b4r_attn_block_bwd (q, k, v recomputed, every score block formed once, dK / dV accumulated in LDS) against autograd, on
     what b4r_attn_block_fwd saved (ctx, lse, keep_bits); both LayerNorm variants in front of the block."""

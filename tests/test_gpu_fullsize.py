@@ -172,7 +172,8 @@ def test_ml20m_model_slice_at_the_full_vocabulary_matches_oracle():
         compare_grads(grads, grads_ref, st["valid_count"])
 
 
-def test_trimmed_batch_gives_the_loss_and_gradients_of_the_padded_batch():
+@pytest.mark.parametrize("longest,cols_want", [(90, 96), (60, 64), (150, 160)])
+def test_trimmed_batch_gives_the_loss_and_gradients_of_the_padded_batch(longest, cols_want):
     """make_batches(trim_padding=True) cuts a batch to the columns its longest sequence needs (the reference pads every row to
     max_seq_len, bert4rec_preprocessor.py:105-110): padded keys are masked and padded positions carry no loss, so the loss sums and
     every gradient are those of the full-width batch -- in eval mode and in train mode (dropout is indexed by row*H + column of the
@@ -181,10 +182,10 @@ def test_trimmed_batch_gives_the_loss_and_gradients_of_the_padded_batch():
     eng, _ = build(ML1M)
     B, L, P = 64, 200, 40
     full = orc.synthetic_batch(B, L, P, ML1M.vocab_size, seed=11, ragged=True)
-    keep = full["input_mask"].sum(1) <= 90          # rows that fit 96 columns
+    keep = full["input_mask"].sum(1) <= longest     # rows that fit cols_want columns
     full = {k: v[keep].contiguous() for k, v in full.items()}
     cols = du.trimmed_length(int(full["input_mask"].sum(1).max()), L)
-    assert cols == 96 and int(keep.sum()) >= 16
+    assert cols == cols_want and int(keep.sum()) >= 12
     slots = du.trimmed_length(int((full["masked_lm_weights"] != 0).sum(1).max()), P, 4)
     assert slots < P
     cut = {k: v[:, :(cols if k in du.PER_TOKEN_KEYS else slots)].contiguous() for k, v in full.items()}

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_fwd_kernel(AttnP p) {
   const int L = p.L, H = p.H, ld3 = 3 * H;
   const int64_t row0 = (int64_t)b * L;
   const float amax = b4r_seq_amax(p.mask + row0, L);   // all threads, before any early exit
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i = lane & 15, g = lane >> 4;
 
   load_head_rows(sK, p.qkv + hd * 32, row0 + q0, ld3, ROWS_WG, L - q0);   // Q tile in the K region
   __syncthreads();
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_dq_kernel(AttnP p) {
   const int L = p.L, H = p.H, ld3 = 3 * H;
   const int64_t row0 = (int64_t)b * L;
   const float amax = b4r_seq_amax(p.mask + row0, L);   // all threads, before any early exit
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i = lane & 15, g = lane >> 4;
 
   load_head_rows(sK, p.qkv + hd * 32, row0 + q0, ld3, ROWS_WG, L - q0);   // Q tile
   load_head_rows(sV, p.dctx + hd * 32, row0 + q0, H, ROWS_WG, L - q0);    // dO tile
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_dkv_kernel(AttnP p) {
   const int L = p.L, H = p.H, ld3 = 3 * H;
   const int64_t row0 = (int64_t)b * L;
   const float amax = b4r_seq_amax(p.mask + row0, L);   // all threads, before any early exit
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i = lane & 15, g = lane >> 4;
 
   load_head_rows(sQ, p.qkv + hd * 32, row0, ld3, Lp, L);
   load_head_rows(sdO, p.dctx + hd * 32, row0, H, Lp, L);

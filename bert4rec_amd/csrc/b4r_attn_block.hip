@@ -67,7 +67,7 @@ __global__ __launch_bounds__(1024) void attn_block_fwd_kernel(AbP p) {
   const int nthreads = blockDim.x;
   const int b = blockIdx.x, L = p.L;
   const int64_t row0 = (int64_t)b * L;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4, qq = i >> 2, pp = i & 3;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i = lane & 15, g = lane >> 4, qq = i >> 2, pp = i & 3;
 
   // ---- phase 0: weights and the key mask ------------------------------------------------------------------------------
   AF_MARK(0);
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(1024) void attn_block_bwd_kernel(AbBwdP p) {
   const int nthreads = blockDim.x;
   const int b = blockIdx.x;
   const int64_t row0 = (int64_t)b * L;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4, qq = i >> 2, pp = i & 3;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i = lane & 15, g = lane >> 4, qq = i >> 2, pp = i & 3;
   const int tok = 16 * wave + i, tokc = min(tok, L - 1);
   const bool live = tok < L;
   char* scratch = scratch_all + wave * 2048;

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_rx_fwd_kernel(AttnRxP p) {
   const int b = wg.b, hd = wg.hd, q0 = wg.x * ROWS_WG;
   const int L = p.L, H = p.H, ld3 = 3 * H;
   const int64_t row0 = (int64_t)b * L;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i = lane & 15, g = lane >> 4;
   const float amax = b4r_seq_amax(p.mask + row0, L);
 
   const int q = q0 + 16 * wave + i;
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_rx_dq_kernel(AttnRxP p) {
   const int b = wg.b, hd = wg.hd, q0 = wg.x * ROWS_WG;
   const int L = p.L, H = p.H, ld3 = 3 * H;
   const int64_t row0 = (int64_t)b * L;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i = lane & 15, g = lane >> 4;
   const float amax = b4r_seq_amax(p.mask + row0, L);
 
   const int q = q0 + 16 * wave + i;
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_rx_dkv_kernel(AttnRxP p) {
   const int b = wg.b, hd = wg.hd;
   const int L = p.L, H = p.H, ld3 = 3 * H;
   const int64_t row0 = (int64_t)b * L;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i = lane & 15, g = lane >> 4;
   const int64_t bh = (int64_t)b * p.heads + hd;
   const float amax = b4r_seq_amax(p.mask + row0, L);
 

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(64 * FW) void ffn_fwd_kernel(FfnP p) {
   __syncthreads();
   FF_MARK(2);
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i = lane & 15, g = lane >> 4;
   const LaneK lk = lane_consts(lane);
   const DropCtx dctx = b4r_drop_ctx(p.drop);
   const int Nn = ffn_rows(p);
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(64 * FW) void ffn_bwd_dx_kernel(FfnP p) {
   if (threadIdx.x < INNER) sb1[threadIdx.x] = p.b1[threadIdx.x];
   __syncthreads();
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i = lane & 15, g = lane >> 4;
   const LaneK lk = lane_consts(lane);
   const DropCtx dctx = b4r_drop_ctx(p.drop);
   const int Nn = ffn_rows(p);
@@ -322,7 +322,7 @@ constexpr int CH_IMG = CH_TOK * HID * 4;   // hi + lo image of one [32, 64] chun
 __global__ __launch_bounds__(64 * FW) void ffn_bwd_dw_kernel(FfnP p) {
   __shared__ __attribute__((aligned(16))) char smem_dw[4 * CH_IMG];
   FF_MARK(30);
-  const int lane = threadIdx.x & 63, ib = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+  const int lane = threadIdx.x & 63, ib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i = lane & 15, g = lane >> 4;
   const LaneK lk = lane_consts(lane);
   const DropCtx dctx = b4r_drop_ctx(p.drop);
 

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
   __shared__ __attribute__((aligned(16))) float sA[BM * LDS_A];
   __shared__ __attribute__((aligned(16))) float sB[B_NK ? BN * LDS_BK : BK * LDS_BN];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tile_m = blockIdx.x / p.tiles_n, tile_n = blockIdx.x % p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int h = lane >> 5, l31 = lane & 31;
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnP p) {
   __shared__ __attribute__((aligned(16))) float sB[TK * TB];
   __shared__ float sRed[4 * TB];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i0 = blockIdx.x * TB, j0 = blockIdx.y * TB, z = blockIdx.z;
   const int r_begin = z * p.chunk;
   const int r_end = min(p.R, r_begin + p.chunk);
@@ -324,7 +324,7 @@ __device__ __forceinline__ void reduce_store(const ReduceJobView& job, int64_t e
 __device__ __forceinline__ void slab_reduce_block(const ReduceJobView& job, int block, float (*sp)[RE]) {
   const int64_t total = (int64_t)job.Mo * job.No;
   const int mat_blocks = reduce_mat_blocks(job.S, total);
-  const int lane = threadIdx.x & 63, zl = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, zl = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const bool vec = (total % 4 == 0) && ((reinterpret_cast<uintptr_t>(job.slab) & 15) == 0);   // block-uniform
   if (block < mat_blocks && job.S <= RZ) {
     // few slabs (the head's table gradient: 16 slabs of V x H): a thread owns 4 elements and reads all slabs itself, every load in

@@ -381,7 +381,7 @@ __device__ __forceinline__ void epilogue_tile_ln_bwd(const RxP& p, const DropCtx
 template <int EPI, bool A_DROP, int NKB>
 __global__ __launch_bounds__(256) void rx_gemm_kn_kernel(RxP p) {
   extern __shared__ __attribute__((aligned(16))) float s_lds[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int lid = xcd_logical_id(blockIdx.x, p.n_items);
   if (lid >= abs(p.n_items)) return;   // block-uniform, before any barrier
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void rx_gemm_nk_kernel(RxP p) {
   constexpr int NLD = (32 * F4_PER_ROW) / 256;        // float4 per thread per tile: 2 (K = 64) or 1 (K = 32)
   constexpr int BROW = 8 * NKB + 4;                   // dwords per plane row: K bf16 + 16 bytes pad (conflict-free b128)
   constexpr int PLANE = 32 * BROW * 4;                // bytes per plane
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int lid = xcd_logical_id(blockIdx.x, p.n_items);
   if (lid >= abs(p.n_items)) return;   // block-uniform, before any barrier
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256) void rx_gemm_kloop_kernel(RxP p) {
   extern __shared__ __attribute__((aligned(16))) float s_lds[];
   constexpr int BROW = 36, PLANE = NT * 32 * BROW * 4;     // B planes: [NT*32 rows][64 bf16 + pad]
   constexpr int NLD = (NT * 32 * 16) / 256;                // float4 per thread per B chunk tile ([N,K] layout)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int m0 = blockIdx.x * 128 + wave * 32;
   const int nb = blockIdx.y * (32 * NT);            // first column of this workgroup's pass over N
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(256) void rx_gemm_wide_kernel(RxP p) {
   char* sA = s_w;
   char* sB = s_w + A_BYTES;
   float* stage = reinterpret_cast<float*>(s_w + A_BYTES + B_BYTES) + (threadIdx.x >> 6) * (32 * ST_LD);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
   const int ntn = (p.N + TN - 1) / TN;
   const int lid = xcd_logical_id(blockIdx.x, p.n_items);   // the column tiles of one row block share its A chunks
@@ -965,7 +965,7 @@ __device__ __forceinline__ void rx_gemm_tn_body(const RxTnP& p, const int block)
   constexpr int NLD = KS / 16;                       // float4 per thread per operand per chunk
   constexpr int PLANE = KS * 128;                    // bytes per image
   extern __shared__ __attribute__((aligned(16))) char s_tn[];   // [A hi | A lo | B hi | B lo]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   const int n_items = p.tiles_i * p.tiles_j * p.S;

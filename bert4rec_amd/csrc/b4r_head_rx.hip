@@ -103,7 +103,7 @@ __global__ __launch_bounds__(64 * WAVES) void head_fwd_kernel(HeadP p) {
   constexpr int H = 32 * NKH, TB = 2 * NKH * IMG_BYTES, HEAD_CH = head_ch(NKH), PART_LD = part_ld(NKH);
   char* img = smem_head;
   float* sBias = reinterpret_cast<float*>(img + HEAD_CH * TB);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i = lane & 15, g = lane >> 4;
   const int m = blockIdx.x * ROWS_WG + 16 * wave + i;
   const int mc = min(m, p.M - 1);
   bf16x8 th[NKH], tl[NKH];
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(64 * WAVES) void head_dE_kernel(HeadP p) {
   char* img = smem_head;
   float* sLse = reinterpret_cast<float*>(img + HEAD_CH * TB);
   int* sY = reinterpret_cast<int*>(sLse + HEAD_CH * 16);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), i = lane & 15, g = lane >> 4;
   const int v = blockIdx.x * ROWS_WG + 16 * wave + i;
   const bool vlive = v < p.V;
   const int vc = min(v, p.V - 1);

@@ -40,7 +40,7 @@ struct LnFwdP {
 template <int LPR, int NV, bool EMBED>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdP p) {
   constexpr int RPW = 64 / LPR;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int sub = lane % LPR, slot = lane / LPR;
   const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * RPW + slot;
   if (row >= p.rows) return;  // whole LPR-group exits together; shuffles below stay inside the group
@@ -114,7 +114,7 @@ template <int LPR, int NV, bool EMBED>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdP p) {
   constexpr int RPW = 64 / LPR;
   extern __shared__ float sred[];  // [4*RPW][2*H]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int sub = lane % LPR, slot = lane / LPR;
   DropCtx dctx = b4r_drop_ctx(p.drop);
 
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(float* logits, int V, i
   __shared__ float s_val[4];
   __shared__ int s_idx[4];
   __shared__ float s_sum[4];
-  const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* row = logits + (int64_t)m * ld;
   const int nv = ld / 4;
   int64_t y = y_true[m];
@@ -1086,7 +1086,7 @@ __global__ __launch_bounds__(256) void sample_candidates_kernel(const float* log
   int* s_out = reinterpret_cast<int*>(s_key + V);
   __shared__ float s_v[2][4];
   __shared__ int s_i[2][4];
-  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t rk = b4r_hash32((uint32_t)row * 0x9E3779B9u + seed_hi);
   for (int v = tid; v < V; v += 256) {
     uint32_t h = b4r_hash32((uint32_t)v ^ seed_lo);

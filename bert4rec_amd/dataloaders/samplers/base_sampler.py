@@ -53,14 +53,10 @@ class BaseSampler(abc.ABC):
         ...
 
     @abc.abstractmethod
-    def is_fully_prepared(self) -> bool:
+    def is_fully_prepared(self) -> bool:   # True when sample() can run on the constructor's arguments alone
         ...
 
-    def set_source(self, source: list):
-        self.source = list(source)
-
-    def set_vocab(self, vocab: list):
-        self.vocab = list(vocab)
-
-    def set_sample_size(self, sample_size: int):
-        self.sample_size = sample_size
+    # the setters copy, like the constructor: a caller's later edits of its list do not reach the sampler
+    def set_sample_size(self, sample_size: int): self.sample_size = sample_size
+    def set_vocab(self, vocab: list): self.vocab = list(vocab)
+    def set_source(self, source: list): self.source = list(source)

@@ -1,38 +1,47 @@
-"""mirrors bert4rec/evaluation/base_evaluator.py:14-79"""
+"""What every evaluator offers: a metric set that is reset / read / saved together, a negative sampler, an `evaluate`.
+
+Public names as in bert4rec/evaluation/base_evaluator.py:14-79; the results file is `eval_results.json` when a directory is given."""
 import abc
 import json
+import logging
 import pathlib
 from typing import Union
 
 from ..dataloaders import samplers
-from .evaluation_metrics import EvaluationMetric
+from .evaluation_metrics import EvaluationMetric  # noqa: F401  (re-exported for type annotations of subclasses)
+
+RESULTS_FILE = "eval_results.json"
+_log = logging.getLogger(__name__)
 
 
 class BaseEvaluator(abc.ABC):
     def __init__(self, metrics: list, sampler: Union[str, "samplers.BaseSampler"] = "popular", dataloader=None):
         self.sampler = samplers.get(sampler)
-        self._metrics = metrics
+        missing = [what for what in ("sample_size", "source") if getattr(self.sampler, what, None) is None]
+        if missing:   # legal: evaluate() may receive them later
+            _log.info("%s: sampler without %s", type(self).__name__, " and ".join(missing))
         self.dataloader = dataloader
+        self._metrics = metrics
         self.reset_metrics()
-
-    def reset_metrics(self) -> None:
-        for metric in self._metrics:
-            metric.reset()
 
     @abc.abstractmethod
     def evaluate(self, model, test_data) -> list:
-        pass
+        """rank the held-out item of every user of test_data against its negatives; returns the updated metric objects"""
 
+    # ---- the metric set ------------------------------------------------------------------------------------------------------------
     def get_metrics(self) -> list:
         return self._metrics
 
+    def reset_metrics(self) -> None:
+        for m in self._metrics:
+            m.reset()
+
     def get_metrics_results(self) -> dict:
-        return {metric.name: metric.result() for metric in self._metrics}
+        return {m.name: m.result() for m in self._metrics}
 
     def save_results(self, save_path: pathlib.Path) -> pathlib.Path:
-        save_path = pathlib.Path(save_path)
-        if save_path.is_dir():
-            save_path = save_path.joinpath("eval_results.json")
-        with open(save_path, "w") as f:
-            json.dump(self.get_metrics_results(), f, indent=4)
-        return save_path
+        target = pathlib.Path(save_path)
+        if target.is_dir():
+            target = target / RESULTS_FILE
+        target.write_text(json.dumps(self.get_metrics_results(), indent=4))
+        return target

@@ -1,4 +1,5 @@
-"""Tokenizer factory (mirrors bert4rec/tokenizers/__init__.py)."""
+"""Tokenizers by name.  `get("simple", **kwargs)` builds one, `get(instance)` passes it through — the call shapes of
+bert4rec/tokenizers/__init__.py; `tokenizers_map` is the public registry a caller may extend."""
 from typing import Union
 
 from .base_tokenizer import BaseTokenizer
@@ -8,8 +9,9 @@ tokenizers_map = {"simple": SimpleTokenizer}
 
 
 def get(identifier: Union[str, BaseTokenizer] = "simple", **kwargs) -> BaseTokenizer:
-    if isinstance(identifier, str) and identifier in tokenizers_map:
-        return tokenizers_map[identifier](**kwargs)
     if isinstance(identifier, BaseTokenizer):
-        return identifier
-    raise ValueError(f"{identifier} is not known!")
+        return identifier                    # already built: keyword arguments do not apply
+    cls = tokenizers_map.get(identifier) if isinstance(identifier, str) else None
+    if cls is None:
+        raise ValueError(f"{identifier} is not known!")
+    return cls(**kwargs)

@@ -1,4 +1,6 @@
-"""mirrors bert4rec/tokenizers/base_tokenizer.py"""
+"""Interface of a tokenizer: items <-> integer ids, with a vocabulary that can be frozen, exported and re-imported.
+
+Public names as in bert4rec/tokenizers/base_tokenizer.py."""
 import abc
 import pathlib
 
@@ -17,6 +19,15 @@ class BaseTokenizer(abc.ABC):
     @abc.abstractmethod
     def identifier(self):
         pass
+
+    def generate_vocab_from_ds(self, ds):
+        """grow the vocabulary over an iterable of item sequences (a dataset of 1-D vectors in the reference)"""
+        for items in ds:
+            self.tokenize(items)
+
+    @property
+    def max_seq_len(self) -> int:
+        return self._max_len
 
     def get_vocab(self):
         return self._vocab

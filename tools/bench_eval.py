@@ -5,7 +5,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bert4rec_amd import config, dataloaders, evaluation, models
 from bert4rec_amd.models.components import networks
-from oracle import bert4rec_oracle as orc
+from synth import synthetic_batch
 
 V, B, L, USERS = 3709, 256, 200, 6040
 enc = networks.Bert4RecEncoder(V, **config.get_encoder_config("ml-1m_64"))
@@ -14,7 +14,7 @@ rng = np.random.default_rng(0)
 pop = (rng.zipf(1.2, size=1000000) % (V - 3) + 3).tolist()
 smp = dataloaders.samplers.get("pop_random", source=pop, vocab=list(range(V)), sample_size=100, seed=1)
 nb = (USERS + B - 1) // B
-batches = [orc.synthetic_batch(B, L, 1, V, seed=i, ragged=True, finetune=True) for i in range(nb)]
+batches = [synthetic_batch(B, L, 1, V, seed=i, ragged=True, finetune=True) for i in range(nb)]
 for name, dev in (("device sampler (b4r_sample_candidates)", True), ("host sampler (np.random.choice per user)", False)):
     ev = evaluation.get(sampler=smp, device_sampling=dev)
     ev.evaluate_batch(model, batches[0]); ev.reset_metrics()

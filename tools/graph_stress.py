@@ -4,11 +4,11 @@ sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 from bert4rec_amd import _lib
 from bert4rec_amd.engine import make_adamw_config
 import test_gpu_model as T
-from oracle import bert4rec_oracle as orc
+from synth import synthetic_batch
 lib = _lib.load()
 lib.b4r_set_gemm_mode(1)
 cfg_o, shp = T.CONFIGS["tiny"]
-batch = orc.synthetic_batch(shp["B"], shp["L"], shp["P"], cfg_o.vocab_size, seed=8, ragged=True)
+batch = synthetic_batch(shp["B"], shp["L"], shp["P"], cfg_o.vocab_size, seed=8, ragged=True)
 hp = make_adamw_config(num_warmup_steps=2, num_train_steps=200)
 def run(graphed, steps=8):
     eng, _ = T.build(cfg_o); eng.set_seed(77)

@@ -1133,6 +1133,156 @@ __global__ __launch_bounds__(256) void rx_gemm_tn_pair_kernel(RxTnP p0, RxTnP p1
   else rx_gemm_tn_body<KS, B_DROP1, 0>(p1, (int)blockIdx.x - n0);
 }
 
+// ---- the same product on 128 x 128 output tiles (Mo and No multiples of 128: the weight gradients of the wide configurations) ------
+// With 64 x 64 tiles every operand column block is fetched by Mo/64 or No/64 workgroups: at ML-20M (dW1 = x^T.dfpre, 256 x 1024
+// over 25 600 rows) 0.84 GB cross the L2s per launch for 0.13 GB of operands, and a workgroup spends a chunk mostly on staging
+// (12 MFMAs per wave against 8 float4 converted per thread).  Here a wave owns 64 x 64 (2 x 2 blocks of 32 x 32): four times the
+// matrix work per staged byte.  Chunks of 32 rows; image rows are 256 bytes, the 64-byte quarter index XORed with row & 3, so the
+// four rows of a half-wave's transposed read cover all 64 banks.
+constexpr int TN128_KS = 32;
+__device__ __forceinline__ int tn128_off(int row, int c4) {   // bytes; c4 = float4 index (0..31) within the 128 columns
+  return row * 256 + 32 * ((c4 >> 2) ^ (2 * (row & 3))) + 8 * (c4 & 3);
+}
+template <bool B_DROP>
+__global__ __launch_bounds__(256, 2) void rx_gemm_tn128_kernel(RxTnP p) {
+  constexpr int KS = TN128_KS, NLD = KS / 8, PLANE = KS * 256;
+  extern __shared__ __attribute__((aligned(16))) char s_tn[];   // [A hi | A lo | B hi | B lo]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int n_items = p.tiles_i * p.tiles_j * p.S;
+  const int item = xcd_logical_id((int)blockIdx.x, n_items);
+  if (item >= n_items) return;                            // block-uniform, before any barrier
+  const int z = item / (p.tiles_i * p.tiles_j);
+  const int t = item % (p.tiles_i * p.tiles_j);
+  const int ti = t / p.tiles_j, tj = t % p.tiles_j;
+  const int i0 = ti * 128, j0 = tj * 128;
+  const int r_begin = min(p.R, z * p.chunk), r_end = min(p.R, r_begin + p.chunk);
+  const bool do_cs = p.colsum_slab != nullptr && ti == 0;
+  const bool do_csa = p.colsum_a_slab != nullptr && tj == 0;
+  const DropCtx dctx = b4r_drop_ctx(p.drop);
+
+  const int c4 = tid & 31, srow = tid >> 5;   // thread -> (row tid/32 + 8*j, float4 column tid%32)
+  const int ca = i0 + 4 * c4, cb = j0 + 4 * c4;
+  struct Chunk { f32x4 a[NLD], b[NLD]; };
+  auto fetch = [&](Chunk& c, int k0) {
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int row = min(k0 + srow + 8 * j, p.R - 1);
+      c.a[j] = *reinterpret_cast<const f32x4*>(p.A + (int64_t)row * p.lda + ca);
+      c.b[j] = *reinterpret_cast<const f32x4*>(p.B + (int64_t)row * p.ldb + cb);
+    }
+  };
+  f32x4 cs = {0.f, 0.f, 0.f, 0.f}, csa = {0.f, 0.f, 0.f, 0.f};
+  auto stash = [&](const Chunk& c, int k0) {
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+      const int lrow = srow + 8 * j, row = k0 + lrow;
+      const bool live = row < r_end;
+      f32x4 va = c.a[j], vb = c.b[j];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        va[e] = live ? va[e] : 0.f;
+        vb[e] = live ? vb[e] : 0.f;
+      }
+      if (B_DROP) vb = b4r_drop4(dctx, vb, (uint64_t)row * (uint64_t)p.No + (uint64_t)cb);
+      cs += vb;
+      csa += va;
+      const int off = tn128_off(lrow, c4);
+      bf16x4 ah, al, bh, bl;
+      b4r_split4(va, ah, al);
+      b4r_split4(vb, bh, bl);
+      *reinterpret_cast<bf16x4*>(s_tn + off) = ah;
+      *reinterpret_cast<bf16x4*>(s_tn + PLANE + off) = al;
+      *reinterpret_cast<bf16x4*>(s_tn + 2 * PLANE + off) = bh;
+      *reinterpret_cast<bf16x4*>(s_tn + 3 * PLANE + off) = bl;
+    }
+  };
+  // transposed fragments as in rx_gemm_tn_body; block b of the wave = columns 64 w + 32 b .. of the tile
+  const int qq = (lane & 15) >> 2, pp = lane & 3, gb = (lane >> 4) & 1;
+  int tr_a[2], tr_b[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    tr_a[b] = tn128_off(8 * h + qq, 4 * (2 * (2 * wm + b) + gb) + pp);
+    tr_b[b] = tn128_off(8 * h + qq, 4 * (2 * (2 * wn + b) + gb) + pp);
+  }
+  typedef __attribute__((address_space(3))) s16x4* lds_ptr;
+  auto tr8 = [&](int plane, int addr, int kb) {
+    const char* src = s_tn + plane * PLANE + addr + kb * (16 * 256);
+    const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(src));
+    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(src + 4 * 256));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < 2; ++bj)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[bi][bj][i] = 0.f;
+  auto products = [&]() {
+#pragma unroll
+    for (int kb = 0; kb < KS / 16; ++kb) {
+      bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        ah[b] = tr8(0, tr_a[b], kb); al[b] = tr8(1, tr_a[b], kb);
+        bh[b] = tr8(2, tr_b[b], kb); bl[b] = tr8(3, tr_b[b], kb);
+      }
+#pragma unroll
+      for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < 2; ++bj) acc[bi][bj] = mfma3(ah[bi], al[bi], bh[bj], bl[bj], acc[bi][bj]);
+    }
+  };
+  Chunk c0, c1;
+  if (r_begin < r_end) fetch(c0, r_begin);
+  for (int k0 = r_begin; k0 < r_end; k0 += 2 * KS) {
+    fetch(c1, k0 + KS);              // unconditional look-ahead (rows are clamped; stash() zeroes what lies beyond r_end)
+    __syncthreads();                 // every wave is done with the previous chunk's images
+    stash(c0, k0);
+    __syncthreads();
+    products();
+    if (k0 + KS >= r_end) break;     // block-uniform
+    fetch(c0, k0 + 2 * KS);
+    __syncthreads();
+    stash(c1, k0 + KS);
+    __syncthreads();
+    products();
+  }
+  if (do_cs || do_csa) {             // 8 row groups per column quad, summed in a fixed order
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(s_tn);   // [2][8 row groups][128 columns]
+    *reinterpret_cast<f32x4*>(red + srow * 128 + 4 * c4) = cs;
+    *reinterpret_cast<f32x4*>(red + 1024 + srow * 128 + 4 * c4) = csa;
+    __syncthreads();
+    const int which = tid >> 7, c = tid & 127;
+    float sum = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) sum += red[which * 1024 + g * 128 + c];
+    if (which == 0 && do_cs) p.colsum_slab[(int64_t)z * p.No + j0 + c] = sum;
+    if (which == 1 && do_csa) p.colsum_a_slab[(int64_t)z * p.Mo + i0 + c] = sum;
+  }
+  float* slab = p.slab + (int64_t)z * p.Mo * p.No;
+#pragma unroll
+  for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+    for (int bj = 0; bj < 2; ++bj) {
+      const int col = j0 + 32 * (2 * wn + bj) + r;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int row = i0 + 32 * (2 * wm + bi) + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        slab[(int64_t)row * p.No + col] = acc[bi][bj][reg];
+      }
+    }
+}
+
+// 128 x 128 tiles when both output dimensions allow it (B4R_TN_WIDE=0: the 64 x 64 kernel everywhere)
+inline bool tn_wide_tiles(int Mo, int No) {
+  static const int on = getenv("B4R_TN_WIDE") ? atoi(getenv("B4R_TN_WIDE")) : 1;
+  return on && Mo >= 128 && No >= 128 && Mo % 128 == 0 && No % 128 == 0;
+}
+
 constexpr int TN_KS = 64;   // measured on the ML-1M shapes: 32 -> 1.185, 64 -> 1.173, 128 -> 1.197 ms/step
 
 inline int tn_single_tile_cap() {
@@ -1141,8 +1291,11 @@ inline int tn_single_tile_cap() {
 }
 int rx_tn_split(int R, int Mo, int No) {
   static const int wg_target = getenv("B4R_TN_TARGET") ? atoi(getenv("B4R_TN_TARGET")) : 512;
-  const int tiles = b4r_cdiv(Mo, 64) * b4r_cdiv(No, 64);
-  int S = b4r_cdiv(wg_target, tiles);
+  static const int wg_target_wide = getenv("B4R_TN_TARGET_WIDE") ? atoi(getenv("B4R_TN_TARGET_WIDE")) : 256;   // measured at ML-20M: 128 -> 10.83, 256 -> 9.55, 384 -> 9.54, 512 -> 9.56 ms per step (64 x 64 tiles: 9.85)
+  const bool wide = tn_wide_tiles(Mo, No);
+  const int tw = wide ? 128 : 64;
+  const int tiles = b4r_cdiv(Mo, tw) * b4r_cdiv(No, tw);
+  int S = b4r_cdiv(wide ? wg_target_wide : wg_target, tiles);
   const int max_s = b4r_cdiv(R, 2 * TN_KS);  // at least two chunks per workgroup
   if (S > max_s) S = max_s;
   const int cap = tiles == 1 ? tn_single_tile_cap() : 256;   // one 64 x 64 output tile: the slices are the only parallelism
@@ -1270,7 +1423,8 @@ static RxTnP make_tn_params(const b4r_gemm_tn_desc* d, float* scratch, int S) {
   RxTnP p;
   p.A = d->A; p.B = d->B; p.lda = d->lda; p.ldb = d->ldb;
   p.R = d->R; p.Mo = d->Mo; p.No = d->No;
-  p.tiles_i = b4r_cdiv(d->Mo, 64); p.tiles_j = b4r_cdiv(d->No, 64); p.S = S;
+  const int tw = (tn_wide_tiles(d->Mo, d->No) && d->dgrad_out == nullptr) ? 128 : 64;
+  p.tiles_i = b4r_cdiv(d->Mo, tw); p.tiles_j = b4r_cdiv(d->No, tw); p.S = S;
   p.chunk = b4r_cdiv(b4r_cdiv(d->R, S), TN_KS) * TN_KS;
   p.a_lim = up4i(d->Mo); p.b_lim = up4i(d->No);
   p.slab = scratch;
@@ -1288,6 +1442,14 @@ int b4r_gemm_rx_tn_launch(const b4r_gemm_tn_desc* d, float* scratch, hipStream_t
   const int dgrad = d->dgrad_out == nullptr ? 0 : (d->dgrad_gelu_pre ? 2 : 1);   // b4r_gemm_tn_f32 has checked the shape contract
   const int64_t items = (int64_t)p.tiles_i * p.tiles_j * S;
   dim3 grid(xcd_grid(items));
+  if (dgrad == 0 && tn_wide_tiles(d->Mo, d->No)) {
+    constexpr size_t lds128 = (size_t)4 * TN128_KS * 256;   // 32 KB
+    if (b_drop) hipLaunchKernelGGL((rx_gemm_tn128_kernel<true>), grid, dim3(256), lds128, stream, p);
+    else hipLaunchKernelGGL((rx_gemm_tn128_kernel<false>), grid, dim3(256), lds128, stream, p);
+    B4R_CHECK_LAUNCH("b4r_gemm_tn_f32 (bf16x3, 128 x 128 tiles)");
+    return b4r_launch_slab_reduce_full(p.slab, S, d->Mo, d->No, d->out, d->ldo, d->accumulate, p.colsum_slab, d->colsum,
+                                       p.colsum_a_slab, d->colsum_a, stream);
+  }
   constexpr size_t lds = (size_t)4 * TN_KS * 128;
   static bool lds_raised = false;
   if (lds > 48 * 1024 && !lds_raised) {
@@ -1312,6 +1474,7 @@ int b4r_gemm_rx_tn_launch(const b4r_gemm_tn_desc* d, float* scratch, hipStream_t
 
 // d0 with dropout on its B operand, d1 without, neither with an input-gradient tail: the two products of b4r_encoder_layer_bwd
 bool b4r_gemm_rx_tn_pair_supported(const b4r_gemm_tn_desc* d0, const b4r_gemm_tn_desc* d1) {
+  if (tn_wide_tiles(d0->Mo, d0->No) || tn_wide_tiles(d1->Mo, d1->No)) return false;   // those run rx_gemm_tn128_kernel, one launch each
   return b4r_gemm_rx_tn_supported(d0) && b4r_gemm_rx_tn_supported(d1) && !d0->dgrad_out && !d1->dgrad_out &&
          !(d1->b_dropout && d1->rng && d1->drop_rate > 0.f);
 }

@@ -247,7 +247,9 @@ def test_gemm_k_tail_padded_rows():
     assert T.maxdiff(c, ref) < TOL
 
 
-@pytest.mark.parametrize("R,Mo,No", [(1000, 64, 192), (517, 300, 64), (4096, 64, 64), (33, 5, 9)])
+# the last three: 128 x 128 output tiles (rx_gemm_tn128_kernel), incl. a row count that ends inside a chunk and a single tile
+@pytest.mark.parametrize("R,Mo,No", [(1000, 64, 192), (517, 300, 64), (4096, 64, 64), (33, 5, 9), (3000, 256, 1024), (1237, 1024, 256),
+                                     (70, 128, 128)])
 def test_gemm_tn_weight_gradient(R, Mo, No):
     A, B = rnd(R, Mo, seed=10), rnd(R, No, seed=11)
     ref = A.double().t() @ B.double()
@@ -324,8 +326,9 @@ def test_gemm_tn_with_fused_input_gradient(R, rate):
     assert T.maxdiff(dx, Bd @ W.double().t()) < 1e-4
 
 
-def test_gemm_tn_dropout_on_b():
-    R, Mo, No, rate, seed, step, sid = 700, 64, 64, 0.3, 5, 11, 2
+@pytest.mark.parametrize("Mo,No", [(64, 64), (256, 128)])
+def test_gemm_tn_dropout_on_b(Mo, No):
+    R, rate, seed, step, sid = 700, 0.3, 5, 11, 2
     A, B = rnd(R, Mo, seed=12), rnd(R, No, seed=13)
     st = T.new_state(seed, step)
     keep = orc.dropout_keep_mask((R, No), rate, seed, step, sid).double()

@@ -662,7 +662,7 @@ __device__ __forceinline__ int wide_off(int row, int ch) {   // image 0 (hi); lo
 // TM x TN = 128 x 128 (wide N) or 64 x 64 (N = 64 with a long K: the products that reduce over the FFN width or 3H);
 // the 4 waves always form a 2 x 2 grid of (TM/2) x (TN/2) quarters
 template <bool B_NK, int EPI, bool A_DROP, int TM, int TN, int WIDE_DEPTH = 1>
-__global__ __launch_bounds__(256) void rx_gemm_wide_kernel(RxP p) {
+__global__ __launch_bounds__(256, 2) void rx_gemm_wide_kernel(RxP p) {   // two waves per SIMD: without the bound the 128 x 128, depth-2, [K,N] instances take 268 registers = ONE workgroup per CU
   extern __shared__ __attribute__((aligned(16))) char s_w[];
   constexpr int RB = TM / 64, CB = TN / 64;                 // 32-row / 32-column blocks per wave
   constexpr int A_BYTES = TM * 64 * 2, B_BYTES = TN * 64 * 2;
@@ -1127,8 +1127,11 @@ __global__ __launch_bounds__(256) void rx_gemm_tn_kernel(RxTnP p) {
 // two independent weight-gradient products in ONE launch (the workgroups of the second follow those of the first; n0 is a
 // multiple of 8, so both keep their XCD mapping): dWo = ctx^T.dropmask(dz1) and dWqkv = x^T.dqkv of an encoder layer are each too
 // short (12 / 17 us) to reach the memory system's rate on their own
+#ifndef TN_PAIR_OCC
+#define TN_PAIR_OCC 3   // waves per SIMD the register allocation aims at (tools/build_variant.sh -DTN_PAIR_OCC=4 to compare)
+#endif
 template <int KS, bool B_DROP0, bool B_DROP1>
-__global__ __launch_bounds__(256) void rx_gemm_tn_pair_kernel(RxTnP p0, RxTnP p1, int n0) {
+__global__ __launch_bounds__(256, TN_PAIR_OCC) void rx_gemm_tn_pair_kernel(RxTnP p0, RxTnP p1, int n0) {
   if ((int)blockIdx.x < n0) rx_gemm_tn_body<KS, B_DROP0, 0>(p0, (int)blockIdx.x);
   else rx_gemm_tn_body<KS, B_DROP1, 0>(p1, (int)blockIdx.x - n0);
 }

@@ -1139,20 +1139,20 @@ __global__ __launch_bounds__(256, TN_PAIR_OCC) void rx_gemm_tn_pair_kernel(RxTnP
 // ---- the same product on 128 x 128 output tiles (Mo and No multiples of 128: the weight gradients of the wide configurations) ------
 // With 64 x 64 tiles every operand column block is fetched by Mo/64 or No/64 workgroups: at ML-20M (dW1 = x^T.dfpre, 256 x 1024
 // over 25 600 rows) 0.84 GB cross the L2s per launch for 0.13 GB of operands, and a workgroup spends a chunk mostly on staging
-// (12 MFMAs per wave against 8 float4 converted per thread).  Here a wave owns 64 x 64 (2 x 2 blocks of 32 x 32): four times the
-// matrix work per staged byte.  Chunks of 32 rows; image rows are 256 bytes, the 64-byte quarter index XORed with row & 3, so the
+// (12 MFMAs per wave against 8 float4 converted per thread).  Here a workgroup of 8 waves owns 128 x 128, a wave 64 x 32 (two blocks of 32 x 32): four times
+// the matrix work per staged byte, and two waves per SIMD even with one workgroup on the CU (with 4 waves of 64 x 64 a CU held 4).  Chunks of 32 rows; image rows are 256 bytes, the 64-byte quarter index XORed with row & 3, so the
 // four rows of a half-wave's transposed read cover all 64 banks.
 constexpr int TN128_KS = 32;
 __device__ __forceinline__ int tn128_off(int row, int c4) {   // bytes; c4 = float4 index (0..31) within the 128 columns
   return row * 256 + 32 * ((c4 >> 2) ^ (2 * (row & 3))) + 8 * (c4 & 3);
 }
 template <bool B_DROP>
-__global__ __launch_bounds__(256, 2) void rx_gemm_tn128_kernel(RxTnP p) {
-  constexpr int KS = TN128_KS, NLD = KS / 8, PLANE = KS * 256;
+__global__ __launch_bounds__(512, 2) void rx_gemm_tn128_kernel(RxTnP p) {
+  constexpr int KS = TN128_KS, NLD = KS / 16, PLANE = KS * 256;
   extern __shared__ __attribute__((aligned(16))) char s_tn[];   // [A hi | A lo | B hi | B lo]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave >> 2, wn = wave & 3;   // 8 waves: 2 x 4 grid of 64 x 32 pieces (two 32 x 32 blocks each)
   const int n_items = p.tiles_i * p.tiles_j * p.S;
   const int item = xcd_logical_id((int)blockIdx.x, n_items);
   if (item >= n_items) return;                            // block-uniform, before any barrier
@@ -1165,13 +1165,13 @@ __global__ __launch_bounds__(256, 2) void rx_gemm_tn128_kernel(RxTnP p) {
   const bool do_csa = p.colsum_a_slab != nullptr && tj == 0;
   const DropCtx dctx = b4r_drop_ctx(p.drop);
 
-  const int c4 = tid & 31, srow = tid >> 5;   // thread -> (row tid/32 + 8*j, float4 column tid%32)
+  const int c4 = tid & 31, srow = tid >> 5;   // thread -> (row tid/32 + 16*j, float4 column tid%32)
   const int ca = i0 + 4 * c4, cb = j0 + 4 * c4;
   struct Chunk { f32x4 a[NLD], b[NLD]; };
   auto fetch = [&](Chunk& c, int k0) {
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
-      const int row = min(k0 + srow + 8 * j, p.R - 1);
+      const int row = min(k0 + srow + 16 * j, p.R - 1);
       c.a[j] = *reinterpret_cast<const f32x4*>(p.A + (int64_t)row * p.lda + ca);
       c.b[j] = *reinterpret_cast<const f32x4*>(p.B + (int64_t)row * p.ldb + cb);
     }
@@ -1180,7 +1180,7 @@ __global__ __launch_bounds__(256, 2) void rx_gemm_tn128_kernel(RxTnP p) {
   auto stash = [&](const Chunk& c, int k0) {
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
-      const int lrow = srow + 8 * j, row = k0 + lrow;
+      const int lrow = srow + 16 * j, row = k0 + lrow;
       const bool live = row < r_end;
       f32x4 va = c.a[j], vb = c.b[j];
 #pragma unroll
@@ -1201,14 +1201,12 @@ __global__ __launch_bounds__(256, 2) void rx_gemm_tn128_kernel(RxTnP p) {
       *reinterpret_cast<bf16x4*>(s_tn + 3 * PLANE + off) = bl;
     }
   };
-  // transposed fragments as in rx_gemm_tn_body; block b of the wave = columns 64 w + 32 b .. of the tile
+  // transposed fragments as in rx_gemm_tn_body; A block b of the wave = columns 64 wm + 32 b .. of the A image, B block = 32 wn ..
   const int qq = (lane & 15) >> 2, pp = lane & 3, gb = (lane >> 4) & 1;
-  int tr_a[2], tr_b[2];
+  int tr_a[2];
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    tr_a[b] = tn128_off(8 * h + qq, 4 * (2 * (2 * wm + b) + gb) + pp);
-    tr_b[b] = tn128_off(8 * h + qq, 4 * (2 * (2 * wn + b) + gb) + pp);
-  }
+  for (int b = 0; b < 2; ++b) tr_a[b] = tn128_off(8 * h + qq, 4 * (2 * (2 * wm + b) + gb) + pp);
+  const int tr_b = tn128_off(8 * h + qq, 4 * (2 * wn + gb) + pp);
   typedef __attribute__((address_space(3))) s16x4* lds_ptr;
   auto tr8 = [&](int plane, int addr, int kb) {
     const char* src = s_tn + plane * PLANE + addr + kb * (16 * 256);
@@ -1216,26 +1214,17 @@ __global__ __launch_bounds__(256, 2) void rx_gemm_tn128_kernel(RxTnP p) {
     const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(src + 4 * 256));
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo4, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
   };
-  f32x16 acc[2][2];
+  f32x16 acc[2];
 #pragma unroll
   for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
-    for (int bj = 0; bj < 2; ++bj)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[bi][bj][i] = 0.f;
+    for (int i = 0; i < 16; ++i) acc[bi][i] = 0.f;
   auto products = [&]() {
 #pragma unroll
     for (int kb = 0; kb < KS / 16; ++kb) {
-      bf16x8 ah[2], al[2], bh[2], bl[2];
+      const bf16x8 bh = tr8(2, tr_b, kb), bl = tr8(3, tr_b, kb);
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        ah[b] = tr8(0, tr_a[b], kb); al[b] = tr8(1, tr_a[b], kb);
-        bh[b] = tr8(2, tr_b[b], kb); bl[b] = tr8(3, tr_b[b], kb);
-      }
-#pragma unroll
-      for (int bi = 0; bi < 2; ++bi)
-#pragma unroll
-        for (int bj = 0; bj < 2; ++bj) acc[bi][bj] = mfma3(ah[bi], al[bi], bh[bj], bl[bj], acc[bi][bj]);
+      for (int bi = 0; bi < 2; ++bi) acc[bi] = mfma3(tr8(0, tr_a[bi], kb), tr8(1, tr_a[bi], kb), bh, bl, acc[bi]);
     }
   };
   Chunk c0, c1;
@@ -1253,30 +1242,29 @@ __global__ __launch_bounds__(256, 2) void rx_gemm_tn128_kernel(RxTnP p) {
     __syncthreads();
     products();
   }
-  if (do_cs || do_csa) {             // 8 row groups per column quad, summed in a fixed order
+  if (do_cs || do_csa) {             // 16 row groups per column quad, summed in a fixed order
     __syncthreads();
-    float* red = reinterpret_cast<float*>(s_tn);   // [2][8 row groups][128 columns]
+    float* red = reinterpret_cast<float*>(s_tn);   // [2][16 row groups][128 columns]
     *reinterpret_cast<f32x4*>(red + srow * 128 + 4 * c4) = cs;
-    *reinterpret_cast<f32x4*>(red + 1024 + srow * 128 + 4 * c4) = csa;
+    *reinterpret_cast<f32x4*>(red + 2048 + srow * 128 + 4 * c4) = csa;
     __syncthreads();
-    const int which = tid >> 7, c = tid & 127;
-    float sum = 0.f;
+    if (tid < 256) {
+      const int which = tid >> 7, c = tid & 127;
+      float sum = 0.f;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) sum += red[which * 1024 + g * 128 + c];
-    if (which == 0 && do_cs) p.colsum_slab[(int64_t)z * p.No + j0 + c] = sum;
-    if (which == 1 && do_csa) p.colsum_a_slab[(int64_t)z * p.Mo + i0 + c] = sum;
+      for (int g = 0; g < 16; ++g) sum += red[which * 2048 + g * 128 + c];
+      if (which == 0 && do_cs) p.colsum_slab[(int64_t)z * p.No + j0 + c] = sum;
+      if (which == 1 && do_csa) p.colsum_a_slab[(int64_t)z * p.Mo + i0 + c] = sum;
+    }
   }
   float* slab = p.slab + (int64_t)z * p.Mo * p.No;
+  const int col = j0 + 32 * wn + r;
 #pragma unroll
   for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
-    for (int bj = 0; bj < 2; ++bj) {
-      const int col = j0 + 32 * (2 * wn + bj) + r;
-#pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int row = i0 + 32 * (2 * wm + bi) + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-        slab[(int64_t)row * p.No + col] = acc[bi][bj][reg];
-      }
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = i0 + 32 * (2 * wm + bi) + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      slab[(int64_t)row * p.No + col] = acc[bi][reg];
     }
 }
 
@@ -1447,8 +1435,8 @@ int b4r_gemm_rx_tn_launch(const b4r_gemm_tn_desc* d, float* scratch, hipStream_t
   dim3 grid(xcd_grid(items));
   if (dgrad == 0 && tn_wide_tiles(d->Mo, d->No)) {
     constexpr size_t lds128 = (size_t)4 * TN128_KS * 256;   // 32 KB
-    if (b_drop) hipLaunchKernelGGL((rx_gemm_tn128_kernel<true>), grid, dim3(256), lds128, stream, p);
-    else hipLaunchKernelGGL((rx_gemm_tn128_kernel<false>), grid, dim3(256), lds128, stream, p);
+    if (b_drop) hipLaunchKernelGGL((rx_gemm_tn128_kernel<true>), grid, dim3(512), lds128, stream, p);
+    else hipLaunchKernelGGL((rx_gemm_tn128_kernel<false>), grid, dim3(512), lds128, stream, p);
     B4R_CHECK_LAUNCH("b4r_gemm_tn_f32 (bf16x3, 128 x 128 tiles)");
     return b4r_launch_slab_reduce_full(p.slab, S, d->Mo, d->No, d->out, d->ldo, d->accumulate, p.colsum_slab, d->colsum,
                                        p.colsum_a_slab, d->colsum_a, stream);

@@ -342,9 +342,11 @@ int b4r_attn_rx_bwd_launch(const float* qkv, const int64_t* mask, const float* c
                            int B, int L, int heads, float qscale, float* dqkv, const DropArgs& drop,
                            const uint32_t* keep_bits, hipStream_t stream, hipStream_t stream_dkv);
 
+int64_t b4r_attn32_keep_words(int32_t B, int32_t L, int32_t heads);
 extern "C" int64_t b4r_attn_keep_words(int32_t B, int32_t L, int32_t heads) {
   if (B <= 0 || L <= 0 || heads <= 0) return 0;
-  return b4r_attn_rx_keep_words(B, L, heads);
+  // round 1's layout (b4r_attn_rx.hip), then one word per (query, 32-key tile) for b4r_attn32.hip's backward
+  return b4r_attn_rx_keep_words(B, L, heads) + b4r_attn32_keep_words(B, L, heads);
 }
 
 extern "C" int b4r_attn_fwd(const float* qkv, const int64_t* input_mask, int32_t B, int32_t L, int32_t heads, float* ctx,

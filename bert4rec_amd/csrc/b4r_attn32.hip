@@ -1,0 +1,601 @@
+// Attention half of a Keras TransformerEncoderBlock (post-LN), forward and backward, ONE launch each, one workgroup per sequence
+// (hidden size 64, two heads of 32, L <= 224, split-precision bf16x3 arithmetic) -- round 3's rebuild of b4r_attn_block.hip on
+// 32-token tiles:
+//
+//   * a wave owns 32 tokens (L = 200: 7 waves, two per SIMD, 256 registers each; round 2: 13 waves of 16 tokens under a 128-register
+//     cap, 17-21 of them spilled) and works on 32 x 32 score blocks with v_mfma_f32_32x32x16_bf16: a quarter of the instructions per
+//     score element, twice the matrix work per LDS fragment byte;
+//   * the index a product sums over is always put on the accumulator ROWS of the product before it (b4r_tile32.h), so accumulators
+//     feed the next product from registers; in the backward only dS crosses LDS (wave-private, 4 KB);
+//   * backward, key-owner schedule: wave w keeps K_w, V_w (operand form) and the dK_w, dV_w accumulators in registers for a whole head
+//     and walks the query tiles (w + s) mod NT; only the dQ partial of a step is added into the query tile's accumulator in LDS (one
+//     conflict-free 16-byte read-modify-write per 4 registers, ordered by the step barrier => bitwise reproducible);
+//   * x and dz1 rows are read once per head by the wave that owns them, straight into operand registers;
+//   * attention-dropout decisions travel as one 32-bit word per (query, key tile): the backward loads them with scalar loads and
+//     uses them as lane masks (v_cndmask with an SGPR pair): one instruction per element.
+//
+// Reference: tfm TransformerEncoderBlock / Keras MultiHeadAttention as constructed at
+// bert4rec/models/components/networks/bert4rec_encoder.py:136-147 and called at :220-222 (key-padding mask -1e9,
+// query scaled by 1/sqrt(d) after its bias, attention dropout on the probabilities, output dropout, residual,
+// self_attention_layer_norm); the backward is tape.gradient of that call (bert4rec_model.py:166-167).
+#include "b4r_tile32.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+// timing experiments only (tools/build_variant.sh ... -DA32_EXP=..): 1 no exp / dropout arithmetic, 2 no hi / lo split of Pd and dS,
+// 4 no dS scratch + dQ product + accumulator update, 8 no barrier per step, 16 no dV / dK products, 32 no S / dA products
+#ifndef A32_EXP
+#define A32_EXP 0
+#endif
+
+// A32_PROF (tools/build_variant.sh ... -DA32_PROF): lane 0 of wave 0 of workgroup 0 stamps the shader clock at phase boundaries
+#ifdef A32_PROF
+__device__ long long g_a32_prof[64];
+__device__ long long g_a32_sweep[2][64];
+#define A32_MARK(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_a32_prof[k] = clock64(); } while (0)
+// stamps inside the sweep of head 0, by lane 0 of waves 0 and 4
+#define A32_SWEEP(k) do { if (blockIdx.x == 0 && hd == 0 && (threadIdx.x & 255) == 0 && (k) < 64) g_a32_sweep[threadIdx.x >> 8][k] = clock64(); } while (0)
+#else
+#define A32_MARK(k) do { } while (0)
+#define A32_SWEEP(k) do { } while (0)
+#endif
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// weights: 32 x 32 fp32 blocks -> hi / lo panel tiles (tile gt at img + gt * P_TILE).  src(gt) = address of the block's element
+// (0, 0), ld(gt) its row pitch.  One float4 per thread and turn; the loads of TURNS turns are requested before the first conversion.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int TURNS, typename SrcFn>
+__device__ __forceinline__ void stage_tiles(char* img, int ntiles, int nthreads, SrcFn src) {
+  const int total = ntiles * 256;
+  for (int f0 = threadIdx.x; f0 < total; f0 += TURNS * nthreads) {
+    f32x4 v[TURNS];
+    int dst[TURNS];
+#pragma unroll
+    for (int u = 0; u < TURNS; ++u) {
+      const int f = min(f0 + u * nthreads, total - 1);   // clamped: every load unconditional
+      const int gt = f >> 8, row = (f >> 3) & 31, q4 = f & 7;
+      int ld;
+      const float* s0 = src(gt, ld);
+      v[u] = *reinterpret_cast<const f32x4*>(s0 + (int64_t)row * ld + 4 * q4);
+      dst[u] = gt * P_TILE + p_chunk(row, q4 >> 1) + 8 * (q4 & 1);
+    }
+#pragma unroll
+    for (int u = 0; u < TURNS; ++u) {
+      if (f0 + u * nthreads < total) {
+        bf16x4 hh, ll;
+        b4r_split4(v[u], hh, ll);
+        *reinterpret_cast<bf16x4*>(img + dst[u]) = hh;
+        *reinterpret_cast<bf16x4*>(img + dst[u] + P_IMG) = ll;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// ROW layout of a wave's 32 x 64 fp32 block of a [N, 64] tensor: turn i (0..7) = rows 4i + (lane >> 4), columns 4 (lane & 15) .. +3
+// (a wave-instruction moves 1 KB of consecutive addresses); rows beyond L are clamped to the last row.
+// ---------------------------------------------------------------------------------------------------------------------------
+// Addresses are a wave-uniform base (the sequence's first row) + a 32-bit lane offset: global_load saddr + voffset, no 64-bit lane
+// arithmetic to keep in registers.
+struct RowLay { int row, c4, wave32, L; };
+__device__ __forceinline__ RowLay row_lay(int lane, int wave, int L) {
+  RowLay k;
+  k.row = lane >> 4; k.c4 = lane & 15; k.wave32 = 32 * wave; k.L = L;
+  return k;
+}
+__device__ __forceinline__ uint32_t rl_off(const RowLay& k, int i) { return (uint32_t)(min(k.wave32 + 4 * i + k.row, k.L - 1) * HID + 4 * k.c4); }
+__device__ __forceinline__ f32x4 ld4(const float* base, uint32_t off) { return *reinterpret_cast<const f32x4*>(base + off); }
+__device__ __forceinline__ void st4(float* base, uint32_t off, const f32x4 v) { *reinterpret_cast<f32x4*>(base + off) = v; }
+// ... -> bf16 hi / lo images of two column panels (tile0: columns 0..31, tile1: 32..63), natural column order
+__device__ __forceinline__ void rl_to_panels(const RowLay& k, char* tile0, char* tile1, int i, const f32x4 v) {
+  bf16x4 hh, ll;
+  b4r_split4(v, hh, ll);
+  char* d8 = ((k.c4 & 8) ? tile1 : tile0) + p_chunk(4 * i + k.row, (k.c4 & 7) >> 1) + 8 * (k.c4 & 1);
+  *reinterpret_cast<bf16x4*>(d8) = hh;
+  *reinterpret_cast<bf16x4*>(d8 + P_IMG) = ll;
+}
+// accumulator layout (rows 32 rt + (t & 3) + 8 (t >> 2) + 4h = columns of the tensor, lane r = token) -> row layout, through 8 KB of
+// the wave's own LDS: two [32 tokens][32 columns] fp32 halves, 16-byte chunk c of row `row` at chunk position c ^ (row & 7)
+// (conflict-free both ways)
+__device__ __forceinline__ void acc_to_rl(const RowLay& k, char* halfA, char* halfB, int r, int h, const f32x16 (&v)[2], f32x4 (&out)[8]) {
+#pragma unroll
+  for (int gp = 0; gp < 4; ++gp) {
+    *reinterpret_cast<f32x4*>(halfA + r * 128 + 16 * ((2 * gp + h) ^ (r & 7))) = (f32x4){v[0][4 * gp], v[0][4 * gp + 1], v[0][4 * gp + 2], v[0][4 * gp + 3]};
+    *reinterpret_cast<f32x4*>(halfB + r * 128 + 16 * ((2 * gp + h) ^ (r & 7))) = (f32x4){v[1][4 * gp], v[1][4 * gp + 1], v[1][4 * gp + 2], v[1][4 * gp + 3]};
+  }
+  const char* src = (k.c4 & 8) ? halfB : halfA;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = 4 * i + k.row;
+    out[i] = *reinterpret_cast<const f32x4*>(src + row * 128 + 16 * ((k.c4 & 7) ^ (row & 7)));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------------------------------------
+struct A32BwdP {
+  const float* x; const float* dz1; const float* ctx; const float* lse; const uint32_t* bits; const int64_t* mask;
+  const float* Wqkv; const float* bqkv; const float* Wo;
+  const float* zprev; const float* meanp; const float* rstdp; const float* gprev;     // the LayerNorm that produced x
+  const int64_t* ids; const float* table; const float* pos; int V;                    // ... or the embedding stage (ids != NULL)
+  float* dqkv; float* da; float* ln_part;
+  int B, L, NT;
+  float qscale;
+  DropArgs drop_p, drop_o, drop_e;
+};
+
+// LDS of the backward (bytes): [Q images NT x 4 KB | dO images | dQ accumulators (fp32, register layout) | per-wave scratch (K^T
+// staging, then dS) | weight slices of one head 32 KB | key mask adders, -lse, D, biases, LayerNorm partials]
+__host__ __device__ constexpr int bwd32_small_floats(int NT) { return 3 * NT * 32 + 192 + NT * 128 + 8; }
+__host__ __device__ constexpr int bwd32_lds(int NT) { return 4 * NT * P_TILE + 8 * P_TILE + bwd32_small_floats(NT) * 4; }
+
+template <bool EMBED, bool DROP>
+__global__ __launch_bounds__(512, 2) void attn32_bwd_kernel(A32BwdP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem32[];
+  const int NT = p.NT, L = p.L;
+  char* const QIMG = smem32;
+  char* const DOIMG = QIMG + NT * P_TILE;
+  char* const DQACC = DOIMG + NT * P_TILE;
+  char* const SCRALL = DQACC + NT * P_TILE;
+  char* const WIMG = SCRALL + NT * P_TILE;            // [Wq 2 tiles | Wk 2 | Wv 2 | Wo rows of the head: 2 panels]
+  float* const sAdd = reinterpret_cast<float*>(WIMG + 8 * P_TILE);   // (mask adder - amax) * log2e per key, -inf beyond L
+  float* const sCS = sAdd + NT * 32;                  // -lse * log2e per query of this head (-inf: pad)
+  float* const sD = sCS + NT * 32;                    // rowsum(dctx * ctx) per query of this head
+  float* const sbq = sD + NT * 32;                    // bqkv [192]
+  float* const sred = sbq + 192;                      // [NT][128] LayerNorm partials
+  int* const sflag = reinterpret_cast<int*>(sred + NT * 128);   // [NT] steps of the sweep each wave has finished
+
+  const int nthreads = blockDim.x;
+  const int b = blockIdx.x;
+  const int64_t row0 = (int64_t)b * L;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char* const scr = SCRALL + wave * P_TILE;
+  // Lane constants are derived from an OPAQUE copy of the lane id inside each head pass and again in the epilogue: hipcc otherwise
+  // hoists every lane-invariant address, dropout hash and fragment offset of both heads to the kernel's entry and spills them (70-100
+  // registers in scratch); recomputing them costs ~60 vector instructions per pass.
+#define A32_LANE_CONSTS()                                                           \
+  int ln = lane;                                                                    \
+  asm volatile("" : "+v"(ln));                                                      \
+  const Lane32 lk = lane32(ln);                                                     \
+  const int r = lk.r, h = lk.h;                                                     \
+  const int tok = 32 * wave + r, tokc = min(tok, L - 1);                            \
+  const bool live = tok < L;                                                        \
+  const RowLay rl = row_lay(ln, wave, L);                                           \
+  const int rl_row = rl.row, rl_c4 = rl.c4;                                         \
+  (void)tokc; (void)live; (void)rl_row; (void)rl_c4
+
+  // key mask: one turn (at least 32 threads per 32 tokens)
+  const int64_t mval = (int)threadIdx.x < L ? p.mask[row0 + threadIdx.x] : 0;
+  const int any_key = mval != 0 ? 1 : 0;
+  for (int k = threadIdx.x; k < 192; k += nthreads) sbq[k] = p.bqkv[k];
+  const float amax = __syncthreads_or(any_key) ? 0.0f : -1e9f;
+  const bool dead = amax != 0.0f;   // every key masked: Keras' -1e9 absorbs the scores, the softmax is uniform over all L keys
+  if ((int)threadIdx.x < NT * 32)
+    sAdd[threadIdx.x] = (int)threadIdx.x < L ? (((1.0f - (float)mval) * -1e9f) - amax) * LOG2E : -INFINITY;
+
+  const DropCtx dcp = b4r_drop_ctx(p.drop_p);
+  const DropCtx dco = b4r_drop_ctx(p.drop_o);
+  const float pscale = DROP ? dcp.scale : 1.0f;
+
+  // the wave's 32 x 64 fp32 block of a [N, 64] tensor in ROW layout (RowLay): 1 KB contiguous per wave-instruction
+  const float* const xb = p.x + row0 * HID;       // wave-uniform bases of the sequence's rows
+  const float* const dzb = p.dz1 + row0 * HID;
+  const float* const ctxb = p.ctx + row0 * HID;
+  float* const dab = p.da + row0 * HID;
+  float* const dqkvb = p.dqkv + row0 * (3 * HID);
+  char* const ownA = QIMG + wave * P_TILE;
+  char* const ownB = DOIMG + wave * P_TILE;
+  char* const ownC = DQACC + wave * P_TILE;
+
+  f32x16 dx[2];   // dX^T[hidden 32 rt + ..][token] of ONE head: the first head's waits in `da` (the wave's own rows) for the epilogue --
+                  // 32 registers that the sweep of the second head needs
+
+  A32_MARK(0);
+  for (int hd = 0; hd < 2; ++hd) {
+    A32_LANE_CONSTS();
+    const int64_t bh = (int64_t)b * 2 + hd;
+    // ---- requests first: x and dz1 rows of the wave's tokens (row layout, coalesced), lse, the ctx columns of this head -----------
+    f32x4 xr[8], yr[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { xr[i] = ld4(xb, rl_off(rl, i)); yr[i] = ld4(dzb, rl_off(rl, i)); }
+    const float lse_q = live ? (p.lse + bh * L)[(uint32_t)tok] : INFINITY;
+    f32x4 cx[4];
+#pragma unroll
+    for (int gp = 0; gp < 4; ++gp) cx[gp] = ld4(ctxb, (uint32_t)(tokc * HID + 32 * hd + 4 * h + 8 * gp));
+    A32_MARK(1 + 10 * hd);
+    lds_barrier();   // every wave is done with the previous head's weight slices (the wave's own tiles were free before)
+    A32_MARK(2 + 10 * hd);
+    // tiles 0..5: W_j[hidden 32 rt ..][features 32 hd ..] (j = q, k, v; tile 2j + rt); 6, 7: Wo[32 hd ..][hidden 32 (gt - 6) ..]
+    stage_tiles<5>(WIMG, 8, nthreads, [&](int gt, int& ld) __attribute__((always_inline)) -> const float* {
+      const bool wo = gt >= 6;
+      ld = wo ? HID : 3 * HID;
+      return wo ? p.Wo + (int64_t)32 * hd * HID + 32 * (gt - 6) : p.Wqkv + (int64_t)32 * (gt & 1) * (3 * HID) + HID * (gt >> 1) + 32 * hd;
+    });
+    // x -> images in the wave's Q / dO tiles, dropmask(dz1) -> images in its dQ-accumulator tile and scratch
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      rl_to_panels(rl, ownA, ownB, i, xr[i]);
+      f32x4 dy = yr[i];
+      if (dco.on) dy = b4r_drop4(dco, dy, (uint64_t)(row0 + 32 * wave + 4 * i + rl_row) * HID + (uint64_t)(4 * rl_c4));
+      rl_to_panels(rl, ownC, scr, i, dy);
+    }
+    A32_MARK(3 + 10 * hd);
+    lds_barrier();
+    A32_MARK(4 + 10 * hd);
+
+    // ---- q~, k, v of this head (recomputed) and dctx = dropmask(dz1).Wo^T, transposed: rows = feature, lane = token -------------
+    f32x16 qT, kT, vT, dcT;
+    {
+      const f32x16 bq = rows_of(sbq + 32 * hd, h), bk = rows_of(sbq + HID + 32 * hd, h), bv = rows_of(sbq + 2 * HID + 32 * hd, h);
+      qT = bq; kT = bk; vT = bv; dcT = zero16();
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const char* xt = ((ks >> 1) ? ownB : ownA) + lk.rowc[ks & 1];    // B = x^T[k = hidden][token]: chunk 2 (ks & 1) + h of row `token`
+        const char* yt = ((ks >> 1) ? scr : ownC) + lk.rowc[ks & 1];
+        const bf16x8 xh = row_at(xt), xl = row_at(xt + P_IMG), yh = row_at(yt), yl = row_at(yt + P_IMG);
+        const char* wq = WIMG + (ks >> 1) * P_TILE;
+        const int a0 = lk.trn[ks & 1][0], a1 = lk.trn[ks & 1][1];
+        qT = mfma32x3(tr_pair(wq + a0, wq + a1), tr_pair(wq + P_IMG + a0, wq + P_IMG + a1), xh, xl, qT);
+        const char* wk = wq + 2 * P_TILE;
+        kT = mfma32x3(tr_pair(wk + a0, wk + a1), tr_pair(wk + P_IMG + a0, wk + P_IMG + a1), xh, xl, kT);
+        const char* wv = wq + 4 * P_TILE;
+        vT = mfma32x3(tr_pair(wv + a0, wv + a1), tr_pair(wv + P_IMG + a0, wv + P_IMG + a1), xh, xl, vT);
+        const char* wo = WIMG + (6 + (ks >> 1)) * P_TILE + lk.rowc[ks & 1];   // A = Wo[row = context column][k = hidden], by rows
+        dcT = mfma32x3(row_at(wo), row_at(wo + P_IMG), yh, yl, dcT);
+      }
+      qT = qT * (p.qscale * LOG2E);
+    }
+    A32_MARK(5 + 10 * hd);
+    // D = sum_c dctx * ctx over this head's 32 columns (the softmax backward's row term)
+    {
+      float d = 0.f;
+#pragma unroll
+      for (int gp = 0; gp < 4; ++gp)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d = fmaf(dcT[4 * gp + e], cx[gp][e], d);
+      d += other_half(d, h);
+      if (h == 0) { sD[tok] = d; sCS[tok] = -lse_q * LOG2E; }
+    }
+    // operand forms and images of the wave's tile (the x / dz1 images are dead: every read of them is in front of these writes)
+    bf16x8 kBh[2], kBl[2], vBh[2], vBl[2];     // K^T, V^T [feature][key] as B operands of S = Q~.K^T and dA = dO.V^T
+#pragma unroll
+    for (int s = 0; s < 2; ++s) { acc_frag(kT, s, kBh[s], kBl[s]); acc_frag(vT, s, vBh[s], vBl[s]); }
+    acc_to_rows(ownA, lk, qT);
+    acc_to_rows(ownB, lk, dcT);
+    acc_to_rows(scr, lk, kT);
+    bf16x8 kTh[2], kTl[2];                     // K^T[feature position][key] as the A operand of dQ^T = K^T.dS^T
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      kTh[s] = tr_pair(scr + lk.trn[s][0], scr + lk.trn[s][1]);
+      kTl[s] = tr_pair(scr + P_IMG + lk.trn[s][0], scr + P_IMG + lk.trn[s][1]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(ownC + j * 1024 + lane * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    A32_MARK(6 + 10 * hd);
+    if (lane == 0) sflag[wave] = 0;
+    lds_barrier();   // images, D, -lse of every tile in place; accumulators zero; (the K^T reads above have landed: lgkmcnt(0))
+    A32_MARK(7 + 10 * hd);
+
+    // ---- the sweep: wave w (key tile w) x query tile (w + s) mod NT.  A step is a VECTOR phase (S, dA of this tile -> Pd, dS as
+    // operand fragments; dS also to the wave's scratch image) and a MATRIX phase of ten 3-instruction products issued back to back:
+    // dV, dK (two query halves each), S, dA of the NEXT tile (two feature halves each), the dQ partial (two key halves).  Every
+    // product's LDS fragments are requested two products ahead (hipcc otherwise puts each read next to its use: a wave then waits
+    // out the LDS latency in front of every product, and two waves per SIMD cannot cover that).  No barrier inside the sweep: the dQ
+    // accumulator of tile t was last touched by wave w + 1 in ITS previous step, a flag per wave orders that (fixed order of the
+    // additions => bitwise reproducible).
+    f32x16 dK = zero16(), dV = zero16(), S, dA;
+    const float adk = sAdd[tok];
+    if (dead) {   // S = -lse for every key: the scores are absorbed by the mask adder
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { kBh[ks][e] = (__bf16)0.f; kBl[ks][e] = (__bf16)0.f; }
+    }
+#define A32_LD_TR(img, s2, H, Lo)                                                \
+  H = tr_pair((img) + lk.trp[s2][0], (img) + lk.trp[s2][1]);                     \
+  Lo = tr_pair((img) + P_IMG + lk.trp[s2][0], (img) + P_IMG + lk.trp[s2][1])
+#define A32_LD_ROW(img, ks, H, Lo)                                               \
+  H = row_at((img) + lk.rowc[ks]);                                               \
+  Lo = row_at((img) + P_IMG + lk.rowc[ks])
+#define A32_LD_SCR(ks, H, Lo)                                                    \
+  H = tr_pair(scr + lk.trn[ks][0], scr + lk.trn[ks][1]);                         \
+  Lo = tr_pair(scr + P_IMG + lk.trn[ks][0], scr + P_IMG + lk.trn[ks][1])
+#define A32_SB() __builtin_amdgcn_sched_barrier(0)
+    auto tile_of = [&](int s) __attribute__((always_inline)) { const int t = wave + s; return t >= NT ? t - NT : t; };
+    typedef const __attribute__((address_space(4))) uint64_t* kmask_ptr;   // constant address space: scalar loads
+    {   // S, dA of the first tile
+      const char* qimg = QIMG + wave * P_TILE;
+      const char* dimg = DOIMG + wave * P_TILE;
+      S = rows_of(sCS + 32 * wave, h);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) S[e] += adk;
+      dA = zero16();
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 ah, al;
+        A32_LD_ROW(qimg, ks, ah, al);
+        S = mfma32x3(ah, al, kBh[ks], kBl[ks], S);
+        A32_LD_ROW(dimg, ks, ah, al);
+        dA = mfma32x3(ah, al, vBh[ks], vBl[ks], dA);
+      }
+    }
+    for (int s = 0; s < NT; ++s) {
+      const int t = tile_of(s), tn = tile_of(s + 1);   // (the last step forms S / dA of a tile nobody uses: no branch in the body)
+      const char* qimg = QIMG + t * P_TILE;
+      const char* dimg = DOIMG + t * P_TILE;
+      const char* qn = QIMG + tn * P_TILE;
+      const char* dn = DOIMG + tn * P_TILE;
+      A32_SWEEP(2 + 4 * s);
+      // ---- vector phase ------------------------------------------------------------------------------------------------------
+      bf16x8 f0h, f0l, f1h, f1l;
+      A32_LD_TR(dimg, 0, f0h, f0l);   // the first two products' fragments travel during the vector phase
+      A32_LD_TR(qimg, 0, f1h, f1l);
+      const f32x16 Dq = rows_of(sD + 32 * t, h);
+      uint64_t km[16];   // keep decisions of the 32 x 32 block: register tt's lane mask over the keys
+      if (DROP) {
+        kmask_ptr mp = (kmask_ptr)(reinterpret_cast<const uint64_t*>(p.bits) + ((bh * NT + wave) * NT + t) * 16);
+#pragma unroll
+        for (int tt = 0; tt < 16; ++tt) km[tt] = mp[tt];
+      }
+      bf16x8 pdh[2], pdl[2], dsh[2], dsl[2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        f32x8 pd, ds;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int tt = 8 * s2 + j;
+          const float pr = (A32_EXP & 1) ? S[tt] : __builtin_amdgcn_exp2f(S[tt]);
+          if (A32_EXP & 1) { pd[j] = pr; ds[j] = dA[tt]; } else
+          if (DROP) {
+            const float kf = __builtin_amdgcn_inverse_ballot_w64(km[tt]) ? pscale : 0.f;
+            pd[j] = pr * kf;
+            ds[j] = pr * fmaf(dA[tt], kf, -Dq[tt]);
+          } else {
+            pd[j] = pr;
+            ds[j] = pr * (dA[tt] - Dq[tt]);
+          }
+        }
+        split8(pd, pdh[s2], pdl[s2]);
+        split8(ds, dsh[s2], dsl[s2]);
+        // dS -> the wave's [key][query] scratch image: registers 4a .. 4a+3 of this half are queries 16 s2 + 8a + 4h + (0..3)
+        const s16x8 hv = __builtin_bit_cast(s16x8, dsh[s2]), lv = __builtin_bit_cast(s16x8, dsl[s2]);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          char* w8 = scr + p_chunk(r, 2 * s2 + a) + 8 * h;
+          *reinterpret_cast<s16x4*>(w8) = a ? __builtin_shufflevector(hv, hv, 4, 5, 6, 7) : __builtin_shufflevector(hv, hv, 0, 1, 2, 3);
+          *reinterpret_cast<s16x4*>(w8 + P_IMG) = a ? __builtin_shufflevector(lv, lv, 4, 5, 6, 7) : __builtin_shufflevector(lv, lv, 0, 1, 2, 3);
+        }
+      }
+      // S of the next tile starts from -lse (per query) + the key's mask adder
+      S = rows_of(sCS + 32 * tn, h);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) S[e] += adk;
+      A32_SWEEP(3 + 4 * s);
+      A32_SB();
+      // ---- matrix phase: ten products, fragments requested two products ahead ---------------------------------------------------
+      bf16x8 f2h, f2l, f3h, f3l, f4h, f4l, f5h, f5l, f6h, f6l, f7h, f7l, f8h, f8l, f9h, f9l;
+      A32_LD_TR(dimg, 1, f2h, f2l);
+      dV = mfma32x3(f0h, f0l, pdh[0], pdl[0], dV);   // dV^T[feature][key] += dO^T[feature][query] . Pd[query][key], queries 0..15
+      A32_SB();
+      A32_LD_TR(qimg, 1, f3h, f3l);
+      dK = mfma32x3(f1h, f1l, dsh[0], dsl[0], dK);   // dK^T += Q~^T . dS
+      A32_SB();
+      A32_LD_ROW(qn, 0, f4h, f4l);
+      dV = mfma32x3(f2h, f2l, pdh[1], pdl[1], dV);
+      A32_SB();
+      A32_LD_ROW(dn, 0, f5h, f5l);
+      dK = mfma32x3(f3h, f3l, dsh[1], dsl[1], dK);
+      A32_SB();
+      A32_LD_ROW(qn, 1, f6h, f6l);
+      S = mfma32x3(f4h, f4l, kBh[0], kBl[0], S);     // S[query][key] = Q~ . K^T of the next tile
+      A32_SB();
+      A32_LD_ROW(dn, 1, f7h, f7l);
+      dA = mfma32x3(f5h, f5l, vBh[0], vBl[0], zero16());
+      A32_SB();
+      A32_LD_SCR(0, f8h, f8l);
+      S = mfma32x3(f6h, f6l, kBh[1], kBl[1], S);
+      A32_SB();
+      A32_LD_SCR(1, f9h, f9l);
+      dA = mfma32x3(f7h, f7l, vBh[1], vBl[1], dA);
+      A32_SB();
+      // dQ^T[feature position][query] = K^T[.][key] . dS^T[key][query]  (B by transposed reads of the scratch image)
+      f32x16 dQp = mfma32x3(kTh[0], kTl[0], f8h, f8l, zero16());
+      dQp = mfma32x3(kTh[1], kTl[1], f9h, f9l, dQp);
+      A32_SWEEP(4 + 4 * s);
+      if (s > 0) {   // the accumulator's previous addition (wave w + 1, its step s - 1) must be in place
+        const volatile int* f = sflag + (wave + 1 < NT ? wave + 1 : 0);
+        while (*f < s) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+      }
+      char* acc = DQACC + t * P_TILE + lane * 16;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4* a4 = reinterpret_cast<f32x4*>(acc + j * 1024);
+        *a4 = *a4 + (f32x4){dQp[4 * j], dQp[4 * j + 1], dQp[4 * j + 2], dQp[4 * j + 3]};
+      }
+      asm volatile("" ::: "memory");
+      *reinterpret_cast<volatile int*>(sflag + wave) = s + 1;   // LDS operations of a wave complete in order: the sums are in place
+      A32_SWEEP(5 + 4 * s);
+    }
+    lds_barrier();   // every accumulator is complete
+
+    // ---- results of this head for the wave's tokens: registers 8s .. 8s+7 = features 16s + 8h + (0..7) ----------------------------
+    A32_MARK(8 + 10 * hd);
+    f32x16 gq;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(ownC + j * 1024 + lane * 16);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gq[4 * j + e] = a4[e] * p.qscale;
+    }
+    const f32x16 gk = dK * LN2;   // Q~ carries log2(e)
+    if (live) {
+      const uint32_t dst = (uint32_t)(tok * (3 * HID) + 32 * hd + 8 * h);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const int o = 8 * s + 4 * hf;
+          st4(dqkvb, dst + 16 * s + 4 * hf, (f32x4){gq[o], gq[o + 1], gq[o + 2], gq[o + 3]});
+          st4(dqkvb, dst + HID + 16 * s + 4 * hf, (f32x4){gk[o], gk[o + 1], gk[o + 2], gk[o + 3]});
+          st4(dqkvb, dst + 2 * HID + 16 * s + 4 * hf, (f32x4){dV[o], dV[o + 1], dV[o + 2], dV[o + 3]});
+        }
+      }
+    }
+    // dX^T[hidden][token] += W_j[hidden][feature] . g_j^T[feature][token], j = q, k, v: A by rows of the weight slices
+    dx[0] = zero16(); dx[1] = zero16();
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const f32x16& gsrc = j == 0 ? gq : (j == 1 ? gk : dV);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 gh, gl;
+        acc_frag(gsrc, s, gh, gl);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          const char* wj = WIMG + (2 * j + rt) * P_TILE + lk.rowc[s];
+          dx[rt] = mfma32x3(row_at(wj), row_at(wj + P_IMG), gh, gl, dx[rt]);
+        }
+      }
+    }
+    A32_MARK(9 + 10 * hd);
+    if (hd == 0) {   // the first head's dX waits in `da`, in row layout (the sweep is over: the wave's Q / dO tiles are free)
+      f32x4 o[8];
+      acc_to_rl(rl, ownA, ownB, r, h, dx, o);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (32 * wave + 4 * i + rl_row < L) st4(dab, rl_off(rl, i), o[i]);
+    }
+  }
+
+  A32_MARK(30);
+  // ---- dx = dX + dz1 (residual), then back through the LayerNorm (and, for layer 0, the dropout) that produced x: row layout -----
+  A32_LANE_CONSTS();
+  const DropCtx dce = b4r_drop_ctx(p.drop_e);
+  f32x4 dxr[8];
+  acc_to_rl(rl, ownA, ownB, r, h, dx, dxr);
+  const f32x4 gm = *reinterpret_cast<const f32x4*>(p.gprev + 4 * rl_c4);
+  f32x4 dgam = {0.f, 0.f, 0.f, 0.f}, dbet = {0.f, 0.f, 0.f, 0.f};
+  f32x4 dzo[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int trow = 32 * wave + 4 * i + rl_row;
+    const bool lv = trow < L;
+    const int64_t grow = row0 + min(trow, L - 1);
+    f32x4 d4 = (dxr[i] + ld4(dab, rl_off(rl, i))) + ld4(dzb, rl_off(rl, i));
+    f32x4 zz;
+    if (EMBED) {
+      d4 = b4r_drop4(dce, d4, (uint64_t)(row0 + trow) * HID + (uint64_t)(4 * rl_c4));
+      int64_t id = p.ids[grow];
+      if (id < 0 || id >= p.V) id = 0;   // as the forward: out-of-range ids read the PAD row
+      zz = *reinterpret_cast<const f32x4*>(p.table + id * HID + 4 * rl_c4) +
+           *reinterpret_cast<const f32x4*>(p.pos + (int64_t)min(trow, L - 1) * HID + 4 * rl_c4);
+    } else {
+      zz = ld4(p.zprev + row0 * HID, rl_off(rl, i));
+    }
+    const float mean = (p.meanp + row0)[(uint32_t)min(trow, L - 1)], rstd = (p.rstdp + row0)[(uint32_t)min(trow, L - 1)];
+    const f32x4 xhat = (zz - mean) * rstd;
+    const f32x4 ge = d4 * gm;
+    const float c1 = row_allsum16(sum4(ge)) * (1.0f / HID), c2 = row_allsum16(sum4(ge * xhat)) * (1.0f / HID);
+    if (lv) { dgam += d4 * xhat; dbet += d4; }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dzo[i][e] = rstd * (ge[e] - c1 - xhat[e] * c2);
+  }
+  // column sums over the wave's tokens: the four lane rows hold different tokens of the same columns
+  float* const myred = sred + wave * 128;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    dgam[e] += other_row(dgam[e]); dgam[e] += other_half(dgam[e], h);
+    dbet[e] += other_row(dbet[e]); dbet[e] += other_half(dbet[e], h);
+  }
+  if (lane < 16) {
+    *reinterpret_cast<f32x4*>(&myred[4 * rl_c4]) = dgam;
+    *reinterpret_cast<f32x4*>(&myred[64 + 4 * rl_c4]) = dbet;
+  }
+  A32_MARK(31);
+  lds_barrier();
+  for (int k = threadIdx.x; k < 128; k += nthreads) {
+    float acc = 0.f;
+    for (int w = 0; w < NT; ++w) acc += sred[w * 128 + k];
+    p.ln_part[(int64_t)b * 128 + k] = acc;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (32 * wave + 4 * i + rl_row < L) st4(dab, rl_off(rl, i), dzo[i]);
+  A32_MARK(32);
+}
+
+bool al16(const void* q) { return q == nullptr || b4r_aligned16(q); }
+
+}  // namespace
+
+int32_t b4r_attn32_supported(int32_t hidden_size, int32_t num_heads, int32_t L) {
+  return (hidden_size == HID && num_heads == 2 && L > 0 && L <= 224 && b4r_get_gemm_mode() == B4R_GEMM_BF16X3) ? 1 : 0;
+}
+
+// attention-dropout decisions of one layer: [B][head][key tile][query tile][16 register pairs] x 2 uint32
+int64_t b4r_attn32_keep_words(int32_t B, int32_t L, int32_t heads) {
+  const int64_t NT = b4r_cdiv(L, 32);
+  return (int64_t)B * heads * NT * NT * 32;
+}
+
+#ifdef A32_PROF
+extern "C" int b4r_debug_a32_prof(long long* host_out) {   // 64 stamps of the last backward launch (after a device synchronisation)
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_a32_prof), 64 * sizeof(long long)) == hipSuccess ? 0 : -4;
+}
+extern "C" int b4r_debug_a32_sweep(long long* host_out) {   // [2 waves][64] stamps inside the sweep of head 0
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_a32_sweep), 128 * sizeof(long long)) == hipSuccess ? 0 : -4;
+}
+#endif
+int64_t b4r_attn_rx_keep_words(int B, int L, int heads);
+int b4r_launch_slab_reduce_full(const float* slab, int S, int Mo, int No, float* out, int ldo, int accumulate,
+                                const float* cslab, float* colsum, const float* caslab, float* colsum_a, hipStream_t stream);
+
+int b4r_attn32_bwd(const b4r_attn_block_bwd_desc* d, b4r_stream_t stream) {
+  B4R_CHECK_ARG(d != nullptr, B4R_E_BADARG, "b4r_attn_block_bwd: null descriptor");
+  B4R_CHECK_ARG(b4r_attn32_supported(d->H, d->heads, d->L), B4R_E_SHAPE,
+                "b4r_attn_block_bwd: needs hidden size 64, 2 heads, L <= 224 and the bf16x3 mode (H=%d heads=%d L=%d)", d->H, d->heads,
+                d->L);
+  B4R_CHECK_ARG(d->B > 0 && d->x && d->dz1 && d->ctx && d->lse && d->input_mask && d->Wqkv && d->bqkv && d->Wo && d->prev_mean &&
+                    d->prev_rstd && d->prev_gamma && d->dqkv && d->dx_prev && d->dprev_gamma && d->scratch,
+                B4R_E_BADARG, "b4r_attn_block_bwd: null argument");
+  const bool embed = d->emb_ids != nullptr;
+  B4R_CHECK_ARG(embed ? (d->emb_table && d->emb_pos && d->emb_vocab > 0) : (d->prev_z != nullptr), B4R_E_BADARG,
+                "b4r_attn_block_bwd: needs prev_z, or emb_ids + emb_table + emb_pos");
+  B4R_CHECK_ARG(al16(d->x) && al16(d->dz1) && al16(d->ctx) && al16(d->Wqkv) && al16(d->Wo) && al16(d->prev_z) && al16(d->prev_gamma) &&
+                    al16(d->emb_table) && al16(d->emb_pos) && al16(d->dqkv) && al16(d->dx_prev) && al16(d->keep_bits),
+                B4R_E_ALIGN, "b4r_attn_block_bwd: operands must be 16-byte aligned");
+  A32BwdP p{};
+  p.x = d->x; p.dz1 = d->dz1; p.ctx = d->ctx; p.lse = d->lse; p.mask = d->input_mask;
+  p.bits = d->keep_bits ? d->keep_bits + b4r_attn_rx_keep_words(d->B, d->L, d->heads) : nullptr;   // behind round 1's layout
+  p.Wqkv = d->Wqkv; p.bqkv = d->bqkv; p.Wo = d->Wo;
+  p.zprev = d->prev_z; p.meanp = d->prev_mean; p.rstdp = d->prev_rstd; p.gprev = d->prev_gamma;
+  p.ids = d->emb_ids; p.table = d->emb_table; p.pos = d->emb_pos; p.V = d->emb_vocab;
+  p.dqkv = d->dqkv; p.da = d->dx_prev; p.ln_part = d->scratch;
+  p.B = d->B; p.L = d->L; p.NT = b4r_cdiv(d->L, 32);
+  p.qscale = 1.0f / sqrtf(32.0f);
+  p.drop_p = b4r_make_drop(d->rng, d->probs_stream, d->probs_rate, d->rng != nullptr);
+  p.drop_o = b4r_make_drop(d->rng, d->out_stream, d->out_rate, d->rng != nullptr);
+  p.drop_e = b4r_make_drop(d->rng, d->emb_stream, d->emb_rate, d->rng != nullptr && embed);
+  B4R_CHECK_ARG(!p.drop_p.rng || d->keep_bits, B4R_E_BADARG, "b4r_attn_block_bwd: attention dropout needs the forward's keep_bits");
+  const size_t sh = (size_t)bwd32_lds(p.NT);
+  const dim3 grid((unsigned)d->B), block((unsigned)(64 * p.NT));
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  const bool drop = p.drop_p.rng != nullptr && p.drop_p.thr != 0;
+#define A32_BWD_CASE(E_, D_)                                                                          \
+  {                                                                                                   \
+    rc = b4r_raise_lds((const void*)attn32_bwd_kernel<E_, D_>, sh, "b4r_attn_block_bwd");             \
+    if (rc) return rc;                                                                                \
+    hipLaunchKernelGGL((attn32_bwd_kernel<E_, D_>), grid, block, sh, s, p);                           \
+  }
+  if (embed) { if (drop) A32_BWD_CASE(true, true) else A32_BWD_CASE(true, false) }
+  else { if (drop) A32_BWD_CASE(false, true) else A32_BWD_CASE(false, false) }
+#undef A32_BWD_CASE
+  B4R_CHECK_LAUNCH("b4r_attn_block_bwd");
+  // gamma / beta gradients of the previous LayerNorm: ordered sum over the sequences (queued with the caller's reductions)
+  return b4r_launch_slab_reduce_full(d->scratch, d->B, 1, 128, d->dprev_gamma, 128, 0, nullptr, nullptr, nullptr, nullptr, s);
+}

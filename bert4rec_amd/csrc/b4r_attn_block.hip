@@ -27,6 +27,7 @@ struct AbP {
   const float* x; const int64_t* mask;
   const float* Wqkv; const float* bqkv; const float* Wo; const float* bo; const float* g1; const float* be1;
   float* qkv; float* ctx; float* lse; uint32_t* bits;
+  uint32_t* bits32;   // the same decisions as one word per (query, 32-key tile), the layout b4r_attn32.hip's backward reads (or NULL)
   float* z1; float* x1; float* mean1; float* rstd1;
   int B, L, KT;
   float qscale, eps;
@@ -257,6 +258,17 @@ __global__ __launch_bounds__(1024) void attn_block_fwd_kernel(AbP p) {
         uint32_t* wo = p.bits + ((bh * p.KT + wave) * 2) * 64 + lane;
         wo[0] = w[0];
         wo[64] = w[1];
+      }
+      if (p.bits32) {   // [b][head][key tile T][query tile][16 register pairs][2]: bit k of the word = key 32 T + k
+        const int NT = (L + 31) >> 5, qt = tok >> 5, qr = tok & 31;
+        const int slot = (qr & 24) | ((qr & 3) << 1) | ((qr >> 2) & 1);   // query 16s + 8a + 4h' + b -> 16s + 8a + 2b + h'
+        for (int T = 0; T < NT; ++T) {
+          const uint32_t by = (w[T >> 2] >> (8 * (T & 3))) & 0xFFu;        // the nibbles of the 16-key tiles 2T, 2T + 1
+          uint32_t part = ((by & 15u) | ((by >> 4) << 16)) << (4 * g);     // rows 4g .. 4g+3 of each
+          part |= (uint32_t)__shfl_xor((int)part, 16, 64);
+          part |= (uint32_t)__shfl_xor((int)part, 32, 64);
+          if (g == 0 && live) p.bits32[((bh * NT + T) * NT + qt) * 32 + slot] = part;
+        }
       }
     } else {
 #pragma unroll
@@ -716,6 +728,14 @@ bool al16(const void* q) { return q == nullptr || b4r_aligned16(q); }
 
 }  // namespace
 
+int32_t b4r_attn32_supported(int32_t hidden_size, int32_t num_heads, int32_t L);
+int b4r_attn32_bwd(const b4r_attn_block_bwd_desc* d, b4r_stream_t stream);
+int64_t b4r_attn_rx_keep_words(int B, int L, int heads);
+static bool use_attn32() {
+  static const bool on = !(getenv("B4R_ATTN32") && atoi(getenv("B4R_ATTN32")) == 0);
+  return on;
+}
+
 extern "C" int32_t b4r_attn_block_supported(int32_t hidden_size, int32_t num_heads, int32_t L) {
   return (hidden_size == HID && num_heads == 2 && L > 0 && L <= 256 && b4r_get_gemm_mode() == B4R_GEMM_BF16X3) ? 1 : 0;
 }
@@ -738,6 +758,7 @@ int b4r_launch_slab_reduce_full(const float* slab, int S, int Mo, int No, float*
 
 extern "C" int b4r_attn_block_bwd(const b4r_attn_block_bwd_desc* d, b4r_stream_t stream) {
   B4R_CHECK_ARG(d != nullptr, B4R_E_BADARG, "b4r_attn_block_bwd: null descriptor");
+  if (use_attn32() && b4r_attn32_supported(d->H, d->heads, d->L)) return b4r_attn32_bwd(d, stream);
   B4R_CHECK_ARG(b4r_attn_block_bwd_supported(d->H, d->heads, d->L), B4R_E_SHAPE,
                 "b4r_attn_block_bwd: needs hidden size 64, 2 heads, L <= 208 and the bf16x3 mode (H=%d heads=%d L=%d)", d->H, d->heads,
                 d->L);
@@ -805,6 +826,7 @@ extern "C" int b4r_attn_block_fwd(const b4r_attn_block_desc* d, b4r_stream_t str
   p.drop_p = b4r_make_drop(d->rng, d->probs_stream, d->probs_rate, d->rng != nullptr);
   p.drop_o = b4r_make_drop(d->rng, d->out_stream, d->out_rate, d->rng != nullptr);
   B4R_CHECK_ARG(!p.drop_p.rng || d->keep_bits, B4R_E_BADARG, "b4r_attn_block_fwd: attention dropout needs keep_bits");
+  if (p.bits && use_attn32() && b4r_attn32_supported(d->H, d->heads, d->L)) p.bits32 = p.bits + b4r_attn_rx_keep_words(d->B, d->L, d->heads);
   if (embed) {
     p.ids = d->emb_ids; p.table = d->emb_table; p.pos = d->emb_pos; p.g0 = d->emb_gamma; p.be0 = d->emb_beta; p.V = d->emb_vocab;
     p.x_out = d->emb_x; p.mean0 = d->emb_mean; p.rstd0 = d->emb_rstd; p.eps0 = d->emb_eps;

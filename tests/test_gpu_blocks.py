@@ -214,8 +214,9 @@ def test_attn_block_forward_matches_fp64(B, L, p_rate, o_rate):
     _lib.check(lib.b4r_attn_fwd(P(out["qkv"]), P(maskd), B, L, 2, P(ctx2), P(lse2), P(st), site_p, p_rate, P(bits2), stream()))
     torch.cuda.synchronize()
     assert T.maxdiff(ctx2, out["ctx"]) < 2e-5
-    if p_rate > 0:
-        assert torch.equal(bits2, bits)
+    if p_rate > 0:   # round 1's layout comes first in the buffer; behind it the block keeps one word per (query, 32-key tile)
+        n_old = B * 2 * ((L + 15) // 16) * 128
+        assert torch.equal(bits2[:n_old], bits[:n_old])
 
 
 def attn_bwd_reference(t, mask, B, L, p_rate, o_rate, e_rate, seed, step, site_p, site_o, site_e, prev, eps=1e-12):

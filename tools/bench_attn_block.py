@@ -58,6 +58,35 @@ if hasattr(lib, "b4r_debug_ab_prof"):   # a -DAB_PROF build: phase stamps of wor
     for k in sorted(names, key=lambda k: t[k]):
         print("%-32s +%7d cycles  (total %8d)" % (names[k], t[k] - prev, t[k] - t[0]))
         prev = t[k]
+if hasattr(lib, "b4r_debug_a32_prof"):   # a -DA32_PROF build of b4r_attn32.hip: phase stamps of wave 0 of workgroup 0
+    bwd(); torch.cuda.synchronize()
+    buf = (C.c_longlong * 64)()
+    lib.b4r_debug_a32_prof.argtypes = [C.c_void_p]
+    assert lib.b4r_debug_a32_prof(buf) == 0
+    t = list(buf)
+    names = {0: "start"}
+    for hd in (0, 1):
+        for k, n in ((1, "x / dz1 loads issued"), (2, "barrier (region free)"), (3, "weights staged"), (4, "barrier"), (5, "q k v dctx projected"),
+                     (6, "images / D / K^T written"), (7, "barrier"), (8, "sweep done"), (9, "dqkv stored + dX")):
+            names[k + 10 * hd] = "h%d %s" % (hd, n)
+    names.update({30: "epilogue start", 31: "epilogue: loads + column sums", 32: "end"})
+    prev = t[0]
+    for k in sorted(names, key=lambda k: t[k]):
+        print("%-36s +%7d cycles  (total %8d)" % (names[k], t[k] - prev, t[k] - t[0]))
+        prev = t[k]
+if hasattr(lib, "b4r_debug_a32_sweep"):
+    buf = (C.c_longlong * 128)()
+    lib.b4r_debug_a32_sweep.argtypes = [C.c_void_p]
+    assert lib.b4r_debug_a32_sweep(buf) == 0
+    t = list(buf)
+    NT = (L + 31) // 32
+    for w in (0, 1):
+        tw = t[64 * w:64 * w + 64]
+        print("sweep of head 0, wave %d: m12 %d" % (4 * w, tw[1] - tw[0]))
+        for s in range(NT):
+            a = tw[2 + 4 * s:6 + 4 * s]
+            nxt = tw[2 + 4 * (s + 1)] if 2 + 4 * (s + 1) < 64 else a[3]
+            print("   step %d: vector phase %6d  matrix phase issue %6d  flag wait + accumulate %6d  (-> next step %6d)   (start %d)" % (s, a[1] - a[0], a[2] - a[1], a[3] - a[2], nxt - a[3], a[0] - t[0]))
 # the whole layer forward (attention half + feed-forward half in one launch)
 I = 256
 W1, b1, W2, b2 = r(H, I, sc=0.1), r(I, sc=0.1), r(I, H, sc=0.1), r(H, sc=0.1)

@@ -75,7 +75,7 @@ class AttnBlockBwdDesc(C.Structure):
                 ("prev_mean", C.c_void_p), ("prev_rstd", C.c_void_p), ("prev_gamma", C.c_void_p), ("emb_ids", C.c_void_p),
                 ("emb_table", C.c_void_p), ("emb_pos", C.c_void_p), ("emb_vocab", C.c_int32), ("emb_stream", C.c_uint32),
                 ("emb_rate", C.c_float), ("dqkv", C.c_void_p), ("dx_prev", C.c_void_p), ("dprev_gamma", C.c_void_p),
-                ("scratch", C.c_void_p)]
+                ("scratch", C.c_void_p), ("dWqkv", C.c_void_p), ("dbqkv", C.c_void_p), ("dw_scratch", C.c_void_p)]
 
 
 class FfnDesc(C.Structure):
@@ -149,6 +149,7 @@ PROTOTYPES = {
     "b4r_attn_block_fwd": (C.c_int, [C.POINTER(AttnBlockDesc), _P]),
     "b4r_attn_block_bwd_supported": (_I32, [_I32, _I32, _I32]),
     "b4r_attn_block_bwd_scratch_floats": (_I64, [_I32]),
+    "b4r_attn_block_bwd_dw_scratch_floats": (_I64, [_I32]),
     "b4r_attn_block_bwd": (C.c_int, [C.POINTER(AttnBlockBwdDesc), _P]),
     "b4r_mlm_rows": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P, _P, _P]),
     "b4r_encoder_layer_supported": (_I32, [_I32, _I32, _I32, _I32]),

@@ -122,6 +122,7 @@ struct A32BwdP {
   const float* zprev; const float* meanp; const float* rstdp; const float* gprev;     // the LayerNorm that produced x
   const int64_t* ids; const float* table; const float* pos; int V;                    // ... or the embedding stage (ids != NULL)
   float* dqkv; float* da; float* ln_part;
+  float* dw_slab; float* db_slab;   // per-sequence partials of dWqkv [B][64][192] and dbqkv [B][192] (or NULL: dqkv is written instead)
   int B, L, NT;
   float qscale;
   DropArgs drop_p, drop_o, drop_e;
@@ -129,7 +130,7 @@ struct A32BwdP {
 
 // LDS of the backward (bytes): [Q images NT x 4 KB | dO images | dQ accumulators (fp32, register layout) | per-wave scratch (K^T
 // staging, then dS) | weight slices of one head 32 KB | key mask adders, -lse, D, biases, LayerNorm partials]
-__host__ __device__ constexpr int bwd32_small_floats(int NT) { return 3 * NT * 32 + 192 + NT * 128 + 8; }
+__host__ __device__ constexpr int bwd32_small_floats(int NT) { return 3 * NT * 32 + 192 + NT * 128 + 8 + NT * 96; }
 __host__ __device__ constexpr int bwd32_lds(int NT) { return 4 * NT * P_TILE + 8 * P_TILE + bwd32_small_floats(NT) * 4; }
 
 template <bool EMBED, bool DROP>
@@ -147,6 +148,7 @@ __global__ __launch_bounds__(512, 2) void attn32_bwd_kernel(A32BwdP p) {
   float* const sbq = sD + NT * 32;                    // bqkv [192]
   float* const sred = sbq + 192;                      // [NT][128] LayerNorm partials
   int* const sflag = reinterpret_cast<int*>(sred + NT * 128);   // [NT] steps of the sweep each wave has finished
+  float* const sdb = reinterpret_cast<float*>(sflag + 8);      // [NT][96] column sums of dq | dk | dv over a wave's tokens
 
   const int nthreads = blockDim.x;
   const int b = blockIdx.x;
@@ -432,7 +434,8 @@ __global__ __launch_bounds__(512, 2) void attn32_bwd_kernel(A32BwdP p) {
       for (int e = 0; e < 4; ++e) gq[4 * j + e] = a4[e] * p.qscale;
     }
     const f32x16 gk = dK * LN2;   // Q~ carries log2(e)
-    if (live) {
+    const bool fold = p.dw_slab != nullptr;   // dWqkv / dbqkv formed here instead of writing dqkv for a weight-gradient launch
+    if (live && p.dqkv != nullptr) {
       const uint32_t dst = (uint32_t)(tok * (3 * HID) + 32 * hd + 8 * h);
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -468,6 +471,54 @@ __global__ __launch_bounds__(512, 2) void attn32_bwd_kernel(A32BwdP p) {
 #pragma unroll
       for (int i = 0; i < 8; ++i)
         if (32 * wave + 4 * i + rl_row < L) st4(dab, rl_off(rl, i), o[i]);
+    }
+    if (fold) {
+      A32_LANE_CONSTS();   // (shadows the pass's constants: nothing lane-derived has to survive the sweep for this section)
+      // dWqkv[hidden][feature] = sum over the sequence's tokens of x^T . dqkv: the wave's dq, dk, dv rows go to images (its Q, dO and
+      // scratch tiles; registers 8s .. 8s+7 are features 16s + 8h + .. : natural column order), x comes back as images of two column
+      // panels (the wave's dQ-accumulator tile and its tile of the weight region), then wave w forms output tile w of the six
+      // (j = q, k, v; hidden rows 32 rt ..) over ALL token tiles.  Pad tokens contribute zeros (their dq, dk, dv are zero).
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const f32x16& gsrc = j == 0 ? gq : (j == 1 ? gk : dV);
+        acc_to_rows(j == 0 ? ownA : (j == 1 ? ownB : scr), lk, gsrc);
+#pragma unroll
+        for (int tt = 0; tt < 16; ++tt) {
+          const float cs = half_sum31(gsrc[tt]);
+          if (r == 31) sdb[wave * 96 + 32 * j + 16 * (tt >> 3) + 8 * h + (tt & 7)] = cs;
+        }
+      }
+      f32x4 xr2[8];   // x rows again (L2)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) xr2[i] = ld4(xb, rl_off(rl, i));
+      lds_barrier();   // every wave is done with the weight slices (dX): their region takes the second x panel
+#pragma unroll
+      for (int i = 0; i < 8; ++i) rl_to_panels(rl, ownC, WIMG + wave * P_TILE, i, xr2[i]);
+      lds_barrier();
+      for (int tile = wave; tile < 6; tile += NT) {
+        const int j = tile >> 1, rt = tile & 1;
+        const char* gimg = j == 0 ? QIMG : (j == 1 ? DOIMG : SCRALL);
+        const char* ximg = rt ? WIMG : DQACC;
+        f32x16 acc = zero16();
+        for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const char* xa = ximg + kt * P_TILE;
+            const char* gb = gimg + kt * P_TILE;
+            acc = mfma32x3(tr_pair(xa + lk.trn[s][0], xa + lk.trn[s][1]), tr_pair(xa + P_IMG + lk.trn[s][0], xa + P_IMG + lk.trn[s][1]),
+                           tr_pair(gb + lk.trn[s][0], gb + lk.trn[s][1]), tr_pair(gb + P_IMG + lk.trn[s][0], gb + P_IMG + lk.trn[s][1]), acc);
+          }
+        }
+        float* dst = p.dw_slab + (int64_t)b * (HID * 3 * HID) + HID * j + 32 * hd + r;
+#pragma unroll
+        for (int tt = 0; tt < 16; ++tt) dst[(32 * rt + (tt & 3) + 8 * (tt >> 2) + 4 * h) * (3 * HID)] = acc[tt];
+      }
+      for (int k = threadIdx.x; k < 96; k += nthreads) {
+        float acc = 0.f;
+        for (int w = 0; w < NT; ++w) acc += sdb[w * 96 + k];
+        p.db_slab[(int64_t)b * (3 * HID) + HID * (k >> 5) + 32 * hd + (k & 31)] = acc;
+      }
+      if (hd == 1) lds_barrier();   // the epilogue reuses the tiles the images are in
     }
   }
 
@@ -560,13 +611,15 @@ int b4r_attn32_bwd(const b4r_attn_block_bwd_desc* d, b4r_stream_t stream) {
                 "b4r_attn_block_bwd: needs hidden size 64, 2 heads, L <= 224 and the bf16x3 mode (H=%d heads=%d L=%d)", d->H, d->heads,
                 d->L);
   B4R_CHECK_ARG(d->B > 0 && d->x && d->dz1 && d->ctx && d->lse && d->input_mask && d->Wqkv && d->bqkv && d->Wo && d->prev_mean &&
-                    d->prev_rstd && d->prev_gamma && d->dqkv && d->dx_prev && d->dprev_gamma && d->scratch,
+                    d->prev_rstd && d->prev_gamma && d->dx_prev && d->dprev_gamma && d->scratch,
                 B4R_E_BADARG, "b4r_attn_block_bwd: null argument");
+  B4R_CHECK_ARG(d->dqkv || d->dWqkv, B4R_E_BADARG, "b4r_attn_block_bwd: needs dqkv, or dWqkv + dbqkv + dw_scratch");
+  B4R_CHECK_ARG(!d->dWqkv || (d->dbqkv && d->dw_scratch), B4R_E_BADARG, "b4r_attn_block_bwd: dWqkv needs dbqkv and dw_scratch");
   const bool embed = d->emb_ids != nullptr;
   B4R_CHECK_ARG(embed ? (d->emb_table && d->emb_pos && d->emb_vocab > 0) : (d->prev_z != nullptr), B4R_E_BADARG,
                 "b4r_attn_block_bwd: needs prev_z, or emb_ids + emb_table + emb_pos");
   B4R_CHECK_ARG(al16(d->x) && al16(d->dz1) && al16(d->ctx) && al16(d->Wqkv) && al16(d->Wo) && al16(d->prev_z) && al16(d->prev_gamma) &&
-                    al16(d->emb_table) && al16(d->emb_pos) && al16(d->dqkv) && al16(d->dx_prev) && al16(d->keep_bits),
+                    al16(d->emb_table) && al16(d->emb_pos) && al16(d->dqkv) && al16(d->dx_prev) && al16(d->keep_bits) && al16(d->dw_scratch),
                 B4R_E_ALIGN, "b4r_attn_block_bwd: operands must be 16-byte aligned");
   A32BwdP p{};
   p.x = d->x; p.dz1 = d->dz1; p.ctx = d->ctx; p.lse = d->lse; p.mask = d->input_mask;
@@ -575,6 +628,8 @@ int b4r_attn32_bwd(const b4r_attn_block_bwd_desc* d, b4r_stream_t stream) {
   p.zprev = d->prev_z; p.meanp = d->prev_mean; p.rstdp = d->prev_rstd; p.gprev = d->prev_gamma;
   p.ids = d->emb_ids; p.table = d->emb_table; p.pos = d->emb_pos; p.V = d->emb_vocab;
   p.dqkv = d->dqkv; p.da = d->dx_prev; p.ln_part = d->scratch;
+  const bool fold = d->dWqkv != nullptr;
+  if (fold) { p.dw_slab = d->dw_scratch; p.db_slab = d->dw_scratch + (int64_t)d->B * (HID * 3 * HID); }
   p.B = d->B; p.L = d->L; p.NT = b4r_cdiv(d->L, 32);
   p.qscale = 1.0f / sqrtf(32.0f);
   p.drop_p = b4r_make_drop(d->rng, d->probs_stream, d->probs_rate, d->rng != nullptr);
@@ -597,5 +652,7 @@ int b4r_attn32_bwd(const b4r_attn_block_bwd_desc* d, b4r_stream_t stream) {
 #undef A32_BWD_CASE
   B4R_CHECK_LAUNCH("b4r_attn_block_bwd");
   // gamma / beta gradients of the previous LayerNorm: ordered sum over the sequences (queued with the caller's reductions)
-  return b4r_launch_slab_reduce_full(d->scratch, d->B, 1, 128, d->dprev_gamma, 128, 0, nullptr, nullptr, nullptr, nullptr, s);
+  rc = b4r_launch_slab_reduce_full(d->scratch, d->B, 1, 128, d->dprev_gamma, 128, 0, nullptr, nullptr, nullptr, nullptr, s);
+  if (rc != B4R_OK || !fold) return rc;
+  return b4r_launch_slab_reduce_full(p.dw_slab, d->B, HID, 3 * HID, d->dWqkv, 3 * HID, 0, p.db_slab, d->dbqkv, nullptr, nullptr, s);
 }

@@ -736,6 +736,8 @@ static bool use_attn32() {
   return on;
 }
 
+bool b4r_attn32_active(int H, int heads, int L) { return use_attn32() && b4r_attn32_supported(H, heads, L) != 0; }
+
 extern "C" int32_t b4r_attn_block_supported(int32_t hidden_size, int32_t num_heads, int32_t L) {
   return (hidden_size == HID && num_heads == 2 && L > 0 && L <= 256 && b4r_get_gemm_mode() == B4R_GEMM_BF16X3) ? 1 : 0;
 }
@@ -752,6 +754,7 @@ extern "C" int b4r_debug_ab_prof(long long* host_out) {   // 64 stamps of the la
 }
 #endif
 extern "C" int64_t b4r_attn_block_bwd_scratch_floats(int32_t B) { return (int64_t)(B > 0 ? B : 0) * 128; }
+extern "C" int64_t b4r_attn_block_bwd_dw_scratch_floats(int32_t B) { return (int64_t)(B > 0 ? B : 0) * (HID * 3 * HID + 3 * HID); }
 
 int b4r_launch_slab_reduce_full(const float* slab, int S, int Mo, int No, float* out, int ldo, int accumulate,
                                 const float* cslab, float* colsum, const float* caslab, float* colsum_a, hipStream_t stream);
@@ -759,6 +762,7 @@ int b4r_launch_slab_reduce_full(const float* slab, int S, int Mo, int No, float*
 extern "C" int b4r_attn_block_bwd(const b4r_attn_block_bwd_desc* d, b4r_stream_t stream) {
   B4R_CHECK_ARG(d != nullptr, B4R_E_BADARG, "b4r_attn_block_bwd: null descriptor");
   if (use_attn32() && b4r_attn32_supported(d->H, d->heads, d->L)) return b4r_attn32_bwd(d, stream);
+  B4R_CHECK_ARG(d->dWqkv == nullptr && d->dqkv != nullptr, B4R_E_SHAPE, "b4r_attn_block_bwd: dWqkv inside the launch needs L <= 224 (this path writes dqkv)");
   B4R_CHECK_ARG(b4r_attn_block_bwd_supported(d->H, d->heads, d->L), B4R_E_SHAPE,
                 "b4r_attn_block_bwd: needs hidden size 64, 2 heads, L <= 208 and the bf16x3 mode (H=%d heads=%d L=%d)", d->H, d->heads,
                 d->L);

@@ -38,6 +38,7 @@ int b4r_ffn_block_bwd_marked(const b4r_ffn_desc* d, hipStream_t stream, hipEvent
 int b4r_embed_grads(const float* x, const int64_t* ids, int B, int L, int H, float* table_grad, int64_t V, int hot_rows,
                     float* hot_scratch, float* dpos, float* colsum_scratch, hipStream_t stream);
 int b4r_gemm_tn_pair(const b4r_gemm_tn_desc* d0, float* scratch0, const b4r_gemm_tn_desc* d1, float* scratch1, hipStream_t stream);
+bool b4r_attn32_active(int H, int heads, int L);   // b4r_attn_block.hip: the 32-token-tile backward (it can form dWqkv / dbqkv itself)
 int b4r_ce_finalize_launch(const float* row_scratch, int M, b4r_train_state* state, int overwrite, hipStream_t stream);
 int b4r_attn_bwd_streams(const float* qkv, const int64_t* input_mask, const float* ctx, const float* lse, const float* dctx,
                          int32_t B, int32_t L, int32_t heads, float qscale, float* dqkv, const uint32_t* rng,
@@ -268,6 +269,7 @@ WsLayout make_ws_layout(const b4r_model_config& c, int B, int L, int P) {
     add(2 * std::max(b4r_ln_bwd_scratch_floats((int)N, (int)H), b4r_gemm_ln_bwd_partial_floats((int)N)));
     if (H == 64 && I == 256) add(b4r_ffn_block_bwd_scratch_floats((int)N));   // partial slabs of the fused feed-forward backward
     add(b4r_attn_block_bwd_scratch_floats(B));
+    add(b4r_attn_block_bwd_dw_scratch_floats(B));
   }
   add(std::max(b4r_ln_bwd_scratch_floats((int)N, (int)H), b4r_gemm_ln_bwd_partial_floats((int)N)));
   if (M > 0) {
@@ -493,6 +495,13 @@ extern "C" int b4r_encoder_layer_bwd(const b4r_ffn_desc* ffn, const b4r_attn_blo
   hipStream_t s = (hipStream_t)stream;
   RC(b4r_ffn_block_bwd(ffn, stream));
   RC(b4r_attn_block_bwd(attn, stream));
+  if (attn->dWqkv != nullptr) {   // the attention block formed dWqkv / dbqkv itself (its descriptor's dWqkv: same buffers expected)
+    B4R_CHECK_ARG(attn->dWqkv == dWqkv && attn->dbqkv == dbqkv, B4R_E_BADARG,
+                  "b4r_encoder_layer_bwd: the attention descriptor's dWqkv / dbqkv must be the call's");
+    const b4r_gemm_tn_desc d1 = tn_desc(attn->ctx, H, attn->dz1, H, dWo, H, N, H, H, dbo, attn->out_rate > 0.f ? attn->rng : nullptr,
+                                        attn->out_stream, attn->out_rate, 1);
+    return b4r_gemm_tn_f32(&d1, tn_scratch, stream);
+  }
   // dWo = ctx^T . dropmask(dz1) and dWqkv = x^T . dqkv (+ their bias gradients): one launch
   const b4r_gemm_tn_desc d_wo = tn_desc(attn->ctx, H, attn->dz1, H, dWo, H, N, H, H, dbo, attn->out_rate > 0.f ? attn->rng : nullptr,
                                         attn->out_stream, attn->out_rate, 1);
@@ -891,6 +900,7 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
     RC(gemm_tn(ws + w.x1[i], H, ws + w.df, I, grads + pl.w1[i], I, N, H, I, grads + pl.b1[i], nullptr, nullptr, 0, 0.f, 0,
                take(b4r_gemm_tn_scratch_floats(N, H, I)), s_tn));
     }
+    const bool dw_folded = attn_bwd_fused(cfg, L) && b4r_attn32_active(H, cfg->num_heads, L);
     if (attn_bwd_fused(cfg, L)) {
       // dWo = ctx^T . dropmask(dz1) (+ bias gradient); then the attention block's backward in one launch: dqkv and, through the
       // LayerNorm in front of this layer, da (for layer 0: through the embedding stage's dropout and LayerNorm)
@@ -920,6 +930,10 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
       }
       bd.dqkv = ws + w.dqkv; bd.dx_prev = ws + w.da;
       bd.scratch = take(b4r_attn_block_bwd_scratch_floats(B));
+      if (dw_folded) {   // dWqkv / dbqkv inside the launch: no [N, 3H] round trip, no weight-gradient launch for them
+        bd.dqkv = nullptr; bd.dWqkv = grads + pl.wqkv[i]; bd.dbqkv = grads + pl.bqkv[i];
+        bd.dw_scratch = take(b4r_attn_block_bwd_dw_scratch_floats(B));
+      }
       RC(b4r_attn_block_bwd(&bd, stream));
     } else {
     // attention output projection: dctx = dropmask(dz1) . Wo^T and dWo = ctx^T . dropmask(dz1) (+ bias gradient) read dz1
@@ -956,6 +970,12 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
                       params + pl.emb_ln_g, grads + pl.emb_ln_g, grads + pl.emb_ln_b, take(ln_scratch), s, batch->input_word_ids,
                       params + pl.word_emb, params + pl.pos_emb, L, V, rng, B4R_STREAM_EMB, od));
     }
+    if (!side4 && dw_folded) {   // only dWo is left (its inputs are ready since the feed-forward backward)
+      RC(gemm_tn(ws + w.ctx[i], H, ws + w.db, H, grads + pl.wo[i], H, N, H, H, grads + pl.bo[i], nullptr, rng, B4R_STREAM_ATTN_OUT(i), od, 1,
+                 wo_scratch_of_layer, s));
+      continue;
+    }
+    if (side4 && dw_folded) continue;
     if (!side4 && attn_bwd_fused(cfg, L)) {   // dWo (inputs ready since the feed-forward backward) and dWqkv: one launch
       const b4r_gemm_tn_desc d_wo = tn_desc(ws + w.ctx[i], H, ws + w.db, H, grads + pl.wo[i], H, N, H, H, grads + pl.bo[i], rng,
                                             B4R_STREAM_ATTN_OUT(i), od, 1);

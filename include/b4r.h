@@ -425,9 +425,15 @@ typedef struct b4r_attn_block_bwd_desc {
   const int64_t* emb_ids; const float* emb_table; const float* emb_pos; int32_t emb_vocab; uint32_t emb_stream; float emb_rate;
   float* dqkv; float* dx_prev; float* dprev_gamma;
   float* scratch;
+  /* optional (L <= 224): the weight gradients of the q | k | v projections formed inside the launch, dWqkv [H,3H] = x^T.dqkv and dbqkv
+   * [3H] = its column sums (tape.gradient of bert4rec_encoder.py:220-222 wrt query / key / value kernel and bias) as ordered sums
+   * over per-sequence partials in dw_scratch (b4r_attn_block_bwd_dw_scratch_floats(B) floats, 16-byte aligned); dqkv may then be
+   * NULL: nothing of size [B*L,3H] is written. */
+  float* dWqkv; float* dbqkv; float* dw_scratch;
 } b4r_attn_block_bwd_desc;
 int32_t b4r_attn_block_bwd_supported(int32_t hidden_size, int32_t num_heads, int32_t L);
 int64_t b4r_attn_block_bwd_scratch_floats(int32_t B);
+int64_t b4r_attn_block_bwd_dw_scratch_floats(int32_t B);
 int b4r_attn_block_bwd(const b4r_attn_block_bwd_desc* d, b4r_stream_t stream);
 
 typedef struct b4r_ffn_desc {

@@ -325,6 +325,22 @@ def test_attn_block_backward_matches_fp64_autograd(B, L, p_rate, o_rate, embed):
     for k, v in first.items():
         assert torch.equal(v, out[k]), k     # ordered accumulation of dK / dV in LDS: bitwise reproducible
 
+    # the same launch can form dWqkv = x^T.dqkv and dbqkv itself (no [N, 3H] round trip): ordered sums over per-sequence partials
+    dw = torch.full((64, 192), nan, dtype=torch.float32, device=DEV)
+    dbq = torch.full((192,), nan, dtype=torch.float32, device=DEV)
+    dws = torch.empty(lib.b4r_attn_block_bwd_dw_scratch_floats(B), dtype=torch.float32, device=DEV)
+    out["da"].fill_(nan)
+    bd.dqkv, bd.dWqkv, bd.dbqkv, bd.dw_scratch = None, P(dw), P(dbq), P(dws)
+    _lib.check(lib.b4r_attn_block_bwd(C.byref(bd), stream()), "b4r_attn_block_bwd (dWqkv inside)")
+    torch.cuda.synchronize()
+    close(dw, ref["x"].T @ ref["dqkv"], "dWqkv")
+    close(dbq, ref["dqkv"].sum(0), "dbqkv")
+    assert torch.equal(out["da"], first["da"])
+    dw1, db1 = dw.clone(), dbq.clone()
+    _lib.check(lib.b4r_attn_block_bwd(C.byref(bd), stream()), "b4r_attn_block_bwd (dWqkv inside)")
+    torch.cuda.synchronize()
+    assert torch.equal(dw, dw1) and torch.equal(dbq, db1)
+
 
 # ---------------------------------------------------------------------------------------------------------------------------
 # one whole encoder layer = the two halves (b4r_encoder_layer_fwd / _bwd)

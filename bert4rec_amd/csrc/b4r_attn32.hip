@@ -123,6 +123,7 @@ struct A32BwdP {
   const int64_t* ids; const float* table; const float* pos; int V;                    // ... or the embedding stage (ids != NULL)
   float* dqkv; float* da; float* ln_part;
   float* dw_slab; float* db_slab;   // per-sequence partials of dWqkv [B][64][192] and dbqkv [B][192] (or NULL: dqkv is written instead)
+  float* dwo_slab; float* dbo_slab; // ... of dWo [B][64][64] and dbo [B][64] (or NULL)
   int B, L, NT;
   float qscale;
   DropArgs drop_p, drop_o, drop_e;
@@ -192,6 +193,53 @@ __global__ __launch_bounds__(512, 2) void attn32_bwd_kernel(A32BwdP p) {
   char* const ownB = DOIMG + wave * P_TILE;
   char* const ownC = DQACC + wave * P_TILE;
 
+  // ---- dWo = ctx^T . dropmask(dz1) and dbo, before the heads: ctx and dropmask(dz1) rows of the whole sequence as images (two
+  // column panels each, in the waves' own tiles), output tile (context half, hidden half) = wave 0..3 over all token tiles.  The
+  // dropmask(dz1) images stay where the first head's projections expect them.
+  const bool fold_wo = p.dwo_slab != nullptr;
+  if (fold_wo) {
+    A32_LANE_CONSTS();
+    f32x4 dbo = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const bool lv = 32 * wave + 4 * i + rl_row < L;
+      f32x4 dy = ld4(dzb, rl_off(rl, i));
+      const f32x4 cr = ld4(ctxb, rl_off(rl, i));
+      if (dco.on) dy = b4r_drop4(dco, dy, (uint64_t)(row0 + 32 * wave + 4 * i + rl_row) * HID + (uint64_t)(4 * rl_c4));
+      if (!lv) dy = (f32x4){0.f, 0.f, 0.f, 0.f};   // pad tokens: no contribution
+      dbo += dy;
+      rl_to_panels(rl, ownC, scr, i, dy);
+      rl_to_panels(rl, ownA, ownB, i, cr);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { dbo[e] += other_row(dbo[e]); dbo[e] += other_half(dbo[e], h); }
+    if (lane < 16) *reinterpret_cast<f32x4*>(&sdb[wave * 96 + 4 * rl_c4]) = dbo;
+    lds_barrier();
+    for (int tile = wave; tile < 4; tile += NT) {
+      const int ci = tile >> 1, hj = tile & 1;
+      const char* cimg = ci ? DOIMG : QIMG;
+      const char* yimg = hj ? SCRALL : DQACC;
+      f32x16 acc = zero16();
+      for (int kt = 0; kt < NT; ++kt) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const char* ca = cimg + kt * P_TILE;
+          const char* yb = yimg + kt * P_TILE;
+          acc = mfma32x3(tr_pair(ca + lk.trn[s][0], ca + lk.trn[s][1]), tr_pair(ca + P_IMG + lk.trn[s][0], ca + P_IMG + lk.trn[s][1]),
+                         tr_pair(yb + lk.trn[s][0], yb + lk.trn[s][1]), tr_pair(yb + P_IMG + lk.trn[s][0], yb + P_IMG + lk.trn[s][1]), acc);
+        }
+      }
+      float* dst = p.dwo_slab + (int64_t)b * (HID * HID) + 32 * hj + r;
+#pragma unroll
+      for (int tt = 0; tt < 16; ++tt) dst[(32 * ci + (tt & 3) + 8 * (tt >> 2) + 4 * h) * HID] = acc[tt];
+    }
+    for (int k = threadIdx.x; k < HID; k += nthreads) {
+      float acc = 0.f;
+      for (int w = 0; w < NT; ++w) acc += sdb[w * 96 + k];
+      p.dbo_slab[(int64_t)b * HID + k] = acc;
+    }
+  }
+
   f32x16 dx[2];   // dX^T[hidden 32 rt + ..][token] of ONE head: the first head's waits in `da` (the wave's own rows) for the epilogue --
                   // 32 registers that the sweep of the second head needs
 
@@ -201,8 +249,9 @@ __global__ __launch_bounds__(512, 2) void attn32_bwd_kernel(A32BwdP p) {
     const int64_t bh = (int64_t)b * 2 + hd;
     // ---- requests first: x and dz1 rows of the wave's tokens (row layout, coalesced), lse, the ctx columns of this head -----------
     f32x4 xr[8], yr[8];
+    const bool dy_staged = fold_wo && hd == 0;   // the dWo section left the dropmask(dz1) images in place
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { xr[i] = ld4(xb, rl_off(rl, i)); yr[i] = ld4(dzb, rl_off(rl, i)); }
+    for (int i = 0; i < 8; ++i) { xr[i] = ld4(xb, rl_off(rl, i)); yr[i] = dy_staged ? xr[i] : ld4(dzb, rl_off(rl, i)); }
     const float lse_q = live ? (p.lse + bh * L)[(uint32_t)tok] : INFINITY;
     f32x4 cx[4];
 #pragma unroll
@@ -220,6 +269,7 @@ __global__ __launch_bounds__(512, 2) void attn32_bwd_kernel(A32BwdP p) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       rl_to_panels(rl, ownA, ownB, i, xr[i]);
+      if (dy_staged) continue;
       f32x4 dy = yr[i];
       if (dco.on) dy = b4r_drop4(dco, dy, (uint64_t)(row0 + 32 * wave + 4 * i + rl_row) * HID + (uint64_t)(4 * rl_c4));
       rl_to_panels(rl, ownC, scr, i, dy);
@@ -630,6 +680,9 @@ int b4r_attn32_bwd(const b4r_attn_block_bwd_desc* d, b4r_stream_t stream) {
   p.dqkv = d->dqkv; p.da = d->dx_prev; p.ln_part = d->scratch;
   const bool fold = d->dWqkv != nullptr;
   if (fold) { p.dw_slab = d->dw_scratch; p.db_slab = d->dw_scratch + (int64_t)d->B * (HID * 3 * HID); }
+  const bool fold_wo = d->dWo != nullptr;
+  B4R_CHECK_ARG(!fold_wo || (fold && d->dbo), B4R_E_BADARG, "b4r_attn_block_bwd: dWo needs dbo and the dWqkv outputs");
+  if (fold_wo) { p.dwo_slab = p.db_slab + (int64_t)d->B * (3 * HID); p.dbo_slab = p.dwo_slab + (int64_t)d->B * (HID * HID); }
   p.B = d->B; p.L = d->L; p.NT = b4r_cdiv(d->L, 32);
   p.qscale = 1.0f / sqrtf(32.0f);
   p.drop_p = b4r_make_drop(d->rng, d->probs_stream, d->probs_rate, d->rng != nullptr);
@@ -654,5 +707,7 @@ int b4r_attn32_bwd(const b4r_attn_block_bwd_desc* d, b4r_stream_t stream) {
   // gamma / beta gradients of the previous LayerNorm: ordered sum over the sequences (queued with the caller's reductions)
   rc = b4r_launch_slab_reduce_full(d->scratch, d->B, 1, 128, d->dprev_gamma, 128, 0, nullptr, nullptr, nullptr, nullptr, s);
   if (rc != B4R_OK || !fold) return rc;
-  return b4r_launch_slab_reduce_full(p.dw_slab, d->B, HID, 3 * HID, d->dWqkv, 3 * HID, 0, p.db_slab, d->dbqkv, nullptr, nullptr, s);
+  rc = b4r_launch_slab_reduce_full(p.dw_slab, d->B, HID, 3 * HID, d->dWqkv, 3 * HID, 0, p.db_slab, d->dbqkv, nullptr, nullptr, s);
+  if (rc != B4R_OK || !fold_wo) return rc;
+  return b4r_launch_slab_reduce_full(p.dwo_slab, d->B, HID, HID, d->dWo, HID, 0, p.dbo_slab, d->dbo, nullptr, nullptr, s);
 }

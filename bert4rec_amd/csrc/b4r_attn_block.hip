@@ -754,7 +754,9 @@ extern "C" int b4r_debug_ab_prof(long long* host_out) {   // 64 stamps of the la
 }
 #endif
 extern "C" int64_t b4r_attn_block_bwd_scratch_floats(int32_t B) { return (int64_t)(B > 0 ? B : 0) * 128; }
-extern "C" int64_t b4r_attn_block_bwd_dw_scratch_floats(int32_t B) { return (int64_t)(B > 0 ? B : 0) * (HID * 3 * HID + 3 * HID); }
+extern "C" int64_t b4r_attn_block_bwd_dw_scratch_floats(int32_t B) {
+  return (int64_t)(B > 0 ? B : 0) * (HID * 3 * HID + 3 * HID + HID * HID + HID);   // dWqkv, dbqkv, dWo, dbo partials per sequence
+}
 
 int b4r_launch_slab_reduce_full(const float* slab, int S, int Mo, int No, float* out, int ldo, int accumulate,
                                 const float* cslab, float* colsum, const float* caslab, float* colsum_a, hipStream_t stream);

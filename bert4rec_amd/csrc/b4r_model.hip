@@ -496,8 +496,9 @@ extern "C" int b4r_encoder_layer_bwd(const b4r_ffn_desc* ffn, const b4r_attn_blo
   RC(b4r_ffn_block_bwd(ffn, stream));
   RC(b4r_attn_block_bwd(attn, stream));
   if (attn->dWqkv != nullptr) {   // the attention block formed dWqkv / dbqkv itself (its descriptor's dWqkv: same buffers expected)
-    B4R_CHECK_ARG(attn->dWqkv == dWqkv && attn->dbqkv == dbqkv, B4R_E_BADARG,
-                  "b4r_encoder_layer_bwd: the attention descriptor's dWqkv / dbqkv must be the call's");
+    B4R_CHECK_ARG(attn->dWqkv == dWqkv && attn->dbqkv == dbqkv && (attn->dWo == nullptr || (attn->dWo == dWo && attn->dbo == dbo)),
+                  B4R_E_BADARG, "b4r_encoder_layer_bwd: the attention descriptor's dWqkv / dbqkv / dWo / dbo must be the call's");
+    if (attn->dWo != nullptr) return B4R_OK;
     const b4r_gemm_tn_desc d1 = tn_desc(attn->ctx, H, attn->dz1, H, dWo, H, N, H, H, dbo, attn->out_rate > 0.f ? attn->rng : nullptr,
                                         attn->out_stream, attn->out_rate, 1);
     return b4r_gemm_tn_f32(&d1, tn_scratch, stream);
@@ -933,6 +934,7 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
       if (dw_folded) {   // dWqkv / dbqkv inside the launch: no [N, 3H] round trip, no weight-gradient launch for them
         bd.dqkv = nullptr; bd.dWqkv = grads + pl.wqkv[i]; bd.dbqkv = grads + pl.bqkv[i];
         bd.dw_scratch = take(b4r_attn_block_bwd_dw_scratch_floats(B));
+        if (!side4) { bd.dWo = grads + pl.wo[i]; bd.dbo = grads + pl.bo[i]; }   // ... nor for dWo / dbo
       }
       RC(b4r_attn_block_bwd(&bd, stream));
     } else {
@@ -970,12 +972,7 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
                       params + pl.emb_ln_g, grads + pl.emb_ln_g, grads + pl.emb_ln_b, take(ln_scratch), s, batch->input_word_ids,
                       params + pl.word_emb, params + pl.pos_emb, L, V, rng, B4R_STREAM_EMB, od));
     }
-    if (!side4 && dw_folded) {   // only dWo is left (its inputs are ready since the feed-forward backward)
-      RC(gemm_tn(ws + w.ctx[i], H, ws + w.db, H, grads + pl.wo[i], H, N, H, H, grads + pl.bo[i], nullptr, rng, B4R_STREAM_ATTN_OUT(i), od, 1,
-                 wo_scratch_of_layer, s));
-      continue;
-    }
-    if (side4 && dw_folded) continue;
+    if (dw_folded) continue;   // every weight gradient of the attention half came out of its backward launch
     if (!side4 && attn_bwd_fused(cfg, L)) {   // dWo (inputs ready since the feed-forward backward) and dWqkv: one launch
       const b4r_gemm_tn_desc d_wo = tn_desc(ws + w.ctx[i], H, ws + w.db, H, grads + pl.wo[i], H, N, H, H, grads + pl.bo[i], rng,
                                             B4R_STREAM_ATTN_OUT(i), od, 1);

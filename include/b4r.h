@@ -428,8 +428,11 @@ typedef struct b4r_attn_block_bwd_desc {
   /* optional (L <= 224): the weight gradients of the q | k | v projections formed inside the launch, dWqkv [H,3H] = x^T.dqkv and dbqkv
    * [3H] = its column sums (tape.gradient of bert4rec_encoder.py:220-222 wrt query / key / value kernel and bias) as ordered sums
    * over per-sequence partials in dw_scratch (b4r_attn_block_bwd_dw_scratch_floats(B) floats, 16-byte aligned); dqkv may then be
-   * NULL: nothing of size [B*L,3H] is written. */
+   * NULL: nothing of size [B*L,3H] is written.  With dWo / dbo given as well (they need the three above) the launch also forms
+   * dWo [H,H] = ctx^T.dropmask(dz1) and dbo [H] (attention_output kernel / bias): no weight-gradient launch is left for the
+   * attention half. */
   float* dWqkv; float* dbqkv; float* dw_scratch;
+  float* dWo; float* dbo;
 } b4r_attn_block_bwd_desc;
 int32_t b4r_attn_block_bwd_supported(int32_t hidden_size, int32_t num_heads, int32_t L);
 int64_t b4r_attn_block_bwd_scratch_floats(int32_t B);

@@ -330,16 +330,23 @@ def test_attn_block_backward_matches_fp64_autograd(B, L, p_rate, o_rate, embed):
     dbq = torch.full((192,), nan, dtype=torch.float32, device=DEV)
     dws = torch.empty(lib.b4r_attn_block_bwd_dw_scratch_floats(B), dtype=torch.float32, device=DEV)
     out["da"].fill_(nan)
-    bd.dqkv, bd.dWqkv, bd.dbqkv, bd.dw_scratch = None, P(dw), P(dbq), P(dws)
-    _lib.check(lib.b4r_attn_block_bwd(C.byref(bd), stream()), "b4r_attn_block_bwd (dWqkv inside)")
+    dwo = torch.full((64, 64), nan, dtype=torch.float32, device=DEV)
+    dbo = torch.full((64,), nan, dtype=torch.float32, device=DEV)
+    bd.dqkv, bd.dWqkv, bd.dbqkv, bd.dw_scratch, bd.dWo, bd.dbo = None, P(dw), P(dbq), P(dws), P(dwo), P(dbo)
+    _lib.check(lib.b4r_attn_block_bwd(C.byref(bd), stream()), "b4r_attn_block_bwd (weight gradients inside)")
     torch.cuda.synchronize()
     close(dw, ref["x"].T @ ref["dqkv"], "dWqkv")
     close(dbq, ref["dqkv"].sum(0), "dbqkv")
+    dy = t["dz1"].double()
+    if o_rate > 0:
+        dy = dy * orc.dropout_keep_mask((N, 64), o_rate, seed, step, site_o).double() / (1.0 - o_rate)
+    close(dwo, out["ctx"].detach().cpu().double().T @ dy, "dWo")
+    close(dbo, dy.sum(0), "dbo")
     assert torch.equal(out["da"], first["da"])
-    dw1, db1 = dw.clone(), dbq.clone()
-    _lib.check(lib.b4r_attn_block_bwd(C.byref(bd), stream()), "b4r_attn_block_bwd (dWqkv inside)")
+    keep = [v.clone() for v in (dw, dbq, dwo, dbo)]
+    _lib.check(lib.b4r_attn_block_bwd(C.byref(bd), stream()), "b4r_attn_block_bwd (weight gradients inside)")
     torch.cuda.synchronize()
-    assert torch.equal(dw, dw1) and torch.equal(dbq, db1)
+    assert all(torch.equal(a, b_) for a, b_ in zip(keep, (dw, dbq, dwo, dbo)))
 
 
 # ---------------------------------------------------------------------------------------------------------------------------

@@ -51,10 +51,41 @@ DTYPE = "f32 (bf16x3 split products on the bf16 matrix cores, fp32 accumulate; s
 
 
 # launch label of the library's timer -> kernel name in the rocprofv3 summaries
-KERNEL_OF_LABEL = {"b4r_attn_block_fwd": "attn_block_fwd_kernel", "b4r_attn_block_bwd": "attn_block_bwd_kernel",
+KERNEL_OF_LABEL = {"b4r_attn_block_fwd": "attn_block_fwd_kernel", "b4r_attn_block_bwd": "attn32_bwd_kernel",
                    "b4r_ffn_block_fwd": "ffn_fwd_kernel", "b4r_ffn_block_bwd (dx)": "ffn_bwd_dx_kernel",
                    "b4r_ffn_block_bwd (dw)": "ffn_bwd_dw_kernel", "masked-LM head forward (fused)": "head_fwd_kernel",
                    "masked-LM head dE (fused)": "head_dE_kernel"}
+
+
+def library_hash():
+    """sha256 of the libb4r_hip.so this process runs (B4R_LIB_PATH or the in-tree build): ties a number to a build"""
+    import hashlib
+    path = os.environ.get("B4R_LIB_PATH") or os.path.join(ROOT, "bert4rec_amd", "libb4r_hip.so")
+    try:
+        return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
+def profile_build(path):
+    """the library hash a committed profile summary was taken with (tools/prof.sh writes <tag>_build_<config>.json next to it)"""
+    import re
+    m = re.match(r"(.*/r[0-9a-z_]*?)_(pmc|stepbytes)_(.*)\.(txt|json)$", path)
+    if not m:
+        return None
+    try:
+        return json.load(open(f"{m.group(1)}_build_{m.group(3)}.json")).get("lib_sha256")
+    except (OSError, ValueError):
+        return None
+
+
+def stamp(entry, path):
+    """source + the build it was measured on; stale = not the library loaded now (the figure then describes another build)"""
+    taken = profile_build(os.path.join(ROOT, path))
+    entry["source"] = path
+    entry["source_lib_sha256"] = taken
+    entry["stale"] = (taken is None) or (taken != library_hash())
+    return entry
 
 
 def profiled_traffic(kernel, config):
@@ -77,7 +108,7 @@ def profiled_traffic(kernel, config):
                     tot += k * (float(cols[i_rd + off]) + float(cols[i_wr + off]))
                     n += k
             if n > 0:
-                return {"bytes": round(tot / n * 1e6), "source": os.path.relpath(path, ROOT)}
+                return stamp({"bytes": round(tot / n * 1e6)}, os.path.relpath(path, ROOT))
         except (OSError, ValueError, IndexError):
             continue
     return None
@@ -90,7 +121,7 @@ def profiled_step_bytes(config):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_stepbytes_{config}.json")), reverse=True):
         try:
             d = json.load(open(path))
-            return {"bytes": int(d["hbm_bytes_per_step"]), "source": os.path.relpath(path, ROOT)}
+            return stamp({"bytes": int(d["hbm_bytes_per_step"])}, os.path.relpath(path, ROOT))
         except (OSError, ValueError, KeyError):
             continue
     return None
@@ -143,7 +174,11 @@ def algorithmic_work(label, V, H, NL, NH, I, L, P, B):
     if label.startswith("b4r_attn_block_fwd"):
         return "hbm", 3 * act + small, "x in; ctx, z1 out (x1 is formed on load by the feed-forward kernels); lse, statistics, dropout bits"
     if label.startswith("b4r_attn_block_bwd"):
-        return "hbm", 4 * act + 3 * act + act + small, "x, dz1, ctx, previous z in; dqkv [N,3H], dx_prev out; lse, statistics, dropout bits"
+        nt = (L + 31) // 32
+        small_b = B * NH * L * 4 + 2 * N * 4 + B * NH * nt * nt * 32 * 4                  # lse, mean / rstd, keep words
+        slabs = B * (H * 3 * H + 3 * H + H * H + H) * 4                                   # dWqkv, dbqkv, dWo, dbo partials per sequence
+        return "hbm", 4 * act + act + slabs + small_b, ("x, dz1, ctx, previous z in; dx_prev out; per-sequence partials of dWqkv / dbqkv / "
+                                                        "dWo / dbo out (no [N,3H] round trip); lse, statistics, dropout words")
     if label.startswith("b4r_attn_fwd"):
         return "mfma", N * 4 * L * H, "QK^T + PV"
     if label.startswith("b4r_attn_bwd dq"):
@@ -322,18 +357,33 @@ def main():
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)
     os.close(saved_stdout)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed_region(offset):
+        """EXACTLY args.steps steps between barriers + device synchronisation; the max over ranks"""
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(offset + i)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if use_dist:
+            t = torch.tensor([el], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    # a region shorter than 200 ms (the driver's 20 steps are 12 ms) is repeated and the MEDIAN region reported: one region of that
+    # length moves by several per cent with the clock state it starts in.  Every rank takes the same decision (the first region's
+    # time is already the max over ranks).
+    regions = [timed_region(args.warmup)]
+    repeats = 1 if regions[0] >= 0.2 else max(7, min(51, int(0.2 / max(regions[0], 1e-6)) | 1))
+    for k in range(1, repeats):
+        if use_dist:
+            dist.barrier()
+        regions.append(timed_region(args.warmup + k * args.steps))
+    regions.sort()
+    elapsed = regions[len(regions) // 2]
     st = eng.read_state()
     loss = st["loss_sum"] / max(st["valid_count"], 1.0)
     assert np.isfinite(loss), "training diverged"
@@ -374,6 +424,7 @@ def main():
                 r = {"kernel": label, "selection": selection,
                      "bound": bound, "achieved": round(ach, 1), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
                      "traffic": tr["bytes"] if tr else None, "traffic_source": tr["source"] if tr else None,
+                     "traffic_stale": tr["stale"] if tr else None, "traffic_lib_sha256": tr["source_lib_sha256"] if tr else None,
                      "algorithmic_" + ("bytes" if bound == "hbm" else "flops"): int(amount), "what_is_counted": what,
                      "avg_launch_us": round(avg_us, 2), "launches_per_step": cnt,
                      "timer": "hipEvents on the launch stream behind every launch of 10 extra steps (b4r_timing_begin/_end)"}
@@ -393,8 +444,8 @@ def main():
             sb = profiled_step_bytes(args.config)
             if sb:
                 gbs = sb["bytes"] / (ms * 1e-3) / 1e9
-                step_hbm = {"hbm_bytes_per_step": sb["bytes"], "source": sb["source"], "achieved_GBs": round(gbs, 1),
-                            "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+                step_hbm = {"hbm_bytes_per_step": sb["bytes"], "source": sb["source"], "source_lib_sha256": sb["source_lib_sha256"],
+                            "stale": sb["stale"], "achieved_GBs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
 
         # ---- the materialising masked-LM-head projection (forward / evaluation API), replayed on live buffers ----------------
         if args.no_breakdown:      # profiling runs (tools/prof.sh): the train step only, no replays in the kernel statistics
@@ -437,6 +488,7 @@ def main():
         tr = profiled_traffic("rx_gemm_nk_kernel<1, false, 4>", args.config)
         if tr:
             roofline_mat["traffic"], roofline_mat["traffic_source"] = tr["bytes"], tr["source"]
+            roofline_mat["traffic_stale"], roofline_mat["traffic_lib_sha256"] = tr["stale"], tr["source_lib_sha256"]
         if roofline is None:
             roofline = roofline_mat
 
@@ -467,6 +519,7 @@ def main():
 
         # ---- CPU baseline: the oracle's train step on the host cores (rank 0, N=1 only) ---------------------------
         cpu = None
+        topk = None
         if world == 1 and args.cpu_steps > 0 and args.config in ("ml1m", "steam"):
             from oracle import bert4rec_oracle as orc
             # the GPU box exposes every host core but a one-GPU job owns a 16-core share: more threads only thrash
@@ -491,8 +544,36 @@ def main():
                              f"step, torch-CPU fp32 restatement of the reference math (TF2 unavailable), "
                              f"{c_el / args.cpu_steps * 1e3:.0f} ms/step"}
 
+            # ---- the checker once more: top-10 item lists of the GPU forward against the oracle's, same weights, one batch ------
+            # ("ranked top-k bit-exact" holds for the ranking step given equal hidden states; across two float implementations of the
+            # encoder the lists can differ where two logits are closer than their rounding: this is how often, and by how much)
+            w_now = eng.export_named()
+            for n_, p_ in params.items():
+                if n_ in w_now:
+                    params[n_] = w_now[n_].detach().cpu().reshape(p_.shape).clone()
+            with torch.no_grad():
+                lo = orc.model_forward(params, batches[0], cfg_o)["mlm_logits"].reshape(B * P, -1)[:, :V]
+            eng.forward(prepared[0][0], training=False, pooler=False)
+            lg = eng.region("mlm_logits", B, L, P)[:, :V].detach().cpu()
+            valid = (batches[0]["masked_lm_ids"].reshape(-1) != 0)
+            to, tg = torch.topk(lo[valid], 10).indices, torch.topk(lg[valid], 10).indices
+            same = (to == tg).all(1)
+            gap = 0.0
+            if not bool(same.all()):
+                rows_ = torch.nonzero(~same).reshape(-1)
+                first = (to[rows_] != tg[rows_]).float().argmax(1)
+                lo_v = lo[valid]
+                a_, b_ = to[rows_, first], tg[rows_, first]
+                gap = float((lo_v[rows_, a_] - lo_v[rows_, b_]).abs().max())
+            topk = {"slots": int(valid.sum()), "top10_identical_share": round(float(same.float().mean()), 6),
+                    "max_logit_gap_where_different": gap, "max_abs_logit_diff": round(float((lo[valid] - lg[valid]).abs().max()), 7),
+                    "against": "oracle forward (CPU fp32 restatement; parity with TF2 unpinned, DESIGN.md §1), same weights, batch 0"}
+
         result = {"metric": "masked positions/sec", "value": round(value, 1), "unit": "masked positions/s",
                   "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+                  "repeats": len(regions), "ms_min": round(regions[0] / args.steps * 1e3, 4), "ms_max": round(regions[-1] / args.steps * 1e3, 4),
+                  "timing": f"median of {len(regions)} timed regions of {args.steps} steps each" if len(regions) > 1 else "one timed region",
+                  "lib_sha256": library_hash(),
                   "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
                   "config": {"workload": f"{args.config}: full train step, B={B}/GPU L={L} P={P} H={H} layers={NL} heads={NH} "
                                          f"inner={I} V={V} dropout {od}/{ad}, full-vocab masked-LM head, {int(valid_per_step)} "
@@ -500,7 +581,7 @@ def main():
                              "global_batch": B * world, "seq_len": L, "parallelism": f"dp{world}",
                              "launch_mode": "hipGraph replay" if graphs else "eager"},
                   "per_gpu": round(value / world, 1), "final_loss": round(loss, 5),
-                  "roofline": roofline, "roofline_head": roofline_head, "step_hbm": step_hbm, "roofline_materialising": roofline_mat, "eval": ev,
+                  "roofline": roofline, "roofline_head": roofline_head, "step_hbm": step_hbm, "roofline_materialising": roofline_mat, "eval": ev, "topk_agreement": topk,
                   "cpu_baseline": cpu, "step_breakdown": breakdown}
         print(json.dumps(result), flush=True)
     if use_dist:

@@ -128,7 +128,7 @@ PROTOTYPES = {
     "b4r_train_step": (C.c_int, [C.POINTER(ModelConfig), C.POINTER(AdamWConfig), C.POINTER(Batch), _P, _P, _P, _P, _P,
                                  _I64, _P, _P]),
     "b4r_rank_scratch_bytes": (_I64, [_I32, _I32]),
-    "b4r_rank_candidates": (C.c_int, [_P, _I32, _P, _P, _P, _I32, _P, _I32, _I32, _P, _P, _P, _P, _P, _I64, _P]),
+    "b4r_rank_candidates": (C.c_int, [_P, _I32, _P, _P, _P, _I32, _I32, _P, _I32, _I32, _P, _P, _P, _P, _P, _I64, _P]),
     "b4r_rank_metrics": (C.c_int, [_P, _I32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I32, _P, _P, _P]),
     "b4r_mlm_transform_rows": (C.c_int, [C.POINTER(ModelConfig), _P, _P, _I64, _P, _I32, _P, _P, _P]),
     "b4r_embed_ln_fwd": (C.c_int, [_P, _I32, _I32, _P, _I32, _P, _P, _P, _I32, _F, _P, _P, _P, _P, _F, _P]),

@@ -31,7 +31,10 @@ constexpr int RANK_LDS_MAX = 8192;    // candidates per row the one-workgroup pa
 __device__ __forceinline__ int64_t cand_at(const int64_t* cand, int64_t r, int C, int j) { return cand ? cand[r * C + j] : (int64_t)j; }
 
 // scores of candidates j0 .. j0 + n - 1 of row r into sc[0..n) (LDS or global); tile: [tc][H + 1] floats; sh: hidden row [H]
-__device__ __forceinline__ void score_tile(const float* sh, float* tile, const float* table, const float* bias, int H,
+// A candidate id outside [0, V) (the device sampler's -1 for a row that ran out of drawable items, or a caller's id beyond the
+// vocabulary) scores -inf and loads nothing: the reference raises ValueError there (popular_random_sampler.py:104-109), the
+// evaluator reports it after the batch -- the kernel must not read in front of / behind the table meanwhile.
+__device__ __forceinline__ void score_tile(const float* sh, float* tile, const float* table, const float* bias, int H, int V,
                                            const int64_t* cand, int64_t r, int C, int j0, int n, int tc, float* sc,
                                            float* scores_out) {
   const int tid = threadIdx.x;
@@ -42,7 +45,7 @@ __device__ __forceinline__ void score_tile(const float* sh, float* tile, const f
     for (int f = tid; f < m * h4; f += RT) {
       const int row = f / h4, c4 = f - row * h4;
       const int64_t c = cand_at(cand, r, C, j0 + base + row);
-      const f32x4 v = *reinterpret_cast<const f32x4*>(table + c * H + 4 * c4);
+      const f32x4 v = (c >= 0 && c < V) ? *reinterpret_cast<const f32x4*>(table + c * H + 4 * c4) : (f32x4){0.f, 0.f, 0.f, 0.f};
       float* dst = tile + row * (H + 1) + 4 * c4;
       dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3];
     }
@@ -52,7 +55,8 @@ __device__ __forceinline__ void score_tile(const float* sh, float* tile, const f
       float acc = 0.f;
       for (int k = 0; k < H; ++k) acc = __builtin_fmaf(sh[k], e[k], acc);   // k-ordered fp32 fma chain (the contract)
       const int j = j0 + base + tid;
-      const float s = acc + bias[cand_at(cand, r, C, j)];
+      const int64_t cj = cand_at(cand, r, C, j);
+      const float s = (cj >= 0 && cj < V) ? acc + bias[cj] : -INFINITY;
       sc[j - j0] = s;
       if (scores_out) scores_out[r * (int64_t)C + j] = s;
     }
@@ -63,7 +67,7 @@ __device__ __forceinline__ int tile_rows(int H) { return min(RT, 16384 / H); }
 
 // ---- path 1: one workgroup per row, scores in LDS ------------------------------------------------------------------------
 __global__ __launch_bounds__(RT) void rank_row_kernel(const float* hidden, int hidden_ld, const int64_t* hidden_row,
-                                                      const float* table, const float* bias, int H, const int64_t* cand,
+                                                      const float* table, const float* bias, int H, int V, const int64_t* cand,
                                                       int C, const int64_t* gt, int64_t* ranking, int32_t* gt_rank,
                                                       float* scores_out) {
   extern __shared__ float sm_rank[];   // [H] hidden row | [C] scores | tile
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(RT) void rank_row_kernel(const float* hidden, int h
   const int64_t hr = hidden_row ? hidden_row[r] : r;
   for (int k = tid; k < H; k += RT) sh[k] = hidden[hr * hidden_ld + k];
   if (tid == 0) s_best = 0x7fffffff;
-  score_tile(sh, tile, table, bias, H, cand, r, C, 0, C, tile_rows(H), sc, scores_out);
+  score_tile(sh, tile, table, bias, H, V, cand, r, C, 0, C, tile_rows(H), sc, scores_out);
   __syncthreads();
   const int64_t g = gt ? gt[r] : -1;
   for (int j = tid; j < C; j += RT) {
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(RT) void rank_row_kernel(const float* hidden, int h
 
 // ---- path 2a: scores of one (row, 256-candidate tile) to global memory ------------------------------------------------
 __global__ __launch_bounds__(RT) void rank_scores_kernel(const float* hidden, int hidden_ld, const int64_t* hidden_row,
-                                                         const float* table, const float* bias, int H, const int64_t* cand,
+                                                         const float* table, const float* bias, int H, int V, const int64_t* cand,
                                                          int C, int64_t r0, float* scores /* [rows][C] */) {
   extern __shared__ float sm_rank[];   // [H] | tile
   float* sh = sm_rank; float* tile = sm_rank + H;
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(RT) void rank_scores_kernel(const float* hidden, in
   for (int k = threadIdx.x; k < H; k += RT) sh[k] = hidden[hr * hidden_ld + k];
   const int j0 = blockIdx.x * RT, n = min(RT, C - j0);
   // scores_out indexing inside score_tile is r * C + j with the GLOBAL row; offset the base so that row r0 lands on row 0
-  score_tile(sh, tile, table, bias, H, cand, r, C, j0, n, tile_rows(H), scores + (blockIdx.y * (int64_t)C + j0), nullptr);
+  score_tile(sh, tile, table, bias, H, V, cand, r, C, j0, n, tile_rows(H), scores + (blockIdx.y * (int64_t)C + j0), nullptr);
 }
 
 // ---- path 2b: stable descending argsort of each row's scores ----------------------------------------------------------
@@ -243,11 +247,12 @@ extern "C" int64_t b4r_rank_scratch_bytes(int32_t R, int32_t C) {
 }
 
 extern "C" int b4r_rank_candidates(const float* hidden, int32_t hidden_ld, const int64_t* hidden_row, const float* table,
-                                   const float* bias, int32_t H, const int64_t* cand, int32_t R, int32_t C,
+                                   const float* bias, int32_t H, int32_t V, const int64_t* cand, int32_t R, int32_t C,
                                    const int64_t* gt, int64_t* ranking, int32_t* gt_rank, float* scores, void* scratch,
                                    int64_t scratch_bytes, b4r_stream_t stream) {
   B4R_CHECK_ARG(hidden && table && bias, B4R_E_BADARG, "b4r_rank_candidates: null argument");
-  B4R_CHECK_ARG(R > 0 && C > 0 && H > 0 && H % 4 == 0 && H <= 4096 && hidden_ld >= H, B4R_E_SHAPE, "b4r_rank_candidates: bad shape");
+  B4R_CHECK_ARG(R > 0 && C > 0 && H > 0 && H % 4 == 0 && H <= 4096 && hidden_ld >= H && V > 0, B4R_E_SHAPE, "b4r_rank_candidates: bad shape");
+  B4R_CHECK_ARG(cand != nullptr || C <= V, B4R_E_SHAPE, "b4r_rank_candidates: cand == NULL ranks items 0 .. C-1, C = %d exceeds the table's %d rows", C, V);
   B4R_CHECK_ARG(b4r_aligned16(table), B4R_E_ALIGN, "b4r_rank_candidates: the table must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   const int tc = std::min(RT, 16384 / H);
@@ -256,7 +261,7 @@ extern "C" int b4r_rank_candidates(const float* hidden, int32_t hidden_ld, const
     const size_t sh = (size_t)(H + C) * sizeof(float) + tile;
     int rc = b4r_raise_lds((const void*)rank_row_kernel, sh, "b4r_rank_candidates");
     if (rc) return rc;
-    hipLaunchKernelGGL(rank_row_kernel, dim3(R), dim3(RT), sh, s, hidden, hidden_ld, hidden_row, table, bias, H, cand, C, gt,
+    hipLaunchKernelGGL(rank_row_kernel, dim3(R), dim3(RT), sh, s, hidden, hidden_ld, hidden_row, table, bias, H, V, cand, C, gt,
                        ranking, gt_rank, scores);
     B4R_CHECK_LAUNCH("b4r_rank_candidates");
     return B4R_OK;
@@ -276,7 +281,7 @@ extern "C" int b4r_rank_candidates(const float* hidden, int32_t hidden_ld, const
   uint32_t* v1 = k1 + group * C;
   for (int64_t r0 = 0; r0 < R; r0 += group) {
     const int n = (int)std::min<int64_t>(group, R - r0);
-    hipLaunchKernelGGL(rank_scores_kernel, dim3(b4r_cdiv(C, RT), n), dim3(RT), sh, s, hidden, hidden_ld, hidden_row, table, bias, H,
+    hipLaunchKernelGGL(rank_scores_kernel, dim3(b4r_cdiv(C, RT), n), dim3(RT), sh, s, hidden, hidden_ld, hidden_row, table, bias, H, V,
                        cand, C, r0, sc);
     if (scores) {
       if (hipMemcpyAsync(scores + r0 * C, sc, (size_t)n * C * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {

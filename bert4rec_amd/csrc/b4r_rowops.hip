@@ -1046,7 +1046,7 @@ extern "C" int b4r_mlm_rows(const int64_t* masked_lm_positions, const int64_t* m
 // Weighted sampling without replacement (what np.random.choice(vocab, size, False, p) followed by dropping the excluded
 // items draws: successive picks proportional to p among what is left) as Gumbel top-k: key_v = log p_v + G_v with
 // G_v = -log(-log u_v); the C largest keys, in descending order, are the sample in draw order.  u_v comes from a counter
-// hash of (seed, row, v) with 24 bits, so it lies strictly inside (0, 1).
+// hash of (seed, row, v) with 23 bits, so it lies strictly inside (0, 1).
 // (value, index) of the larger key; equal keys: the lower index (np.random.choice's order of draws is not affected: ties of 24-bit
 // Gumbel keys are broken the same way everywhere in this kernel)
 __device__ __forceinline__ void keep_larger(float& best, int& bidx, float ov, int oi) {
@@ -1091,7 +1091,7 @@ __global__ __launch_bounds__(256) void sample_candidates_kernel(const float* log
   for (int v = tid; v < V; v += 256) {
     uint32_t h = b4r_hash32((uint32_t)v ^ seed_lo);
     h = b4r_hash32(h + rk);
-    const float u = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u = ((float)(h >> 9) + 0.5f) * (1.0f / 8388608.0f);   // 23 bits: (k + 0.5) / 2^23 is exact, strictly inside (0, 1)
     s_key[v] = logp[v] - __logf(-__logf(u));  // -inf + finite = -inf: zero-probability items are never drawn
   }
   __syncthreads();

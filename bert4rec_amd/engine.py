@@ -502,7 +502,7 @@ class Engine:
             scratch = torch.empty(min(need, max(Cn * 20, 4 << 30)) // 4 + 4, dtype=torch.float32, device=self.device)
         _lib.check(self.lib.b4r_rank_candidates(_ptr(hidden), hidden.stride(0), _ptr(rows_d),
                                                 _ptr(self.view("word_embeddings/embeddings")),
-                                                _ptr(self.view("cls/predictions/output_bias/bias")), H, _ptr(cand), R, Cn,
+                                                _ptr(self.view("cls/predictions/output_bias/bias")), H, self.cfg.vocab_size, _ptr(cand), R, Cn,
                                                 _ptr(gt_d), _ptr(ranking), _ptr(gt_rank), _ptr(scores), _ptr(scratch),
                                                 0 if scratch is None else scratch.numel() * 4,
                                                 _stream(self.device)), "b4r_rank_candidates")

@@ -77,6 +77,8 @@ class BERT4RecEvaluator(BaseEvaluator):
         _, sums, users = self._dev
         if getattr(self, "_short", None) is not None and bool(self._short.cpu()[0]):   # checked once, not per batch
             self._short.zero_()
+            sums.zero_()    # nothing of the aborted evaluation may leak into the next one
+            users.zero_()
             raise ValueError(f"The exclusion lists reduce the vocab too much to take a sample of size {self.sampler.sample_size} "
                              f"(since no duplicates are allowed).")
         sums_h, users_h = sums.cpu().tolist(), int(users.cpu()[0])
@@ -89,7 +91,9 @@ class BERT4RecEvaluator(BaseEvaluator):
         """all-reduce what THIS evaluate() call added on each rank: [gain sums | user count] as float64"""
         import torch.distributed as dist
         mine = [(m.partial()[0] - b[0], m.partial()[1] - b[1]) for m, b in zip(self._metrics, before)]
-        dev = self._dev[0].device if (self._dev is not None and dist.get_backend(group) == "nccl") else "cpu"
+        # the buffer's device follows the BACKEND (a rank that saw no batch has no device accumulators, but must still join an
+        # nccl collective with a device tensor)
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else "cpu"
         buf = torch.tensor([g for g, _ in mine] + [float(mine[0][1]) if mine else 0.0], dtype=torch.float64, device=dev)
         dist.all_reduce(buf, group=group)
         tot = buf.cpu().tolist()
@@ -113,7 +117,10 @@ class BERT4RecEvaluator(BaseEvaluator):
         return np.asarray(cands, dtype=np.int64), np.asarray(gts, dtype=np.int64)
 
     def _device_sampler_ready(self, model) -> bool:
+        # a sampler seeded the reference's way (np.random.seed(seed) per call, popular_random_sampler.py:88-90) keeps ITS stream: the
+        # device sampler draws from another one, so it only replaces unseeded samplers
         return (self.device_sampling and isinstance(self.sampler, samplers.PopularRandomSampler)
+                and getattr(self.sampler, "seed", None) is None
                 and not self.sampler.allow_duplicates and self.sampler.is_fully_prepared()
                 and getattr(model, "engine", None) is not None and model.engine.device.type == "cuda"
                 and model.engine.cfg.vocab_size * 4 <= 150 * 1024   # b4r_sample_candidates keeps the V keys in LDS
@@ -144,8 +151,9 @@ class BERT4RecEvaluator(BaseEvaluator):
         self._draws += 1
         if self._short is None or self._short.device != dev:
             self._short = torch.zeros(1, dtype=torch.bool, device=dev)
+        rank, _ = _dist_rank_world(None)   # every data-parallel rank draws from its own stream
         cand = eng.sample_candidates(self._logp, exclude, gt, self.sampler.sample_size,
-                                     seed=(self._seed << 32) ^ self._draws, short_flag=self._short)
+                                     seed=((self._seed << 32) ^ self._draws) ^ (rank << 48), short_flag=self._short)
         return cand, gt
 
     def evaluate_batch(self, model, test_batch: dict, candidates=None, ground_truth=None):
@@ -186,6 +194,8 @@ class BERT4RecEvaluator(BaseEvaluator):
         if getattr(self, "_dev", None) is not None:
             self._dev[1].zero_()
             self._dev[2].zero_()
+        if getattr(self, "_short", None) is not None:
+            self._short.zero_()
         super().reset_metrics()
 
 

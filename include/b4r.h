@@ -144,7 +144,10 @@ int b4r_workspace_region(const b4r_model_config* cfg, int32_t B, int32_t L, int3
  * rows of the sequence output that the masked-LM head gathers (about P/L of them: 20 % at ML-1M) -- forward and backward.  Loss, metrics
  * and every gradient are unchanged (the other rows of that output reach neither the loss nor, through attention, any row that does);
  * "sequence_output" / "encoder_output_<last>" are then only defined on those rows, which is why the forward / evaluation API never sets
- * the flag.  b4r_train_step uses it; ignored where the fused feed-forward block does not apply. */
+ * the flag.  b4r_train_step uses it; ignored where the fused feed-forward block does not apply.
+ * PRECONDITION: the valid masked-LM slots (masked_lm_ids != 0) of one sequence name distinct positions -- what the reference's
+ * preprocessor and b4r_mask_batch produce (dataloader_utils.py:221-226 samples positions without replacement).  Two valid slots on
+ * one position would each write that row's gradient (last writer wins) where the scatter-add path sums them. */
 #define B4R_FLAG_HEAD_ROWS_ONLY 16
 /* b4r_backward only, with B4R_FLAG_FUSED_HEAD: the call begins by SETTING the state's sums (loss_sum, valid_count, correct_masked,
  * correct_all, slots_all; gradient norms to 0) from the loss rows the logits-free head left in the workspace -- what
@@ -214,10 +217,12 @@ int b4r_sample_candidates(const float* logp, int32_t V, const int64_t* exclude, 
  * Only the scores asked for are formed (the reference computes all B*P*V logits and reads 101 per user).  Up to 8192
  * candidates per row run in one launch; more (the whole vocabulary of Beauty / Reddit) take a radix argsort per row and
  * need `scratch` (b4r_rank_scratch_bytes(R, C) bytes for one pass over all rows; at least C*20, rows are then ranked in
- * groups; 16-byte aligned). */
+ * groups; 16-byte aligned).  V = rows of `table` / entries of `bias`: a candidate id outside [0, V) scores -inf and reads nothing
+ * (the reference raises ValueError for a row without enough drawable items, popular_random_sampler.py:104-109; the device
+ * sampler marks such rows with -1 and the evaluator reports them after the batch). */
 int64_t b4r_rank_scratch_bytes(int32_t R, int32_t C);
 int b4r_rank_candidates(const float* hidden, int32_t hidden_ld, const int64_t* hidden_row, const float* table,
-                        const float* bias, int32_t H, const int64_t* cand, int32_t R, int32_t C, const int64_t* gt,
+                        const float* bias, int32_t H, int32_t V, const int64_t* cand, int32_t R, int32_t C, const int64_t* gt,
                         int64_t* ranking, int32_t* gt_rank, float* scores, void* scratch, int64_t scratch_bytes,
                         b4r_stream_t stream);
 /* replaces the metric loop of bert4rec_evaluator.py:118-120 over evaluation_metrics.py:47-112 for a batch of ranks:

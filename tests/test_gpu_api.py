@@ -200,10 +200,13 @@ def test_evaluator_device_sampling_matches_host_sampling_in_distribution():
     model = make_model(V, seed=13)
     rng = np.random.default_rng(3)
     pop = rng.zipf(1.3, size=20000) % (V - 3) + 3                       # skewed item popularity over real items
-    smp = dataloaders.samplers.get("pop_random", source=pop.tolist(), vocab=list(range(V)), sample_size=100, seed=7)
+    smp = dataloaders.samplers.get("pop_random", source=pop.tolist(), vocab=list(range(V)), sample_size=100)
     batches = [orc.synthetic_batch(B, L, 4, V, seed=50 + i, ragged=True, finetune=True) for i in range(6)]
     ev_dev = evaluation.get(sampler=smp, device_sampling=True, seed=1)
     assert ev_dev._device_sampler_ready(model)
+    # a sampler seeded the reference's way keeps its own numpy stream (equal seeds, equal samples): no device sampling for it
+    seeded = dataloaders.samplers.get("pop_random", source=pop.tolist(), vocab=list(range(V)), sample_size=100, seed=7)
+    assert not evaluation.get(sampler=seeded, device_sampling=True)._device_sampler_ready(model)
     cand, gt = ev_dev.sample_candidates_device(model, batches[0])
     cand, gt = cand.cpu().numpy(), gt.cpu().numpy()
     assert cand.shape == (B, 101) and np.array_equal(cand[:, 100], gt)
@@ -223,6 +226,29 @@ def test_evaluator_device_sampling_matches_host_sampling_in_distribution():
     # an untrained model ranks the ground truth anywhere among 101: both estimates of HR@10 sit near 10/101, within noise
     for k in ("HR@10", "NDCG@10", "MAP"):
         assert abs(rd[k] - rh[k]) < 0.06, (k, rd[k], rh[k])
+
+
+def test_evaluator_reports_rows_without_enough_drawable_items_and_reads_nothing_out_of_range():
+    """popular_random_sampler.py:104-109 raises ValueError when the exclusions leave fewer than sample_size items.  The device
+    sampler marks such rows with -1 candidates: the ranking kernel must score them -inf WITHOUT reading table[-1] / bias[-1]
+    (the item table is the first tensor of the parameter buffer), and the evaluator raises once, with nothing left behind."""
+    V, B, L = 112, 8, 20     # 109 real items, ~20 of them excluded per user: fewer than the 100 negatives asked for
+    model = make_model(V, seed=5)
+    rng = np.random.default_rng(2)
+    pop = rng.integers(3, V, size=4000)
+    smp = dataloaders.samplers.get("pop_random", source=pop.tolist(), vocab=list(range(V)), sample_size=100)
+    ev = evaluation.get(sampler=smp, device_sampling=True, seed=3)
+    assert ev._device_sampler_ready(model)
+    batch = orc.synthetic_batch(B, L, 4, V, seed=9, ragged=True, finetune=True)
+    ev.evaluate_batch(model, batch)            # enqueues sampling + ranking of rows full of -1 candidates
+    torch.cuda.synchronize()                   # a fault would surface here
+    with pytest.raises(ValueError):
+        ev.get_metrics_results()
+    assert ev.get_metrics_results()["Valid Ranks"] == 0      # the aborted evaluation left nothing in the accumulators
+    # ids beyond the vocabulary given to rank_items score -inf: they rank behind every real item
+    ranked = model.rank_items(batch, [[[5, V + 7, 6, -3]]] * B)
+    for r in ranked:
+        assert sorted(r[0][:2].tolist()) == [5, 6] and sorted(r[0][2:].tolist()) == [-3, V + 7]
 
 
 def test_ndcg_after_training_matches_the_oracle_trained_the_same_way():

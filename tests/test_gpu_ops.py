@@ -545,7 +545,7 @@ def test_rank_candidates_bit_exact_against_c_oracle(R, Cn, H, V):
     gt_rank = torch.empty(R, dtype=torch.int32, device=DEV)
     scores = torch.empty(R, Cn, device=DEV)
     hd, td, bd, cd, gd = hidden.to(DEV), table.to(DEV), bias.to(DEV), cand.to(DEV), gt.to(DEV)  # keep alive
-    _lib.check(lib.b4r_rank_candidates(P(hd), H, None, P(td), P(bd), H, P(cd), R, Cn, P(gd), P(ranking), P(gt_rank),
+    _lib.check(lib.b4r_rank_candidates(P(hd), H, None, P(td), P(bd), H, table.shape[0], P(cd), R, Cn, P(gd), P(ranking), P(gt_rank),
                                        P(scores), None, 0, stream()))
     assert np.array_equal(scores.cpu().numpy().view(np.uint32), sc.view(np.uint32)), "scores not bit-identical"
     assert np.array_equal(ranking.cpu().numpy(), rk)
@@ -585,7 +585,7 @@ def test_whole_vocabulary_ranking_bit_exact_against_c_oracle(R, V, H, group_rows
     nbytes = need if group_rows == 0 else group_rows * V * 20   # a smaller scratch: rows are ranked in groups
     scratch = torch.empty(nbytes // 4, dtype=torch.float32, device=DEV)
     hd, td, bd, gd = hidden.to(DEV), table.to(DEV), bias.to(DEV), gt.to(DEV)
-    _lib.check(lib.b4r_rank_candidates(P(hd), H, None, P(td), P(bd), H, None, R, V, P(gd), P(ranking), P(gt_rank), P(scores),
+    _lib.check(lib.b4r_rank_candidates(P(hd), H, None, P(td), P(bd), H, V, None, R, V, P(gd), P(ranking), P(gt_rank), P(scores),
                                        P(scratch), nbytes, stream()))
     torch.cuda.synchronize()
     assert np.array_equal(scores.cpu().numpy().view(np.uint32), sc.view(np.uint32)), "scores not bit-identical"
@@ -595,7 +595,7 @@ def test_whole_vocabulary_ranking_bit_exact_against_c_oracle(R, V, H, group_rows
     pos3, pos7 = int(np.nonzero(order[0] == 3)[0][0]), int(np.nonzero(order[0] == 7)[0][0])
     assert sc[0, 3] == sc[0, 7] and pos3 + 1 == pos7
     # too little scratch is refused, never computed another way
-    assert lib.b4r_rank_candidates(P(hd), H, None, P(td), P(bd), H, None, R, V, P(gd), P(ranking), P(gt_rank), None,
+    assert lib.b4r_rank_candidates(P(hd), H, None, P(td), P(bd), H, V, None, R, V, P(gd), P(ranking), P(gt_rank), None,
                                    P(scratch), V * 20 - 16, stream()) == -5
 
 
@@ -843,7 +843,7 @@ def test_sample_candidates_takes_the_largest_gumbel_keys_in_order():
     for r in range(R):
         rk = orc._hash32_int((r * 0x9E3779B9 + seed_hi) & 0xFFFFFFFF)
         h = orc._hash32((orc._hash32(v ^ seed_lo) + rk) & 0xFFFFFFFF)
-        u = ((h >> 8).double() + 0.5) / 16777216.0
+        u = ((h >> 9).double() + 0.5) / 8388608.0
         key = logp32.double() - torch.log(-torch.log(u))
         banned = set(int(x) for x in ex[r].tolist() if 0 <= x < V) | {int(gt[r])}
         key[list(banned)] = -float("inf")

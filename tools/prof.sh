@@ -18,6 +18,11 @@ rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- python3 $root/bench.py --steps 4 --warmup 2 $common "$@" > $out/pmc_fetch.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- python3 $root/bench.py --steps 4 --warmup 2 $common "$@" > $out/pmc_write.log 2>&1 || exit 1
 cd $root
+python3 - > $out/summary/${tag}_build_${cfg}.json <<PY
+import hashlib, json, os, subprocess
+lib = os.environ.get("B4R_LIB_PATH") or "bert4rec_amd/libb4r_hip.so"
+print(json.dumps({"lib": lib, "lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]}))
+PY
 cp $out/trace/*/*_kernel_stats.csv $out/summary/${tag}_kernel_stats_${cfg}.csv
 python3 tools/stats.py $out/trace 25 40 > $out/summary/${tag}_kernel_stats_${cfg}.txt
 python3 tools/seq.py $out/trace > $out/summary/${tag}_step_sequence_${cfg}.txt

@@ -99,11 +99,15 @@ __device__ __forceinline__ void rl_to_panels(const RowLay& k, char* tile0, char*
 // accumulator layout (rows 32 rt + (t & 3) + 8 (t >> 2) + 4h = columns of the tensor, lane r = token) -> row layout, through 8 KB of
 // the wave's own LDS: two [32 tokens][32 columns] fp32 halves, 16-byte chunk c of row `row` at chunk position c ^ (row & 7)
 // (conflict-free both ways)
+// KORD: the accumulators' registers 8s .. 8s+7 are columns 16s + 8h + (0..7) (the output of a product whose A operand was a
+// transposed read of an image in swapped column order) instead of the D layout's rows
+template <bool KORD = false>
 __device__ __forceinline__ void acc_to_rl(const RowLay& k, char* halfA, char* halfB, int r, int h, const f32x16 (&v)[2], f32x4 (&out)[8]) {
 #pragma unroll
   for (int gp = 0; gp < 4; ++gp) {
-    *reinterpret_cast<f32x4*>(halfA + r * 128 + 16 * ((2 * gp + h) ^ (r & 7))) = (f32x4){v[0][4 * gp], v[0][4 * gp + 1], v[0][4 * gp + 2], v[0][4 * gp + 3]};
-    *reinterpret_cast<f32x4*>(halfB + r * 128 + 16 * ((2 * gp + h) ^ (r & 7))) = (f32x4){v[1][4 * gp], v[1][4 * gp + 1], v[1][4 * gp + 2], v[1][4 * gp + 3]};
+    const int c = KORD ? 4 * (gp >> 1) + 2 * h + (gp & 1) : 2 * gp + h;   // 16-byte chunk (4 columns) of registers 4 gp .. 4 gp + 3
+    *reinterpret_cast<f32x4*>(halfA + r * 128 + 16 * (c ^ (r & 7))) = (f32x4){v[0][4 * gp], v[0][4 * gp + 1], v[0][4 * gp + 2], v[0][4 * gp + 3]};
+    *reinterpret_cast<f32x4*>(halfB + r * 128 + 16 * (c ^ (r & 7))) = (f32x4){v[1][4 * gp], v[1][4 * gp + 1], v[1][4 * gp + 2], v[1][4 * gp + 3]};
   }
   const char* src = (k.c4 & 8) ? halfB : halfA;
 #pragma unroll
@@ -629,6 +633,292 @@ __global__ __launch_bounds__(512, 2) void attn32_bwd_kernel(A32BwdP p) {
   A32_MARK(32);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// forward.  One workgroup per sequence, wave w owns tokens 32w .. 32w+31 end to end:
+//   x rows (row layout, coalesced; for the first layer formed here from the embedding tables) -> images; Wqkv, Wo -> images
+//   q~, k, v of BOTH heads for its tokens (transposed: rows = feature, lane = token), K / V rows -> the images every wave reads
+//   per head: S^T[key][query] = K . Q~^T for all key tiles (the score row of a query lives in one lane's registers and its partner
+//   half: softmax without LDS), dropout decisions from the counter hash (one hash per 4 keys) -> Pd, O^T = V^T . Pd^T
+//   y^T = Wo^T . O^T, then in row layout: bias, dropout, residual, LayerNorm; ctx, z1 (, x1), statistics leave as whole rows.
+// LDS: [Wo images 16 KB | region A 16 KB per 32 tokens: first Wqkv images 48 KB + the waves' x images, then K / V images of both
+// heads, then the waves' transposition space | key mask adders, bqkv]
+// ---------------------------------------------------------------------------------------------------------------------------
+struct A32FwdP {
+  const float* x; const int64_t* mask;
+  const float* Wqkv; const float* bqkv; const float* Wo; const float* bo; const float* g1; const float* be1;
+  float* qkv; float* ctx; float* lse; uint32_t* bits;
+  float* z1; float* x1; float* mean1; float* rstd1;
+  int B, L, NT;
+  float qscale, eps;
+  DropArgs drop_p, drop_o;
+  const int64_t* ids; const float* table; const float* pos; const float* g0; const float* be0;
+  float* x_out; float* mean0; float* rstd0;
+  int V; float eps0;
+  DropArgs drop_e;
+};
+
+__host__ __device__ constexpr int fwd32_region_a(int NT) { return 4 * NT * P_TILE > 12 * P_TILE + 2 * NT * P_TILE ? 4 * NT * P_TILE : 12 * P_TILE + 2 * NT * P_TILE; }
+__host__ __device__ constexpr int fwd32_lds(int NT) { return 4 * P_TILE + fwd32_region_a(NT) + (NT * 32 + 192) * 4; }
+
+template <int NTT, bool DROP>
+__global__ __launch_bounds__(512, 2) void attn32_fwd_kernel(A32FwdP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem32[];
+  const int NT = p.NT, L = p.L;
+  char* const WOIMG = smem32;                       // [context half][hidden panel]: tile 2 ci + hj
+  char* const RA = smem32 + 4 * P_TILE;
+  char* const WQKV = RA;                            // phase 1: tile 2 cp + rt (column panel cp = 0..5 of [64][192], hidden rows 32 rt ..)
+  char* const XIMG = RA + 12 * P_TILE;              // phase 1: wave w's x images: two column panels
+  char* const KV = RA;                              // phase 2: [head][K | V][token tile]
+  float* const sAdd = reinterpret_cast<float*>(RA + fwd32_region_a(NT));   // (mask adder - amax) * log2e per key, -inf beyond L
+  float* const sbq = sAdd + NT * 32;
+
+  const int nthreads = blockDim.x;
+  const int b = blockIdx.x;
+  const int64_t row0 = (int64_t)b * L;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  A32_LANE_CONSTS();
+  char* const own = RA + wave * 4 * P_TILE;         // phase 3: 16 KB of transposition space per wave
+
+  const int64_t mval = (int)threadIdx.x < L ? p.mask[row0 + threadIdx.x] : 0;
+  const int any_key = mval != 0 ? 1 : 0;
+  for (int k = threadIdx.x; k < 192; k += nthreads) sbq[k] = p.bqkv[k];
+
+  // ---- the wave's x rows (row layout).  First layer: x = dropout(LayerNorm(table[id] + position)), written out with its statistics
+  const float* const xb = (p.ids != nullptr ? p.x_out : p.x) + row0 * HID;
+  f32x4 xr[8];
+  if (p.ids != nullptr) {
+    const DropCtx dce = b4r_drop_ctx(p.drop_e);
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(p.g0 + 4 * rl_c4), be = *reinterpret_cast<const f32x4*>(p.be0 + 4 * rl_c4);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int trow = 32 * wave + 4 * i + rl_row, trc = min(trow, L - 1);
+      int64_t id = p.ids[row0 + trc];
+      if (id < 0 || id >= p.V) id = 0;   // out-of-range ids read the PAD row, as b4r_embed_ln_fwd does
+      const f32x4 e = *reinterpret_cast<const f32x4*>(p.table + id * HID + 4 * rl_c4) +
+                      *reinterpret_cast<const f32x4*>(p.pos + (int64_t)trc * HID + 4 * rl_c4);
+      const float mean = row_allsum16(sum4(e)) * (1.0f / HID);
+      const f32x4 d = e - mean;
+      const float rstd = rsqrtf(row_allsum16(sum4(d * d)) * (1.0f / HID) + p.eps0);
+      f32x4 y;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float inv = rstd * gm[c];
+        y[c] = e[c] * inv + (be[c] - mean * inv);
+      }
+      y = b4r_drop4(dce, y, (uint64_t)(row0 + trow) * HID + (uint64_t)(4 * rl_c4));
+      xr[i] = y;
+      if (trow < L) {
+        st4(p.x_out + row0 * HID, rl_off(rl, i), y);
+        if (rl_c4 == 0) {
+          if (p.mean0) p.mean0[row0 + trow] = mean;
+          if (p.rstd0) p.rstd0[row0 + trow] = rstd;
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) xr[i] = ld4(xb, rl_off(rl, i));
+  }
+  // weights: Wqkv [64][192] as 6 column panels x 2 row tiles, Wo [64][64] as tile 2 ci + hj (context rows 32 ci .., hidden 32 hj ..)
+  stage_tiles<5>(WOIMG, 16, nthreads, [&](int gt, int& ld) __attribute__((always_inline)) -> const float* {
+    const bool wo = gt < 4;
+    const int g = wo ? gt : gt - 4;
+    ld = wo ? HID : 3 * HID;
+    return wo ? p.Wo + (int64_t)32 * (g >> 1) * HID + 32 * (g & 1) : p.Wqkv + (int64_t)32 * (g & 1) * (3 * HID) + 32 * (g >> 1);
+  });
+#pragma unroll
+  for (int i = 0; i < 8; ++i) rl_to_panels(rl, XIMG + wave * 2 * P_TILE, XIMG + wave * 2 * P_TILE + P_TILE, i, xr[i]);
+  const float amax = __syncthreads_or(any_key) ? 0.0f : -1e9f;   // (barrier: the weight images and sbq are in place)
+  if ((int)threadIdx.x < NT * 32)
+    sAdd[threadIdx.x] = (int)threadIdx.x < L ? (((1.0f - (float)mval) * -1e9f) - amax) * LOG2E : -INFINITY;
+
+  // ---- q~, k, v of both heads (transposed), the wave's tokens ------------------------------------------------------------------
+  bf16x8 qBh[2][2], qBl[2][2];     // [head][k-step]: Q~^T[feature][query] as the B operand of S^T = K . Q~^T
+  f32x16 kT[2], vT[2];
+  {
+    bf16x8 xh[4], xl[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const char* xt = XIMG + (wave * 2 + (ks >> 1)) * P_TILE + lk.rowc[ks & 1];
+      xh[ks] = row_at(xt); xl[ks] = row_at(xt + P_IMG);
+    }
+#pragma unroll
+    for (int hd = 0; hd < 2; ++hd) {
+      f32x16 acc[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        acc[j] = rows_of(sbq + HID * j + 32 * hd, h);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const char* wt = WQKV + (2 * (2 * j + hd) + (ks >> 1)) * P_TILE;
+          const int a0 = lk.trn[ks & 1][0], a1 = lk.trn[ks & 1][1];
+          acc[j] = mfma32x3(tr_pair(wt + a0, wt + a1), tr_pair(wt + P_IMG + a0, wt + P_IMG + a1), xh[ks], xl[ks], acc[j]);
+        }
+      }
+      acc[0] = acc[0] * p.qscale;
+      if (p.qkv != nullptr && live) {   // b4r_attn_fwd's layout (compatibility output; the train step does not ask for it)
+        float* dst = p.qkv + (row0 + tok) * (3 * HID) + 32 * hd + 4 * h;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int gp = 0; gp < 4; ++gp)
+            *reinterpret_cast<f32x4*>(dst + HID * j + 8 * gp) = (f32x4){acc[j][4 * gp], acc[j][4 * gp + 1], acc[j][4 * gp + 2], acc[j][4 * gp + 3]};
+      }
+      acc[0] = acc[0] * LOG2E;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) acc_frag(acc[0], s, qBh[hd][s], qBl[hd][s]);
+      kT[hd] = acc[1]; vT[hd] = acc[2];
+    }
+  }
+  if (amax != 0.0f) {   // every key masked: Keras' -1e9 absorbs the scores -> a uniform softmax over the L keys (lse = log L)
+#pragma unroll
+    for (int hd = 0; hd < 2; ++hd)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { qBh[hd][s][e] = (__bf16)0.f; qBl[hd][s][e] = (__bf16)0.f; }
+  }
+  lds_barrier();   // every wave is done with the Wqkv and x images: region A takes the K / V images
+#pragma unroll
+  for (int hd = 0; hd < 2; ++hd) {
+    f32x16 kk = kT[hd], vv = vT[hd];
+    if (!live) { kk = zero16(); vv = zero16(); }   // pad tokens: zero rows (their keys are masked anyway; no NaN may enter P . V)
+    acc_to_rows(KV + ((2 * hd) * NT + wave) * P_TILE, lk, kk);
+    acc_to_rows(KV + ((2 * hd + 1) * NT + wave) * P_TILE, lk, vv);
+  }
+  lds_barrier();
+
+  // ---- attention, one head at a time --------------------------------------------------------------------------------------
+  const DropCtx dcp = b4r_drop_ctx(p.drop_p);
+  f32x16 O[2];
+  const int qt = wave;
+  const int slot = (r & 24) | ((r & 3) << 1) | ((r >> 2) & 1);   // query 16s + 8a + 4h' + b -> 16s + 8a + 2b + h' (the backward's register pairs)
+#pragma unroll
+  for (int hd = 0; hd < 2; ++hd) {
+    const char* kimg = KV + (2 * hd) * NT * P_TILE;
+    const char* vimg = KV + (2 * hd + 1) * NT * P_TILE;
+    const int64_t bh = (int64_t)b * 2 + hd;
+    f32x16 S[NTT];
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NTT; ++t) {
+      if (t < NT) {   // (wave-uniform; NTT is the compile-time bound of the token tiles)
+        S[t] = rows_of(sAdd + 32 * t, h);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const char* ka = kimg + t * P_TILE + lk.rowc[ks];
+          S[t] = mfma32x3(row_at(ka), row_at(ka + P_IMG), qBh[hd][ks], qBl[hd][ks], S[t]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) S[t][e] = -INFINITY;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NTT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) m = fmaxf(m, S[t][e]);
+    m = fmaxf(m, other_half(m, h));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NTT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { S[t][e] = __builtin_amdgcn_exp2f(S[t][e] - m); sum += S[t][e]; }
+    sum += other_half(sum, h);
+    const float inv = 1.0f / sum;
+    if (h == 0 && live && p.lse) p.lse[bh * L + tok] = m * LN2 + __logf(sum);
+    O[hd] = zero16();
+    const uint64_t dbase = ((uint64_t)bh * L + (uint64_t)(live ? tok : 0)) * (uint64_t)B4R_ATTN_PITCH;
+#pragma unroll
+    for (int t = 0; t < NTT; ++t) {
+      if (t >= NT) continue;
+      if (DROP) {
+        uint32_t word = 0;
+        const float sc = inv * dcp.scale;
+#pragma unroll
+        for (int gp = 0; gp < 4; ++gp) {
+          const B4rKeep4 k4 = b4r_keep4p(dcp, dbase + (uint64_t)(32 * t + 8 * gp + 4 * h));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) S[t][4 * gp + e] = k4.k[e] ? S[t][4 * gp + e] * sc : 0.f;
+          word |= k4.bits() << (8 * gp + 4 * h);
+        }
+        word |= other_half_u(word, h);
+        if (h == 0 && live) p.bits[((bh * NT + t) * NT + qt) * 32 + slot] = word;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) S[t][e] *= inv;
+      }
+      // O^T[feature][query] += V^T[feature][keys of tile t] . Pd^T[key][query]
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 ph, pl;
+        acc_frag(S[t], s2, ph, pl);
+        const char* va = vimg + t * P_TILE;
+        O[hd] = mfma32x3(tr_pair(va + lk.trp[s2][0], va + lk.trp[s2][1]), tr_pair(va + P_IMG + lk.trp[s2][0], va + P_IMG + lk.trp[s2][1]),
+                         ph, pl, O[hd]);
+      }
+    }
+  }
+
+  // ---- y^T[hidden][token] = Wo^T . ctx^T: registers 8s .. 8s+7 of O are context columns 16s + 8h + .. of the head: natural k order
+  f32x16 y[2] = {zero16(), zero16()};
+#pragma unroll
+  for (int hd = 0; hd < 2; ++hd)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 oh, ol;
+      acc_frag(O[hd], s, oh, ol);
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const char* wt = WOIMG + (2 * hd + rt) * P_TILE;
+        y[rt] = mfma32x3(tr_pair(wt + lk.trn[s][0], wt + lk.trn[s][1]), tr_pair(wt + P_IMG + lk.trn[s][0], wt + P_IMG + lk.trn[s][1]), oh, ol, y[rt]);
+      }
+    }
+  lds_barrier();   // every wave is done with the K / V images: the waves' transposition space overlays them
+
+  // ---- row layout: ctx out; z1 = x + dropout(y + bo), LayerNorm ------------------------------------------------------------------
+  {
+    f32x4 cr[8];
+    acc_to_rl<true>(rl, own, own + P_TILE, r, h, O, cr);
+    if (p.ctx) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (32 * wave + 4 * i + rl_row < L) st4(p.ctx + row0 * HID, rl_off(rl, i), cr[i]);
+    }
+  }
+  f32x4 yr[8];
+  acc_to_rl(rl, own + 2 * P_TILE, own + 3 * P_TILE, r, h, y, yr);   // (the second 8 KB of the wave's space: no wait for the ctx reads)
+  const DropCtx dco = b4r_drop_ctx(p.drop_o);
+  const f32x4 bo4 = *reinterpret_cast<const f32x4*>(p.bo + 4 * rl_c4);
+  const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.g1 + 4 * rl_c4), be4 = *reinterpret_cast<const f32x4*>(p.be1 + 4 * rl_c4);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int trow = 32 * wave + 4 * i + rl_row;
+    const f32x4 res = ld4(xb, rl_off(rl, i));
+    const f32x4 z = res + b4r_drop4(dco, yr[i] + bo4, (uint64_t)(row0 + trow) * HID + (uint64_t)(4 * rl_c4));
+    const float mean = row_allsum16(sum4(z)) * (1.0f / HID);
+    const f32x4 d = z - mean;
+    const float rstd = rsqrtf(row_allsum16(sum4(d * d)) * (1.0f / HID) + p.eps);
+    if (trow < L) {
+      if (p.z1) st4(p.z1 + row0 * HID, rl_off(rl, i), z);
+      if (p.x1) {
+        f32x4 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float inv = rstd * g4[c];
+          o[c] = fmaf(z[c], inv, fmaf(-mean, inv, be4[c]));   // x1_load4's formula, rounding for rounding
+        }
+        st4(p.x1 + row0 * HID, rl_off(rl, i), o);
+      }
+      if (rl_c4 == 0) {
+        if (p.mean1) p.mean1[row0 + trow] = mean;
+        if (p.rstd1) p.rstd1[row0 + trow] = rstd;
+      }
+    }
+  }
+}
+
 bool al16(const void* q) { return q == nullptr || b4r_aligned16(q); }
 
 }  // namespace
@@ -710,4 +1000,53 @@ int b4r_attn32_bwd(const b4r_attn_block_bwd_desc* d, b4r_stream_t stream) {
   rc = b4r_launch_slab_reduce_full(p.dw_slab, d->B, HID, 3 * HID, d->dWqkv, 3 * HID, 0, p.db_slab, d->dbqkv, nullptr, nullptr, s);
   if (rc != B4R_OK || !fold_wo) return rc;
   return b4r_launch_slab_reduce_full(p.dwo_slab, d->B, HID, HID, d->dWo, HID, 0, p.dbo_slab, d->dbo, nullptr, nullptr, s);
+}
+
+int b4r_attn32_fwd(const b4r_attn_block_desc* d, b4r_stream_t stream) {
+  B4R_CHECK_ARG(d != nullptr, B4R_E_BADARG, "b4r_attn_block_fwd: null descriptor");
+  B4R_CHECK_ARG(b4r_attn32_supported(d->H, d->heads, d->L), B4R_E_SHAPE,
+                "b4r_attn_block_fwd: needs hidden size 64, 2 heads, L <= 224 and the bf16x3 mode (H=%d heads=%d L=%d)", d->H, d->heads, d->L);
+  const bool embed = d->emb_ids != nullptr;
+  B4R_CHECK_ARG(d->B > 0 && (d->x || embed) && d->input_mask && d->Wqkv && d->bqkv && d->Wo && d->bo && d->ln_gamma && d->ln_beta &&
+                    (d->x1 || (d->z1 && d->mean1 && d->rstd1)),
+                B4R_E_BADARG, "b4r_attn_block_fwd: null argument (outputs: x1, or z1 + mean1 + rstd1)");
+  B4R_CHECK_ARG(!embed || (d->emb_table && d->emb_pos && d->emb_gamma && d->emb_beta && d->emb_x && d->emb_vocab > 0 &&
+                           al16(d->emb_table) && al16(d->emb_pos) && al16(d->emb_gamma) && al16(d->emb_beta) && al16(d->emb_x)),
+                B4R_E_BADARG, "b4r_attn_block_fwd: the embedding mode needs emb_table, emb_pos, emb_gamma, emb_beta, emb_x (16-byte "
+                "aligned) and emb_vocab");
+  B4R_CHECK_ARG(al16(d->x) && al16(d->Wqkv) && al16(d->Wo) && al16(d->bo) && al16(d->ln_gamma) && al16(d->ln_beta) && al16(d->qkv) &&
+                    al16(d->ctx) && al16(d->z1) && al16(d->x1) && al16(d->keep_bits),
+                B4R_E_ALIGN, "b4r_attn_block_fwd: operands must be 16-byte aligned");
+  A32FwdP p{};
+  p.x = d->x; p.mask = d->input_mask; p.Wqkv = d->Wqkv; p.bqkv = d->bqkv; p.Wo = d->Wo; p.bo = d->bo;
+  p.g1 = d->ln_gamma; p.be1 = d->ln_beta; p.qkv = d->qkv; p.ctx = d->ctx; p.lse = d->lse;
+  p.bits = d->keep_bits ? d->keep_bits + b4r_attn_rx_keep_words(d->B, d->L, d->heads) : nullptr;   // behind round 1's layout
+  p.z1 = d->z1; p.x1 = d->x1; p.mean1 = d->mean1; p.rstd1 = d->rstd1;
+  p.B = d->B; p.L = d->L; p.NT = b4r_cdiv(d->L, 32);
+  p.qscale = 1.0f / sqrtf(32.0f); p.eps = d->ln_eps;
+  p.drop_p = b4r_make_drop(d->rng, d->probs_stream, d->probs_rate, d->rng != nullptr);
+  p.drop_o = b4r_make_drop(d->rng, d->out_stream, d->out_rate, d->rng != nullptr);
+  B4R_CHECK_ARG(!p.drop_p.rng || d->keep_bits, B4R_E_BADARG, "b4r_attn_block_fwd: attention dropout needs keep_bits");
+  if (embed) {
+    p.ids = d->emb_ids; p.table = d->emb_table; p.pos = d->emb_pos; p.g0 = d->emb_gamma; p.be0 = d->emb_beta; p.V = d->emb_vocab;
+    p.x_out = d->emb_x; p.mean0 = d->emb_mean; p.rstd0 = d->emb_rstd; p.eps0 = d->emb_eps;
+    p.drop_e = b4r_make_drop(d->rng, d->emb_stream, d->emb_rate, d->rng != nullptr);
+  }
+  const bool drop = p.drop_p.rng != nullptr && p.drop_p.thr != 0;
+  const size_t sh = (size_t)fwd32_lds(p.NT);
+  const dim3 grid((unsigned)d->B), block((unsigned)(64 * p.NT));
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+#define A32_FWD_CASE(N_, D_)                                                                          \
+  {                                                                                                   \
+    rc = b4r_raise_lds((const void*)attn32_fwd_kernel<N_, D_>, sh, "b4r_attn_block_fwd");             \
+    if (rc) return rc;                                                                                \
+    hipLaunchKernelGGL((attn32_fwd_kernel<N_, D_>), grid, block, sh, s, p);                           \
+  }
+  if (p.NT <= 2) { if (drop) A32_FWD_CASE(2, true) else A32_FWD_CASE(2, false) }
+  else if (p.NT <= 4) { if (drop) A32_FWD_CASE(4, true) else A32_FWD_CASE(4, false) }
+  else { if (drop) A32_FWD_CASE(7, true) else A32_FWD_CASE(7, false) }
+#undef A32_FWD_CASE
+  B4R_CHECK_LAUNCH("b4r_attn_block_fwd");
+  return B4R_OK;
 }

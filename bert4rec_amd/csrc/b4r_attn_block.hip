@@ -344,7 +344,7 @@ __global__ __launch_bounds__(1024) void attn_block_fwd_kernel(AbP p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float inv = rstd * gm[e];
-        out[e] = z[hb][e] * inv + (be[e] - mean * inv);
+        out[e] = fmaf(z[hb][e], inv, fmaf(-mean, inv, be[e]));
       }
       if (p.z1) *reinterpret_cast<f32x4*>(p.z1 + off) = z[hb];
       if (p.x1) *reinterpret_cast<f32x4*>(p.x1 + off) = out;
@@ -807,8 +807,11 @@ extern "C" int b4r_attn_block_bwd(const b4r_attn_block_bwd_desc* d, b4r_stream_t
   return b4r_launch_slab_reduce_full(d->scratch, d->B, 1, 128, d->dprev_gamma, 128, 0, nullptr, nullptr, nullptr, nullptr, s);
 }
 
+int b4r_attn32_fwd(const b4r_attn_block_desc* d, b4r_stream_t stream);
 extern "C" int b4r_attn_block_fwd(const b4r_attn_block_desc* d, b4r_stream_t stream) {
   B4R_CHECK_ARG(d != nullptr, B4R_E_BADARG, "b4r_attn_block_fwd: null descriptor");
+  static const bool fwd32 = !(getenv("B4R_ATTN32_FWD") && atoi(getenv("B4R_ATTN32_FWD")) == 0);
+  if (fwd32 && use_attn32() && b4r_attn32_supported(d->H, d->heads, d->L)) return b4r_attn32_fwd(d, stream);
   B4R_CHECK_ARG(b4r_attn_block_supported(d->H, d->heads, d->L), B4R_E_SHAPE,
                 "b4r_attn_block_fwd: needs hidden size 64, 2 heads, L <= 256 and the bf16x3 mode (H=%d heads=%d L=%d)", d->H, d->heads,
                 d->L);

@@ -152,7 +152,7 @@ __device__ __forceinline__ f32x8 x1_load8(const X1Src& s, int64_t tok, int col) 
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const float inv = rstd * gm[e];
-    y[e] = z[e] * inv + (be[e] - mean * inv);
+    y[e] = fmaf(z[e], inv, fmaf(-mean, inv, be[e]));   // explicit: every kernel that forms x1 rounds alike
   }
   return y;
 }
@@ -165,7 +165,7 @@ __device__ __forceinline__ f32x4 x1_load4(const X1Src& s, int64_t tok, int col) 
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const float inv = rstd * gm[e];
-    y[e] = z[e] * inv + (be[e] - mean * inv);
+    y[e] = fmaf(z[e], inv, fmaf(-mean, inv, be[e]));   // explicit: every kernel that forms x1 rounds alike
   }
   return y;
 }

@@ -34,12 +34,15 @@ constexpr float LN2 = 0.6931471805599453f;
 #ifdef A32_PROF
 __device__ long long g_a32_prof[64];
 __device__ long long g_a32_sweep[2][64];
+__device__ long long g_a32f_prof[32];
+#define A32F_MARK(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_a32f_prof[k] = clock64(); } while (0)
 #define A32_MARK(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_a32_prof[k] = clock64(); } while (0)
 // stamps inside the sweep of head 0, by lane 0 of waves 0 and 4
 #define A32_SWEEP(k) do { if (blockIdx.x == 0 && hd == 0 && (threadIdx.x & 255) == 0 && (k) < 64) g_a32_sweep[threadIdx.x >> 8][k] = clock64(); } while (0)
 #else
 #define A32_MARK(k) do { } while (0)
 #define A32_SWEEP(k) do { } while (0)
+#define A32F_MARK(k) do { } while (0)
 #endif
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -679,11 +682,13 @@ __global__ __launch_bounds__(512, 2) void attn32_fwd_kernel(A32FwdP p) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   A32_LANE_CONSTS();
   char* const own = RA + wave * 4 * P_TILE;         // phase 3: 16 KB of transposition space per wave
+  // (s_setprio(1) for waves 4.., the younger wave of every SIMD, was measured: forward 42.7 / 42.9 us with, 43.0 / 42.2 without)
 
   const int64_t mval = (int)threadIdx.x < L ? p.mask[row0 + threadIdx.x] : 0;
   const int any_key = mval != 0 ? 1 : 0;
   for (int k = threadIdx.x; k < 192; k += nthreads) sbq[k] = p.bqkv[k];
 
+  A32F_MARK(0);
   // ---- the wave's x rows (row layout).  First layer: x = dropout(LayerNorm(table[id] + position)), written out with its statistics
   const float* const xb = (p.ids != nullptr ? p.x_out : p.x) + row0 * HID;
   f32x4 xr[8];
@@ -720,6 +725,7 @@ __global__ __launch_bounds__(512, 2) void attn32_fwd_kernel(A32FwdP p) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) xr[i] = ld4(xb, rl_off(rl, i));
   }
+  A32F_MARK(1);
   // weights: Wqkv [64][192] as 6 column panels x 2 row tiles, Wo [64][64] as tile 2 ci + hj (context rows 32 ci .., hidden 32 hj ..)
   stage_tiles<5>(WOIMG, 16, nthreads, [&](int gt, int& ld) __attribute__((always_inline)) -> const float* {
     const bool wo = gt < 4;
@@ -729,7 +735,9 @@ __global__ __launch_bounds__(512, 2) void attn32_fwd_kernel(A32FwdP p) {
   });
 #pragma unroll
   for (int i = 0; i < 8; ++i) rl_to_panels(rl, XIMG + wave * 2 * P_TILE, XIMG + wave * 2 * P_TILE + P_TILE, i, xr[i]);
+  A32F_MARK(2);
   const float amax = __syncthreads_or(any_key) ? 0.0f : -1e9f;   // (barrier: the weight images and sbq are in place)
+  A32F_MARK(3);
   if ((int)threadIdx.x < NT * 32)
     sAdd[threadIdx.x] = (int)threadIdx.x < L ? (((1.0f - (float)mval) * -1e9f) - amax) * LOG2E : -INFINITY;
 
@@ -779,7 +787,9 @@ __global__ __launch_bounds__(512, 2) void attn32_fwd_kernel(A32FwdP p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { qBh[hd][s][e] = (__bf16)0.f; qBl[hd][s][e] = (__bf16)0.f; }
   }
+  A32F_MARK(4);
   lds_barrier();   // every wave is done with the Wqkv and x images: region A takes the K / V images
+  A32F_MARK(5);
 #pragma unroll
   for (int hd = 0; hd < 2; ++hd) {
     f32x16 kk = kT[hd], vv = vT[hd];
@@ -787,7 +797,9 @@ __global__ __launch_bounds__(512, 2) void attn32_fwd_kernel(A32FwdP p) {
     acc_to_rows(KV + ((2 * hd) * NT + wave) * P_TILE, lk, kk);
     acc_to_rows(KV + ((2 * hd + 1) * NT + wave) * P_TILE, lk, vv);
   }
+  A32F_MARK(6);
   lds_barrier();
+  A32F_MARK(7);
 
   // ---- attention, one head at a time --------------------------------------------------------------------------------------
   const DropCtx dcp = b4r_drop_ctx(p.drop_p);
@@ -815,6 +827,7 @@ __global__ __launch_bounds__(512, 2) void attn32_fwd_kernel(A32FwdP p) {
         for (int e = 0; e < 16; ++e) S[t][e] = -INFINITY;
       }
     }
+    A32F_MARK(8 + 4 * hd);
 #pragma unroll
     for (int t = 0; t < NTT; ++t)
 #pragma unroll
@@ -828,6 +841,7 @@ __global__ __launch_bounds__(512, 2) void attn32_fwd_kernel(A32FwdP p) {
     sum += other_half(sum, h);
     const float inv = 1.0f / sum;
     if (h == 0 && live && p.lse) p.lse[bh * L + tok] = m * LN2 + __logf(sum);
+    A32F_MARK(9 + 4 * hd);
     O[hd] = zero16();
     const uint64_t dbase = ((uint64_t)bh * L + (uint64_t)(live ? tok : 0)) * (uint64_t)B4R_ATTN_PITCH;
 #pragma unroll
@@ -861,6 +875,7 @@ __global__ __launch_bounds__(512, 2) void attn32_fwd_kernel(A32FwdP p) {
     }
   }
 
+  A32F_MARK(16);
   // ---- y^T[hidden][token] = Wo^T . ctx^T: registers 8s .. 8s+7 of O are context columns 16s + 8h + .. of the head: natural k order
   f32x16 y[2] = {zero16(), zero16()};
 #pragma unroll
@@ -875,7 +890,9 @@ __global__ __launch_bounds__(512, 2) void attn32_fwd_kernel(A32FwdP p) {
         y[rt] = mfma32x3(tr_pair(wt + lk.trn[s][0], wt + lk.trn[s][1]), tr_pair(wt + P_IMG + lk.trn[s][0], wt + P_IMG + lk.trn[s][1]), oh, ol, y[rt]);
       }
     }
+  A32F_MARK(17);
   lds_barrier();   // every wave is done with the K / V images: the waves' transposition space overlays them
+  A32F_MARK(18);
 
   // ---- row layout: ctx out; z1 = x + dropout(y + bo), LayerNorm ------------------------------------------------------------------
   {
@@ -887,6 +904,7 @@ __global__ __launch_bounds__(512, 2) void attn32_fwd_kernel(A32FwdP p) {
         if (32 * wave + 4 * i + rl_row < L) st4(p.ctx + row0 * HID, rl_off(rl, i), cr[i]);
     }
   }
+  A32F_MARK(19);
   f32x4 yr[8];
   acc_to_rl(rl, own + 2 * P_TILE, own + 3 * P_TILE, r, h, y, yr);   // (the second 8 KB of the wave's space: no wait for the ctx reads)
   const DropCtx dco = b4r_drop_ctx(p.drop_o);
@@ -936,6 +954,9 @@ int64_t b4r_attn32_keep_words(int32_t B, int32_t L, int32_t heads) {
 #ifdef A32_PROF
 extern "C" int b4r_debug_a32_prof(long long* host_out) {   // 64 stamps of the last backward launch (after a device synchronisation)
   return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_a32_prof), 64 * sizeof(long long)) == hipSuccess ? 0 : -4;
+}
+extern "C" int b4r_debug_a32f_prof(long long* host_out) {   // stamps of the last forward launch
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_a32f_prof), 32 * sizeof(long long)) == hipSuccess ? 0 : -4;
 }
 extern "C" int b4r_debug_a32_sweep(long long* host_out) {   // [2 waves][64] stamps inside the sweep of head 0
   return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_a32_sweep), 128 * sizeof(long long)) == hipSuccess ? 0 : -4;

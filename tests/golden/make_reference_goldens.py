@@ -125,9 +125,8 @@ def main():
     # last-L truncation (finetuning or short rows), the random window of a long training row (python `random`, seeded here)
     # and the right-padding of input_word_ids / input_mask / labels.  With apply_mlm the training branch reseeds `random`
     # from the OS (seed=None) and the finetuning branch wraps the label in tf.constant (a placeholder here), so for
-    # mask_last_token_only (dataloader_utils.py:264-269) only its two numpy outputs are captured; prepare_inference
-    # (bert4rec_preprocessor.py:125-168) = process_element(history[-(L-1):] + ["[UNK]"], True, True) + tf.expand_dims and is
-    # pinned through these two captures.
+    # mask_last_token_only (dataloader_utils.py:264-269) only its two numpy outputs are captured here; prepare_inference
+    # (bert4rec_preprocessor.py:125-168) is captured directly in section 5.
     import random as _random
     pre_mod = importlib.import_module("bert4rec.dataloaders.preprocessors.bert4rec_preprocessor")
     vocab_items = [f"item{j}" for j in range(40)]
@@ -166,6 +165,25 @@ def main():
         ml_cases.append({"sequence": seq.tolist(), "mask_token_id": 1, "masked_token_ids": np.asarray(toks).tolist(),
                          "masked_lm_positions": np.asarray(pos).tolist(), "masked_lm_ids_by_definition": [int(seq[-1])]})
     out["mask_last_token_only"] = ml_cases
+
+    # ---- 5. prepare_inference, captured directly (bert4rec_preprocessor.py:125-168) -----------------------------------------
+    # It calls process_element(history[-(L-1):] + ["[UNK]"], apply_mlm=True, finetuning=True) and wraps every array with
+    # tf.expand_dims(tf.constant(value), axis=0); the finetuning branch of process_element wraps its label in tf.constant.  Both tf
+    # calls are given their numpy meaning for this capture (constant = asarray, expand_dims = numpy's): the reference's own python /
+    # numpy code then runs end to end and every key it returns is recorded.
+    tf_stub = pre_mod.tf
+    tf_stub.constant = lambda v, *a, **k: np.asarray(v)
+    tf_stub.expand_dims = lambda v, axis=0: np.expand_dims(np.asarray(v), axis)
+    du_tf = getattr(du, "tf", None)
+    if du_tf is not None:
+        du_tf.constant = tf_stub.constant
+    pi_cases = []
+    for n in (1, 4, L_ - 1, L_, 30):
+        hist = [vocab_items[(5 * j + n) % 40] for j in range(n)]
+        r = PP.prepare_inference(list(hist))
+        pi_cases.append({"history": hist, "out": {k: np.asarray(v).tolist() for k, v in r.items()},
+                         "dtypes": {k: str(np.asarray(v).dtype) for k, v in r.items()}})
+    out["prepare_inference"] = {"max_seq_len": L_, "max_predictions_per_seq": P_, "cases": pi_cases}
 
     with open(OUT, "w") as f:
         json.dump(out, f, indent=1)

@@ -194,6 +194,25 @@ def test_truncation_window_and_padding_match_reference_process_element():
     assert inf["masked_lm_weights"].tolist() == [[1, 0, 0, 0, 0]] and inf["input_mask"].tolist() == [[1] * L]
 
 
+def test_prepare_inference_matches_the_reference_run():
+    """bert4rec_preprocessor.py:125-168 executed in the build container (tests/golden/make_reference_goldens.py section 5): every key,
+    value, shape and dtype of what the reference returns for histories shorter than, equal to and longer than max_seq_len - 1; the device path's token matrix
+    (finetuning rows of the same histories + [UNK]) holds the same rows."""
+    PP, _ = _gold_preprocessor()
+    g = GOLD["prepare_inference"]
+    for c in g["cases"]:
+        got = PP.prepare_inference(list(c["history"]))
+        assert set(got) == set(c["out"])
+        for k, want in c["out"].items():
+            assert np.asarray(got[k]).tolist() == want and str(np.asarray(got[k]).dtype) == c["dtypes"][k], (k, c["history"])
+        # the device masker's input for the same request: the [U, L] token matrix row + its finetune flag
+        L = g["max_seq_len"]
+        tm = PP.token_rows(du.SequenceDataset([c["history"][-(L - 1):] + ["[UNK]"]]), True)
+        assert tm.tokens.tolist() == c["out"]["labels"] and tm.finetune_rows.tolist() == [1]
+    with pytest.raises(ValueError):
+        PP.prepare_inference("item1")
+
+
 def test_mask_last_token_only_matches_reference():
     for c in GOLD["mask_last_token_only"]:
         toks, pos, ids = du.mask_last_token_only(np.array(c["sequence"], dtype=np.int64), c["mask_token_id"])

@@ -254,3 +254,52 @@ def test_dropout_group_fields_are_unbiased_and_uncorrelated():
     a = orc.dropout_keep_mask((3, 2, 10, 10), rate, 1, 2, 3, row_pitch=orc.ATTN_PITCH)
     flat = orc.dropout_keep_mask((3 * 2 * 10 * orc.ATTN_PITCH,), rate, 1, 2, 3).view(3, 2, 10, orc.ATTN_PITCH)
     assert torch.equal(a, flat[..., :10])
+
+
+def test_encoder_block_agrees_with_an_independent_implementation():
+    """A restatement slip check, NOT a parity pin (the float path stays "parity unpinned": TensorFlow is not available).
+    The oracle's encoder stack (einsum attention with the additive -1e9 key mask, post-LN, erf-GELU) against PyTorch's own
+    nn.TransformerEncoderLayer (norm_first=False, activation=gelu [erf form], batch_first) with the weights mapped over: an
+    implementation written by other people for the same published block.  Both see the same embedded input."""
+    torch.manual_seed(0)
+    cfg = orc.OracleConfig(vocab_size=50, hidden_size=64, num_layers=2, num_attention_heads=2, max_sequence_length=24, inner_dim=256)
+    params = orc.init_params(cfg, seed=9)
+    for k in params:   # biases and LayerNorm offsets away from their init values (0 / 1), so that a swapped pair would show
+        if k.endswith("bias") or k.endswith("beta"):
+            params[k] = 0.1 * torch.randn_like(params[k])
+        if k.endswith("gamma"):
+            params[k] = 1.0 + 0.2 * torch.randn_like(params[k])
+    B, L, H, h, d = 5, 24, 64, 2, 32
+    ids = torch.randint(3, 50, (B, L))
+    lens = torch.tensor([24, 7, 1, 15, 24])
+    mask = (torch.arange(L)[None, :] < lens[:, None]).to(torch.int64)
+    out = orc.encoder_forward(params, ids, mask, cfg)
+    # the block input of the oracle: embedding + position + LayerNorm (restated in three lines; dropout off)
+    x = params["word_embeddings/embeddings"][ids] + params["position_embedding/embeddings"][:L][None]
+    x = orc.layer_norm(x, params["embeddings/layer_norm/gamma"], params["embeddings/layer_norm/beta"], cfg.ln_eps)
+    for i in range(cfg.num_layers):
+        pre = f"transformer/layer_{i}"
+        layer = torch.nn.TransformerEncoderLayer(d_model=H, nhead=h, dim_feedforward=256, dropout=0.0, activation="gelu",
+                                                 layer_norm_eps=cfg.ln_eps, batch_first=True, norm_first=False)
+        with torch.no_grad():
+            wq, wk, wv = (params[f"{pre}/self_attention/{n}/kernel"].reshape(H, H) for n in ("query", "key", "value"))
+            bq, bk, bv = (params[f"{pre}/self_attention/{n}/bias"].reshape(H) for n in ("query", "key", "value"))
+            layer.self_attn.in_proj_weight.copy_(torch.cat([wq.t(), wk.t(), wv.t()], 0))     # torch: y = x W^T
+            layer.self_attn.in_proj_bias.copy_(torch.cat([bq, bk, bv], 0))
+            layer.self_attn.out_proj.weight.copy_(params[f"{pre}/self_attention/attention_output/kernel"].reshape(H, H).t())
+            layer.self_attn.out_proj.bias.copy_(params[f"{pre}/self_attention/attention_output/bias"])
+            layer.norm1.weight.copy_(params[f"{pre}/self_attention_layer_norm/gamma"])
+            layer.norm1.bias.copy_(params[f"{pre}/self_attention_layer_norm/beta"])
+            layer.linear1.weight.copy_(params[f"{pre}/intermediate/kernel"].t())
+            layer.linear1.bias.copy_(params[f"{pre}/intermediate/bias"])
+            layer.linear2.weight.copy_(params[f"{pre}/output/kernel"].t())
+            layer.linear2.bias.copy_(params[f"{pre}/output/bias"])
+            layer.norm2.weight.copy_(params[f"{pre}/output_layer_norm/gamma"])
+            layer.norm2.bias.copy_(params[f"{pre}/output_layer_norm/beta"])
+        layer.eval()
+        with torch.no_grad():
+            # key padding as the float adder Keras uses (a boolean mask would put -inf: same softmax wherever a key is valid)
+            kpm = (1.0 - mask.float()) * -1e9
+            x = layer(x, src_key_padding_mask=kpm)
+        got = out["encoder_outputs"][i]
+        assert float((x - got).abs().max()) < 2e-5, (i, float((x - got).abs().max()))

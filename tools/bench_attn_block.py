@@ -74,6 +74,19 @@ if hasattr(lib, "b4r_debug_a32_prof"):   # a -DA32_PROF build of b4r_attn32.hip:
     for k in sorted(names, key=lambda k: t[k]):
         print("%-36s +%7d cycles  (total %8d)" % (names[k], t[k] - prev, t[k] - t[0]))
         prev = t[k]
+if hasattr(lib, "b4r_debug_a32f_prof"):   # phase stamps of wave 0 of workgroup 0 of the forward
+    fwd(); torch.cuda.synchronize()
+    buf = (C.c_longlong * 32)()
+    lib.b4r_debug_a32f_prof.argtypes = [C.c_void_p]
+    assert lib.b4r_debug_a32f_prof(buf) == 0
+    t = list(buf)
+    names = {0: "start", 1: "x rows loaded / formed", 2: "weights + x images staged", 3: "barrier", 4: "q k v of both heads", 5: "barrier",
+             6: "K / V images written", 7: "barrier", 8: "h0 scores", 9: "h0 softmax", 12: "h1 scores (after h0 dropout + P.V)", 13: "h1 softmax",
+             16: "h1 dropout + P.V", 17: "output projection", 18: "barrier", 19: "ctx out (row layout)", 20: "end"}
+    prev = t[0]
+    for k in sorted(names, key=lambda k: t[k]):
+        print("fwd %-36s +%7d cycles  (total %8d)" % (names[k], t[k] - prev, t[k] - t[0]))
+        prev = t[k]
 if hasattr(lib, "b4r_debug_a32_sweep"):
     buf = (C.c_longlong * 128)()
     lib.b4r_debug_a32_sweep.argtypes = [C.c_void_p]

@@ -97,8 +97,8 @@ class BERT4RecEvaluator(BaseEvaluator):
         buf = torch.tensor([g for g, _ in mine] + [float(mine[0][1]) if mine else 0.0], dtype=torch.float64, device=dev)
         dist.all_reduce(buf, group=group)
         tot = buf.cpu().tolist()
-        for m, (g, u), g_all in zip(self._metrics, mine, tot[:-1]):
-            m.absorb(g_all - g, int(round(tot[-1])) - u)
+        for m, b, g_all in zip(self._metrics, before, tot[:-1]):
+            m.restore(b[0] + g_all, b[1] + int(round(tot[-1])))   # the same two additions on every rank: identical metrics everywhere
 
     def sample_candidates(self, test_batch: dict):
         """bert4rec_evaluator.py:75-108 -> (candidates [R,101] int64, ground truth [R] int64), slots in batch order."""

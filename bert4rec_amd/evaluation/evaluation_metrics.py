@@ -55,6 +55,11 @@ class EvaluationMetric:
     def partial(self) -> Tuple[float, int]:
         return self._gain_sum, self._users
 
+    def restore(self, gain_sum: float, users: int) -> None:
+        """set the accumulators (the data-parallel merge: state before the evaluation + the sum over all ranks, the same
+        two numbers on every rank)"""
+        self._gain_sum, self._users = float(gain_sum), int(users)
+
     def reset(self) -> None:
         self._gain_sum, self._users = 0.0, 0
 

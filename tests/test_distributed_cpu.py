@@ -37,13 +37,18 @@ def _sum_loss_grads(params, batch):
     return float(loss_sum), float(mask.sum()), dict(zip(names, gs))
 
 
+def _rows_for(world):
+    return B if world == 2 else 10     # 10 rows over 4 ranks: 3 / 3 / 3 / 1 -- uneven shards, no empty one
+
+
 def _worker(rank, world, port, ret):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.manual_seed(0)
     params = orc.init_params(CFG, 3)
-    full = orc.synthetic_batch(B, L, P, CFG.vocab_size, seed=4, ragged=True)
-    sl = shard_rows(B, rank, world)
+    Bw = _rows_for(world)
+    full = orc.synthetic_batch(Bw, L, P, CFG.vocab_size, seed=4, ragged=True)
+    sl = shard_rows(Bw, rank, world)
     local = {k: v[sl] for k, v in full.items()}
     loss_sum, count, grads = _sum_loss_grads(params, local)
     eng = Engine(make_model_config(CFG.vocab_size, 64, 1, 2, 12, 64, 0.0, 0.0), "cpu")
@@ -66,18 +71,22 @@ def _worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-def test_two_rank_allreduce_equals_single_process_step():
+@pytest.mark.parametrize("world", [2, 4])
+def test_allreduce_of_the_gradient_tail_equals_single_process_step(world):
+    """world 4: 10 rows in uneven shards, so the ranks' valid counts differ -- the division happens after the reduction"""
     port = _free_port()
     with mp.Manager() as mgr:
         ret = mgr.dict()
-        mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+        mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
         state, grads, pad = ret["state"], ret["grads"], ret["pad"]
     params = orc.init_params(CFG, 3)
-    full = orc.synthetic_batch(B, L, P, CFG.vocab_size, seed=4, ragged=True)
+    Bw = _rows_for(world)
+    full = orc.synthetic_batch(Bw, L, P, CFG.vocab_size, seed=4, ragged=True)
     loss_ref, grads_ref, _ = orc.loss_and_grads(params, full, CFG, training=False)
     count = float((full["masked_lm_ids"] != 0).sum())
-    assert float(state[_lib.ST_VALID]) == count and float(state[_lib.ST_SLOTS_ALL]) == B * P
-    assert float(state[_lib.ST_CORRECT_MASKED]) == 3.0 and float(state[_lib.ST_CORRECT_ALL]) == 4.0 and pad == 0.0
+    assert float(state[_lib.ST_VALID]) == count and float(state[_lib.ST_SLOTS_ALL]) == Bw * P
+    assert float(state[_lib.ST_CORRECT_MASKED]) == sum(1.0 + r for r in range(world)) and float(state[_lib.ST_CORRECT_ALL]) == 2.0 * world
+    assert pad == 0.0
     assert abs(float(state[_lib.ST_LOSS_SUM]) / count - float(loss_ref)) < 1e-5
     for n, g in grads_ref.items():
         got = grads[n] / count          # the optimizer kernel applies 1/valid_count after the reduction
@@ -99,12 +108,12 @@ class _RanksModel:
         return None, torch.as_tensor(batch["ranks"], dtype=torch.int32), None, None
 
 
-def _eval_batches():
+def _eval_batches(sizes=(7, 5, 9, 4, 6)):
     g = torch.Generator().manual_seed(11)
-    return [{"ranks": torch.randint(1, 60, (n,), generator=g)} for n in (7, 5, 9, 4, 6)]
+    return [{"ranks": torch.randint(1, 60, (n,), generator=g)} for n in sizes]
 
 
-def _eval_worker(rank, world, port, ret):
+def _eval_worker(rank, world, port, ret, sizes=(7, 5, 9, 4, 6)):
     from bert4rec_amd import evaluation
     from bert4rec_amd.dataloaders import samplers
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -112,7 +121,7 @@ def _eval_worker(rank, world, port, ret):
     ev = evaluation.get("bert4rec", sampler=samplers.get("random", vocab=list(range(3, 200)), sample_size=10))
     ev.evaluate_batch = lambda model, batch: evaluation.BERT4RecEvaluator.evaluate_batch(
         ev, model, batch, candidates=[[0]] * len(batch["ranks"]), ground_truth=[0] * len(batch["ranks"]))
-    ev.evaluate(_RanksModel(), _eval_batches())
+    ev.evaluate(_RanksModel(), _eval_batches(sizes))
     ret[rank] = {k: float(v) for k, v in ev.get_metrics_results().items()}
     dist.barrier()
     dist.destroy_process_group()
@@ -134,3 +143,24 @@ def test_two_rank_evaluation_equals_single_process_metrics():
     assert want["Valid Ranks"] == 31 == r0["Valid Ranks"]
     for k, v in want.items():
         assert abs(r0[k] - v) < 1e-12, k
+
+
+@pytest.mark.parametrize("sizes", [(7, 5, 9, 4, 6), (8, 3, 5)])
+def test_four_rank_evaluation_with_a_batch_count_not_divisible_by_the_world(sizes):
+    """5 batches over 4 ranks (rank 0 takes two), and 3 batches over 4 ranks: rank 3 evaluates NOTHING and must still join the one
+    all-reduce with a tensor of the right size and device"""
+    from bert4rec_amd import evaluation
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_eval_worker, args=(4, port, ret, sizes), nprocs=4, join=True)
+        rs = [dict(ret[r]) for r in range(4)]
+    ms = evaluation.default_metrics()
+    for b in _eval_batches(sizes):
+        for m in ms:
+            m.update(b["ranks"].numpy())
+    want = {m.name: float(m.result()) for m in ms}
+    assert all(r == rs[0] for r in rs)
+    assert rs[0]["Valid Ranks"] == sum(sizes)
+    for k, v in want.items():
+        assert abs(rs[0][k] - v) < 1e-12, k

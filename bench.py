@@ -377,7 +377,7 @@ def main():
     # length moves by several per cent with the clock state it starts in.  Every rank takes the same decision (the first region's
     # time is already the max over ranks).
     regions = [timed_region(args.warmup)]
-    repeats = 1 if regions[0] >= 0.2 else max(7, min(51, int(0.2 / max(regions[0], 1e-6)) | 1))
+    repeats = 1 if (regions[0] >= 0.2 or args.no_breakdown) else max(7, min(51, int(0.2 / max(regions[0], 1e-6)) | 1))   # (profiling runs: one region)
     for k in range(1, repeats):
         if use_dist:
             dist.barrier()

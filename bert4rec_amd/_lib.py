@@ -76,7 +76,8 @@ class AttnBlockBwdDesc(C.Structure):
                 ("emb_table", C.c_void_p), ("emb_pos", C.c_void_p), ("emb_vocab", C.c_int32), ("emb_stream", C.c_uint32),
                 ("emb_rate", C.c_float), ("dqkv", C.c_void_p), ("dx_prev", C.c_void_p), ("dprev_gamma", C.c_void_p),
                 ("scratch", C.c_void_p), ("dWqkv", C.c_void_p), ("dbqkv", C.c_void_p), ("dw_scratch", C.c_void_p),
-                ("dWo", C.c_void_p), ("dbo", C.c_void_p)]
+                ("dWo", C.c_void_p), ("dbo", C.c_void_p), ("dz1_slot_positions", C.c_void_p), ("dz1_slot_ids", C.c_void_p),
+                ("dz1_slots", C.c_int32)]
 
 
 class FfnDesc(C.Structure):

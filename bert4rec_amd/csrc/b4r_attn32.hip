@@ -131,6 +131,9 @@ struct A32BwdP {
   float* dqkv; float* da; float* ln_part;
   float* dw_slab; float* db_slab;   // per-sequence partials of dWqkv [B][64][192] and dbqkv [B][192] (or NULL: dqkv is written instead)
   float* dwo_slab; float* dbo_slab; // ... of dWo [B][64][64] and dbo [B][64] (or NULL)
+  // the rows of dz1 that carry a gradient (or NULL: all of them): row clamp(slot_pos[b][j]) where slot_ids[b][j] != 0, j < slots; every
+  // other row of dz1 counts as zero and is never read (the last layer of a train step: only the masked-LM rows)
+  const int64_t* slot_pos; const int64_t* slot_ids; int slots;
   int B, L, NT;
   float qscale;
   DropArgs drop_p, drop_o, drop_e;
@@ -138,7 +141,7 @@ struct A32BwdP {
 
 // LDS of the backward (bytes): [Q images NT x 4 KB | dO images | dQ accumulators (fp32, register layout) | per-wave scratch (K^T
 // staging, then dS) | weight slices of one head 32 KB | key mask adders, -lse, D, biases, LayerNorm partials]
-__host__ __device__ constexpr int bwd32_small_floats(int NT) { return 3 * NT * 32 + 192 + NT * 128 + 8 + NT * 96; }
+__host__ __device__ constexpr int bwd32_small_floats(int NT) { return 3 * NT * 32 + 192 + NT * 128 + 8 + NT * 96 + NT * 32; }
 __host__ __device__ constexpr int bwd32_lds(int NT) { return 4 * NT * P_TILE + 8 * P_TILE + bwd32_small_floats(NT) * 4; }
 
 template <bool EMBED, bool DROP>
@@ -157,6 +160,7 @@ __global__ __launch_bounds__(512, 2) void attn32_bwd_kernel(A32BwdP p) {
   float* const sred = sbq + 192;                      // [NT][128] LayerNorm partials
   int* const sflag = reinterpret_cast<int*>(sred + NT * 128);   // [NT] steps of the sweep each wave has finished
   float* const sdb = reinterpret_cast<float*>(sflag + 8);      // [NT][96] column sums of dq | dk | dv over a wave's tokens
+  float* const sHas = sdb + NT * 96;                            // [NT * 32] 1 where the token's dz1 row carries a gradient
 
   const int nthreads = blockDim.x;
   const int b = blockIdx.x;
@@ -176,6 +180,13 @@ __global__ __launch_bounds__(512, 2) void attn32_bwd_kernel(A32BwdP p) {
   const RowLay rl = row_lay(ln, wave, L);                                           \
   const int rl_row = rl.row, rl_c4 = rl.c4;                                         \
   (void)tokc; (void)live; (void)rl_row; (void)rl_c4
+  // turn i of the wave's dz1 rows (row layout); rows without a gradient are zero and not read
+#define A32_DZ_ROW()                                                                \
+  auto dz_row = [&](int i_) __attribute__((always_inline)) -> f32x4 {              \
+    const bool has_ = sHas[min(32 * wave + 4 * i_ + rl.row, L - 1)] != 0.f;         \
+    return has_ ? ld4(dzb, rl_off(rl, i_)) : (f32x4){0.f, 0.f, 0.f, 0.f};          \
+  };                                                                                \
+  (void)dz_row
 
   // key mask: one turn (at least 32 threads per 32 tokens)
   const int64_t mval = (int)threadIdx.x < L ? p.mask[row0 + threadIdx.x] : 0;
@@ -183,8 +194,19 @@ __global__ __launch_bounds__(512, 2) void attn32_bwd_kernel(A32BwdP p) {
   for (int k = threadIdx.x; k < 192; k += nthreads) sbq[k] = p.bqkv[k];
   const float amax = __syncthreads_or(any_key) ? 0.0f : -1e9f;
   const bool dead = amax != 0.0f;   // every key masked: Keras' -1e9 absorbs the scores, the softmax is uniform over all L keys
-  if ((int)threadIdx.x < NT * 32)
+  if ((int)threadIdx.x < NT * 32) {
     sAdd[threadIdx.x] = (int)threadIdx.x < L ? (((1.0f - (float)mval) * -1e9f) - amax) * LOG2E : -INFINITY;
+    sHas[threadIdx.x] = p.slot_pos != nullptr ? 0.f : 1.f;
+  }
+  if (p.slot_pos != nullptr) {   // (block-uniform)
+    lds_barrier();
+    for (int j = threadIdx.x; j < p.slots; j += nthreads)
+      if (p.slot_ids[(int64_t)b * p.slots + j] != 0) {
+        const int64_t q = p.slot_pos[(int64_t)b * p.slots + j];
+        sHas[q < 0 ? 0 : (q >= L ? L - 1 : (int)q)] = 1.f;
+      }
+  }
+  lds_barrier();
 
   const DropCtx dcp = b4r_drop_ctx(p.drop_p);
   const DropCtx dco = b4r_drop_ctx(p.drop_o);
@@ -206,11 +228,12 @@ __global__ __launch_bounds__(512, 2) void attn32_bwd_kernel(A32BwdP p) {
   const bool fold_wo = p.dwo_slab != nullptr;
   if (fold_wo) {
     A32_LANE_CONSTS();
+    A32_DZ_ROW();
     f32x4 dbo = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const bool lv = 32 * wave + 4 * i + rl_row < L;
-      f32x4 dy = ld4(dzb, rl_off(rl, i));
+      f32x4 dy = dz_row(i);
       const f32x4 cr = ld4(ctxb, rl_off(rl, i));
       if (dco.on) dy = b4r_drop4(dco, dy, (uint64_t)(row0 + 32 * wave + 4 * i + rl_row) * HID + (uint64_t)(4 * rl_c4));
       if (!lv) dy = (f32x4){0.f, 0.f, 0.f, 0.f};   // pad tokens: no contribution
@@ -253,12 +276,13 @@ __global__ __launch_bounds__(512, 2) void attn32_bwd_kernel(A32BwdP p) {
   A32_MARK(0);
   for (int hd = 0; hd < 2; ++hd) {
     A32_LANE_CONSTS();
+    A32_DZ_ROW();
     const int64_t bh = (int64_t)b * 2 + hd;
     // ---- requests first: x and dz1 rows of the wave's tokens (row layout, coalesced), lse, the ctx columns of this head -----------
     f32x4 xr[8], yr[8];
     const bool dy_staged = fold_wo && hd == 0;   // the dWo section left the dropmask(dz1) images in place
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { xr[i] = ld4(xb, rl_off(rl, i)); yr[i] = dy_staged ? xr[i] : ld4(dzb, rl_off(rl, i)); }
+    for (int i = 0; i < 8; ++i) { xr[i] = ld4(xb, rl_off(rl, i)); yr[i] = dy_staged ? xr[i] : dz_row(i); }
     const float lse_q = live ? (p.lse + bh * L)[(uint32_t)tok] : INFINITY;
     f32x4 cx[4];
 #pragma unroll
@@ -582,6 +606,7 @@ __global__ __launch_bounds__(512, 2) void attn32_bwd_kernel(A32BwdP p) {
   A32_MARK(30);
   // ---- dx = dX + dz1 (residual), then back through the LayerNorm (and, for layer 0, the dropout) that produced x: row layout -----
   A32_LANE_CONSTS();
+  A32_DZ_ROW();
   const DropCtx dce = b4r_drop_ctx(p.drop_e);
   f32x4 dxr[8];
   acc_to_rl(rl, ownA, ownB, r, h, dx, dxr);
@@ -593,7 +618,7 @@ __global__ __launch_bounds__(512, 2) void attn32_bwd_kernel(A32BwdP p) {
     const int trow = 32 * wave + 4 * i + rl_row;
     const bool lv = trow < L;
     const int64_t grow = row0 + min(trow, L - 1);
-    f32x4 d4 = (dxr[i] + ld4(dab, rl_off(rl, i))) + ld4(dzb, rl_off(rl, i));
+    f32x4 d4 = (dxr[i] + ld4(dab, rl_off(rl, i))) + dz_row(i);
     f32x4 zz;
     if (EMBED) {
       d4 = b4r_drop4(dce, d4, (uint64_t)(row0 + trow) * HID + (uint64_t)(4 * rl_c4));
@@ -989,6 +1014,9 @@ int b4r_attn32_bwd(const b4r_attn_block_bwd_desc* d, b4r_stream_t stream) {
   p.zprev = d->prev_z; p.meanp = d->prev_mean; p.rstdp = d->prev_rstd; p.gprev = d->prev_gamma;
   p.ids = d->emb_ids; p.table = d->emb_table; p.pos = d->emb_pos; p.V = d->emb_vocab;
   p.dqkv = d->dqkv; p.da = d->dx_prev; p.ln_part = d->scratch;
+  B4R_CHECK_ARG((d->dz1_slot_positions == nullptr) == (d->dz1_slot_ids == nullptr) && (d->dz1_slot_positions == nullptr || d->dz1_slots > 0),
+                B4R_E_BADARG, "b4r_attn_block_bwd: dz1_slot_positions, dz1_slot_ids and dz1_slots go together");
+  p.slot_pos = d->dz1_slot_positions; p.slot_ids = d->dz1_slot_ids; p.slots = d->dz1_slots;
   const bool fold = d->dWqkv != nullptr;
   if (fold) { p.dw_slab = d->dw_scratch; p.db_slab = d->dw_scratch + (int64_t)d->B * (HID * 3 * HID); }
   const bool fold_wo = d->dWo != nullptr;

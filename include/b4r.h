@@ -438,6 +438,10 @@ typedef struct b4r_attn_block_bwd_desc {
    * attention half. */
   float* dWqkv; float* dbqkv; float* dw_scratch;
   float* dWo; float* dbo;
+  /* optional (L <= 224): dz1 is SPARSE -- only the rows b*L + clamp(dz1_slot_positions[b][j]) with dz1_slot_ids[b][j] != 0 (j <
+   * dz1_slots) carry a gradient, every other row counts as zero and is never read: the caller need not clear them.  The last encoder
+   * layer of a train step (B4R_FLAG_HEAD_ROWS_ONLY): the masked-LM slots of the batch, bert4rec_model.py:76-81. */
+  const int64_t* dz1_slot_positions; const int64_t* dz1_slot_ids; int32_t dz1_slots;
 } b4r_attn_block_bwd_desc;
 int32_t b4r_attn_block_bwd_supported(int32_t hidden_size, int32_t num_heads, int32_t L);
 int64_t b4r_attn_block_bwd_scratch_floats(int32_t B);

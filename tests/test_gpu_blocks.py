@@ -348,6 +348,32 @@ def test_attn_block_backward_matches_fp64_autograd(B, L, p_rate, o_rate, embed):
     torch.cuda.synchronize()
     assert all(torch.equal(a, b_) for a, b_ in zip(keep, (dw, dbq, dwo, dbo)))
 
+    # sparse dz1 (the last layer of a train step): only the rows named by (slot positions, slot ids != 0) exist; the launch must give
+    # bit for bit what it gives for the dense tensor with zeros elsewhere, without ever reading the other rows (NaN there)
+    Ps = 5
+    gen = torch.Generator().manual_seed(B + L)
+    slot_pos = torch.stack([torch.randperm(L, generator=gen)[:Ps] if L >= Ps else torch.arange(Ps) % L for _ in range(B)]).to(torch.int64)
+    slot_id = torch.randint(3, 90, (B, Ps), generator=gen).to(torch.int64)
+    slot_id[:, -1] = 0                                                   # a padded slot: its row carries nothing
+    rows = (torch.arange(B)[:, None] * L + slot_pos)[slot_id != 0]
+    dense = torch.zeros(N, 64)
+    dense[rows] = t["dz1"][rows]
+    sparse = torch.full((N, 64), nan)
+    sparse[rows] = t["dz1"][rows]
+    res = []
+    for dz, slots in ((dense, False), (sparse, True)):
+        dzd, sposd, sidd = dz.to(DEV), slot_pos.to(DEV), slot_id.to(DEV)
+        bd.dz1 = P(dzd)
+        bd.dz1_slot_positions, bd.dz1_slot_ids, bd.dz1_slots = (P(sposd), P(sidd), Ps) if slots else (None, None, 0)
+        for v in (dw, dbq, dwo, dbo, out["da"], out["dln"]):
+            v.fill_(nan)
+        _lib.check(lib.b4r_attn_block_bwd(C.byref(bd), stream()), "b4r_attn_block_bwd (sparse dz1)")
+        torch.cuda.synchronize()
+        res.append([v.clone() for v in (dw, dbq, dwo, dbo, out["da"], out["dln"])])
+    assert all(bool(torch.isfinite(v).all()) for v in res[1])
+    for name, a, b_ in zip(("dWqkv", "dbqkv", "dWo", "dbo", "dx_prev", "dprev_gamma"), *res):
+        assert torch.equal(a, b_), (name, float((a - b_).abs().max()))
+
 
 # ---------------------------------------------------------------------------------------------------------------------------
 # one whole encoder layer = the two halves (b4r_encoder_layer_fwd / _bwd)

@@ -273,20 +273,43 @@ __global__ __launch_bounds__(512, 2) void attn32_bwd_kernel(A32BwdP p) {
   f32x16 dx[2];   // dX^T[hidden 32 rt + ..][token] of ONE head: the first head's waits in `da` (the wave's own rows) for the epilogue --
                   // 32 registers that the sweep of the second head needs
 
+  // x and dz1 rows of the wave's tokens (row layout, coalesced), lse and the ctx columns of a head are REQUESTED one head ahead: the
+  // second head's while the first one's weight-gradient section still has its slab stores to issue (a load behind those stores waits for
+  // their acknowledgements: 11 k cycles at the top of the second head)
+  f32x4 nxr[8], nyr[8], ncx[4];
+  float nlse;
+#define A32_REQUEST(HD_, SKIP_DY_)                                                                                      \
+  do {                                                                                                                  \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) { nxr[i] = ld4(xb, rl_off(rl, i)); nyr[i] = (SKIP_DY_) ? nxr[i] : dz_row(i); } \
+    nlse = live ? (p.lse + ((int64_t)b * 2 + (HD_)) * L)[(uint32_t)tok] : INFINITY;                                    \
+    _Pragma("unroll") for (int gp = 0; gp < 4; ++gp) ncx[gp] = ld4(ctxb, (uint32_t)(tokc * HID + 32 * (HD_) + 4 * h + 8 * gp)); \
+  } while (0)
+  {
+    A32_LANE_CONSTS();
+    A32_DZ_ROW();
+    A32_REQUEST(0, fold_wo);   // (the dWo section left the dropmask(dz1) images in place)
+  }
   A32_MARK(0);
   for (int hd = 0; hd < 2; ++hd) {
     A32_LANE_CONSTS();
     A32_DZ_ROW();
     const int64_t bh = (int64_t)b * 2 + hd;
-    // ---- requests first: x and dz1 rows of the wave's tokens (row layout, coalesced), lse, the ctx columns of this head -----------
-    f32x4 xr[8], yr[8];
-    const bool dy_staged = fold_wo && hd == 0;   // the dWo section left the dropmask(dz1) images in place
+    f32x4 xr[8], yr[8], cx[4];
+    const bool dy_staged = fold_wo && hd == 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { xr[i] = ld4(xb, rl_off(rl, i)); yr[i] = dy_staged ? xr[i] : dz_row(i); }
-    const float lse_q = live ? (p.lse + bh * L)[(uint32_t)tok] : INFINITY;
-    f32x4 cx[4];
+    for (int i = 0; i < 8; ++i) { xr[i] = nxr[i]; yr[i] = nyr[i]; }
 #pragma unroll
-    for (int gp = 0; gp < 4; ++gp) cx[gp] = ld4(ctxb, (uint32_t)(tokc * HID + 32 * hd + 4 * h + 8 * gp));
+    for (int gp = 0; gp < 4; ++gp) cx[gp] = ncx[gp];
+    const float lse_q = nlse;
+    {   // the carried requests are consumed: nothing of them stays live through the sweep (the compiler cannot know that the loop ends
+        // after the pass that does not refill them)
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { nxr[i] = z4; nyr[i] = z4; }
+#pragma unroll
+      for (int gp = 0; gp < 4; ++gp) ncx[gp] = z4;
+      nlse = 0.f;
+    }
     A32_MARK(1 + 10 * hd);
     lds_barrier();   // every wave is done with the previous head's weight slices (the wave's own tiles were free before)
     A32_MARK(2 + 10 * hd);
@@ -569,9 +592,15 @@ __global__ __launch_bounds__(512, 2) void attn32_bwd_kernel(A32BwdP p) {
           if (r == 31) sdb[wave * 96 + 32 * j + 16 * (tt >> 3) + 8 * h + (tt & 7)] = cs;
         }
       }
-      f32x4 xr2[8];   // x rows again (L2)
+      f32x4 xr2[8];   // x rows again: the next head's request carries them (or, behind the second head, a request of their own)
+      if (hd == 0) {
+        A32_REQUEST(1, false);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) xr2[i] = ld4(xb, rl_off(rl, i));
+        for (int i = 0; i < 8; ++i) xr2[i] = nxr[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xr2[i] = ld4(xb, rl_off(rl, i));
+      }
       lds_barrier();   // every wave is done with the weight slices (dX): their region takes the second x panel
 #pragma unroll
       for (int i = 0; i < 8; ++i) rl_to_panels(rl, ownC, WIMG + wave * P_TILE, i, xr2[i]);
@@ -600,6 +629,8 @@ __global__ __launch_bounds__(512, 2) void attn32_bwd_kernel(A32BwdP p) {
         p.db_slab[(int64_t)b * (3 * HID) + HID * (k >> 5) + 32 * hd + (k & 31)] = acc;
       }
       if (hd == 1) lds_barrier();   // the epilogue reuses the tiles the images are in
+    } else if (hd == 0) {
+      A32_REQUEST(1, false);
     }
   }
 

@@ -420,22 +420,26 @@ __global__ __launch_bounds__(256) void softmax_ce_kernel(float* logits, int V, i
 __device__ __forceinline__ void loss_rows_reduce(const float* rows, int M, float (*s)[256], float (&out)[4]) {
   const int tid = threadIdx.x;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int m0 = tid; m0 < M; m0 += 8 * 256) {
-    f32x4 r[8];
+  constexpr int U = 16;   // loads in flight per thread: the single workgroup that runs this is latency-bound (8 in flight: 8 us at M = 10240)
+  for (int m0 = tid; m0 < M; m0 += U * 256) {
+    f32x4 r[U];
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
+    for (int u = 0; u < U; ++u)
       r[u] = m0 + 256 * u < M ? *reinterpret_cast<const f32x4*>(rows + 4 * (int64_t)(m0 + 256 * u)) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
+    for (int u = 0; u < U; ++u)
       if (m0 + 256 * u < M) acc += r[u];
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q) s[q][tid] = acc[q];
   __syncthreads();
-  if (tid < 4) {
-    float r = 0.f;
-    for (int t = 0; t < 256; ++t) r += s[tid][t];
-    s[tid][0] = r;
+  // the 256 partial sums of a component: lane l of wave q adds partials 4l .. 4l+3 in order, then a fixed butterfly over the 64 lanes
+  // (every run adds the same numbers in the same order; 256 dependent additions by one thread took 2 us)
+  if (tid < 256) {
+    const int q = tid >> 6, l = tid & 63;
+    float v = ((s[q][4 * l] + s[q][4 * l + 1]) + s[q][4 * l + 2]) + s[q][4 * l + 3];
+    v = b4r_wave_sum(v);
+    if (l == 0) s[q][0] = v;
   }
   __syncthreads();
 #pragma unroll

@@ -1051,46 +1051,29 @@ extern "C" int b4r_mlm_rows(const int64_t* masked_lm_positions, const int64_t* m
 // items draws: successive picks proportional to p among what is left) as Gumbel top-k: key_v = log p_v + G_v with
 // G_v = -log(-log u_v); the C largest keys, in descending order, are the sample in draw order.  u_v comes from a counter
 // hash of (seed, row, v) with 23 bits, so it lies strictly inside (0, 1).
-// (value, index) of the larger key; equal keys: the lower index (np.random.choice's order of draws is not affected: ties of 24-bit
-// Gumbel keys are broken the same way everywhere in this kernel)
-__device__ __forceinline__ void keep_larger(float& best, int& bidx, float ov, int oi) {
-  if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+// Round 3: the C draws are no longer made one after the other (a 256-thread tournament + barrier per draw: 127-158 us per 256 rows).
+// The sample is the set of the C largest keys, so the row's workgroup SELECTS them: a 4-pass radix select (8 bits per pass, LDS
+// histogram) finds the C-th largest key, the keys above it (and the lowest-indexed keys equal to it) are gathered, and their order
+// -- descending key, ties by ascending index = the order of the draws -- comes from counting, C x C comparisons spread over the
+// workgroup.  Same keys, same tie rule: the output is what the tournament produced.
+__device__ __forceinline__ uint32_t key_image(float k) {   // ascending unsigned image of a float (-inf smallest)
+  const uint32_t b = __builtin_bit_cast(uint32_t, k);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
-template <int CTRL>
-__device__ __forceinline__ void argmax_dpp(float& best, int& bidx) {
-  const float ov = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, best), CTRL, 0xf, 0xf, false));
-  const int oi = __builtin_amdgcn_update_dpp(0, bidx, CTRL, 0xf, 0xf, false);
-  keep_larger(best, bidx, ov, oi);
-}
-// argmax over the 64 lanes of a wave, result in every lane: rotations inside the 16-lane rows (DPP), then the rows (permlane swaps);
-// no LDS crossbar traffic (__shfl_xor compiles to ds_bpermute_b32: 12 of them per draw were most of this kernel's 173 us)
-__device__ __forceinline__ void wave_argmax(float& best, int& bidx) {
-  argmax_dpp<0x121>(best, bidx);   // row_ror:1
-  argmax_dpp<0x122>(best, bidx);   // row_ror:2
-  argmax_dpp<0x124>(best, bidx);   // row_ror:4
-  argmax_dpp<0x128>(best, bidx);   // row_ror:8
-  {
-    const auto v = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, best), __builtin_bit_cast(unsigned, best), false, false);
-    const auto i = __builtin_amdgcn_permlane16_swap((unsigned)bidx, (unsigned)bidx, false, false);
-    const bool odd = (threadIdx.x & 16) != 0;   // the neighbour row's value: new vdst in odd rows, new vsrc in even rows
-    keep_larger(best, bidx, __builtin_bit_cast(float, odd ? v[0] : v[1]), (int)(odd ? i[0] : i[1]));
-  }
-  {
-    const auto v = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, best), __builtin_bit_cast(unsigned, best), false, false);
-    const auto i = __builtin_amdgcn_permlane32_swap((unsigned)bidx, (unsigned)bidx, false, false);
-    const bool upper = (threadIdx.x & 32) != 0;
-    keep_larger(best, bidx, __builtin_bit_cast(float, upper ? v[0] : v[1]), (int)(upper ? i[0] : i[1]));
-  }
-}
+constexpr int SAMPLE_MAX_C = 1024;   // draws per row the gather / ordering buffers hold
 
 __global__ __launch_bounds__(256) void sample_candidates_kernel(const float* logp, int V, const int64_t* exclude, int E,
                                                                 const int64_t* gt, int C, uint32_t seed_lo,
                                                                 uint32_t seed_hi, int64_t* cand) {
-  extern __shared__ float s_key[];            // [V] keys, then [C] drawn items
-  int* s_out = reinterpret_cast<int*>(s_key + V);
-  __shared__ float s_v[2][4];
-  __shared__ int s_i[2][4];
-  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  extern __shared__ float s_key[];            // [V] keys
+  __shared__ int s_hist[256];
+  __shared__ uint32_t s_selu[SAMPLE_MAX_C];
+  __shared__ int s_seli[SAMPLE_MAX_C];
+  __shared__ int s_tie[256];                  // indices of keys equal to the threshold (more than 256 ties: the lowest 256 seen)
+  __shared__ int s_cnt[4];                    // [0] finite keys, [1] gathered above the threshold, [2] ties seen, [3] scratch
+  __shared__ uint32_t s_prefix;
+  __shared__ int s_remaining;
+  const int row = blockIdx.x, tid = threadIdx.x;
   const uint32_t rk = b4r_hash32((uint32_t)row * 0x9E3779B9u + seed_hi);
   for (int v = tid; v < V; v += 256) {
     uint32_t h = b4r_hash32((uint32_t)v ^ seed_lo);
@@ -1098,6 +1081,7 @@ __global__ __launch_bounds__(256) void sample_candidates_kernel(const float* log
     const float u = ((float)(h >> 9) + 0.5f) * (1.0f / 8388608.0f);   // 23 bits: (k + 0.5) / 2^23 is exact, strictly inside (0, 1)
     s_key[v] = logp[v] - __logf(-__logf(u));  // -inf + finite = -inf: zero-probability items are never drawn
   }
+  if (tid < 4) s_cnt[tid] = 0;
   __syncthreads();
   for (int e = tid; e < E; e += 256) {
     const int64_t id = exclude[(int64_t)row * E + e];
@@ -1106,52 +1090,101 @@ __global__ __launch_bounds__(256) void sample_candidates_kernel(const float* log
   const int64_t g = gt ? gt[row] : -1;
   if (tid == 0 && g >= 0 && g < V) s_key[g] = -INFINITY;
   __syncthreads();
-  int64_t* out = cand + (int64_t)row * (C + 1);
-  // a tournament: every thread keeps the best of ITS keys (v = tid, tid + 256, ...); a draw is the best of the 256 thread-bests, and
-  // only the thread that owned the drawn key looks through its keys again
-  auto own_best = [&](float& best, int& bidx) {
-    best = -INFINITY; bidx = 0x7fffffff;
-    for (int v0 = tid; v0 < V; v0 += 8 * 256) {   // eight LDS reads in flight, then the comparisons (one read at a time cost ~1 us per draw)
-      float k[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) k[u] = v0 + 256 * u < V ? s_key[v0 + 256 * u] : -INFINITY;
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (k[u] > best) { best = k[u]; bidx = v0 + 256 * u; }    // increasing v per thread: the lowest index wins ties
-    }
-  };
-  float my_best; int my_idx;
-  own_best(my_best, my_idx);
-  for (int c = 0; c < C; ++c) {
-    float best = my_best; int bidx = my_idx;
-    wave_argmax(best, bidx);
-    const int buf = c & 1;   // two sets of slots: the next draw's writes cannot overtake this draw's reads
-    if (lane == 0) { s_v[buf][wave] = best; s_i[buf][wave] = bidx; }
-    __syncthreads();
-    best = s_v[buf][0]; bidx = s_i[buf][0];
-#pragma unroll
-    for (int w = 1; w < 4; ++w) keep_larger(best, bidx, s_v[buf][w], s_i[buf][w]);
-    const bool ok = best > -INFINITY;
-    // -1: fewer than C items with non-zero probability are left.  Kept in LDS until the end: a global store per draw would put a
-    // store acknowledgement (the barrier waits for it) on every draw's critical path
-    if (tid == 0) s_out[c] = ok ? bidx : -1;
-    if (ok && (bidx & 255) == tid) {   // this thread owned the drawn key
-      s_key[bidx] = -INFINITY;
-      own_best(my_best, my_idx);
-    }
+  {   // how many keys can be drawn at all
+    int n = 0;
+    for (int v = tid; v < V; v += 256) n += s_key[v] > -INFINITY ? 1 : 0;
+    n = (int)b4r_wave_sum((float)n);
+    if ((tid & 63) == 0) atomicAdd(&s_cnt[0], n);
   }
   __syncthreads();
-  for (int c = tid; c < C; c += 256) out[c] = (int64_t)s_out[c];
+  const int Ce = min(C, s_cnt[0]);            // draws that exist; the rest of the row is -1
+  int64_t* out = cand + (int64_t)row * (C + 1);
+  if (Ce > 0) {
+    // ---- the Ce-th largest key: most significant byte first ---------------------------------------------------------------
+    if (tid == 0) { s_prefix = 0u; s_remaining = Ce; }
+    for (int pass = 0; pass < 4; ++pass) {
+      const int shift = 24 - 8 * pass;
+      s_hist[tid] = 0;
+      __syncthreads();
+      const uint32_t prefix = s_prefix;
+      const uint32_t himask = pass == 0 ? 0u : 0xFFFFFFFFu << (shift + 8);
+      for (int v = tid; v < V; v += 256) {
+        const uint32_t u = key_image(s_key[v]);
+        if ((u & himask) == prefix) atomicAdd(&s_hist[(u >> shift) & 255u], 1);
+      }
+      __syncthreads();
+      if (tid < 64) {   // one wave: the digit D with  #(digit > D) < remaining <= #(digit >= D)
+        const int remaining = s_remaining;
+        int c4[4], above = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) c4[q] = s_hist[255 - (4 * tid + q)];   // lane t holds digits 255 - 4t .. 252 - 4t, descending
+        const int mine = c4[0] + c4[1] + c4[2] + c4[3];
+        int incl = mine;                                                    // inclusive prefix over the lanes (descending digits)
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int n = __shfl_up(incl, o, 64);
+          if (tid >= o) incl += n;
+        }
+        above = incl - mine;                                                // keys with a digit above this lane's four
+        if (above < remaining && remaining <= incl) {                       // exactly one lane
+          int a = above, D = 0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (a < remaining && remaining <= a + c4[q]) { D = 255 - (4 * tid + q); s_remaining = remaining - a; }
+            a += c4[q];
+          }
+          s_prefix = prefix | ((uint32_t)D << shift);
+        }
+      }
+      __syncthreads();
+    }
+    const uint32_t T = s_prefix;              // image of the Ce-th largest key
+    const int n_eq = s_remaining;             // how many keys equal to it belong to the sample (the lowest indices)
+    const int n_gt = Ce - n_eq;
+    // ---- gather: everything above the threshold, and the ties ---------------------------------------------------------------
+    for (int v = tid; v < V; v += 256) {
+      const uint32_t u = key_image(s_key[v]);
+      if (u > T) {
+        const int slot = atomicAdd(&s_cnt[1], 1);
+        s_selu[slot] = u; s_seli[slot] = v;
+      } else if (u == T) {
+        const int slot = atomicAdd(&s_cnt[2], 1);
+        if (slot < 256) s_tie[slot] = v;
+      }
+    }
+    __syncthreads();
+    {   // the n_eq lowest indices among the ties (ties of 23-bit Gumbel keys are rare: normally one key)
+      const int nt = min(s_cnt[2], 256);
+      if (tid < nt) {
+        const int v = s_tie[tid];
+        int r = 0;
+        for (int j = 0; j < nt; ++j) r += s_tie[j] < v ? 1 : 0;
+        if (r < n_eq) { s_selu[n_gt + r] = T; s_seli[n_gt + r] = v; }
+      }
+    }
+    __syncthreads();
+    // ---- order of the draws: descending key, equal keys by ascending index ----------------------------------------------------
+    for (int i = tid; i < Ce; i += 256) {
+      const uint32_t ui = s_selu[i];
+      const int vi = s_seli[i];
+      int r = 0;
+      for (int j = 0; j < Ce; ++j) {
+        const uint32_t uj = s_selu[j];
+        r += (uj > ui || (uj == ui && s_seli[j] < vi)) ? 1 : 0;
+      }
+      out[r] = (int64_t)vi;
+    }
+  }
+  for (int c = Ce + tid; c < C; c += 256) out[c] = -1;   // fewer than C items with non-zero probability are left
   if (tid == 0) out[C] = g;
 }
 
 extern "C" int b4r_sample_candidates(const float* logp, int32_t V, const int64_t* exclude, int32_t E, const int64_t* gt,
                                      int32_t R, int32_t C, uint64_t seed, int64_t* cand, b4r_stream_t stream) {
   B4R_CHECK_ARG(logp && cand && (exclude || E == 0), B4R_E_BADARG, "b4r_sample_candidates: null argument");
-  B4R_CHECK_ARG(V > 0 && R > 0 && C > 0 && E >= 0 && C <= V, B4R_E_SHAPE, "b4r_sample_candidates: bad shape");
-  const size_t lds = ((size_t)V + (size_t)C) * sizeof(float);
-  B4R_CHECK_ARG((size_t)V * sizeof(float) <= 150 * 1024 && lds <= 158 * 1024, B4R_E_SHAPE,
-                "b4r_sample_candidates: vocabulary %d (+ %d draws) does not fit the 160 KB of LDS", V, C);
+  B4R_CHECK_ARG(V > 0 && R > 0 && C > 0 && E >= 0 && C <= V && C <= SAMPLE_MAX_C, B4R_E_SHAPE, "b4r_sample_candidates: bad shape");
+  const size_t lds = (size_t)V * sizeof(float);
+  B4R_CHECK_ARG(lds <= 150 * 1024, B4R_E_SHAPE, "b4r_sample_candidates: vocabulary %d does not fit the LDS (150 KB of keys)", V);
   { int rc = b4r_raise_lds((const void*)sample_candidates_kernel, lds, "b4r_sample_candidates"); if (rc) return rc; }
   hipLaunchKernelGGL(sample_candidates_kernel, dim3(R), dim3(256), lds, (hipStream_t)stream, logp, V, exclude, E, gt, C,
                      (uint32_t)seed, (uint32_t)(seed >> 32), cand);

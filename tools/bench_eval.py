@@ -12,11 +12,12 @@ enc = networks.Bert4RecEncoder(V, **config.get_encoder_config("ml-1m_64"))
 model = models.BERT4RecModel(enc)
 rng = np.random.default_rng(0)
 pop = (rng.zipf(1.2, size=1000000) % (V - 3) + 3).tolist()
-smp = dataloaders.samplers.get("pop_random", source=pop, vocab=list(range(V)), sample_size=100, seed=1)
+smp = dataloaders.samplers.get("pop_random", source=pop, vocab=list(range(V)), sample_size=100)   # unseeded: a seeded sampler keeps its numpy stream
 nb = (USERS + B - 1) // B
 batches = [synthetic_batch(B, L, 1, V, seed=i, ragged=True, finetune=True) for i in range(nb)]
 for name, dev in (("device sampler (b4r_sample_candidates)", True), ("host sampler (np.random.choice per user)", False)):
     ev = evaluation.get(sampler=smp, device_sampling=dev)
+    assert ev._device_sampler_ready(model) == dev
     ev.evaluate_batch(model, batches[0]); ev.reset_metrics()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for bt in batches:

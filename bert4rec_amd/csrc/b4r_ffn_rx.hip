@@ -126,14 +126,17 @@ __global__ __launch_bounds__(64 * FW) void ffn_fwd_kernel(FfnP p) {
 // -----------------------------------------------------------------------------------------------------------
 // backward, input gradient + the attention LayerNorm's backward.  LDS: [W1 image | W2 image | b1 | LayerNorm partials]
 // -----------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64 * FW) void ffn_bwd_dx_kernel(FfnP p) {
+// NW waves per workgroup: 16 (a 128-register cap, 10 registers spilled; the default) or 8 (B4R_FFN_DX_WAVES=8: two waves per SIMD, 256
+// registers, no spill, a wave walks two 16-token tiles at ML-1M -- 3-4 us slower per layer, see the launch site)
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW / 4) void ffn_bwd_dx_kernel(FfnP p) {
   FF_MARK(10);
   extern __shared__ __attribute__((aligned(16))) char smem_ffn[];
   char* w1img = smem_ffn;
   char* w2img = smem_ffn + W_IMG;
   float* sb1 = reinterpret_cast<float*>(smem_ffn + 2 * W_IMG);
   float* sred = sb1 + INNER;   // [FW][128], then [FW][128] for the output LayerNorm (row-list mode)
-  stage_weight_pair(w1img, p.W1, HID, INNER, w2img, p.W2, INNER, HID, 64 * FW);
+  stage_weight_pair(w1img, p.W1, HID, INNER, w2img, p.W2, INNER, HID, 64 * NW);
   if (threadIdx.x < INNER) sb1[threadIdx.x] = p.b1[threadIdx.x];
   __syncthreads();
 
@@ -146,14 +149,14 @@ __global__ __launch_bounds__(64 * FW) void ffn_bwd_dx_kernel(FfnP p) {
   // LayerNorm gamma / beta sums of this wave live in its 128 floats of LDS (32 more live registers per lane spilled 37 VGPRs to
   // scratch: 30 MB of extra HBM writes per launch in profiles/r02_a)
   float* myred = sred + wave * 128;
-  float* myred2 = sred + (FW + wave) * 128;
+  float* myred2 = sred + (NW + wave) * 128;
   myred[lane] = 0.f;
   myred[64 + lane] = 0.f;
   myred2[lane] = 0.f;
   myred2[64 + lane] = 0.f;
   FF_MARK(11);
 
-  for (int t = blockIdx.x + gridDim.x * wave; t < ntiles; t += gridDim.x * FW) {
+  for (int t = blockIdx.x + gridDim.x * wave; t < ntiles; t += gridDim.x * NW) {
     const int j = 16 * t + i, jc = min(j, Nn - 1);
     const int tok = ffn_row(p, jc), tokc = tok;
     const int64_t rowo = (int64_t)tokc * HID + 4 * g;
@@ -302,12 +305,12 @@ __global__ __launch_bounds__(64 * FW) void ffn_bwd_dx_kernel(FfnP p) {
   if (threadIdx.x < 128) {
     float r = 0.f;
 #pragma unroll
-    for (int w = 0; w < FW; ++w) r += sred[w * 128 + threadIdx.x];
+    for (int w = 0; w < NW; ++w) r += sred[w * 128 + threadIdx.x];
     p.ln_part[(int64_t)blockIdx.x * 128 + threadIdx.x] = r;
   } else if (threadIdx.x < 256 && rowmode) {
     float r = 0.f;
 #pragma unroll
-    for (int w = 0; w < FW; ++w) r += sred[(FW + w) * 128 + threadIdx.x - 128];
+    for (int w = 0; w < NW; ++w) r += sred[(NW + w) * 128 + threadIdx.x - 128];
     p.ln2_part[(int64_t)blockIdx.x * 128 + threadIdx.x - 128] = r;
   }
 }
@@ -568,9 +571,19 @@ int b4r_ffn_block_bwd_marked(const b4r_ffn_desc* d, hipStream_t stream, hipEvent
   p.ln_part = sc; sc += (int64_t)gdx * 128;
   p.ln2_part = sc;
   if (rowmode) { p.slotof = d->row_slot; p.dgr = d->slot_grad; p.dz2c = d->dz2_rows; }
-  int rc = b4r_raise_lds((const void*)ffn_bwd_dx_kernel, DX_LDS, "b4r_ffn_block_bwd");
-  if (rc) return rc;
-  hipLaunchKernelGGL(ffn_bwd_dx_kernel, dim3(gdx), dim3(64 * FW), DX_LDS, s, p);
+  // measured (tools/bench_ffn.py, same box, dx + dw + reductions): 16 waves 81.2 / 81.4 us, 8 waves 84.0 / 85.7 us -- the spill-free
+  // 256-register form loses more latency hiding (two waves per SIMD instead of four) than the 10 spilled registers cost
+  static const int dx_waves = getenv("B4R_FFN_DX_WAVES") ? atoi(getenv("B4R_FFN_DX_WAVES")) : 16;
+  int rc;
+  if (dx_waves == 16) {
+    rc = b4r_raise_lds((const void*)ffn_bwd_dx_kernel<16>, DX_LDS, "b4r_ffn_block_bwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL(ffn_bwd_dx_kernel<16>, dim3(gdx), dim3(64 * 16), DX_LDS, s, p);
+  } else {
+    rc = b4r_raise_lds((const void*)ffn_bwd_dx_kernel<8>, DX_LDS, "b4r_ffn_block_bwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL(ffn_bwd_dx_kernel<8>, dim3(gdx), dim3(64 * 8), DX_LDS, s, p);
+  }
   B4R_CHECK_LAUNCH("b4r_ffn_block_bwd (dx)");
   if (after_dx != nullptr && hipEventRecord(after_dx, s) != hipSuccess) {
     b4r_set_error("b4r_ffn_block_bwd: event record failed");

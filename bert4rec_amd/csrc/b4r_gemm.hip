@@ -319,6 +319,19 @@ __device__ __forceinline__ int reduce_mat_blocks(int S, int64_t total) { return 
 __device__ __forceinline__ void reduce_store(const ReduceJobView& job, int64_t eo, float r) {
   const int row = (int)(eo / job.No), col = (int)(eo % job.No);
   float* o = job.out + (int64_t)row * job.ldo + col;
+  if (job.fix != nullptr) {   // integer sum first (order-free), one conversion, one float add
+    long long q = job.fix[eo];
+    if (eo < job.fix_hot_elems) {   // 16 loads in flight: one after the other the 64 slots were 30 us of latency in one workgroup
+      for (int s0 = 0; s0 < job.fix_slots; s0 += 16) {
+        long long v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = s0 + u < job.fix_slots ? job.fix_hot[(int64_t)(s0 + u) * job.fix_hot_elems + eo] : 0ll;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) q += v[u];
+      }
+    }
+    r += (float)q * (1.f / 17592186044416.f);
+  }
   *o = job.accumulate ? (*o + r) : r;
 }
 __device__ __forceinline__ void slab_reduce_block(const ReduceJobView& job, int block, float (*sp)[RE]) {
@@ -484,8 +497,7 @@ __global__ __launch_bounds__(64 * RZ) void multi_slab_reduce_kernel(MultiReduceP
   int j = 0;
   while (j + 1 < p.n && (int)blockIdx.x >= p.block_begin[j + 1]) ++j;
   const B4rReduceJob q = p.jobs[j];
-  const ReduceJobView job{q.slab, q.cslab, q.caslab, q.out, q.colsum, q.colsum_a, q.S, q.Mo, q.No, q.ldo, q.accumulate};
-  slab_reduce_block(job, (int)blockIdx.x - p.block_begin[j], sp);
+  slab_reduce_block(q, (int)blockIdx.x - p.block_begin[j], sp);
 }
 thread_local B4rReduceQueue* g_queue = nullptr;
 }  // namespace
@@ -495,6 +507,24 @@ bool b4r_reduce_queue_push(const B4rReduceJob& job) {
   if (g_queue == nullptr || g_queue->n >= B4R_MAX_REDUCE_JOBS) return false;
   g_queue->jobs[g_queue->n++] = job;
   return true;
+}
+bool b4r_reduce_queue_attach_fixed(const float* out, const long long* fix, const long long* fix_hot, int fix_hot_elems, int fix_slots) {
+  if (g_queue == nullptr) return false;
+  for (int j = 0; j < g_queue->n; ++j) {
+    B4rReduceJob& job = g_queue->jobs[j];
+    if (job.out == out && job.ldo == job.No && job.fix == nullptr) {
+      job.fix = fix; job.fix_hot = fix_hot; job.fix_hot_elems = fix_hot_elems; job.fix_slots = fix_slots;
+      return true;
+    }
+  }
+  return false;
+}
+int b4r_launch_reduce_job(const B4rReduceJob& job, hipStream_t stream) {
+  if (b4r_reduce_queue_push(job)) return B4R_OK;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(slab_reduce_grid(job.S, job.Mo, job.No, job.colsum != nullptr, job.colsum_a != nullptr)),
+                     dim3(64 * RZ), 0, stream, job);
+  B4R_CHECK_LAUNCH("slab_reduce");
+  return B4R_OK;
 }
 int b4r_reduce_queue_flush(hipStream_t stream) {
   B4rReduceQueue* q = g_queue;

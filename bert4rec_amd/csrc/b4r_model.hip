@@ -36,7 +36,8 @@ int b4r_head_rx_dE_launch(const float* T, const float* E, const float* bias, con
                           int H, float* scratch, float* dE, float* db, hipStream_t stream);
 int b4r_ffn_block_bwd_marked(const b4r_ffn_desc* d, hipStream_t stream, hipEvent_t after_dx);
 int b4r_embed_grads(const float* x, const int64_t* ids, int B, int L, int H, float* table_grad, int64_t V, int hot_rows,
-                    float* hot_scratch, float* dpos, float* colsum_scratch, hipStream_t stream);
+                    float* fixed, float* dpos, float* colsum_scratch, hipStream_t stream);
+int64_t b4r_embed_fixed_floats(int64_t V, int H, int hot_rows);
 int b4r_gemm_tn_pair(const b4r_gemm_tn_desc* d0, float* scratch0, const b4r_gemm_tn_desc* d1, float* scratch1, hipStream_t stream);
 bool b4r_attn32_active(int H, int heads, int L);   // b4r_attn_block.hip: the 32-token-tile backward (it can form dWqkv / dbqkv itself)
 int b4r_ce_finalize_launch(const float* row_scratch, int M, b4r_train_state* state, int overwrite, hipStream_t stream);
@@ -253,7 +254,7 @@ WsLayout make_ws_layout(const b4r_model_config& c, int B, int L, int P) {
   w.gath = take(M * H); w.upre = take(M * H); w.u = take(M * H); w.meanm = take(M); w.rstdm = take(M);
   w.t = take(M * H); w.logits = take(M * w.Vp); w.rowsc = take(4 * M); w.pooled = take((int64_t)B * H);
   w.head_lse = take(M); w.head_ylab = take(M);
-  w.dx = take(N * H); w.hot = take(b4r_scatter_hot_scratch_floats(3, (int)H)); w.db = take(N * H); w.da = take(N * H); w.dctx = take(N * H);
+  w.dx = take(N * H); w.hot = take(b4r_embed_fixed_floats(c.vocab_size, (int)H, 3)); w.db = take(N * H); w.da = take(N * H); w.dctx = take(N * H);
   w.maxrows = M;
   w.dz2c = take(w.maxrows * H);
   w.dqkv = take(N * 3 * H); w.df = take(N * I); w.dt = take(M * H); w.dg = take(M * H);
@@ -1001,12 +1002,10 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
   }
   // ---- embedding stage: its dropout -> LayerNorm backward ran with layer 0's QKV product (da = d(item row + position row));
   // what remains: word table scatter-add, position table batch sum
-  // all queued ordered reductions (weight / bias / LayerNorm gradients) in one launch; the item-table gradient must be
-  // complete before the embedding rows are scatter-added on top of it
+  // the item-table scatter sums in 64-bit fixed point beside the float gradient (bitwise reproducible; b4r_rowops.hip), so it
+  // need not wait for the head's part of that gradient: ONE launch then sums every queued ordered reduction (weight / bias /
+  // LayerNorm gradients, the position table) and adds the fixed-point sums to the item table
   RC(order_after(s2, s));
-  RC(b4r_reduce_queue_flush(s));
-  B4rReduceQueue tail_queue;
-  b4r_reduce_queue_begin(&tail_queue);   // the two small reductions below share one launch as well
   RC(b4r_embed_grads(ws + w.da, batch->input_word_ids, B, L, H, grads + pl.word_emb, V, 3, ws + w.hot /* zeroed at the top */,
                      grads + pl.pos_emb, take((int64_t)b4r_cdiv(B, 16) * L * H), s));
   RC(b4r_reduce_queue_flush(s));

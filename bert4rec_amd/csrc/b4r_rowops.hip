@@ -329,13 +329,46 @@ __global__ __launch_bounds__(256) void batch_colsum_kernel(const float* x, int B
   batch_colsum_body(x, B, L, H, bchunk, partial, (int)blockIdx.x, (int)blockIdx.y);
 }
 
+// Item-table scatter-add in 64-bit FIXED POINT (2^-44 units): integer sums do not depend on the order in which the adds arrive, so
+// the item-table gradient -- the one sum of a train step that float atomics left order-dependent -- comes out bit for bit the same
+// on every run.  |value| < 2^19 converts exactly down to 2^-44 (a float of magnitude >= 2^-20 is a multiple of 2^-44 already, so
+// only contributions below 1e-6 are rounded at all, to 5.7e-14); fix [table_rows * H] and hot [HOT_SLOTS][hot_rows * H] (int64,
+// zeroed by the caller) are converted and added to the float gradient by the reduce launch that follows (B4rReduceJob::fix).
+// Destination rows [0, hot_rows) (PAD / MASK / UNK: [MASK] alone is ~20 % of all tokens) are summed in LDS first and leave the
+// workgroup once, into slot (workgroup % HOT_SLOTS) -- every workgroup on one row runs an order of magnitude below the atomic rate.
+constexpr float FIX_SCALE = 17592186044416.f;          // 2^44
+constexpr float FIX_UNSCALE = 1.f / 17592186044416.f;
+__device__ __forceinline__ void scatter_fixed_rows_body(const float* src, const int64_t* idx, int n, int H, long long* fix,
+                                                        int64_t dst_rows, int hot_rows, long long* hot, const int block,
+                                                        const int nblocks) {
+  extern __shared__ unsigned long long s_hot64[];
+  for (int k = threadIdx.x; k < hot_rows * H; k += 256) s_hot64[k] = 0ull;
+  if (hot_rows > 0) __syncthreads();
+  const int64_t total = (int64_t)n * H;
+  for (int64_t t = (int64_t)block * 256 + threadIdx.x; t < total; t += (int64_t)nblocks * 256) {
+    const int i = (int)(t / H), c = (int)(t % H);
+    const int64_t r = idx[i];
+    if (r < 0 || r >= dst_rows) continue;
+    const unsigned long long q = (unsigned long long)__float2ll_rn(src[(int64_t)i * H + c] * FIX_SCALE);
+    if (r < hot_rows) atomicAdd(&s_hot64[(int)r * H + c], q);
+    else atomicAdd(reinterpret_cast<unsigned long long*>(fix) + r * H + c, q);
+  }
+  if (hot_rows > 0) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < hot_rows * H; k += 256) {
+      const unsigned long long v = s_hot64[k];
+      if (v != 0ull) atomicAdd(reinterpret_cast<unsigned long long*>(hot) + (int64_t)(block % HOT_SLOTS) * hot_rows * H + k, v);
+    }
+  }
+}
+
 // the two gradients of the embedding stage from d(item row + position row) [B*L, H] in ONE launch: the item-table scatter-add
 // (workgroups [0, n_scatter)) and the batch sums of the position table (the rest, gx per batch slice): both only read x
-__global__ __launch_bounds__(256) void embed_grads_kernel(const float* x, const int64_t* ids, int n, int H, float* table_grad,
-                                                          int64_t table_rows, int hot_rows, float* hot_slab, int n_scatter, int B, int L,
+__global__ __launch_bounds__(256) void embed_grads_kernel(const float* x, const int64_t* ids, int n, int H, long long* fix,
+                                                          int64_t table_rows, int hot_rows, long long* hot, int n_scatter, int B, int L,
                                                           int bchunk, int gx, float* partial) {
   if ((int)blockIdx.x < n_scatter) {
-    scatter_add_rows_body(x, ids, 0, 1, n, H, table_grad, H, nullptr, table_rows, hot_rows, hot_slab, (int)blockIdx.x, n_scatter);
+    scatter_fixed_rows_body(x, ids, n, H, fix, table_rows, hot_rows, hot, (int)blockIdx.x, n_scatter);
   } else {
     const int k = (int)blockIdx.x - n_scatter;
     batch_colsum_body(x, B, L, H, bchunk, partial, k % gx, k / gx);
@@ -782,22 +815,29 @@ int b4r_batch_colsum(const float* x, int B, int L, int H, float* dpos, float* sc
   return b4r_launch_slab_reduce_full(scratch, S, L, H, dpos, H, 0, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
-// item-table and position-table gradients of the embedding stage in one launch (b4r_backward's tail); hot_scratch as in
-// b4r_scatter_add_rows_impl (zeroed by the caller), colsum_scratch >= ceil(B/16)*L*H floats
+// item-table and position-table gradients of the embedding stage in one launch (b4r_backward's tail).  fixed: b4r_embed_fixed_floats
+// floats, ZEROED by the caller (the 64-bit fixed-point sums of scatter_fixed_rows_body); colsum_scratch >= ceil(B/16)*L*H floats.
+// Both results are completed by reduce jobs: inside the caller's queue when one is active (the item table's job is the one that
+// already sums the head's slabs into table_grad, if there is one: table_grad = slabs + fixed in ONE pass), else launched here.
+int64_t b4r_embed_fixed_floats(int64_t V, int H, int hot_rows) { return 2 * (V * H + (int64_t)HOT_SLOTS * hot_rows * H); }
 int b4r_embed_grads(const float* x, const int64_t* ids, int B, int L, int H, float* table_grad, int64_t V, int hot_rows,
-                    float* hot_scratch, float* dpos, float* colsum_scratch, hipStream_t stream) {
+                    float* fixed, float* dpos, float* colsum_scratch, hipStream_t stream) {
   const int n = B * L, bchunk = 16, S = b4r_cdiv(B, bchunk);
   int n_scatter = b4r_cdiv((int64_t)n * H, 256);
   if (n_scatter > 1024) n_scatter = 1024;
-  if (hot_rows <= 0) hot_scratch = nullptr;
+  if (hot_rows < 0) hot_rows = 0;
+  long long* fix = reinterpret_cast<long long*>(fixed);
+  long long* hot = fix + V * H;
   const int gx = b4r_cdiv((int64_t)L * (H / 4), 256);
-  hipLaunchKernelGGL(embed_grads_kernel, dim3(n_scatter + gx * S), dim3(256), (size_t)(hot_rows > 0 ? hot_rows : 0) * H * sizeof(float),
-                     stream, x, ids, n, H, table_grad, V, hot_rows, hot_scratch, n_scatter, B, L, bchunk, gx, colsum_scratch);
+  hipLaunchKernelGGL(embed_grads_kernel, dim3(n_scatter + gx * S), dim3(256), (size_t)hot_rows * H * sizeof(long long), stream, x, ids,
+                     n, H, fix, V, hot_rows, hot, n_scatter, B, L, bchunk, gx, colsum_scratch);
   B4R_CHECK_LAUNCH("embedding gradients (scatter-add + position sums)");
-  int rc = B4R_OK;
-  if (hot_scratch)
-    rc = b4r_launch_slab_reduce_full(hot_scratch, HOT_SLOTS, hot_rows, H, table_grad, H, 1, nullptr, nullptr, nullptr, nullptr, stream);
-  if (rc) return rc;
+  if (!b4r_reduce_queue_attach_fixed(table_grad, fix, hot, hot_rows * H, HOT_SLOTS)) {
+    B4rReduceJob job{nullptr, nullptr, nullptr, table_grad, nullptr, nullptr, 0, (int)V, H, H, 1};
+    job.fix = fix; job.fix_hot = hot; job.fix_hot_elems = hot_rows * H; job.fix_slots = HOT_SLOTS;
+    int rc = b4r_launch_reduce_job(job, stream);
+    if (rc) return rc;
+  }
   return b4r_launch_slab_reduce_full(colsum_scratch, S, L, H, dpos, H, 0, nullptr, nullptr, nullptr, nullptr, stream);
 }
 

@@ -57,11 +57,21 @@ struct B4rReduceQueue {
   int n;
 };
 void b4r_reduce_queue_begin(B4rReduceQueue* q);                 // queue reductions issued by this thread from now on
-int b4r_reduce_queue_flush(hipStream_t stream);                  // launch them all (one kernel) and stop queueing
+// launch them all (one kernel) and stop queueing.  sq_partial (optional, sq_cap floats): one sum of squares of the stored values per
+// workgroup, *sq_np of them (0 when the launch has more workgroups than sq_cap); *covered: the number of elements the jobs write
+int b4r_reduce_queue_flush(hipStream_t stream, float* sq_partial = nullptr, int sq_cap = 0, int* sq_np = nullptr,
+                           int64_t* covered = nullptr);
 bool b4r_reduce_queue_push(const B4rReduceJob& job);             // false: no queue active (caller reduces immediately)
 // give the queued job that writes `out` a fixed-point addend; false: no queue, or no queued job writes `out`
 bool b4r_reduce_queue_attach_fixed(const float* out, const long long* fix, const long long* fix_hot, int fix_hot_elems, int fix_slots);
 int b4r_launch_reduce_job(const B4rReduceJob& job, hipStream_t stream);   // queued when a queue is active, else launched
+
+// the deferred merge of the logits-free masked-LM head's forward (b4r_head_merge.h), as the hosts pass it around
+struct B4rHeadMerge {
+  const float* part; int slices, M, V;
+  const float* T; const float* E; const float* bias; const int64_t* y;
+  float* row_out; float* lse_out; int32_t* ylab;
+};
 
 // dropout sites (stream ids of the counter-hash RNG); restated in oracle/bert4rec_oracle.py
 #define B4R_STREAM_EMB 0u

@@ -316,7 +316,7 @@ constexpr int RE = 256;    // elements per workgroup when the slabs are shared o
 constexpr int RQ = 4096;   // elements per workgroup when every thread walks all (<= 16) slabs itself
 typedef B4rReduceJob ReduceJobView;
 __device__ __forceinline__ int reduce_mat_blocks(int S, int64_t total) { return (int)((total + (S <= RZ ? RQ : RE) - 1) / (S <= RZ ? RQ : RE)); }
-__device__ __forceinline__ void reduce_store(const ReduceJobView& job, int64_t eo, float r) {
+__device__ __forceinline__ float reduce_store(const ReduceJobView& job, int64_t eo, float r) {
   const int row = (int)(eo / job.No), col = (int)(eo % job.No);
   float* o = job.out + (int64_t)row * job.ldo + col;
   if (job.fix != nullptr) {   // integer sum first (order-free), one conversion, one float add
@@ -332,9 +332,13 @@ __device__ __forceinline__ void reduce_store(const ReduceJobView& job, int64_t e
     }
     r += (float)q * (1.f / 17592186044416.f);
   }
-  *o = job.accumulate ? (*o + r) : r;
+  if (job.accumulate) r += *o;
+  *o = r;
+  return r;
 }
-__device__ __forceinline__ void slab_reduce_block(const ReduceJobView& job, int block, float (*sp)[RE]) {
+// returns the sum of the squares of the values THIS thread stored (the global gradient norm's partial sums, multi_slab_reduce_kernel)
+__device__ __forceinline__ float slab_reduce_block(const ReduceJobView& job, int block, float (*sp)[RE]) {
+  float sq = 0.f;
   const int64_t total = (int64_t)job.Mo * job.No;
   const int mat_blocks = reduce_mat_blocks(job.S, total);
   const int lane = threadIdx.x & 63, zl = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -343,7 +347,7 @@ __device__ __forceinline__ void slab_reduce_block(const ReduceJobView& job, int 
     // few slabs (the head's table gradient: 16 slabs of V x H): a thread owns 4 elements and reads all slabs itself, every load in
     // flight at once.  Same value as the shared-out form below: there wave z's partial sum is slab z alone.
     const int64_t e = (int64_t)block * RQ + 4 * (int64_t)threadIdx.x;
-    if (e >= total) return;
+    if (e >= total) return sq;
     f32x4 v[RZ];
 #pragma unroll
     for (int z = 0; z < RZ; ++z) {
@@ -361,8 +365,8 @@ __device__ __forceinline__ void slab_reduce_block(const ReduceJobView& job, int 
     for (int z = 0; z < RZ; ++z) r += v[z];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      if (e + k < total) reduce_store(job, e + k, r[k]);
-    return;
+      if (e + k < total) { const float w = reduce_store(job, e + k, r[k]); sq = fmaf(w, w, sq); }
+    return sq;
   }
   if (block < mat_blocks) {
     const int64_t e = (int64_t)block * RE + 4 * lane;
@@ -397,10 +401,11 @@ __device__ __forceinline__ void slab_reduce_block(const ReduceJobView& job, int 
         float r = 0.f;
 #pragma unroll
         for (int z = 0; z < RZ; ++z) r += sp[z][l];
-        reduce_store(job, eo, r);
+        const float v = reduce_store(job, eo, r);
+        sq = v * v;
       }
     }
-    return;
+    return sq;
   }
   // column-sum strips: [No of cslab | Mo of caslab], 64 elements per wave-row, 4 wave-rows of the 16 x 64 layout unused
   const int64_t n_cs = job.colsum ? job.No : 0, n_csa = job.colsum_a ? job.Mo : 0;
@@ -427,12 +432,14 @@ __device__ __forceinline__ void slab_reduce_block(const ReduceJobView& job, int 
     for (int z = 0; z < RZ; ++z) r += sp[z][lane];
     if (e < n_cs) job.colsum[idx] = r;
     else job.colsum_a[idx] = r;
+    sq = r * r;
   }
+  return sq;
 }
 
 __global__ __launch_bounds__(64 * RZ) void slab_reduce_kernel(ReduceJobView job) {
   __shared__ __attribute__((aligned(16))) float sp[RZ][RE];
-  slab_reduce_block(job, (int)blockIdx.x, sp);
+  (void)slab_reduce_block(job, (int)blockIdx.x, sp);
 }
 
 int slab_reduce_grid(int S, int Mo, int No, bool cs, bool csa) {
@@ -490,6 +497,7 @@ struct MultiReduceP {
   B4rReduceJob jobs[B4R_MAX_REDUCE_JOBS];
   int block_begin[B4R_MAX_REDUCE_JOBS + 1];
   int n;
+  float* sq_partial;   // optional [gridDim.x]: sum of the squares of everything the workgroup stored
 };
 // all queued reductions in one launch: a workgroup looks up its job, then does what slab_reduce_kernel does
 __global__ __launch_bounds__(64 * RZ) void multi_slab_reduce_kernel(MultiReduceP p) {
@@ -497,7 +505,20 @@ __global__ __launch_bounds__(64 * RZ) void multi_slab_reduce_kernel(MultiReduceP
   int j = 0;
   while (j + 1 < p.n && (int)blockIdx.x >= p.block_begin[j + 1]) ++j;
   const B4rReduceJob q = p.jobs[j];
-  slab_reduce_block(q, (int)blockIdx.x - p.block_begin[j], sp);
+  float sq = slab_reduce_block(q, (int)blockIdx.x - p.block_begin[j], sp);
+  if (p.sq_partial != nullptr) {   // fixed order: wave butterfly, then the 16 waves in turn
+    __shared__ float s_sq[RZ];
+    sq = b4r_wave_sum(sq);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_sq[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float t = 0.f;
+#pragma unroll
+      for (int z = 0; z < RZ; ++z) t += s_sq[z];
+      p.sq_partial[blockIdx.x] = t;
+    }
+  }
 }
 thread_local B4rReduceQueue* g_queue = nullptr;
 }  // namespace
@@ -526,19 +547,27 @@ int b4r_launch_reduce_job(const B4rReduceJob& job, hipStream_t stream) {
   B4R_CHECK_LAUNCH("slab_reduce");
   return B4R_OK;
 }
-int b4r_reduce_queue_flush(hipStream_t stream) {
+int b4r_reduce_queue_flush(hipStream_t stream, float* sq_partial, int sq_cap, int* sq_np, int64_t* covered) {
   B4rReduceQueue* q = g_queue;
   g_queue = nullptr;
+  if (sq_np) *sq_np = 0;
+  if (covered) *covered = 0;
   if (q == nullptr || q->n == 0) return B4R_OK;
   MultiReduceP p;
   p.n = q->n;
   int blocks = 0;
+  int64_t elems = 0;
   for (int j = 0; j < q->n; ++j) {
     p.jobs[j] = q->jobs[j];
     p.block_begin[j] = blocks;
     blocks += slab_reduce_grid(q->jobs[j].S, q->jobs[j].Mo, q->jobs[j].No, q->jobs[j].colsum != nullptr, q->jobs[j].colsum_a != nullptr);
+    elems += (int64_t)q->jobs[j].Mo * q->jobs[j].No + (q->jobs[j].colsum ? q->jobs[j].No : 0) + (q->jobs[j].colsum_a ? q->jobs[j].Mo : 0);
   }
   p.block_begin[q->n] = blocks;
+  // the partial square sums only when they fit the caller's array (else the caller measures the norm with a launch of its own)
+  p.sq_partial = (sq_partial != nullptr && blocks <= sq_cap) ? sq_partial : nullptr;
+  if (p.sq_partial && sq_np) *sq_np = blocks;
+  if (covered) *covered = elems;
   hipLaunchKernelGGL(multi_slab_reduce_kernel, dim3(blocks), dim3(64 * RZ), 0, stream, p);
   B4R_CHECK_LAUNCH("multi_slab_reduce");
   return B4R_OK;

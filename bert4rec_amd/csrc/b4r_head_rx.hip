@@ -18,16 +18,14 @@
 // Tile / image mechanics are those of b4r_rx_tiles.h: the H columns of E (or T) are NKH 32-column images (hi, lo each),
 // interleaved per 16-row tile.
 #include "b4r_rx_tiles.h"
+#include "b4r_head_merge.h"
 
 namespace {
 
 // 16-row tiles per LDS chunk (even): 40 KB of images at H = 64 (three workgroups per CU), 48 KB at 128, 64 KB at 256
 constexpr int head_ch(int nkh) { return nkh == 2 ? 10 : nkh == 4 ? 6 : 4; }
-constexpr int part_ld(int nkh) { return 32 * nkh + 8; }   // floats per (V slice, row): H accumulators, max, sum, best logit, best index
-constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
-// The sweeps work in log2 units: T (or E) is scaled by log2(e) before it is split, so that the softmax exponential is the
-// bare v_exp_f32 (2^x) -- the kernels are bound by VALU issue, every instruction per logit counts.
-__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
+// (part_ld, LOG2E / LN2 and ex2 -- the sweeps work in log2 units, T or E is scaled by log2(e) before it is split so that the softmax
+// exponential is the bare v_exp_f32 -- are in b4r_head_merge.h, shared with the LayerNorm backward that can do the merge)
 
 struct HeadP {
   const float* T; const float* E; const float* bias; const int64_t* y;
@@ -36,6 +34,10 @@ struct HeadP {
   float* slab; float* bslab;      // dE: [slices][V][64], [slices][V]
   int M, V;
   int tiles_per_slice;            // even number of 16-row tiles per slice (of V in the forward, of M in dE)
+  // dE in front of the merge of the forward's V slices (cpart != NULL: the forward ran its sweep only, the LayerNorm backward behind
+  // this launch merges: b4r_head_merge.h): every workgroup forms the lse / label of the rows it sweeps from the forward's partials
+  // itself (head_merge_row's arithmetic, the same bits)
+  const float* cpart; int cslices;
 };
 
 // image index as a function argument: it is a constant after unrolling, so the offset still folds into the instruction
@@ -195,61 +197,33 @@ __global__ __launch_bounds__(64 * WAVES) void head_fwd_kernel(HeadP p) {
     for (int kb = 0; kb < 2 * NKH; ++kb) *reinterpret_cast<f32x4*>(dst + 16 * kb + 4 * g) = acc[kb];
     if (g == 0) {
       dst[H] = mx; dst[H + 1] = sum; dst[H + 2] = best; dst[H + 3] = __int_as_float(bidx);
+      // (max, sum) once more as a compact [slices][M][2] array behind the records: what head_dE_kernel reads when it forms the lse
+      // itself (one 8-byte load per slice and row, coalesced -- out of the records it was a cache line per slice and row, +4 us)
+      float* ms = p.part + (int64_t)gridDim.y * p.M * PART_LD + ((int64_t)blockIdx.y * p.M + m) * 2;
+      ms[0] = mx; ms[1] = sum;
     }
   }
 }
 
-// merge the V slices of every row; H/4 threads per row (4 columns each)
 template <int NKH>
 __global__ __launch_bounds__(256) void head_combine_kernel(const float* part, int slices, int M, int V, const float* T,
                                                            const float* E, const float* bias, const int64_t* y, float* dT,
                                                            float* row_out, float* lse_out, int32_t* ylab) {
-  constexpr int H = 32 * NKH, TPR = 8 * NKH, PART_LD = part_ld(NKH);   // TPR = threads per row: 16, 32 or 64
+  constexpr int TPR = 8 * NKH;
   const int idx = blockIdx.x * 256 + threadIdx.x;
-  const int m = min(idx / TPR, M - 1), c4 = idx % TPR;         // whole TPR-lane groups are in or out of range together
-  if (idx / TPR >= M) return;
-  float mx = -INFINITY;
-#pragma unroll 4
-  for (int s = 0; s < slices; ++s) mx = fmaxf(mx, part[((int64_t)s * M + m) * PART_LD + H]);
-  float sum = 0.f, best = -INFINITY;
-  int bidx = 0x7fffffff;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-  for (int s = 0; s < slices; ++s) {                            // slices in increasing column order: lowest index wins ties
-    const float* src = part + ((int64_t)s * M + m) * PART_LD;
-    const float w = ex2(src[H] - mx);                           // the sweep's maxima are in log2 units
-    sum += src[H + 1] * w;
-    acc += *reinterpret_cast<const f32x4*>(src + 4 * c4) * w;
-    if (src[H + 2] > best) { best = src[H + 2]; bidx = __float_as_int(src[H + 3]); }
-  }
-  const int64_t y64 = y[m];
-  const bool valid = (y64 != 0), y_ok = (y64 >= 0 && y64 < V);
-  f32x4 d = {0.f, 0.f, 0.f, 0.f}, ey = {0.f, 0.f, 0.f, 0.f};
-  if (y_ok) ey = *reinterpret_cast<const f32x4*>(E + y64 * H + 4 * c4);
-  if (valid) d = acc * (1.0f / sum) - ey;
-  *reinterpret_cast<f32x4*>(dT + (int64_t)m * H + 4 * c4) = d;
-  // the label's logit in plain fp32 (the loss needs its value, the metrics only the argmax index): TPR lanes x 4 columns
-  const f32x4 tv = *reinterpret_cast<const f32x4*>(T + (int64_t)m * H + 4 * c4);
-  float xl = (tv[0] * ey[0] + tv[1] * ey[1]) + (tv[2] * ey[2] + tv[3] * ey[3]);
-#pragma unroll
-  for (int o = 1; o < TPR; o <<= 1) xl += __shfl_xor(xl, o, 64);
-  if (c4 == 0) {
-    if (y_ok) xl += bias[y64];
-    const float lse = (mx + __log2f(sum)) * LN2;
-    row_out[4 * (int64_t)m + 0] = (valid && y_ok) ? (lse - xl) : 0.f;
-    row_out[4 * (int64_t)m + 1] = valid ? 1.f : 0.f;
-    row_out[4 * (int64_t)m + 2] = (valid && (int64_t)bidx == y64) ? 1.f : 0.f;
-    row_out[4 * (int64_t)m + 3] = ((int64_t)bidx == y64) ? 1.f : 0.f;
-    lse_out[m] = valid ? lse : INFINITY;                        // +inf => zero gradient rows in head_dE_kernel
-    ylab[m] = (valid && y_ok) ? (int32_t)y64 : -1;
-  }
+  if (idx / TPR >= M) return;                                   // whole TPR-lane groups are in or out of range together
+  constexpr int H = 32 * NKH;
+  const HeadMergeP mp{part, slices, M, V, T, E, bias, y, row_out, lse_out, ylab};
+  const f32x4 d = head_merge_row<NKH>(mp, idx / TPR, idx % TPR);
+  *reinterpret_cast<f32x4*>(dT + (int64_t)(idx / TPR) * H + 4 * (idx % TPR)) = d;
 }
 
 // -----------------------------------------------------------------------------------------------------------
 // dE / db: grid (blocks of 128 rows of E, M slices); wave = 16 rows of E x the slice's rows of T
 // LDS: [T chunk images | lse chunk | label chunk]
 // -----------------------------------------------------------------------------------------------------------
-template <int NKH>
+// FOLD: lse / labels from the forward's partials (HeadP::cpart) instead of the merged arrays
+template <int NKH, bool FOLD>
 __global__ __launch_bounds__(64 * WAVES) void head_dE_kernel(HeadP p) {
   extern __shared__ __attribute__((aligned(16))) char smem_head[];
   typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -276,8 +250,20 @@ __global__ __launch_bounds__(64 * WAVES) void head_dE_kernel(HeadP p) {
   ChunkRegs<NKH> regs;
   auto chunk_valid = [&](int c0) { return min(min(HEAD_CH * 16, m_end - c0), p.M - c0); };
   chunk_fetch<NKH>(regs, p.T, m_begin, chunk_valid(m_begin));
-  float lz = p.lse[min(m_begin + (int)threadIdx.x, p.M - 1)];
-  int yz = p.ylab[min(m_begin + (int)threadIdx.x, p.M - 1)];
+  float lz = INFINITY;
+  int yz = -1;
+  RowPart rp;
+  const bool row_thread = (int)threadIdx.x < HEAD_CH * 16;        // thread t: row t of the chunk
+  auto row_request = [&](int m) __attribute__((always_inline)) {
+    if (!row_thread) return;
+    if (FOLD) row_part_fetch(rp, p.cpart + (int64_t)p.cslices * p.M * part_ld(NKH), p.cslices, p.M, p.y, m);
+    else { lz = p.lse[m]; yz = p.ylab[m]; }
+  };
+  auto row_finish = [&]() __attribute__((always_inline)) {
+    if (FOLD && row_thread) row_part_finish(rp, p.V, lz, yz);
+  };
+  row_request(min(m_begin + (int)threadIdx.x, p.M - 1));
+  row_finish();
   for (int c0 = m_begin; c0 < m_end; c0 += HEAD_CH * 16) {
     const int nrows = min(HEAD_CH * 16, m_end - c0);
     __syncthreads();                                            // the previous chunk has been consumed
@@ -291,8 +277,7 @@ __global__ __launch_bounds__(64 * WAVES) void head_dE_kernel(HeadP p) {
     const int cn = c0 + HEAD_CH * 16;
     if (cn < m_end) {                                           // block-uniform: the next chunk travels during this one
       chunk_fetch<NKH>(regs, p.T, cn, chunk_valid(cn));
-      lz = p.lse[min(cn + (int)threadIdx.x, p.M - 1)];
-      yz = p.ylab[min(cn + (int)threadIdx.x, p.M - 1)];
+      row_request(min(cn + (int)threadIdx.x, p.M - 1));
     }
     for (int tp = 0; tp < nrows / 32; ++tp) {
       f32x4 gv[2];
@@ -313,6 +298,7 @@ __global__ __launch_bounds__(64 * WAVES) void head_dE_kernel(HeadP p) {
       split8(cat(gv[0], gv[1]), gh, gl);
       feed_pair<NKH>(img, fa, 2 * tp, gh, gl, acc);             // dE^T[k][v] += T^T[k][row pair] . g[row pair][v]
     }
+    if (cn < m_end) row_finish();                                // the next chunk's lse / labels from the partials requested above
   }
   dbsum += __shfl_xor(dbsum, 16, 64);
   dbsum += __shfl_xor(dbsum, 32, 64);
@@ -364,14 +350,14 @@ int launch_fwd(const HeadP& p, int slices, float* dT, float* row_out, float* lse
   return B4R_OK;
 }
 
-template <int NKH>
+template <int NKH, bool FOLD = false>
 int launch_dE(const HeadP& p, int slices, hipStream_t stream) {
   static bool raised = false;
   if (!raised) {
-    (void)hipFuncSetAttribute((const void*)head_dE_kernel<NKH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)head_lds(NKH));
+    (void)hipFuncSetAttribute((const void*)head_dE_kernel<NKH, FOLD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)head_lds(NKH));
     raised = true;
   }
-  hipLaunchKernelGGL(head_dE_kernel<NKH>, dim3(b4r_cdiv(p.V, ROWS_WG), slices), dim3(64 * WAVES), head_lds(NKH), stream, p);
+  hipLaunchKernelGGL((head_dE_kernel<NKH, FOLD>), dim3(b4r_cdiv(p.V, ROWS_WG), slices), dim3(64 * WAVES), head_lds(NKH), stream, p);
   B4R_CHECK_LAUNCH("masked-LM head dE (fused)");
   return B4R_OK;
 }
@@ -379,13 +365,19 @@ int launch_dE(const HeadP& p, int slices, hipStream_t stream) {
 }  // namespace
 
 bool b4r_head_rx_hidden_ok(int H) { return H == 64 || H == 128 || H == 256; }
+int b4r_head_rx_fwd_slices(int M, int V, int H);
+// may the dE launch merge the forward's V slices itself (b4r_head_rx_dE_launch with fwd_part)?
+bool b4r_head_rx_combine_foldable(int M, int V, int H) {
+  static const bool off = getenv("B4R_HEAD_FOLD_COMBINE") && atoi(getenv("B4R_HEAD_FOLD_COMBINE")) == 0;
+  return !off && H == 64 && b4r_head_rx_fwd_slices(M, V, H) <= CMAX;
+}
 
 // number of V slices the forward uses / M slices the dE kernel uses, and the scratch they need (floats)
 int b4r_head_rx_fwd_slices(int M, int V, int H) {
   const int per = even_tiles(V, fwd_slices_wanted(M), head_ch(H / 32));
   return b4r_cdiv(b4r_cdiv(V, 16), per);
 }
-int64_t b4r_head_rx_fwd_scratch_floats(int M, int V, int H) { return (int64_t)b4r_head_rx_fwd_slices(M, V, H) * M * (H + 8); }
+int64_t b4r_head_rx_fwd_scratch_floats(int M, int V, int H) { return (int64_t)b4r_head_rx_fwd_slices(M, V, H) * M * (H + 8 + 2); }
 int b4r_head_rx_dE_slices(int M, int V, int H) {
   const int per = even_tiles(M, dE_slices_wanted(V), head_ch(H / 32));
   return b4r_cdiv(b4r_cdiv(M, 16), per);
@@ -417,17 +409,23 @@ int b4r_launch_slab_reduce_full(const float* slab, int S, int Mo, int No, float*
                                 const float* cslab, float* colsum, const float* caslab, float* colsum_a, hipStream_t stream);
 
 // dE [V,H] and db [V] (overwritten, through the ordered slab reduction) from T, E, bias and the forward's lse / labels
+// fwd_part != NULL: the forward ran with only_sweep = 1 and left its per-slice partials there; lse / ylab are not read (y: the labels),
+// the merge itself (dT, loss rows) is the business of the LayerNorm backward behind this launch (b4r_ln_bwd_launch's merge argument)
 int b4r_head_rx_dE_launch(const float* T, const float* E, const float* bias, const float* lse, const int32_t* ylab, int M, int V,
-                          int H, float* scratch, float* dE, float* db, hipStream_t stream) {
+                          int H, float* scratch, float* dE, float* db, hipStream_t stream, const float* fwd_part, const int64_t* y) {
   HeadP p{};
   p.T = T; p.E = E; p.bias = bias; p.lse = lse; p.ylab = ylab; p.M = M; p.V = V;
+  if (fwd_part != nullptr) {
+    B4R_CHECK_ARG(b4r_head_rx_combine_foldable(M, V, H), B4R_E_BADARG, "fused masked-LM head: the merge cannot ride on dE for this shape");
+    p.cpart = fwd_part; p.cslices = b4r_head_rx_fwd_slices(M, V, H); p.y = y;
+  }
   const int slices = b4r_head_rx_dE_slices(M, V, H);
   p.tiles_per_slice = even_tiles(M, dE_slices_wanted(V), head_ch(H / 32));
   p.slab = scratch;
   p.bslab = scratch + (int64_t)slices * V * H;
   int rc;
   switch (H) {
-    case 64: rc = launch_dE<2>(p, slices, stream); break;
+    case 64: rc = fwd_part ? launch_dE<2, true>(p, slices, stream) : launch_dE<2>(p, slices, stream); break;
     case 128: rc = launch_dE<4>(p, slices, stream); break;
     case 256: rc = launch_dE<8>(p, slices, stream); break;
     default: b4r_set_error("fused masked-LM head: hidden size %d not supported (64, 128, 256)", H); return B4R_E_SHAPE;
@@ -460,5 +458,5 @@ extern "C" int b4r_mlm_head_fused_bwd(const float* T, const float* E, const floa
   B4R_CHECK_ARG(M > 0 && V > 0 && b4r_head_rx_hidden_ok(H), B4R_E_SHAPE, "b4r_mlm_head_fused_bwd: bad shape (H = 64, 128 or 256)");
   B4R_CHECK_ARG(b4r_aligned16(T) && b4r_aligned16(E) && b4r_aligned16(scratch), B4R_E_ALIGN,
                 "b4r_mlm_head_fused_bwd: T, E and scratch must be 16-byte aligned");
-  return b4r_head_rx_dE_launch(T, E, bias, lse, labels, M, V, H, scratch, dE, dbias, (hipStream_t)stream);
+  return b4r_head_rx_dE_launch(T, E, bias, lse, labels, M, V, H, scratch, dE, dbias, (hipStream_t)stream, nullptr, nullptr);
 }

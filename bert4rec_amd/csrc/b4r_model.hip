@@ -19,7 +19,8 @@
 int b4r_ln_bwd_launch(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
                       int rows, int H, float* dz, float* dgamma, float* dbeta, float* scratch, const int64_t* ids,
                       const float* table, const float* pos_table, int L, int V, DropArgs drop, hipStream_t stream,
-                      const float* gelu_pre = nullptr);
+                      const float* gelu_pre = nullptr, const B4rHeadMerge* merge = nullptr);
+int b4r_head_rx_fwd_slices(int M, int V, int H);
 int b4r_scatter_add_rows_impl(const float* src, const int64_t* idx, int64_t idx_add_per, int per, int n, int H,
                               float* dst, int dst_ld, const int64_t* skip_if_zero, int64_t dst_rows, int hot_rows,
                               float* hot_scratch, hipStream_t stream);
@@ -33,10 +34,15 @@ int64_t b4r_head_rx_dE_scratch_floats(int M, int V, int H);
 int b4r_head_rx_fwd_launch(const float* T, const float* E, const float* bias, const int64_t* y, int M, int V, int H,
                            float* scratch, float* dT, float* row_out, float* lse, int32_t* ylab, hipStream_t stream);
 int b4r_head_rx_dE_launch(const float* T, const float* E, const float* bias, const float* lse, const int32_t* ylab, int M, int V,
-                          int H, float* scratch, float* dE, float* db, hipStream_t stream);
+                          int H, float* scratch, float* dE, float* db, hipStream_t stream, const float* fwd_part = nullptr,
+                          const int64_t* y = nullptr);
+bool b4r_head_rx_combine_foldable(int M, int V, int H);
+int b4r_head_rx_fwd_launch2(const float* T, const float* E, const float* bias, const int64_t* y, int M, int V, int H,
+                            float* scratch, float* dT, float* row_out, float* lse, int32_t* ylab, int only_sweep, hipStream_t stream);
 int b4r_ffn_block_bwd_marked(const b4r_ffn_desc* d, hipStream_t stream, hipEvent_t after_dx);
 int b4r_embed_grads(const float* x, const int64_t* ids, int B, int L, int H, float* table_grad, int64_t V, int hot_rows,
-                    float* fixed, float* dpos, float* colsum_scratch, hipStream_t stream);
+                    float* fixed, float* dpos, float* colsum_scratch, hipStream_t stream, const float* fin_rows = nullptr,
+                    int fin_M = 0, b4r_train_state* state = nullptr, float* tail = nullptr);
 int64_t b4r_embed_fixed_floats(int64_t V, int H, int hot_rows);
 int b4r_gemm_tn_pair(const b4r_gemm_tn_desc* d0, float* scratch0, const b4r_gemm_tn_desc* d1, float* scratch1, hipStream_t stream);
 bool b4r_attn32_active(int H, int heads, int L);   // b4r_attn_block.hip: the 32-token-tile backward (it can form dWqkv / dbqkv itself)
@@ -48,7 +54,16 @@ int b4r_attn_bwd_streams(const float* qkv, const int64_t* input_mask, const floa
 int b4r_zero2(float* a, int64_t na, float* b, int64_t nb, hipStream_t stream, float* tail = nullptr, b4r_train_state* state = nullptr,
               const float* fin_rows = nullptr, int fin_M = 0);
 int b4r_optimizer_fused(const b4r_adamw_config* hp, float* params, const float* grads, float* adam_m, float* adam_v, int64_t n,
-                        int64_t n_decay, float* scratch, b4r_train_state* state, hipStream_t stream, int sums_from_tail = 0);
+                        int64_t n_decay, float* scratch, b4r_train_state* state, hipStream_t stream, int sums_from_tail = 0,
+                        int np_given = 0);
+// internal flag of b4r_backward (b4r_train_step sets it): the closing reduce launch also leaves the partial sums of squares of the
+// gradients at the start of the workspace (dead by then) and their number in g_norm_np, so that the optimizer needs no norm launch
+#define B4R_FLAG_NORM_PARTIALS_INTERNAL (1 << 20)
+// internal flag of b4r_forward AND b4r_backward of one train step (b4r_train_step sets it on both; fused head + B4R_FLAG_LOSS_SUMS):
+// the forward runs the head's vocabulary sweep only, the backward's dE launch merges the slices (dT, loss rows, lse, labels) in its
+// prologue and the loss / metric sums are formed by one extra workgroup of the embedding-gradient launch -- one launch fewer
+#define B4R_FLAG_DEFER_COMBINE_INTERNAL (1 << 21)
+static thread_local int g_norm_np = 0;
 
 // ---- error message (thread local) ---------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
@@ -281,9 +296,9 @@ WsLayout make_ws_layout(const b4r_model_config& c, int B, int L, int P) {
     if (b4r_head_rx_hidden_ok((int)H)) add(b4r_head_rx_dE_scratch_floats((int)M, (int)V, (int)H));
   }
   add((int64_t)b4r_cdiv(B, 16) * L * H);  // position-table gradient partials
-  // the fused head's forward partials live at the start of the scratch region (consumed before the backward starts)
-  if (M > 0 && b4r_head_rx_hidden_ok((int)H) && s < b4r_head_rx_fwd_scratch_floats((int)M, (int)V, (int)H))
-    s = up4(b4r_head_rx_fwd_scratch_floats((int)M, (int)V, (int)H));
+  // the fused head's forward partials live at the start of the scratch region; a train step's backward merges them itself (its dE
+  // launch), so they stay reserved in front of the backward's own regions
+  if (M > 0 && b4r_head_rx_hidden_ok((int)H)) add(b4r_head_rx_fwd_scratch_floats((int)M, (int)V, (int)H));
   w.scratch = take(s); w.scratch_floats = s;
   w.total = off;
   return w;
@@ -696,8 +711,9 @@ extern "C" int b4r_forward(const b4r_model_config* cfg, const b4r_batch* batch, 
       // no [M,V] tensor: loss rows, log-sum-exp and d loss_sum / d T straight from T, E and the bias
       B4R_CHECK_ARG(b4r_fused_head_supported(cfg), B4R_E_BADARG, "b4r_forward: B4R_FLAG_FUSED_HEAD needs hidden size 64 / 128 / 256 and the bf16x3 mode");
       B4R_CHECK_ARG(batch->masked_lm_ids != nullptr, B4R_E_BADARG, "b4r_forward: B4R_FLAG_FUSED_HEAD needs masked_lm_ids");
-      RC(b4r_head_rx_fwd_launch(ws + w.t, params + pl.word_emb, params + pl.out_bias, batch->masked_lm_ids, M, V, H, ws + w.scratch,
-                                ws + w.dt, ws + w.rowsc, ws + w.head_lse, reinterpret_cast<int32_t*>(ws + w.head_ylab), s));
+      RC(b4r_head_rx_fwd_launch2(ws + w.t, params + pl.word_emb, params + pl.out_bias, batch->masked_lm_ids, M, V, H, ws + w.scratch,
+                                 ws + w.dt, ws + w.rowsc, ws + w.head_lse, reinterpret_cast<int32_t*>(ws + w.head_ylab),
+                                 (flags & B4R_FLAG_DEFER_COMBINE_INTERNAL) ? 1 : 0, s));
     } else {
       RC(gemm(ws + w.t, H, params + pl.word_emb, H, ws + w.logits, (int)w.Vp, M, V, H, 1, B4R_EPI_BIAS, params + pl.out_bias,
               nullptr, 0, nullptr, 0, 1.f, 0, nullptr, 0, 0.f, 0, s));
@@ -775,6 +791,7 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
   B4R_CHECK_ARG(!(flags & B4R_FLAG_GRAD_TAIL) || state, B4R_E_BADARG, "b4r_backward: B4R_FLAG_GRAD_TAIL needs the state");
   const bool head_rows = (flags & B4R_FLAG_HEAD_ROWS_ONLY) && head_rows_ok(cfg, batch);
   const bool loss_sums = (flags & B4R_FLAG_LOSS_SUMS) != 0;
+  const bool defer_combine = (flags & B4R_FLAG_DEFER_COMBINE_INTERNAL) && loss_sums;
   B4R_CHECK_ARG(!loss_sums || ((flags & B4R_FLAG_FUSED_HEAD) && state && batch->masked_lm_ids), B4R_E_BADARG,
                 "b4r_backward: B4R_FLAG_LOSS_SUMS needs B4R_FLAG_FUSED_HEAD, the state and masked_lm_ids");
   // row-list mode with the 32-token-tile attention backward: that kernel is told which rows of the last layer's dz1 exist and never
@@ -782,7 +799,8 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
   const bool sparse_dz1 = head_rows && ffn_fused(cfg) && attn_bwd_fused(cfg, L) && b4r_attn32_active(H, cfg->num_heads, L) &&
                           side_level() != 4;
   RC(b4r_zero2(grads, pl.total, ws + (head_rows ? w.hot : w.dx), head_rows ? (sparse_dz1 ? w.db - w.hot : w.da - w.hot) : w.db - w.dx, s,
-               (flags & B4R_FLAG_GRAD_TAIL) ? grads + pl.total : nullptr, state, loss_sums ? ws + w.rowsc : nullptr, (int)w.M));
+               ((flags & B4R_FLAG_GRAD_TAIL) && !defer_combine) ? grads + pl.total : nullptr, state,
+               (loss_sums && !defer_combine) ? ws + w.rowsc : nullptr, (int)w.M));
 
   // ---- masked-LM head (logits buffer holds d loss_sum / d logits, pad columns zero) --------------------------------
   // s2: independent branches (see SideStream); it is ordered after the memsets here, joined before every reuse of a buffer
@@ -794,12 +812,15 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
   RC(order_after(s, s2));
   float* dlog = ws + w.logits;
   const bool fused_head = (flags & B4R_FLAG_FUSED_HEAD) != 0;
+  const float* fwd_part = nullptr;
   B4R_CHECK_ARG(!fused_head || b4r_fused_head_supported(cfg), B4R_E_BADARG, "b4r_backward: B4R_FLAG_FUSED_HEAD needs hidden size 64 / 128 / 256 and the bf16x3 mode");
   if (fused_head) {
-    // dT came with the forward; dE / d output_bias recompute the logit tiles (b4r_head_rx.hip)
+    // dT came with the forward -- or (defer_combine) the forward left its per-slice partials: dE forms the lse it needs from them, the
+    // transform's LayerNorm backward below merges them into dT as it reads it; dE / d output_bias recompute the logit tiles (b4r_head_rx.hip)
+    fwd_part = defer_combine ? take(b4r_head_rx_fwd_scratch_floats(M, V, H)) : nullptr;   // = ws + w.scratch
     RC(b4r_head_rx_dE_launch(ws + w.t, params + pl.word_emb, params + pl.out_bias, ws + w.head_lse,
                              reinterpret_cast<const int32_t*>(ws + w.head_ylab), M, V, H, take(b4r_head_rx_dE_scratch_floats(M, V, H)),
-                             grads + pl.word_emb, grads + pl.out_bias, s2));
+                             grads + pl.word_emb, grads + pl.out_bias, s2, fwd_part, batch->masked_lm_ids));
   } else {
   // dT = dlogits . E   (K = V is long and the output small: split K so that the whole chip streams dlogits)
   {
@@ -815,10 +836,13 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
   RC(gemm_tn(dlog, Vp, ws + w.t, H, grads + pl.word_emb, H, M, V, H, nullptr, grads + pl.out_bias, nullptr, 0, 0.f, 0,
              take(b4r_gemm_tn_scratch_floats(M, V, H)), s));
   }
-  // LayerNorm of the transform
+  // LayerNorm of the transform (with the deferred merge: dT, the loss rows, lse and labels are formed here, from the forward's partials)
+  const B4rHeadMerge merge{fwd_part, fwd_part ? b4r_head_rx_fwd_slices(M, V, H) : 0, M, V, ws + w.t, params + pl.word_emb,
+                           params + pl.out_bias, batch->masked_lm_ids, ws + w.rowsc, ws + w.head_lse,
+                           reinterpret_cast<int32_t*>(ws + w.head_ylab)};
   RC(b4r_ln_bwd_launch(ws + w.dt, ws + w.u, ws + w.meanm, ws + w.rstdm, params + pl.lnm_g, M, H, ws + w.dt, grads + pl.lnm_g,
                        grads + pl.lnm_b, take(b4r_ln_bwd_scratch_floats(M, H)), nullptr, nullptr, nullptr, 1, 1, nodrop, s,
-                       ws + w.upre));   // ... and straight through the GELU of the transform's dense layer
+                       ws + w.upre, fwd_part ? &merge : nullptr));   // ... and straight through the GELU of the transform's dense layer
   {   // dense layer of the transform: dWd = gath^T . du (+ bias gradient) and dgath = du . Wd^T, one pass over du where the pair
       // kernel applies (hidden size 64)
     b4r_gemm_tn_desc d{};
@@ -1007,8 +1031,22 @@ extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch,
   // LayerNorm gradients, the position table) and adds the fixed-point sums to the item table
   RC(order_after(s2, s));
   RC(b4r_embed_grads(ws + w.da, batch->input_word_ids, B, L, H, grads + pl.word_emb, V, 3, ws + w.hot /* zeroed at the top */,
-                     grads + pl.pos_emb, take((int64_t)b4r_cdiv(B, 16) * L * H), s));
-  RC(b4r_reduce_queue_flush(s));
+                     grads + pl.pos_emb, take((int64_t)b4r_cdiv(B, 16) * L * H), s, defer_combine ? ws + w.rowsc : nullptr, (int)w.M, state,
+                     (defer_combine && (flags & B4R_FLAG_GRAD_TAIL)) ? grads + pl.total : nullptr));
+  g_norm_np = 0;
+  if (flags & B4R_FLAG_NORM_PARTIALS_INTERNAL) {
+    // valid only when the jobs of this launch write EVERY gradient (then each value is squared exactly once, as it is stored)
+    const int64_t Hh = H, Ii = I, Vv = V;
+    const int64_t expected = Vv * Hh + (int64_t)L * Hh + 2 * Hh /* embedding LayerNorm */ +
+                             (int64_t)cfg->num_layers * (Hh * 3 * Hh + Hh * Hh + 2 * Hh * Ii + 3 * Hh + Hh + 2 * Hh + Ii + Hh + 2 * Hh) +
+                             Hh * Hh + Hh + 2 * Hh /* transform */ + Vv /* output bias */;
+    int np = 0;
+    int64_t covered = 0;
+    RC(b4r_reduce_queue_flush(s, ws, 4096, &np, &covered));
+    if (np > 0 && covered == expected) g_norm_np = np;
+  } else {
+    RC(b4r_reduce_queue_flush(s));
+  }
   B4R_CHECK_ARG(scratch_used <= w.scratch_floats, B4R_E_NOMEM, "b4r_backward: internal scratch overflow");
   return B4R_OK;
 }
@@ -1041,15 +1079,27 @@ extern "C" int b4r_train_step(const b4r_model_config* cfg, const b4r_adamw_confi
                               float* grads, float* adam_m, float* adam_v, void* workspace, int64_t workspace_bytes,
                               b4r_train_state* state, b4r_stream_t stream) {
   const int fused = b4r_fused_head_supported(cfg) ? 1 : 0;   // the train step never needs the logits themselves
+  const int defer = (fused && batch && b4r_head_rx_combine_foldable(batch->B * batch->P, cfg->vocab_size, cfg->hidden_size))
+                        ? B4R_FLAG_DEFER_COMBINE_INTERNAL : 0;
   // no b4r_state_begin_step launch: the loss reduction overwrites the sums (B4R_LOSS_OVERWRITE)
   // nothing but the loss, the metrics and the gradients leave a train step: the last layer's feed-forward half runs on the rows the
   // head gathers only (B4R_FLAG_HEAD_ROWS_ONLY; the same flag goes to forward and backward)
   RC(b4r_forward(cfg, batch, params, nullptr, workspace, workspace_bytes, state,
-                 B4R_FLAG_TRAINING | B4R_FLAG_HEAD_ROWS_ONLY | (fused ? B4R_FLAG_FUSED_HEAD : 0), stream));
+                 B4R_FLAG_TRAINING | B4R_FLAG_HEAD_ROWS_ONLY | (fused ? B4R_FLAG_FUSED_HEAD : 0) | defer, stream));
   // with the logits-free head the loss sums are formed inside the backward's first launch (B4R_FLAG_LOSS_SUMS), else by b4r_loss
   if (!fused) RC(b4r_loss(cfg, batch, workspace, workspace_bytes, state, 1 | B4R_LOSS_OVERWRITE, stream));
   RC(b4r_backward(cfg, batch, params, grads, workspace, workspace_bytes, state,
-                  B4R_FLAG_TRAINING | B4R_FLAG_HEAD_ROWS_ONLY | (fused ? B4R_FLAG_FUSED_HEAD | B4R_FLAG_LOSS_SUMS : 0), stream));
+                  B4R_FLAG_TRAINING | B4R_FLAG_HEAD_ROWS_ONLY |
+                      (fused ? B4R_FLAG_FUSED_HEAD | B4R_FLAG_LOSS_SUMS : 0) | defer |
+                      B4R_FLAG_NORM_PARTIALS_INTERNAL, stream));
+  const int np = g_norm_np;   // > 0: the backward's last launch left the norm's partial sums at the start of the workspace
+  g_norm_np = 0;
+  if (np > 0) {
+    B4R_CHECK_ARG(hp && adam_m && adam_v, B4R_E_BADARG, "b4r_train_step: null argument");
+    const ParamLayout pl = make_param_layout(*cfg);
+    return b4r_optimizer_fused(hp, params, grads, adam_m, adam_v, pl.total, pl.n_decay, static_cast<float*>(workspace), state,
+                               (hipStream_t)stream, 0, np);
+  }
   RC(b4r_optimizer_step(cfg, hp, params, grads, adam_m, adam_v, workspace, workspace_bytes, state, stream));
   return B4R_OK;
 }

@@ -5,6 +5,7 @@
 // access: coalesced 16-B vector loads, guide G13); a 64-lane wave therefore owns 64/LPR rows, and row statistics are
 // xor-shuffle reductions inside the LPR-lane group.
 #include "b4r_common.h"
+#include "b4r_head_merge.h"
 
 int b4r_launch_slab_reduce_full(const float* slab, int S, int Mo, int No, float* out, int ldo, int accumulate,
                                 const float* cslab, float* colsum, const float* caslab, float* colsum_a, hipStream_t stream);
@@ -108,9 +109,12 @@ struct LnBwdP {
   int rows, H;
   DropArgs drop;
   const float* gelu_pre;      // optional [rows,H]: dz is further multiplied by gelu'(gelu_pre) (dense+GELU before the LN)
+  HeadMergeP merge;           // MERGE: dy is not read -- it is the masked-LM head's dT, merged here from the forward's V slices
 };
 
-template <int LPR, int NV, bool EMBED>
+// MERGE (LPR = 16, NV = 1: hidden size 64, the thread layout of head_combine_kernel): the LayerNorm of the masked-LM transform in a
+// train step; the lanes of a row also write the row's loss scalars, lse and label (b4r_head_merge.h)
+template <int LPR, int NV, bool EMBED, bool MERGE = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdP p) {
   constexpr int RPW = 64 / LPR;
   extern __shared__ float sred[];  // [4*RPW][2*H]
@@ -142,7 +146,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdP p) {
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       const int c = (v * LPR + sub) * 4;
-      f32x4 d = *reinterpret_cast<const f32x4*>(p.dy + rr * p.H + c);
+      f32x4 d;
+      if (MERGE) d = head_merge_row<2>(p.merge, (int)rr, sub);   // dead lanes repeat row 0 (same values, same addresses)
+      else d = *reinterpret_cast<const f32x4*>(p.dy + rr * p.H + c);
       f32x4 zz;
       if (EMBED) {
         zz = *reinterpret_cast<const f32x4*>(p.table + id * p.H + c) +
@@ -233,6 +239,11 @@ int launch_ln_fwd(const LnFwdP& p, hipStream_t s) {
 template <bool EMBED>
 int launch_ln_bwd(const LnBwdP& p, int grid, hipStream_t s) {
   const int H = p.H;
+  if (p.merge.part != nullptr) {
+    if (EMBED || H != 64) { b4r_set_error("layer norm backward: the head merge needs hidden size 64"); return B4R_E_SHAPE; }
+    hipLaunchKernelGGL((ln_bwd_kernel<16, 1, false, true>), dim3(grid), dim3(256), (size_t)4 * 4 * 2 * H * sizeof(float), s, p);
+    return B4R_OK;
+  }
 #define LN_BWD_CASE(LPR_, NV_)                                                                           \
   {                                                                                                      \
     const size_t sh = (size_t)4 * (64 / LPR_) * 2 * H * sizeof(float);                                   \
@@ -364,17 +375,6 @@ __device__ __forceinline__ void scatter_fixed_rows_body(const float* src, const 
 
 // the two gradients of the embedding stage from d(item row + position row) [B*L, H] in ONE launch: the item-table scatter-add
 // (workgroups [0, n_scatter)) and the batch sums of the position table (the rest, gx per batch slice): both only read x
-__global__ __launch_bounds__(256) void embed_grads_kernel(const float* x, const int64_t* ids, int n, int H, long long* fix,
-                                                          int64_t table_rows, int hot_rows, long long* hot, int n_scatter, int B, int L,
-                                                          int bchunk, int gx, float* partial) {
-  if ((int)blockIdx.x < n_scatter) {
-    scatter_fixed_rows_body(x, ids, n, H, fix, table_rows, hot_rows, hot, (int)blockIdx.x, n_scatter);
-  } else {
-    const int k = (int)blockIdx.x - n_scatter;
-    batch_colsum_body(x, B, L, H, bchunk, partial, k % gx, k / gx);
-  }
-}
-
 // -----------------------------------------------------------------------------------------------------------
 // softmax cross entropy + argmax metrics, one workgroup per row
 // -----------------------------------------------------------------------------------------------------------
@@ -477,6 +477,30 @@ __device__ __forceinline__ void loss_rows_reduce(const float* rows, int M, float
   __syncthreads();
 #pragma unroll
   for (int q = 0; q < 4; ++q) out[q] = s[q][0];
+}
+
+// fin_rows (optional): ONE more workgroup at the end of the grid forms the step's loss / metric sums from the head's per-row scalars
+// (what zero2_kernel's last workgroup does when the rows exist before the backward starts; with the head's merge folded into the dE
+// launch they only exist from there on) and copies them behind the gradients (tail, optional)
+__global__ __launch_bounds__(256) void embed_grads_kernel(const float* x, const int64_t* ids, int n, int H, long long* fix,
+                                                          int64_t table_rows, int hot_rows, long long* hot, int n_scatter, int B, int L,
+                                                          int bchunk, int gx, float* partial, int n_colsum, const float* fin_rows,
+                                                          int fin_M, float* state_f, float* tail) {
+  if ((int)blockIdx.x < n_scatter) {
+    scatter_fixed_rows_body(x, ids, n, H, fix, table_rows, hot_rows, hot, (int)blockIdx.x, n_scatter);
+  } else if ((int)blockIdx.x < n_scatter + n_colsum) {
+    const int k = (int)blockIdx.x - n_scatter;
+    batch_colsum_body(x, B, L, H, bchunk, partial, k % gx, k / gx);
+  } else {
+    __shared__ float s[4][256];
+    float r[4];
+    loss_rows_reduce(fin_rows, fin_M, s, r);
+    if (threadIdx.x == 0) {   // b4r_train_state floats: [4] loss_sum [5] valid_count [6] correct_masked [7] correct_all [8] slots_all [9] [10]
+      state_f[4] = r[0]; state_f[5] = r[1]; state_f[6] = r[2]; state_f[7] = r[3];
+      state_f[8] = (float)fin_M; state_f[9] = 0.f; state_f[10] = 0.f;
+    }
+    if (tail != nullptr && threadIdx.x < 8) tail[threadIdx.x] = threadIdx.x < 4 ? r[threadIdx.x] : (threadIdx.x == 4 ? (float)fin_M : 0.f);
+  }
 }
 
 // the sums into the state: b4r_loss's last launch (the logits-free head's rows or softmax_ce_kernel's)
@@ -736,9 +760,12 @@ __global__ __launch_bounds__(256) void ln_partial_reduce_kernel(const float* par
 int b4r_ln_bwd_launch(const float* dy, const float* z, const float* mean, const float* rstd, const float* gamma,
                       int rows, int H, float* dz, float* dgamma, float* dbeta, float* scratch, const int64_t* ids,
                       const float* table, const float* pos_table, int L, int V, DropArgs drop, hipStream_t stream,
-                      const float* gelu_pre) {
+                      const float* gelu_pre, const B4rHeadMerge* merge) {
   LnBwdP p{};
   p.gelu_pre = gelu_pre;
+  if (merge != nullptr)
+    p.merge = HeadMergeP{merge->part, merge->slices, merge->M, merge->V, merge->T, merge->E, merge->bias, merge->y, merge->row_out,
+                         merge->lse_out, merge->ylab};
   p.dy = dy; p.z = z; p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.dz = dz; p.partial = scratch;
   p.ids = ids; p.table = table; p.pos_table = pos_table; p.L = L; p.V = V;
   p.rows = rows; p.H = H; p.drop = drop;
@@ -763,7 +790,7 @@ extern "C" int b4r_ln_bwd(const float* dy, const float* z, const float* mean, co
                 "b4r_ln_bwd: null argument");
   B4R_CHECK_ARG(rows > 0, B4R_E_SHAPE, "b4r_ln_bwd: bad shape");
   return b4r_ln_bwd_launch(dy, z, mean, rstd, gamma, rows, H, dz, dgamma, dbeta, scratch, nullptr, nullptr, nullptr, 1,
-                           1, b4r_make_drop(nullptr, 0, 0.f, 0), (hipStream_t)stream, nullptr);
+                           1, b4r_make_drop(nullptr, 0, 0.f, 0), (hipStream_t)stream, nullptr, nullptr);
 }
 
 extern "C" int b4r_gather_rows(const float* src, int32_t src_ld, const int64_t* idx, int64_t idx_add_per, int32_t per,
@@ -821,7 +848,8 @@ int b4r_batch_colsum(const float* x, int B, int L, int H, float* dpos, float* sc
 // already sums the head's slabs into table_grad, if there is one: table_grad = slabs + fixed in ONE pass), else launched here.
 int64_t b4r_embed_fixed_floats(int64_t V, int H, int hot_rows) { return 2 * (V * H + (int64_t)HOT_SLOTS * hot_rows * H); }
 int b4r_embed_grads(const float* x, const int64_t* ids, int B, int L, int H, float* table_grad, int64_t V, int hot_rows,
-                    float* fixed, float* dpos, float* colsum_scratch, hipStream_t stream) {
+                    float* fixed, float* dpos, float* colsum_scratch, hipStream_t stream, const float* fin_rows, int fin_M,
+                    b4r_train_state* state, float* tail) {
   const int n = B * L, bchunk = 16, S = b4r_cdiv(B, bchunk);
   int n_scatter = b4r_cdiv((int64_t)n * H, 256);
   if (n_scatter > 1024) n_scatter = 1024;
@@ -829,8 +857,9 @@ int b4r_embed_grads(const float* x, const int64_t* ids, int B, int L, int H, flo
   long long* fix = reinterpret_cast<long long*>(fixed);
   long long* hot = fix + V * H;
   const int gx = b4r_cdiv((int64_t)L * (H / 4), 256);
-  hipLaunchKernelGGL(embed_grads_kernel, dim3(n_scatter + gx * S), dim3(256), (size_t)hot_rows * H * sizeof(long long), stream, x, ids,
-                     n, H, fix, V, hot_rows, hot, n_scatter, B, L, bchunk, gx, colsum_scratch);
+  hipLaunchKernelGGL(embed_grads_kernel, dim3(n_scatter + gx * S + (fin_rows ? 1 : 0)), dim3(256), (size_t)hot_rows * H * sizeof(long long),
+                     stream, x, ids, n, H, fix, V, hot_rows, hot, n_scatter, B, L, bchunk, gx, colsum_scratch, gx * S, fin_rows, fin_M,
+                     reinterpret_cast<float*>(state), tail);
   B4R_CHECK_LAUNCH("embedding gradients (scatter-add + position sums)");
   if (!b4r_reduce_queue_attach_fixed(table_grad, fix, hot, hot_rows * H, HOT_SLOTS)) {
     B4rReduceJob job{nullptr, nullptr, nullptr, table_grad, nullptr, nullptr, 0, (int)V, H, H, 1};
@@ -928,15 +957,21 @@ extern "C" int b4r_global_sqnorm(const float* g, int64_t n, float* scratch, b4r_
 
 // model-level optimizer step: global norm partials, then everything else in one launch.  scratch: >= 1024 floats.  The
 // ticket is reserved[0] of the state (zero-initialised by the caller like the rest of the state, reset by the kernel).
+// np_given > 0: scratch already holds np_given partial sums of squares of the gradients (b4r_backward's closing reduce launch formed
+// them while it wrote the gradients): no norm launch
 int b4r_optimizer_fused(const b4r_adamw_config* hp, float* params, const float* grads, float* adam_m, float* adam_v, int64_t n,
-                        int64_t n_decay, float* scratch, b4r_train_state* state, hipStream_t stream, int sums_from_tail) {
+                        int64_t n_decay, float* scratch, b4r_train_state* state, hipStream_t stream, int sums_from_tail, int np_given) {
   int np = (int)((n / 4 + 1023) / 1024);
   if (np > 1024) np = 1024;
   if (np < 1) np = 1;
   unsigned int* ticket = reinterpret_cast<unsigned int*>(&state->reserved[0]);
-  hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(np), dim3(256), 0, stream, grads, n, scratch,
-                     sums_from_tail ? grads + n : (const float*)nullptr, reinterpret_cast<float*>(state));
-  B4R_CHECK_LAUNCH("global norm");
+  if (np_given > 0 && !sums_from_tail) {
+    np = np_given;
+  } else {
+    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(np), dim3(256), 0, stream, grads, n, scratch,
+                       sums_from_tail ? grads + n : (const float*)nullptr, reinterpret_cast<float*>(state));
+    B4R_CHECK_LAUNCH("global norm");
+  }
   AdamP a;
   a.p = params; a.g = grads; a.m = adam_m; a.v = adam_v; a.n = n; a.n_decay = n_decay; a.hp = *hp; a.st = state;
   int grid = (int)((n / 4 + 255) / 256);

@@ -279,6 +279,38 @@ def test_train_steps_are_bitwise_reproducible():
     assert np.isfinite(l0[-1]) and l0[-1] != l0[0]
 
 
+def test_train_step_takes_the_gradient_norm_from_the_closing_reduce_launch():
+    """b4r_train_step has no norm launch when the backward's closing reduce launch writes every gradient: it squares each value as
+    it stores it.  The norm the optimizer used (state) must be the norm of the gradient buffer the step leaves behind, and the step
+    must have one launch fewer than forward + backward + b4r_optimizer_step."""
+    import ctypes as C
+    cfg_o, shp = CONFIGS["ml1m_slice"]
+    cfg_o = orc.OracleConfig(**{**cfg_o.__dict__, "output_dropout": 0.1, "attention_dropout": 0.1})
+    eng, _ = build(cfg_o)
+    if not eng.fused_head_supported():
+        pytest.skip("the closing reduce launch covers every gradient in the bf16x3 step only")
+    hp = make_adamw_config(num_warmup_steps=2, num_train_steps=20, gradient_clip_norm=0.05)   # small: the clip is active
+    cb, keep = eng.prepare_batch(orc.synthetic_batch(shp["B"], shp["L"], shp["P"], cfg_o.vocab_size, seed=9, ragged=True))
+    eng.set_seed(3)
+    for _ in range(3):
+        eng.train_step(hp, cb)
+    torch.cuda.synchronize()
+    st = eng.read_state()
+    g = eng.grads[:eng.n_params].double()
+    want = float(g.pow(2).sum().sqrt()) / st["valid_count"]
+    assert want > 0.0 and abs(st["grad_norm"] - want) <= 2e-6 * want
+    lib = _lib.load()
+    stream = torch.cuda.current_stream().cuda_stream
+    n = C.c_int32(0)
+    us = (C.c_float * 256)()
+    names = C.create_string_buffer(256 * 128)
+    _lib.check(lib.b4r_timing_begin(stream, 256), "b4r_timing_begin")
+    eng.train_step(hp, cb)
+    _lib.check(lib.b4r_timing_end(C.byref(n), us, names, 128, 256), "b4r_timing_end")
+    labels = [names.raw[j * 128:(j + 1) * 128].split(b"\0", 1)[0].decode() for j in range(n.value)]
+    assert "global norm" not in labels and labels.count("multi_slab_reduce") == 1, labels
+
+
 def test_item_table_gradient_with_hundreds_of_contributions_per_row():
     """The fixed-point item-table sum against autograd on a batch where every item row receives ten or more contributions
     (64 sequences over 37 items; the PAD and [MASK] rows hundreds): same tolerance as the other gradients, and the gradient of an

@@ -7,7 +7,7 @@ from bert4rec_amd import config, dataloaders, evaluation, models
 from bert4rec_amd.models.components import networks
 from synth import synthetic_batch
 
-V, B, L, USERS = 3709, 256, 200, 6040
+V, B, L, USERS = 3709, (int(sys.argv[1]) if len(sys.argv) > 1 else 256), 200, 6040
 enc = networks.Bert4RecEncoder(V, **config.get_encoder_config("ml-1m_64"))
 model = models.BERT4RecModel(enc)
 rng = np.random.default_rng(0)

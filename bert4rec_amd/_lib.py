@@ -101,6 +101,7 @@ ST_LOSS_SUM, ST_VALID, ST_CORRECT_MASKED, ST_CORRECT_ALL, ST_SLOTS_ALL, ST_SQNOR
 EPI_NONE, EPI_BIAS, EPI_BIAS_QSCALE, EPI_BIAS_GELU, EPI_BIAS_DROP_RES, EPI_GELU_BWD, EPI_ADD_RES, EPI_BIAS_TANH = range(8)
 EPI_BIAS_DROP_RES_LN, EPI_ADD_RES_LN_BWD, EPI_BIAS_GELU_LN = 8, 9, 10
 FLAG_TRAINING, FLAG_POOLER, FLAG_FUSED_HEAD, FLAG_GRAD_TAIL, FLAG_HEAD_ROWS_ONLY, FLAG_LOSS_SUMS = 1, 2, 4, 8, 16, 32
+FLAG_ENCODER_ONLY = 64
 LOSS_FUSED_HEAD = 2
 GEMM_F32, GEMM_BF16X3 = 0, 1
 
@@ -171,6 +172,7 @@ PROTOTYPES = {
     "b4r_timing_end": (C.c_int, [C.POINTER(_I32), C.POINTER(C.c_float), C.c_char_p, _I32, _I32]),
     "b4r_mask_batch": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, C.c_double, _F, _F, _I32, C.c_uint64, _P, _P, _P, _P, _P, _P, _P]),
     "b4r_sample_candidates": (C.c_int, [_P, _I32, _P, _I32, _P, _I32, _I32, C.c_uint64, _P, _P]),
+    "b4r_sample_candidates_flagged": (C.c_int, [_P, _I32, _P, _I32, _P, _I32, _I32, C.c_uint64, _P, _P, _P]),
     "b4r_softmax_ce": (C.c_int, [_P, _I32, _I32, _I32, _P, _P, _P, _I32, _P]),
     "b4r_global_sqnorm": (C.c_int, [_P, _I64, _P, _P, _P]),
     "b4r_adamw_step": (C.c_int, [C.POINTER(AdamWConfig), _P, _P, _P, _P, _I64, _I64, _P, _P]),

@@ -685,7 +685,7 @@ extern "C" int b4r_forward(const b4r_model_config* cfg, const b4r_batch* batch, 
     RC(gemm(x, L * H, pooler, H, ws + w.pooled, H, B, H, H, 0, B4R_EPI_BIAS_TANH, pooler + (int64_t)H * H, nullptr, 0, nullptr,
             0, 1.f, 0, nullptr, 0, 0.f, 0, s));
   }
-  if (P > 0) {
+  if (P > 0 && !(flags & B4R_FLAG_ENCODER_ONLY)) {
     // tfm MaskedLM: gather -> dense(gelu) -> LayerNorm -> . E^T + bias
     {   // gather + dense(gelu) + LayerNorm: one launch where the LayerNorm tail applies (hidden size 64), else three
       static const bool fuse = !(getenv("B4R_FUSE_LN") && atoi(getenv("B4R_FUSE_LN")) == 0);

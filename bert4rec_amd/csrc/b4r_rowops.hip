@@ -1139,7 +1139,7 @@ constexpr int SAMPLE_MAX_C = 1024;   // draws per row the gather / ordering buff
 
 __global__ __launch_bounds__(256) void sample_candidates_kernel(const float* logp, int V, const int64_t* exclude, int E,
                                                                 const int64_t* gt, int C, uint32_t seed_lo,
-                                                                uint32_t seed_hi, int64_t* cand) {
+                                                                uint32_t seed_hi, int64_t* cand, uint8_t* short_flag) {
   extern __shared__ float s_key[];            // [V] keys
   __shared__ int s_hist[256];
   __shared__ uint32_t s_selu[SAMPLE_MAX_C];
@@ -1251,18 +1251,27 @@ __global__ __launch_bounds__(256) void sample_candidates_kernel(const float* log
     }
   }
   for (int c = Ce + tid; c < C; c += 256) out[c] = -1;   // fewer than C items with non-zero probability are left
+  if (short_flag != nullptr && Ce < C && tid == 0) *short_flag = 1;   // (every writer stores the same byte)
   if (tid == 0) out[C] = g;
 }
 
+extern "C" int b4r_sample_candidates_flagged(const float* logp, int32_t V, const int64_t* exclude, int32_t E, const int64_t* gt,
+                                             int32_t R, int32_t C, uint64_t seed, int64_t* cand, uint8_t* short_flag,
+                                             b4r_stream_t stream);
 extern "C" int b4r_sample_candidates(const float* logp, int32_t V, const int64_t* exclude, int32_t E, const int64_t* gt,
                                      int32_t R, int32_t C, uint64_t seed, int64_t* cand, b4r_stream_t stream) {
+  return b4r_sample_candidates_flagged(logp, V, exclude, E, gt, R, C, seed, cand, nullptr, stream);
+}
+extern "C" int b4r_sample_candidates_flagged(const float* logp, int32_t V, const int64_t* exclude, int32_t E, const int64_t* gt,
+                                             int32_t R, int32_t C, uint64_t seed, int64_t* cand, uint8_t* short_flag,
+                                             b4r_stream_t stream) {
   B4R_CHECK_ARG(logp && cand && (exclude || E == 0), B4R_E_BADARG, "b4r_sample_candidates: null argument");
   B4R_CHECK_ARG(V > 0 && R > 0 && C > 0 && E >= 0 && C <= V && C <= SAMPLE_MAX_C, B4R_E_SHAPE, "b4r_sample_candidates: bad shape");
   const size_t lds = (size_t)V * sizeof(float);
   B4R_CHECK_ARG(lds <= 150 * 1024, B4R_E_SHAPE, "b4r_sample_candidates: vocabulary %d does not fit the LDS (150 KB of keys)", V);
   { int rc = b4r_raise_lds((const void*)sample_candidates_kernel, lds, "b4r_sample_candidates"); if (rc) return rc; }
   hipLaunchKernelGGL(sample_candidates_kernel, dim3(R), dim3(256), lds, (hipStream_t)stream, logp, V, exclude, E, gt, C,
-                     (uint32_t)seed, (uint32_t)(seed >> 32), cand);
+                     (uint32_t)seed, (uint32_t)(seed >> 32), cand, short_flag);
   B4R_CHECK_LAUNCH("b4r_sample_candidates");
   return B4R_OK;
 }

@@ -103,6 +103,12 @@ class BatchedDataset:
             return self
         if self._device_batches is None or self._device != device:
             self._device_batches = [{k: v.to(device, non_blocking=True) for k, v in b.items()} for b in self.batches]
+            # the (row, slot) pairs with masked_lm_weights != 0, found here on the host copy: the evaluator otherwise looks for them on
+            # the device with one read-back per batch, which makes every batch wait for the previous one's kernels
+            for hb, db in zip(self.batches, self._device_batches):
+                if "masked_lm_weights" in hb:
+                    w = torch.as_tensor(hb["masked_lm_weights"])
+                    db["masked_lm_slot_index"] = torch.nonzero(w.reshape(w.shape[0], -1) != 0).to(device, non_blocking=True)
             self._device = device
         return self
 

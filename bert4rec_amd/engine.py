@@ -308,13 +308,14 @@ class Engine:
         return bool(self.lib.b4r_fused_head_supported(C.byref(self.cfg)))
 
     def forward(self, cb: Batch, training: bool = False, pooler: bool = True, fused_head: bool = False,
-                head_rows_only: bool = False) -> None:
+                head_rows_only: bool = False, encoder_only: bool = False) -> None:
         """fused_head: the loss / backward of the same step must be called with fused_head=True as well, and the
         "mlm_logits" region is not written.  head_rows_only (train steps: forward AND backward): the last layer's feed-forward half
         only on the rows the masked-LM head gathers; "sequence_output" is then defined on those rows only."""
         ws = self.workspace(cb.B, cb.L, cb.P)
         flags = (_lib.FLAG_TRAINING if training else 0) | (_lib.FLAG_POOLER if pooler else 0) | \
-                (_lib.FLAG_FUSED_HEAD if fused_head else 0) | (_lib.FLAG_HEAD_ROWS_ONLY if head_rows_only else 0)
+                (_lib.FLAG_FUSED_HEAD if fused_head else 0) | (_lib.FLAG_HEAD_ROWS_ONLY if head_rows_only else 0) | \
+                (_lib.FLAG_ENCODER_ONLY if encoder_only else 0)
         _lib.check(self.lib.b4r_forward(C.byref(self.cfg), C.byref(cb), _ptr(self.params), _ptr(self.pooler), _ptr(ws),
                                         ws.numel() * 4, _ptr(self.state), flags, _stream(self.device)), "b4r_forward")
 
@@ -451,20 +452,30 @@ class Engine:
         gt = gt.to(device=self.device, dtype=torch.int64).contiguous()
         R, E = exclude.shape
         cand = torch.empty((R, n_samples + 1), dtype=torch.int64, device=self.device)
+        if short_flag is not None:   # a device bool / uint8 [1]: the kernel sets it itself (no scan of cand, no launch)
+            if short_flag.element_size() != 1 or not short_flag.is_cuda:
+                raise ValueError("short_flag must be a one-byte tensor on the GPU")
+            _lib.check(self.lib.b4r_sample_candidates_flagged(_ptr(logp), logp.numel(), _ptr(exclude), E, _ptr(gt), R, n_samples,
+                                                              int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(cand), _ptr(short_flag),
+                                                              _stream(self.device)), "b4r_sample_candidates_flagged")
+            return cand
         _lib.check(self.lib.b4r_sample_candidates(_ptr(logp), logp.numel(), _ptr(exclude), E, _ptr(gt), R, n_samples,
                                                   int(seed) & 0xFFFFFFFFFFFFFFFF, _ptr(cand), _stream(self.device)),
                    "b4r_sample_candidates")
         short = (cand[:, :n_samples] < 0).any()
-        if short_flag is not None:
-            short_flag |= short
-        elif bool(short):
+        if bool(short):
             raise ValueError(f"The exclusion lists reduce the vocab too much to take a sample of size {n_samples} "
                              f"(since no duplicates are allowed).")
         return cand
 
-    def encoder_forward(self, cb: Batch, training: bool = False) -> Batch:
+    def encoder_forward(self, cb: Batch, training: bool = False, ranked_rows_only: bool = False) -> Batch:
         """Encoder only (no masked-LM head): the batch struct without its masked_lm_* pointers -> b4r_forward stops at the
-        sequence output.  Returns that struct (its workspace key is (B, L, 0))."""
+        sequence output.  Returns that struct (its workspace key is (B, L, 0)).
+        ranked_rows_only: the struct keeps its masked_lm_* pointers and the last layer's feed-forward half runs on the rows of the
+        valid slots (masked_lm_ids != 0) only -- "sequence_output" (workspace key (B, L, P)) is defined on those rows alone."""
+        if ranked_rows_only and cb.P > 0 and cb.masked_lm_ids:
+            self.forward(cb, training=training, pooler=False, head_rows_only=True, encoder_only=True)
+            return cb
         enc = Batch(cb.input_word_ids, cb.input_mask, None, None, cb.B, cb.L, 0)
         self.forward(enc, training=training, pooler=False)
         return enc

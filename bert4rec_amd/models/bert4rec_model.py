@@ -240,7 +240,8 @@ class BERT4RecModel:
         return history
 
     # ---- ranking ----------------------------------------------------------------------------------------------------------
-    def _ranked_slot_hidden(self, encoder_input: Dict[str, torch.Tensor], slots: Optional[torch.Tensor] = None):
+    def _ranked_slot_hidden(self, encoder_input: Dict[str, torch.Tensor], slots: Optional[torch.Tensor] = None,
+                            rows: Optional[torch.Tensor] = None):
         """Encoder forward (no logits, no head on the slots nobody ranks), then tfm MaskedLM's transform on the R slots with
         masked_lm_weights == 1 only (all slots when the key is absent).  The reference computes all [B, P, V] logits and
         keeps the valid slots afterwards (bert4rec_model.py:215-220).  Returns (hidden [R,H], slot index [R] = b*P+p,
@@ -250,7 +251,9 @@ class BERT4RecModel:
         if cb.P == 0:
             raise ValueError("rank_items needs masked_lm_positions")
         B, L, P = cb.B, cb.L, cb.P
-        self.engine.encoder_forward(cb, training=False)
+        # rows given: the caller vouches that the ranked slots are exactly the slots with masked_lm_ids != 0 (the evaluator checks it
+        # once per resident batch) -- the last layer's feed-forward half then runs on those rows only
+        enc = self.engine.encoder_forward(cb, training=False, ranked_rows_only=rows is not None and "masked_lm_ids" in keep)
         counts = None
         if slots is None:
             if "masked_lm_weights" in encoder_input and encoder_input["masked_lm_weights"] is not None:
@@ -261,19 +264,20 @@ class BERT4RecModel:
             counts = w.sum(dim=1).tolist()
         if slots.numel() == 0:
             return None, slots, counts
-        pos = keep["masked_lm_positions"].reshape(-1)[slots].clamp(0, L - 1)   # tfm MaskedLM gathers position + b*L
-        rows = torch.div(slots, P, rounding_mode="floor") * L + pos
-        seq = self.engine.region("sequence_output", B, L, 0)
+        if rows is None:                                                           # (the evaluator keeps them for resident batches)
+            pos = keep["masked_lm_positions"].reshape(-1)[slots].clamp(0, L - 1)   # tfm MaskedLM gathers position + b*L
+            rows = torch.div(slots, P, rounding_mode="floor") * L + pos
+        seq = self.engine.region("sequence_output", B, L, enc.P)
         return self.engine.mlm_transform_rows(seq, rows), slots, counts
 
     def rank_items_tensor(self, encoder_input: Dict[str, torch.Tensor], candidates: Optional[torch.Tensor] = None,
                           ground_truth: Optional[torch.Tensor] = None, want_ranking: bool = True,
-                          slots: Optional[torch.Tensor] = None):
+                          slots: Optional[torch.Tensor] = None, rows: Optional[torch.Tensor] = None):
         """Device-side core of rank_items: b4r_rank_candidates on every slot with masked_lm_weights == 1.  candidates:
         [R, C] int64 or None (whole vocabulary, ranked without materialising an [R, V] candidate list).
         Returns (ranking [R,C] int64, gt_rank [R] int32 or None, slot_index [R] int64 (b*P+p), rows_per_batch_entry (None when the
         caller passed `slots`))."""
-        hidden, slots, counts = self._ranked_slot_hidden(encoder_input, slots)
+        hidden, slots, counts = self._ranked_slot_hidden(encoder_input, slots, rows)
         R = int(slots.numel())
         if R == 0:
             return None, None, slots, counts

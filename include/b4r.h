@@ -154,6 +154,10 @@ int b4r_workspace_region(const b4r_model_config* cfg, int32_t B, int32_t L, int3
  * b4r_loss(..., want_grad | B4R_LOSS_FUSED_HEAD | B4R_LOSS_OVERWRITE) does, inside the launch that clears the gradients (the same
  * summation order, bit for bit).  No b4r_state_begin_step / b4r_loss call is then needed between forward and backward. */
 #define B4R_FLAG_LOSS_SUMS 32
+/* b4r_forward only: stop at the sequence output although the batch carries masked_lm_positions / masked_lm_ids -- they then only
+ * name the rows of B4R_FLAG_HEAD_ROWS_ONLY.  What an evaluation wants (BERT4RecModel.rank_items, bert4rec_model.py:203-240, ranks a
+ * handful of slots per user): the last layer's feed-forward half on the ranked rows only, no [B*P, V] logits. */
+#define B4R_FLAG_ENCODER_ONLY 64
 #define B4R_LOSS_FUSED_HEAD 2
 #define B4R_LOSS_OVERWRITE 4 /* b4r_loss: set the state's sums instead of adding to them (= b4r_state_begin_step first) */
 int32_t b4r_fused_head_supported(const b4r_model_config* cfg);
@@ -206,6 +210,10 @@ int b4r_mask_batch(const int64_t* tokens, const int64_t* row_index, const int64_
  * raises ValueError there; the Python layer does too). */
 int b4r_sample_candidates(const float* logp, int32_t V, const int64_t* exclude, int32_t E, const int64_t* gt, int32_t R,
                           int32_t C, uint64_t seed, int64_t* cand, b4r_stream_t stream);
+/* the same; short_flag (optional, one device byte, never cleared here) is set to 1 when a row had fewer than C drawable items: an
+ * evaluation reads it back once at its end instead of scanning cand for -1 after every batch */
+int b4r_sample_candidates_flagged(const float* logp, int32_t V, const int64_t* exclude, int32_t E, const int64_t* gt, int32_t R,
+                                  int32_t C, uint64_t seed, int64_t* cand, uint8_t* short_flag, b4r_stream_t stream);
 
 /* ---- ranking ------------------------------------------------------------------------------------------------
  * replaces BERT4RecModel.rank_items bert4rec_model.py:224-239 (gather candidate logits, tf.argsort DESCENDING,

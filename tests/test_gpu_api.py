@@ -484,3 +484,43 @@ def test_evaluation_on_trimmed_batches_gives_the_same_ranks():
     assert same > 0.99, same                     # (a rank can move by one where two candidate scores agree to ~1e-6)
     for k in results[0]:
         assert abs(results[0][k] - results[1][k]) < 0.01 * max(1.0, abs(results[0][k])), k
+
+
+def test_evaluation_of_resident_batches_equals_evaluation_of_host_batches():
+    """BatchedDataset.cache_on_device keeps the batches in HBM together with the (row, slot) pairs that carry a weight (found on the
+    host copy).  The evaluator then needs no read-back per batch, keeps each batch's constants (slots, ground truth, exclusion
+    rows, ranked rows) from the first pass on, and lets the model run the last layer's feed-forward half on the ranked rows only
+    (B4R_FLAG_ENCODER_ONLY | B4R_FLAG_HEAD_ROWS_ONLY).  Same draws (seed, draw counter, row), same ranks as with host batches --
+    on the first pass (constants formed) and on the second (constants reused)."""
+    ds = datasets.synthetic_dataset(n_users=160, n_items=300, min_len=4, max_len=60, seed=6)
+    dl = dataloaders.get_dataloader_factory("bert4rec").create_ml_1m_dataloader(data_source=ds, max_seq_len=64,
+                                                                               max_predictions_per_seq=12, input_duplication_factor=1)
+    _, _, test = dl.prepare_training(finetuning_split=0.1)
+    V = dl.tokenizer.get_vocab_size()
+    model = make_model(V, seed=4, L=64)
+    source = [t for e in test.examples for t in e["labels"].tolist() if t > 2]
+    smp = dataloaders.samplers.get("pop_random", source=source, vocab=list(range(V)), sample_size=50)
+    host = dataloaders.make_batches(test, batch_size=32, seed=1)
+    resident = dataloaders.make_batches(test, batch_size=32, seed=1).cache_on_device("cuda")
+    first = next(iter(resident))
+    assert first["input_word_ids"].is_cuda and first["masked_lm_slot_index"].shape[1] == 2
+    runs = []
+    for bs, passes in ((host, 1), (resident, 2)):
+        for _ in range(passes):
+            ev = evaluation.get(sampler=smp, device_sampling=True, seed=5)
+            ranks = torch.cat([ev.evaluate_batch(model, b).cpu() for b in bs])
+            runs.append((ranks, ev.get_metrics_results()))
+    assert "_eval_cache" in first and first["_eval_cache"][3] is not None      # ... and the rows-only forward was allowed
+    for ranks, res in runs[1:]:
+        assert res["Valid Ranks"] == runs[0][1]["Valid Ranks"] == 160
+        same = (ranks == runs[0][0]).float().mean().item()
+        assert same > 0.99, same                 # (a rank can move by one where two candidate scores agree to ~1e-6)
+    assert torch.equal(runs[1][0], runs[2][0])   # constants formed vs constants reused: bit for bit
+    # a row that cannot supply its negatives is reported through the flag the sampler kernel sets itself
+    few = dataloaders.samplers.get("pop_random", source=source[:40], vocab=list(range(V)), sample_size=290)
+    ev = evaluation.get(sampler=few, device_sampling=True, seed=5)
+    if ev._device_sampler_ready(model):
+        for b in resident:
+            ev.evaluate_batch(model, b)
+        with pytest.raises(ValueError):
+            ev.get_metrics_results()

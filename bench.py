@@ -216,7 +216,7 @@ def measure_step_breakdown(eng, lib, hp, prepared, nb, n_steps=10):
     return rows
 
 
-def eval_leg(device, V_items=3706, users=2048, seed=0):
+def eval_leg(device, V_items=3706, users=6040, seed=0):
     """Train + evaluate through the product surface on a synthetic Zipf log with successor structure (datasets.make_synthetic,
     order=0.6): dataloader factory -> prepare_training(device_masking) -> trainer -> evaluator (100 popularity negatives per
     user, bert4rec_evaluator.py:60-120).  Returns NDCG@10 / HR@10 and the evaluation throughput."""

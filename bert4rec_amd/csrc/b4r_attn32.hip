@@ -1000,6 +1000,18 @@ bool al16(const void* q) { return q == nullptr || b4r_aligned16(q); }
 int32_t b4r_attn32_supported(int32_t hidden_size, int32_t num_heads, int32_t L) {
   return (hidden_size == HID && num_heads == 2 && L > 0 && L <= 224 && b4r_get_gemm_mode() == B4R_GEMM_BF16X3) ? 1 : 0;
 }
+// Sequences of at most two 32-token tiles leave five of the seven waves of a workgroup without a query / key tile: there round 2's
+// 16-token-tile kernels (one wave per 16 tokens) are faster -- Steam, L = 50: 0.408 against 0.440 ms per train step.  The 32-token-tile
+// kernels are PREFERRED from this length on (they still serve shorter sequences when a descriptor asks for what only they can do).
+static int g_attn32_min_len = getenv("B4R_ATTN32_MIN_L") ? atoi(getenv("B4R_ATTN32_MIN_L")) : 65;
+extern "C" int32_t b4r_attn32_set_min_len(int32_t L) {
+  const int old = g_attn32_min_len;
+  if (L >= 0) g_attn32_min_len = L;
+  return old;
+}
+int32_t b4r_attn32_preferred(int32_t hidden_size, int32_t num_heads, int32_t L) {
+  return (b4r_attn32_supported(hidden_size, num_heads, L) && L >= g_attn32_min_len) ? 1 : 0;
+}
 
 // attention-dropout decisions of one layer: [B][head][key tile][query tile][16 register pairs] x 2 uint32
 int64_t b4r_attn32_keep_words(int32_t B, int32_t L, int32_t heads) {

@@ -729,6 +729,7 @@ bool al16(const void* q) { return q == nullptr || b4r_aligned16(q); }
 }  // namespace
 
 int32_t b4r_attn32_supported(int32_t hidden_size, int32_t num_heads, int32_t L);
+int32_t b4r_attn32_preferred(int32_t hidden_size, int32_t num_heads, int32_t L);   // supported AND long enough to pay (b4r_attn32.hip)
 int b4r_attn32_bwd(const b4r_attn_block_bwd_desc* d, b4r_stream_t stream);
 int64_t b4r_attn_rx_keep_words(int B, int L, int heads);
 static bool use_attn32() {
@@ -736,7 +737,7 @@ static bool use_attn32() {
   return on;
 }
 
-bool b4r_attn32_active(int H, int heads, int L) { return use_attn32() && b4r_attn32_supported(H, heads, L) != 0; }
+bool b4r_attn32_active(int H, int heads, int L) { return use_attn32() && b4r_attn32_preferred(H, heads, L) != 0; }
 
 extern "C" int32_t b4r_attn_block_supported(int32_t hidden_size, int32_t num_heads, int32_t L) {
   return (hidden_size == HID && num_heads == 2 && L > 0 && L <= 256 && b4r_get_gemm_mode() == B4R_GEMM_BF16X3) ? 1 : 0;
@@ -763,7 +764,11 @@ int b4r_launch_slab_reduce_full(const float* slab, int S, int Mo, int No, float*
 
 extern "C" int b4r_attn_block_bwd(const b4r_attn_block_bwd_desc* d, b4r_stream_t stream) {
   B4R_CHECK_ARG(d != nullptr, B4R_E_BADARG, "b4r_attn_block_bwd: null descriptor");
-  if (use_attn32() && b4r_attn32_supported(d->H, d->heads, d->L)) return b4r_attn32_bwd(d, stream);
+  // the 32-token-tile kernel where it is preferred, and wherever the descriptor asks for what only it does (weight gradients inside
+  // the launch, sparse dz1); the forward of the same step wrote the dropout decisions in both layouts (bits32 below)
+  if (use_attn32() && b4r_attn32_supported(d->H, d->heads, d->L) &&
+      (b4r_attn32_preferred(d->H, d->heads, d->L) || d->dWqkv != nullptr || d->dz1_slot_positions != nullptr || d->dqkv == nullptr))
+    return b4r_attn32_bwd(d, stream);
   B4R_CHECK_ARG(d->dWqkv == nullptr && d->dqkv != nullptr, B4R_E_SHAPE, "b4r_attn_block_bwd: dWqkv inside the launch needs L <= 224 (this path writes dqkv)");
   B4R_CHECK_ARG(b4r_attn_block_bwd_supported(d->H, d->heads, d->L), B4R_E_SHAPE,
                 "b4r_attn_block_bwd: needs hidden size 64, 2 heads, L <= 208 and the bf16x3 mode (H=%d heads=%d L=%d)", d->H, d->heads,
@@ -811,7 +816,7 @@ int b4r_attn32_fwd(const b4r_attn_block_desc* d, b4r_stream_t stream);
 extern "C" int b4r_attn_block_fwd(const b4r_attn_block_desc* d, b4r_stream_t stream) {
   B4R_CHECK_ARG(d != nullptr, B4R_E_BADARG, "b4r_attn_block_fwd: null descriptor");
   static const bool fwd32 = !(getenv("B4R_ATTN32_FWD") && atoi(getenv("B4R_ATTN32_FWD")) == 0);
-  if (fwd32 && use_attn32() && b4r_attn32_supported(d->H, d->heads, d->L)) return b4r_attn32_fwd(d, stream);
+  if (fwd32 && use_attn32() && b4r_attn32_preferred(d->H, d->heads, d->L)) return b4r_attn32_fwd(d, stream);
   B4R_CHECK_ARG(b4r_attn_block_supported(d->H, d->heads, d->L), B4R_E_SHAPE,
                 "b4r_attn_block_fwd: needs hidden size 64, 2 heads, L <= 256 and the bf16x3 mode (H=%d heads=%d L=%d)", d->H, d->heads,
                 d->L);

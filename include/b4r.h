@@ -454,6 +454,9 @@ typedef struct b4r_attn_block_bwd_desc {
 int32_t b4r_attn_block_bwd_supported(int32_t hidden_size, int32_t num_heads, int32_t L);
 int64_t b4r_attn_block_bwd_scratch_floats(int32_t B);
 int64_t b4r_attn_block_bwd_dw_scratch_floats(int32_t B);
+/* tuning hook: the shortest sequence length at which the 32-token-tile attention kernels (b4r_attn32.hip) are chosen over the
+ * 16-token-tile ones (default 65; environment B4R_ATTN32_MIN_L).  Returns the previous value; a negative argument only reads it. */
+int32_t b4r_attn32_set_min_len(int32_t L);
 int b4r_attn_block_bwd(const b4r_attn_block_bwd_desc* d, b4r_stream_t stream);
 
 typedef struct b4r_ffn_desc {

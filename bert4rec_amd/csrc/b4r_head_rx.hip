@@ -19,11 +19,14 @@
 // interleaved per 16-row tile.
 #include "b4r_rx_tiles.h"
 #include "b4r_head_merge.h"
+#ifndef HEAD_CH2
+#define HEAD_CH2 10
+#endif
 
 namespace {
 
 // 16-row tiles per LDS chunk (even): 40 KB of images at H = 64 (three workgroups per CU), 48 KB at 128, 64 KB at 256
-constexpr int head_ch(int nkh) { return nkh == 2 ? 10 : nkh == 4 ? 6 : 4; }
+constexpr int head_ch(int nkh) { return nkh == 2 ? HEAD_CH2 : nkh == 4 ? 6 : 4; }
 // (part_ld, LOG2E / LN2 and ex2 -- the sweeps work in log2 units, T or E is scaled by log2(e) before it is split so that the softmax
 // exponential is the bare v_exp_f32 -- are in b4r_head_merge.h, shared with the LayerNorm backward that can do the merge)
 

@@ -173,6 +173,7 @@ PROTOTYPES = {
     "b4r_mask_batch": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, C.c_double, _F, _F, _I32, C.c_uint64, _P, _P, _P, _P, _P, _P, _P]),
     "b4r_sample_candidates": (C.c_int, [_P, _I32, _P, _I32, _P, _I32, _I32, C.c_uint64, _P, _P]),
     "b4r_attn32_set_min_len": (_I32, [_I32]),
+    "b4r_attn32_set_core_fwd": (_I32, [_I32]),
     "b4r_sample_candidates_flagged": (C.c_int, [_P, _I32, _P, _I32, _P, _I32, _I32, C.c_uint64, _P, _P, _P]),
     "b4r_softmax_ce": (C.c_int, [_P, _I32, _I32, _I32, _P, _P, _P, _I32, _P]),
     "b4r_global_sqnorm": (C.c_int, [_P, _I64, _P, _P, _P]),

@@ -993,6 +993,376 @@ __global__ __launch_bounds__(512, 2) void attn32_fwd_kernel(A32FwdP p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The attention CORE alone on 32-token tiles, for every hidden size with 32-wide heads (H = 128: 4 heads, H = 256: 8 heads; the
+// layers around it are tile products there): one workgroup per (sequence, head), q | k | v read from the [N, 3H] projection output
+// (q pre-scaled by 1/sqrt(d): b4r_attn_fwd's contract), the same score / softmax / dropout / sweep code as the resident kernels above
+// -- K and V images in LDS, the score row of a query in one lane pair, dK / dV in registers, the dQ partials ordered by flags.
+// Replaces round 1's attn_rx_fwd / attn_rx_dq / attn_rx_dkv kernels (16-token tiles, three launches) where L <= 224.
+// ---------------------------------------------------------------------------------------------------------------------------
+struct A32CoreFwdP {
+  const float* qkv; const int64_t* mask; float* ctx; float* lse; uint32_t* bits;
+  int B, L, NT, heads;
+  DropArgs drop_p;
+};
+__host__ __device__ constexpr int core_fwd_lds(int NT) { return 2 * NT * P_TILE + NT * 32 * 4; }
+
+// the wave's rows of one 32-column slice of a [N, ld] tensor in ACCUMULATOR layout: register 4 gp + e of lane (r, h) = column
+// 8 gp + 4h + e of token r (what a product with the tokens on the lanes leaves: acc_frag / acc_to_rows take it from there)
+__device__ __forceinline__ f32x16 load_acc_layout(const float* row_col0, int h) {
+  f32x16 v;
+#pragma unroll
+  for (int gp = 0; gp < 4; ++gp) {
+    const f32x4 q = *reinterpret_cast<const f32x4*>(row_col0 + 8 * gp + 4 * h);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[4 * gp + e] = q[e];
+  }
+  return v;
+}
+
+template <int NTT, bool DROP>
+__global__ __launch_bounds__(512, 2) void attn32_core_fwd_kernel(A32CoreFwdP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem32[];
+  const int NT = p.NT, L = p.L;
+  char* const kimg = smem32;                          // K images, one tile per 32 tokens
+  char* const vimg = smem32 + NT * P_TILE;            // V images
+  float* const sAdd = reinterpret_cast<float*>(smem32 + 2 * NT * P_TILE);   // (mask adder - amax) * log2e per key, -inf beyond L
+  const int b = blockIdx.x / p.heads, head = blockIdx.x % p.heads;
+  const int Hh = 32 * p.heads;
+  const int64_t row0 = (int64_t)b * L;
+  const int64_t bh = (int64_t)b * p.heads + head;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  A32_LANE_CONSTS();
+  const int64_t mval = (int)threadIdx.x < L ? p.mask[row0 + threadIdx.x] : 0;
+  const int any_key = mval != 0 ? 1 : 0;
+  // the wave's tokens: q~ = q . log2(e) as the B operand of S^T = K . Q~^T, k and v rows -> the images every wave reads
+  const float* const src = p.qkv + (row0 + tokc) * (3 * Hh) + 32 * head;
+  f32x16 qa = load_acc_layout(src, h), kacc = load_acc_layout(src + Hh, h), vacc = load_acc_layout(src + 2 * Hh, h);
+  const float amax = __syncthreads_or(any_key) ? 0.0f : -1e9f;
+  if ((int)threadIdx.x < NT * 32)
+    sAdd[threadIdx.x] = (int)threadIdx.x < L ? (((1.0f - (float)mval) * -1e9f) - amax) * LOG2E : -INFINITY;
+  qa = qa * (amax != 0.0f ? 0.0f : LOG2E);   // every key masked: Keras' -1e9 absorbs the scores -> a uniform softmax over the L keys
+  bf16x8 qBh[2], qBl[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) acc_frag(qa, s, qBh[s], qBl[s]);
+  if (!live) { kacc = zero16(); vacc = zero16(); }   // pad tokens: zero rows (their keys are masked anyway; no NaN may enter P . V)
+  acc_to_rows(kimg + wave * P_TILE, lk, kacc);
+  acc_to_rows(vimg + wave * P_TILE, lk, vacc);
+  lds_barrier();
+
+  const DropCtx dcp = b4r_drop_ctx(p.drop_p);
+  f32x16 O;
+  const int qt = wave;
+  const int slot = (r & 24) | ((r & 3) << 1) | ((r >> 2) & 1);   // query 16s + 8a + 4h' + b -> 16s + 8a + 2b + h' (the backward's register pairs)
+  {
+  f32x16 S[NTT];
+  float m = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NTT; ++t) {
+    if (t < NT) {   // (wave-uniform; NTT is the compile-time bound of the token tiles)
+      S[t] = rows_of(sAdd + 32 * t, h);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const char* ka = kimg + t * P_TILE + lk.rowc[ks];
+        S[t] = mfma32x3(row_at(ka), row_at(ka + P_IMG), qBh[ks], qBl[ks], S[t]);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) S[t][e] = -INFINITY;
+    }
+  }
+  
+#pragma unroll
+  for (int t = 0; t < NTT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) m = fmaxf(m, S[t][e]);
+  m = fmaxf(m, other_half(m, h));
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < NTT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { S[t][e] = __builtin_amdgcn_exp2f(S[t][e] - m); sum += S[t][e]; }
+  sum += other_half(sum, h);
+  const float inv = 1.0f / sum;
+  if (h == 0 && live && p.lse) p.lse[bh * L + tok] = m * LN2 + __logf(sum);
+  
+  O = zero16();
+  const uint64_t dbase = ((uint64_t)bh * L + (uint64_t)(live ? tok : 0)) * (uint64_t)B4R_ATTN_PITCH;
+#pragma unroll
+  for (int t = 0; t < NTT; ++t) {
+    if (t >= NT) continue;
+    if (DROP) {
+      uint32_t word = 0;
+      const float sc = inv * dcp.scale;
+#pragma unroll
+      for (int gp = 0; gp < 4; ++gp) {
+        const B4rKeep4 k4 = b4r_keep4p(dcp, dbase + (uint64_t)(32 * t + 8 * gp + 4 * h));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) S[t][4 * gp + e] = k4.k[e] ? S[t][4 * gp + e] * sc : 0.f;
+        word |= k4.bits() << (8 * gp + 4 * h);
+      }
+      word |= other_half_u(word, h);
+      if (h == 0 && live) p.bits[((bh * NT + t) * NT + qt) * 32 + slot] = word;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) S[t][e] *= inv;
+    }
+    // O^T[feature][query] += V^T[feature][keys of tile t] . Pd^T[key][query]
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 ph, pl;
+      acc_frag(S[t], s2, ph, pl);
+      const char* va = vimg + t * P_TILE;
+      O = mfma32x3(tr_pair(va + lk.trp[s2][0], va + lk.trp[s2][1]), tr_pair(va + P_IMG + lk.trp[s2][0], va + P_IMG + lk.trp[s2][1]),
+                       ph, pl, O);
+    }
+  }
+  }
+  // O's registers 8s .. 8s+7 are context columns 16s + 8h + (0..7) of the head (V image in swapped column order, transposed reads)
+  if (live) {
+    float* dst = p.ctx + (row0 + tok) * Hh + 32 * head + 8 * h;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      *reinterpret_cast<f32x4*>(dst + 16 * s) = (f32x4){O[8 * s], O[8 * s + 1], O[8 * s + 2], O[8 * s + 3]};
+      *reinterpret_cast<f32x4*>(dst + 16 * s + 4) = (f32x4){O[8 * s + 4], O[8 * s + 5], O[8 * s + 6], O[8 * s + 7]};
+    }
+  }
+}
+
+struct A32CoreBwdP {
+  const float* qkv; const float* dctx; const float* ctx; const float* lse; const uint32_t* bits; const int64_t* mask;
+  float* dqkv;
+  int B, L, NT, heads;
+  float qscale;
+  DropArgs drop_p;
+};
+// LDS (bytes): [Q~ images NT x 4 KB | dO images | dQ accumulators (fp32, register layout) | per-wave scratch | mask adders, -lse, D, flags]
+__host__ __device__ constexpr int core_bwd_lds(int NT) { return 4 * NT * P_TILE + (3 * NT * 32 + 8) * 4; }
+
+template <bool DROP>
+__global__ __launch_bounds__(512, 2) void attn32_core_bwd_kernel(A32CoreBwdP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem32[];
+  const int NT = p.NT, L = p.L;
+  char* const QIMG = smem32;
+  char* const DOIMG = QIMG + NT * P_TILE;
+  char* const DQACC = DOIMG + NT * P_TILE;
+  char* const SCRALL = DQACC + NT * P_TILE;
+  float* const sAdd = reinterpret_cast<float*>(SCRALL + NT * P_TILE);
+  float* const sCS = sAdd + NT * 32;                  // -lse * log2e per query (-inf: pad)
+  float* const sD = sCS + NT * 32;                    // rowsum(dctx * ctx) per query
+  int* const sflag = reinterpret_cast<int*>(sD + NT * 32);
+  const int b = blockIdx.x / p.heads, head = blockIdx.x % p.heads;
+  const int Hh = 32 * p.heads;
+  const int64_t row0 = (int64_t)b * L;
+  const int64_t bh = (int64_t)b * p.heads + head;
+  constexpr int hd = 0; (void)hd;                     // (the stamp macros of the resident kernel name a head)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char* const scr = SCRALL + wave * P_TILE;
+  char* const ownA = QIMG + wave * P_TILE;
+  char* const ownB = DOIMG + wave * P_TILE;
+  char* const ownC = DQACC + wave * P_TILE;
+  A32_LANE_CONSTS();
+  const int64_t mval = (int)threadIdx.x < L ? p.mask[row0 + threadIdx.x] : 0;
+  const int any_key = mval != 0 ? 1 : 0;
+  // the wave's tokens in accumulator layout: q~, k, v of the head, dctx and ctx columns of the head, the query's lse
+  const float* const src = p.qkv + (row0 + tokc) * (3 * Hh) + 32 * head;
+  f32x16 qT = load_acc_layout(src, h), kT = load_acc_layout(src + Hh, h), vT = load_acc_layout(src + 2 * Hh, h);
+  const f32x16 dcT = load_acc_layout(p.dctx + (row0 + tokc) * Hh + 32 * head, h);
+  const f32x16 cxT = load_acc_layout(p.ctx + (row0 + tokc) * Hh + 32 * head, h);
+  const float lse_q = live ? p.lse[bh * L + tok] : INFINITY;
+  const float amax = __syncthreads_or(any_key) ? 0.0f : -1e9f;
+  const bool dead = amax != 0.0f;   // every key masked: Keras' -1e9 absorbs the scores, the softmax is uniform over all L keys
+  if ((int)threadIdx.x < NT * 32)
+    sAdd[threadIdx.x] = (int)threadIdx.x < L ? (((1.0f - (float)mval) * -1e9f) - amax) * LOG2E : -INFINITY;
+  const DropCtx dcp = b4r_drop_ctx(p.drop_p);
+  const float pscale = DROP ? dcp.scale : 1.0f;
+  qT = qT * LOG2E;
+  {   // D = sum_c dctx * ctx over the head's 32 columns (the softmax backward's row term)
+    float d = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) d = fmaf(dcT[e], cxT[e], d);
+    d += other_half(d, h);
+    if (h == 0) { sD[tok] = d; sCS[tok] = -lse_q * LOG2E; }
+  }
+  bf16x8 kBh[2], kBl[2], vBh[2], vBl[2];     // K^T, V^T [feature][key] as B operands of S = Q~.K^T and dA = dO.V^T
+#pragma unroll
+  for (int s = 0; s < 2; ++s) { acc_frag(kT, s, kBh[s], kBl[s]); acc_frag(vT, s, vBh[s], vBl[s]); }
+  acc_to_rows(ownA, lk, qT);
+  acc_to_rows(ownB, lk, dcT);
+  acc_to_rows(scr, lk, kT);
+  lds_barrier();                             // (the wave's own K^T image is written: its transposed reads below may start)
+  bf16x8 kTh[2], kTl[2];                     // K^T[feature position][key] as the A operand of dQ^T = K^T.dS^T
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    kTh[s] = tr_pair(scr + lk.trn[s][0], scr + lk.trn[s][1]);
+    kTl[s] = tr_pair(scr + P_IMG + lk.trn[s][0], scr + P_IMG + lk.trn[s][1]);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(ownC + j * 1024 + lane * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (lane == 0) sflag[wave] = 0;
+  lds_barrier();   // images, D, -lse of every tile in place; accumulators zero; (the K^T reads above have landed: lgkmcnt(0))
+
+  f32x16 dK = zero16(), dV = zero16(), S, dA;
+  const float adk = sAdd[tok];
+  if (dead) {   // S = -lse for every key: the scores are absorbed by the mask adder
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { kBh[ks][e] = (__bf16)0.f; kBl[ks][e] = (__bf16)0.f; }
+  }
+#define A32_LD_TR(img, s2, H, Lo)                                                \
+H = tr_pair((img) + lk.trp[s2][0], (img) + lk.trp[s2][1]);                     \
+Lo = tr_pair((img) + P_IMG + lk.trp[s2][0], (img) + P_IMG + lk.trp[s2][1])
+#define A32_LD_ROW(img, ks, H, Lo)                                               \
+H = row_at((img) + lk.rowc[ks]);                                               \
+Lo = row_at((img) + P_IMG + lk.rowc[ks])
+#define A32_LD_SCR(ks, H, Lo)                                                    \
+H = tr_pair(scr + lk.trn[ks][0], scr + lk.trn[ks][1]);                         \
+Lo = tr_pair(scr + P_IMG + lk.trn[ks][0], scr + P_IMG + lk.trn[ks][1])
+#define A32_SB() __builtin_amdgcn_sched_barrier(0)
+  auto tile_of = [&](int s) __attribute__((always_inline)) { const int t = wave + s; return t >= NT ? t - NT : t; };
+  typedef const __attribute__((address_space(4))) uint64_t* kmask_ptr;   // constant address space: scalar loads
+  {   // S, dA of the first tile
+    const char* qimg = QIMG + wave * P_TILE;
+    const char* dimg = DOIMG + wave * P_TILE;
+    S = rows_of(sCS + 32 * wave, h);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) S[e] += adk;
+    dA = zero16();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 ah, al;
+      A32_LD_ROW(qimg, ks, ah, al);
+      S = mfma32x3(ah, al, kBh[ks], kBl[ks], S);
+      A32_LD_ROW(dimg, ks, ah, al);
+      dA = mfma32x3(ah, al, vBh[ks], vBl[ks], dA);
+    }
+  }
+  for (int s = 0; s < NT; ++s) {
+    const int t = tile_of(s), tn = tile_of(s + 1);   // (the last step forms S / dA of a tile nobody uses: no branch in the body)
+    const char* qimg = QIMG + t * P_TILE;
+    const char* dimg = DOIMG + t * P_TILE;
+    const char* qn = QIMG + tn * P_TILE;
+    const char* dn = DOIMG + tn * P_TILE;
+    A32_SWEEP(2 + 4 * s);
+    // ---- vector phase ------------------------------------------------------------------------------------------------------
+    bf16x8 f0h, f0l, f1h, f1l;
+    A32_LD_TR(dimg, 0, f0h, f0l);   // the first two products' fragments travel during the vector phase
+    A32_LD_TR(qimg, 0, f1h, f1l);
+    const f32x16 Dq = rows_of(sD + 32 * t, h);
+    uint64_t km[16];   // keep decisions of the 32 x 32 block: register tt's lane mask over the keys
+    if (DROP) {
+      kmask_ptr mp = (kmask_ptr)(reinterpret_cast<const uint64_t*>(p.bits) + ((bh * NT + wave) * NT + t) * 16);
+#pragma unroll
+      for (int tt = 0; tt < 16; ++tt) km[tt] = mp[tt];
+    }
+    bf16x8 pdh[2], pdl[2], dsh[2], dsl[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      f32x8 pd, ds;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int tt = 8 * s2 + j;
+        const float pr = (A32_EXP & 1) ? S[tt] : __builtin_amdgcn_exp2f(S[tt]);
+        if (A32_EXP & 1) { pd[j] = pr; ds[j] = dA[tt]; } else
+        if (DROP) {
+          const float kf = __builtin_amdgcn_inverse_ballot_w64(km[tt]) ? pscale : 0.f;
+          pd[j] = pr * kf;
+          ds[j] = pr * fmaf(dA[tt], kf, -Dq[tt]);
+        } else {
+          pd[j] = pr;
+          ds[j] = pr * (dA[tt] - Dq[tt]);
+        }
+      }
+      split8(pd, pdh[s2], pdl[s2]);
+      split8(ds, dsh[s2], dsl[s2]);
+      // dS -> the wave's [key][query] scratch image: registers 4a .. 4a+3 of this half are queries 16 s2 + 8a + 4h + (0..3)
+      const s16x8 hv = __builtin_bit_cast(s16x8, dsh[s2]), lv = __builtin_bit_cast(s16x8, dsl[s2]);
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        char* w8 = scr + p_chunk(r, 2 * s2 + a) + 8 * h;
+        *reinterpret_cast<s16x4*>(w8) = a ? __builtin_shufflevector(hv, hv, 4, 5, 6, 7) : __builtin_shufflevector(hv, hv, 0, 1, 2, 3);
+        *reinterpret_cast<s16x4*>(w8 + P_IMG) = a ? __builtin_shufflevector(lv, lv, 4, 5, 6, 7) : __builtin_shufflevector(lv, lv, 0, 1, 2, 3);
+      }
+    }
+    // S of the next tile starts from -lse (per query) + the key's mask adder
+    S = rows_of(sCS + 32 * tn, h);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) S[e] += adk;
+    A32_SWEEP(3 + 4 * s);
+    A32_SB();
+    // ---- matrix phase: ten products, fragments requested two products ahead ---------------------------------------------------
+    bf16x8 f2h, f2l, f3h, f3l, f4h, f4l, f5h, f5l, f6h, f6l, f7h, f7l, f8h, f8l, f9h, f9l;
+    A32_LD_TR(dimg, 1, f2h, f2l);
+    dV = mfma32x3(f0h, f0l, pdh[0], pdl[0], dV);   // dV^T[feature][key] += dO^T[feature][query] . Pd[query][key], queries 0..15
+    A32_SB();
+    A32_LD_TR(qimg, 1, f3h, f3l);
+    dK = mfma32x3(f1h, f1l, dsh[0], dsl[0], dK);   // dK^T += Q~^T . dS
+    A32_SB();
+    A32_LD_ROW(qn, 0, f4h, f4l);
+    dV = mfma32x3(f2h, f2l, pdh[1], pdl[1], dV);
+    A32_SB();
+    A32_LD_ROW(dn, 0, f5h, f5l);
+    dK = mfma32x3(f3h, f3l, dsh[1], dsl[1], dK);
+    A32_SB();
+    A32_LD_ROW(qn, 1, f6h, f6l);
+    S = mfma32x3(f4h, f4l, kBh[0], kBl[0], S);     // S[query][key] = Q~ . K^T of the next tile
+    A32_SB();
+    A32_LD_ROW(dn, 1, f7h, f7l);
+    dA = mfma32x3(f5h, f5l, vBh[0], vBl[0], zero16());
+    A32_SB();
+    A32_LD_SCR(0, f8h, f8l);
+    S = mfma32x3(f6h, f6l, kBh[1], kBl[1], S);
+    A32_SB();
+    A32_LD_SCR(1, f9h, f9l);
+    dA = mfma32x3(f7h, f7l, vBh[1], vBl[1], dA);
+    A32_SB();
+    // dQ^T[feature position][query] = K^T[.][key] . dS^T[key][query]  (B by transposed reads of the scratch image)
+    f32x16 dQp = mfma32x3(kTh[0], kTl[0], f8h, f8l, zero16());
+    dQp = mfma32x3(kTh[1], kTl[1], f9h, f9l, dQp);
+    A32_SWEEP(4 + 4 * s);
+    if (s > 0) {   // the accumulator's previous addition (wave w + 1, its step s - 1) must be in place
+      const volatile int* f = sflag + (wave + 1 < NT ? wave + 1 : 0);
+      while (*f < s) __builtin_amdgcn_s_sleep(1);
+      asm volatile("" ::: "memory");
+    }
+    char* acc = DQACC + t * P_TILE + lane * 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4* a4 = reinterpret_cast<f32x4*>(acc + j * 1024);
+      *a4 = *a4 + (f32x4){dQp[4 * j], dQp[4 * j + 1], dQp[4 * j + 2], dQp[4 * j + 3]};
+    }
+    asm volatile("" ::: "memory");
+    *reinterpret_cast<volatile int*>(sflag + wave) = s + 1;   // LDS operations of a wave complete in order: the sums are in place
+    A32_SWEEP(5 + 4 * s);
+  }
+  lds_barrier();   // every accumulator is complete
+
+  // results for the wave's tokens: registers 8s .. 8s+7 = features 16s + 8h + (0..7)
+  if (live) {
+    f32x16 gq;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 a4 = *reinterpret_cast<const f32x4*>(ownC + j * 1024 + lane * 16);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gq[4 * j + e] = a4[e] * p.qscale;
+    }
+    const f32x16 gk = dK * LN2;   // Q~ carries log2(e)
+    float* dst = p.dqkv + (row0 + tok) * (3 * Hh) + 32 * head + 8 * h;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int o = 8 * s + 4 * hf;
+        *reinterpret_cast<f32x4*>(dst + 16 * s + 4 * hf) = (f32x4){gq[o], gq[o + 1], gq[o + 2], gq[o + 3]};
+        *reinterpret_cast<f32x4*>(dst + Hh + 16 * s + 4 * hf) = (f32x4){gk[o], gk[o + 1], gk[o + 2], gk[o + 3]};
+        *reinterpret_cast<f32x4*>(dst + 2 * Hh + 16 * s + 4 * hf) = (f32x4){dV[o], dV[o + 1], dV[o + 2], dV[o + 3]};
+      }
+    }
+  }
+}
+
 bool al16(const void* q) { return q == nullptr || b4r_aligned16(q); }
 
 }  // namespace
@@ -1011,6 +1381,70 @@ extern "C" int32_t b4r_attn32_set_min_len(int32_t L) {
 }
 int32_t b4r_attn32_preferred(int32_t hidden_size, int32_t num_heads, int32_t L) {
   return (b4r_attn32_supported(hidden_size, num_heads, L) && L >= g_attn32_min_len) ? 1 : 0;
+}
+
+// ---- the attention core for any number of 32-wide heads (b4r_attn_fwd / b4r_attn_bwd in the bf16x3 mode) ----------------------
+int64_t b4r_attn_rx_keep_words(int B, int L, int heads);
+bool b4r_attn32_core_preferred(int L) {
+  static const bool on = !(getenv("B4R_ATTN32_CORE") && atoi(getenv("B4R_ATTN32_CORE")) == 0);
+  return on && L > 0 && L <= 224 && L >= g_attn32_min_len && b4r_get_gemm_mode() == B4R_GEMM_BF16X3;
+}
+static int g_attn32_core_fwd = getenv("B4R_ATTN32_CORE_FWD") ? atoi(getenv("B4R_ATTN32_CORE_FWD")) : 0;
+bool b4r_attn32_core_fwd_wanted() { return g_attn32_core_fwd != 0; }
+extern "C" int32_t b4r_attn32_set_core_fwd(int32_t on) {
+  const int old = g_attn32_core_fwd;
+  if (on >= 0) g_attn32_core_fwd = on;
+  return old;
+}
+int b4r_attn32_core_fwd_launch(const float* qkv, const int64_t* mask, int B, int L, int heads, float* ctx, float* lse,
+                               const DropArgs& drop, uint32_t* keep_bits, hipStream_t stream) {
+  A32CoreFwdP p{};
+  p.qkv = qkv; p.mask = mask; p.ctx = ctx; p.lse = lse;
+  p.bits = keep_bits ? keep_bits + b4r_attn_rx_keep_words(B, L, heads) : nullptr;   // behind round 1's layout
+  p.B = B; p.L = L; p.NT = b4r_cdiv(L, 32); p.heads = heads;
+  p.drop_p = drop;
+  const bool dropping = drop.rng != nullptr && drop.thr != 0;
+  B4R_CHECK_ARG(!dropping || keep_bits, B4R_E_BADARG, "b4r_attn_fwd: attention dropout needs keep_bits");
+  const size_t sh = (size_t)core_fwd_lds(p.NT);
+  const dim3 grid((unsigned)(B * heads)), block((unsigned)(64 * p.NT));
+  int rc;
+#define A32_CORE_FWD_CASE(N_, D_)                                                                       \
+  {                                                                                                     \
+    rc = b4r_raise_lds((const void*)attn32_core_fwd_kernel<N_, D_>, sh, "b4r_attn_fwd");                \
+    if (rc) return rc;                                                                                  \
+    hipLaunchKernelGGL((attn32_core_fwd_kernel<N_, D_>), grid, block, sh, stream, p);                   \
+  }
+  if (p.NT <= 2) { if (dropping) A32_CORE_FWD_CASE(2, true) else A32_CORE_FWD_CASE(2, false) }
+  else if (p.NT <= 4) { if (dropping) A32_CORE_FWD_CASE(4, true) else A32_CORE_FWD_CASE(4, false) }
+  else { if (dropping) A32_CORE_FWD_CASE(7, true) else A32_CORE_FWD_CASE(7, false) }
+#undef A32_CORE_FWD_CASE
+  B4R_CHECK_LAUNCH("b4r_attn_fwd (32-token tiles)");
+  return B4R_OK;
+}
+int b4r_attn32_core_bwd_launch(const float* qkv, const int64_t* mask, const float* ctx, const float* lse, const float* dctx, int B,
+                               int L, int heads, float qscale, float* dqkv, const DropArgs& drop, const uint32_t* keep_bits,
+                               hipStream_t stream) {
+  A32CoreBwdP p{};
+  p.qkv = qkv; p.mask = mask; p.ctx = ctx; p.lse = lse; p.dctx = dctx; p.dqkv = dqkv;
+  p.bits = keep_bits ? keep_bits + b4r_attn_rx_keep_words(B, L, heads) : nullptr;
+  p.B = B; p.L = L; p.NT = b4r_cdiv(L, 32); p.heads = heads; p.qscale = qscale;
+  p.drop_p = drop;
+  const bool dropping = drop.rng != nullptr && drop.thr != 0;
+  B4R_CHECK_ARG(!dropping || keep_bits, B4R_E_BADARG, "b4r_attn_bwd: attention dropout needs the forward's keep_bits");
+  const size_t sh = (size_t)core_bwd_lds(p.NT);
+  const dim3 grid((unsigned)(B * heads)), block((unsigned)(64 * p.NT));
+  int rc;
+  if (dropping) {
+    rc = b4r_raise_lds((const void*)attn32_core_bwd_kernel<true>, sh, "b4r_attn_bwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL((attn32_core_bwd_kernel<true>), grid, block, sh, stream, p);
+  } else {
+    rc = b4r_raise_lds((const void*)attn32_core_bwd_kernel<false>, sh, "b4r_attn_bwd");
+    if (rc) return rc;
+    hipLaunchKernelGGL((attn32_core_bwd_kernel<false>), grid, block, sh, stream, p);
+  }
+  B4R_CHECK_LAUNCH("b4r_attn_bwd (32-token tiles)");
+  return B4R_OK;
 }
 
 // attention-dropout decisions of one layer: [B][head][key tile][query tile][16 register pairs] x 2 uint32

@@ -39,6 +39,7 @@ struct AttnRxP {
   const float* qkv; const int64_t* mask; const float* ctx; const float* lse_in; const float* dctx;
   float* ctx_out; float* lse_out; float* dqkv;
   uint32_t* bits_out; const uint32_t* bits_in;
+  uint32_t* bits32;   // forward: the same decisions once more as one word per (query, 32-key tile), what b4r_attn32.hip's backward reads (or NULL)
   int B, L, heads, H;
   int KT, KTE;   // 16-row tiles covering L, and KT rounded up to even (the images hold KTE tiles, zero beyond L)
   float qscale;
@@ -150,6 +151,17 @@ __global__ __launch_bounds__(64 * WAVES) void attn_rx_fwd_kernel(AttnRxP p) {
     uint32_t* wo = p.bits_out + ((bh * p.KT + (q0 >> 4) + wave) * 2) * 64 + lane;
     wo[0] = w[0];
     wo[64] = w[1];
+    if (p.bits32) {   // [b][head][key tile T][query tile][16 register pairs][2]: bit k of the word = key 32 T + k
+      const int NT = (L + 31) >> 5, qt = q >> 5, qr = q & 31;
+      const int slot = (qr & 24) | ((qr & 3) << 1) | ((qr >> 2) & 1);   // query 16s + 8a + 4h' + b -> 16s + 8a + 2b + h'
+      for (int T = 0; T < NT; ++T) {
+        const uint32_t by = (w[T >> 2] >> (8 * (T & 3))) & 0xFFu;        // the nibbles of the 16-key tiles 2T, 2T + 1
+        uint32_t part = ((by & 15u) | ((by >> 4) << 16)) << (4 * g);     // rows 4g .. 4g+3 of each
+        part |= (uint32_t)__shfl_xor((int)part, 16, 64);
+        part |= (uint32_t)__shfl_xor((int)part, 32, 64);
+        if (g == 0 && q < L) p.bits32[((bh * NT + T) * NT + qt) * 32 + slot] = part;
+      }
+    }
   } else {
 #pragma unroll
     for (int t = 0; t < KT; ++t) acc[t] = acc[t] * inv;
@@ -376,10 +388,26 @@ int set_lds(K kernel, size_t bytes) { return b4r_raise_lds((const void*)kernel, 
 int64_t b4r_attn_rx_keep_words(int B, int L, int heads) { return (int64_t)B * heads * b4r_cdiv(L, 16) * 128; }
 
 // called by b4r_attn_fwd / b4r_attn_bwd (argument checks already done there) in the bf16x3 mode
+// b4r_attn32.hip: the core on 32-token tiles (one workgroup per sequence and head, one launch each way), preferred from L = 65 to 224
+bool b4r_attn32_core_preferred(int L);
+bool b4r_attn32_core_fwd_wanted();
+int64_t b4r_attn_rx_keep_words(int B, int L, int heads);
+int b4r_attn32_core_fwd_launch(const float* qkv, const int64_t* mask, int B, int L, int heads, float* ctx, float* lse,
+                               const DropArgs& drop, uint32_t* keep_bits, hipStream_t stream);
+int b4r_attn32_core_bwd_launch(const float* qkv, const int64_t* mask, const float* ctx, const float* lse, const float* dctx, int B,
+                               int L, int heads, float qscale, float* dqkv, const DropArgs& drop, const uint32_t* keep_bits,
+                               hipStream_t stream);
+
 int b4r_attn_rx_fwd_launch(const float* qkv, const int64_t* mask, int B, int L, int heads, float* ctx, float* lse,
                            const DropArgs& drop, uint32_t* keep_bits, hipStream_t stream) {
+  // The forward stays on the 16-token-tile kernel below (ML-20M shape: 110 us against 133 for the 32-token-tile core, whose 112
+  // score registers per lane leave one workgroup per CU) and writes the dropout decisions in the backward core's layout as well;
+  // B4R_ATTN32_CORE_FWD=1 / b4r_attn32_set_core_fwd selects the 32-token-tile forward.
+  if (b4r_attn32_core_preferred(L) && b4r_attn32_core_fwd_wanted())
+    return b4r_attn32_core_fwd_launch(qkv, mask, B, L, heads, ctx, lse, drop, keep_bits, stream);
   AttnRxP p{};
   p.qkv = qkv; p.mask = mask; p.ctx_out = ctx; p.lse_out = lse; p.bits_out = keep_bits;
+  if (keep_bits != nullptr && b4r_attn32_core_preferred(L)) p.bits32 = keep_bits + b4r_attn_rx_keep_words(B, L, heads);
   p.B = B; p.L = L; p.heads = heads; p.H = heads * 32;
   p.KT = b4r_cdiv(L, 16);
   p.drop = drop;
@@ -409,6 +437,8 @@ int b4r_attn_rx_bwd_launch(const float* qkv, const int64_t* mask, const float* c
                            int B, int L, int heads, float qscale, float* dqkv, const DropArgs& drop,
                            const uint32_t* keep_bits, hipStream_t stream, hipStream_t stream_dkv) {
   // stream_dkv: the dK/dV kernel may run on another stream (it writes other columns of dqkv than dQ does)
+  if (b4r_attn32_core_preferred(L))   // one launch forms dq, dk and dv (on `stream`: callers that split the streams order them)
+    return b4r_attn32_core_bwd_launch(qkv, mask, ctx, lse, dctx, B, L, heads, qscale, dqkv, drop, keep_bits, stream);
   AttnRxP p{};
   p.qkv = qkv; p.mask = mask; p.ctx = ctx; p.lse_in = lse; p.dctx = dctx; p.dqkv = dqkv; p.bits_in = keep_bits;
   p.B = B; p.L = L; p.heads = heads; p.H = heads * 32; p.qscale = qscale;

@@ -457,6 +457,9 @@ int64_t b4r_attn_block_bwd_dw_scratch_floats(int32_t B);
 /* tuning hook: the shortest sequence length at which the 32-token-tile attention kernels (b4r_attn32.hip) are chosen over the
  * 16-token-tile ones (default 65; environment B4R_ATTN32_MIN_L).  Returns the previous value; a negative argument only reads it. */
 int32_t b4r_attn32_set_min_len(int32_t L);
+/* tuning hook: b4r_attn_fwd on the 32-token-tile core as well (default 0: the forward stays on 16-token tiles, only b4r_attn_bwd
+ * uses the core; environment B4R_ATTN32_CORE_FWD).  Returns the previous value; a negative argument only reads it. */
+int32_t b4r_attn32_set_core_fwd(int32_t on);
 int b4r_attn_block_bwd(const b4r_attn_block_bwd_desc* d, b4r_stream_t stream);
 
 typedef struct b4r_ffn_desc {

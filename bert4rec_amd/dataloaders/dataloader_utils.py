@@ -79,6 +79,19 @@ class ExampleDataset:
         return ExampleDataset([self.examples[i] for i in idx])
 
 
+class ResidentBatch(dict):
+    """A batch dict whose tensors stay in HBM between epochs (the six tensors of the reference's batches, nothing else, as keys) plus
+    per-batch constants as ATTRIBUTES: slot_index [R, 2] = the (row, slot) pairs with masked_lm_weights != 0, found once on the host
+    copy or when the batch is frozen -- the evaluator otherwise looks for them on the device with a read-back per batch, which makes
+    every batch wait for the kernels of the one before; eval_cache = what the evaluator derives from them on its first pass."""
+    __slots__ = ("slot_index", "eval_cache")
+
+    def __init__(self, tensors, slot_index=None):
+        super().__init__(tensors)
+        self.slot_index = slot_index
+        self.eval_cache = None
+
+
 class BatchedDataset:
     """List of batch dicts (torch int64 [B, .]).  Iterating yields the same batches every epoch (== tf .cache())."""
 
@@ -102,13 +115,13 @@ class BatchedDataset:
         if device.type != "cuda":
             return self
         if self._device_batches is None or self._device != device:
-            self._device_batches = [{k: v.to(device, non_blocking=True) for k, v in b.items()} for b in self.batches]
-            # the (row, slot) pairs with masked_lm_weights != 0, found here on the host copy: the evaluator otherwise looks for them on
-            # the device with one read-back per batch, which makes every batch wait for the previous one's kernels
-            for hb, db in zip(self.batches, self._device_batches):
-                if "masked_lm_weights" in hb:
+            self._device_batches = []
+            for hb in self.batches:
+                idx = None
+                if "masked_lm_weights" in hb:   # found on the host copy: no device read-back
                     w = torch.as_tensor(hb["masked_lm_weights"])
-                    db["masked_lm_slot_index"] = torch.nonzero(w.reshape(w.shape[0], -1) != 0).to(device, non_blocking=True)
+                    idx = torch.nonzero(w.reshape(w.shape[0], -1) != 0).to(device, non_blocking=True)
+                self._device_batches.append(ResidentBatch({k: v.to(device, non_blocking=True) for k, v in hb.items()}, idx))
             self._device = device
         return self
 
@@ -241,7 +254,8 @@ class DeviceMaskedBatches:
             epoch, self.epoch = self.epoch, self.epoch + 1
             return self._build(epoch)
         if self._frozen is None:
-            self._frozen = list(self._build(0))
+            # batches that stay: the (row, slot) pairs with a weight are found once, here (one read-back per batch, at build time)
+            self._frozen = [ResidentBatch(b, torch.nonzero(b["masked_lm_weights"] != 0)) for b in self._build(0)]
         return iter(self._frozen)
 
 

@@ -140,11 +140,11 @@ class BERT4RecEvaluator(BaseEvaluator):
             with np.errstate(divide="ignore"):
                 self._logp = torch.from_numpy(np.log(p).astype(np.float32)).to(eng.device)
         dev = eng.device
-        pre = test_batch.get("masked_lm_slot_index") if isinstance(test_batch, dict) else None
+        pre = getattr(test_batch, "slot_index", None)   # dataloader_utils.ResidentBatch: a batch that stays in HBM
         resident = (pre is not None and torch.is_tensor(pre) and pre.device.type == dev.type and pre.ndim == 2 and pre.shape[1] == 2
                     and (dev.index is None or pre.device.index == dev.index))
-        cached = test_batch.get("_eval_cache") if resident else None
-        if cached is not None:                                  # a batch BatchedDataset.cache_on_device keeps in HBM, seen before
+        cached = test_batch.eval_cache if resident else None
+        if cached is not None:                                  # a resident batch seen before
             self._slots, gt, exclude, self._rows = cached
         else:
             w = torch.as_tensor(test_batch["masked_lm_weights"]).to(dev)
@@ -168,7 +168,7 @@ class BERT4RecEvaluator(BaseEvaluator):
                 # masked_lm_ids != 0 only: allowed when those ARE the ranked slots (checked here, once per resident batch)
                 same = bool(((ids_t != 0) == (w != 0)).all()) and int(torch.unique(rows).numel()) == int(rows.numel())
                 self._rows = rows if same else None
-                test_batch["_eval_cache"] = (self._slots, gt, exclude, self._rows)
+                test_batch.eval_cache = (self._slots, gt, exclude, self._rows)
         if self._slots.numel() == 0:
             return torch.empty((0, self.sampler.sample_size + 1), dtype=torch.int64), torch.empty((0,), dtype=torch.int64)
         self._draws += 1

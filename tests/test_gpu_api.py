@@ -503,14 +503,14 @@ def test_evaluation_of_resident_batches_equals_evaluation_of_host_batches():
     host = dataloaders.make_batches(test, batch_size=32, seed=1)
     resident = dataloaders.make_batches(test, batch_size=32, seed=1).cache_on_device("cuda")
     first = next(iter(resident))
-    assert first["input_word_ids"].is_cuda and first["masked_lm_slot_index"].shape[1] == 2
+    assert first["input_word_ids"].is_cuda and first.slot_index.shape[1] == 2 and set(first) == set(next(iter(host)))
     runs = []
     for bs, passes in ((host, 1), (resident, 2)):
         for _ in range(passes):
             ev = evaluation.get(sampler=smp, device_sampling=True, seed=5)
             ranks = torch.cat([ev.evaluate_batch(model, b).cpu() for b in bs])
             runs.append((ranks, ev.get_metrics_results()))
-    assert "_eval_cache" in first and first["_eval_cache"][3] is not None      # ... and the rows-only forward was allowed
+    assert first.eval_cache is not None and first.eval_cache[3] is not None      # ... and the rows-only forward was allowed
     for ranks, res in runs[1:]:
         assert res["Valid Ranks"] == runs[0][1]["Valid Ranks"] == 160
         same = (ranks == runs[0][0]).float().mean().item()

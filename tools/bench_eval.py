@@ -16,10 +16,9 @@ smp = dataloaders.samplers.get("pop_random", source=pop, vocab=list(range(V)), s
 nb = (USERS + B - 1) // B
 batches = [synthetic_batch(B, L, 1, V, seed=i, ragged=True, finetune=True) for i in range(nb)]
 def on_device(b):   # what BatchedDataset.cache_on_device leaves: device tensors + the valid (row, slot) pairs found on the host
-    d = {k: torch.as_tensor(v).cuda() for k, v in b.items()}
+    from bert4rec_amd.dataloaders.dataloader_utils import ResidentBatch
     w = torch.as_tensor(b["masked_lm_weights"])
-    d["masked_lm_slot_index"] = torch.nonzero(w.reshape(w.shape[0], -1) != 0).cuda()
-    return d
+    return ResidentBatch({k: torch.as_tensor(v).cuda() for k, v in b.items()}, torch.nonzero(w.reshape(w.shape[0], -1) != 0).cuda())
 cached = [on_device(b) for b in batches]
 modes = (("device sampler, batches resident in HBM", True, cached), ("device sampler, host batches", True, batches),
          ("host sampler (np.random.choice per user)", False, batches))

@@ -311,6 +311,34 @@ def test_train_step_takes_the_gradient_norm_from_the_closing_reduce_launch():
     assert "global norm" not in labels and labels.count("multi_slab_reduce") == 1, labels
 
 
+def test_encoder_only_forward_on_the_ranked_rows_equals_the_full_forward_there():
+    """B4R_FLAG_ENCODER_ONLY | B4R_FLAG_HEAD_ROWS_ONLY (what an evaluation runs): no masked-LM head although the batch carries
+    masked_lm_positions / masked_lm_ids, the last layer's feed-forward half only on the rows of the valid slots.  Those rows of the
+    sequence output must be bit for bit the full forward's; the logits region must stay untouched."""
+    cfg_o, shp = CONFIGS["ml1m_slice"]
+    eng, _ = build(cfg_o)
+    batch = orc.synthetic_batch(shp["B"], shp["L"], shp["P"], cfg_o.vocab_size, seed=12, ragged=True)
+    cb, keep = eng.prepare_batch(batch)
+    B, L, P = cb.B, cb.L, cb.P
+    eng.forward(cb, training=False, pooler=False)
+    torch.cuda.synchronize()
+    full = eng.region("sequence_output", B, L, P).clone()
+    eng.region("sequence_output", B, L, P).fill_(float("nan"))
+    eng.region("mlm_logits", B, L, P).fill_(7.0)
+    eng.forward(cb, training=False, pooler=False, head_rows_only=True, encoder_only=True)
+    torch.cuda.synchronize()
+    got = eng.region("sequence_output", B, L, P)
+    valid = (batch["masked_lm_ids"] != 0)
+    rows = (torch.arange(B)[:, None] * L + batch["masked_lm_positions"].clamp(0, L - 1))[valid].to(got.device)
+    assert rows.numel() > 0 and torch.equal(got[rows], full[rows])
+    assert bool((eng.region("mlm_logits", B, L, P) == 7.0).all())
+    if eng.fused_head_supported():   # (the fused feed-forward block: only there are the other rows skipped)
+        others = torch.ones(B * L, dtype=torch.bool, device=got.device)
+        others[rows] = False
+        skipped = torch.isnan(got[others]).all(dim=1).float().mean().item()   # (rows of padded slots may be written too: harmless)
+        assert skipped > 0.7, skipped
+
+
 def test_item_table_gradient_with_hundreds_of_contributions_per_row():
     """The fixed-point item-table sum against autograd on a batch where every item row receives ten or more contributions
     (64 sequences over 37 items; the PAD and [MASK] rows hundreds): same tolerance as the other gradients, and the gradient of an

@@ -597,9 +597,26 @@ extern "C" int32_t b4r_fused_head_supported(const b4r_model_config* cfg) {
   return (cfg != nullptr && b4r_head_rx_hidden_ok(cfg->hidden_size) && b4r_get_gemm_mode() == B4R_GEMM_BF16X3) ? 1 : 0;
 }
 
+// The public entry points take the documented flags only: the internal bits (B4R_FLAG_*_INTERNAL) couple a forward and a backward
+// of ONE b4r_train_step call and are set there alone.
+static int forward_impl(const b4r_model_config* cfg, const b4r_batch* batch, const float* params, const float* pooler, void* workspace,
+                        int64_t workspace_bytes, b4r_train_state* state, int32_t flags, b4r_stream_t stream);
+static int backward_impl(const b4r_model_config* cfg, const b4r_batch* batch, const float* params, float* grads, void* workspace,
+                         int64_t workspace_bytes, b4r_train_state* state, int32_t flags, b4r_stream_t stream);
+constexpr int32_t B4R_PUBLIC_FLAGS = 0xFFFF;
 extern "C" int b4r_forward(const b4r_model_config* cfg, const b4r_batch* batch, const float* params, const float* pooler,
                            void* workspace, int64_t workspace_bytes, b4r_train_state* state, int32_t flags,
                            b4r_stream_t stream) {
+  return forward_impl(cfg, batch, params, pooler, workspace, workspace_bytes, state, flags & B4R_PUBLIC_FLAGS, stream);
+}
+extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch, const float* params, float* grads,
+                            void* workspace, int64_t workspace_bytes, b4r_train_state* state, int32_t flags,
+                            b4r_stream_t stream) {
+  return backward_impl(cfg, batch, params, grads, workspace, workspace_bytes, state, flags & B4R_PUBLIC_FLAGS, stream);
+}
+
+static int forward_impl(const b4r_model_config* cfg, const b4r_batch* batch, const float* params, const float* pooler, void* workspace,
+                        int64_t workspace_bytes, b4r_train_state* state, int32_t flags, b4r_stream_t stream) {
   RC(check_cfg(cfg));
   RC(check_batch(batch, cfg, false));
   B4R_CHECK_ARG(params && workspace, B4R_E_BADARG, "b4r_forward: null params/workspace");
@@ -760,9 +777,8 @@ extern "C" int b4r_loss(const b4r_model_config* cfg, const b4r_batch* batch, voi
                         want_grad & (1 | B4R_LOSS_OVERWRITE), stream);
 }
 
-extern "C" int b4r_backward(const b4r_model_config* cfg, const b4r_batch* batch, const float* params, float* grads,
-                            void* workspace, int64_t workspace_bytes, b4r_train_state* state, int32_t flags,
-                            b4r_stream_t stream) {
+static int backward_impl(const b4r_model_config* cfg, const b4r_batch* batch, const float* params, float* grads, void* workspace,
+                         int64_t workspace_bytes, b4r_train_state* state, int32_t flags, b4r_stream_t stream) {
   RC(check_cfg(cfg));
   RC(check_batch(batch, cfg, true));
   B4R_CHECK_ARG(params && grads && workspace && batch->masked_lm_ids, B4R_E_BADARG, "b4r_backward: null argument");
@@ -1084,12 +1100,12 @@ extern "C" int b4r_train_step(const b4r_model_config* cfg, const b4r_adamw_confi
   // no b4r_state_begin_step launch: the loss reduction overwrites the sums (B4R_LOSS_OVERWRITE)
   // nothing but the loss, the metrics and the gradients leave a train step: the last layer's feed-forward half runs on the rows the
   // head gathers only (B4R_FLAG_HEAD_ROWS_ONLY; the same flag goes to forward and backward)
-  RC(b4r_forward(cfg, batch, params, nullptr, workspace, workspace_bytes, state,
-                 B4R_FLAG_TRAINING | B4R_FLAG_HEAD_ROWS_ONLY | (fused ? B4R_FLAG_FUSED_HEAD : 0) | defer, stream));
+  RC(forward_impl(cfg, batch, params, nullptr, workspace, workspace_bytes, state,
+                  B4R_FLAG_TRAINING | B4R_FLAG_HEAD_ROWS_ONLY | (fused ? B4R_FLAG_FUSED_HEAD : 0) | defer, stream));
   // with the logits-free head the loss sums are formed inside the backward's first launch (B4R_FLAG_LOSS_SUMS), else by b4r_loss
   if (!fused) RC(b4r_loss(cfg, batch, workspace, workspace_bytes, state, 1 | B4R_LOSS_OVERWRITE, stream));
-  RC(b4r_backward(cfg, batch, params, grads, workspace, workspace_bytes, state,
-                  B4R_FLAG_TRAINING | B4R_FLAG_HEAD_ROWS_ONLY |
+  RC(backward_impl(cfg, batch, params, grads, workspace, workspace_bytes, state,
+                   B4R_FLAG_TRAINING | B4R_FLAG_HEAD_ROWS_ONLY |
                       (fused ? B4R_FLAG_FUSED_HEAD | B4R_FLAG_LOSS_SUMS : 0) | defer |
                       B4R_FLAG_NORM_PARTIALS_INTERNAL, stream));
   const int np = g_norm_np;   // > 0: the backward's last launch left the norm's partial sums at the start of the workspace

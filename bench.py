@@ -43,7 +43,11 @@ CONFIGS = {
     "ml20m": (26732, 256, 2, 8, 1024, 200, 40, 256, 0.1, 0.1, 0.2),      # layers as in ml-20m_256.json
     "ml20m_4l": (26732, 256, 4, 8, 1024, 200, 40, 256, 0.1, 0.1, 0.2),   # BASELINE.json configs[3]: the 4-layer variant
     "steam": (13047, 64, 2, 2, 256, 50, 20, 256, 0.1, 0.1, 0.4),
+    # ml-1m_128.json: the encoder the reference's own ML-1M example trains (examples/bert4rec_ml_1m_example.py:21-25)
+    "ml1m_128": (3709, 128, 2, 4, 512, 200, 40, 256, 0.5, 0.2, 0.2),
 }
+# BASELINE.json configs[3] / [4] (+ the reference's ML-1M example encoder): short driver-visible legs behind the headline number
+OTHER_LEGS = (("steam", 150, 30), ("ml20m_4l", 24, 6), ("ml1m_128", 60, 15))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); 6.29 TB/s is the measured copy rate
 BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md); the split-precision kernels run on it
@@ -261,6 +265,63 @@ def eval_leg(device, V_items=3706, users=6040, seed=0):
             "chance_level_HR@10": round(10 / 101, 4)}
 
 
+def launch_command(n_gpus, argv, port):
+    """the command the driver itself uses for N > 1 (one rank per GPU over RCCL, rendezvous on 127.0.0.1)"""
+    passed = [a for a in argv if a != "--dry-launch"]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + passed
+
+
+def launch_ranks(n_gpus, argv, dry=False):
+    """Start the N ranks of `python bench.py --gpus N` as child processes and return their exit status."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = launch_command(n_gpus, argv, port)
+    if dry:
+        print(json.dumps({"launch": cmd, "ranks": n_gpus}), flush=True)
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def other_config_leg(name, steps, warmup, device):
+    """One more configuration of BASELINE.json timed the same way (full train steps on S-full synthetic batches resident in HBM,
+    eager launches, device synchronised on both sides), short enough to ride behind the headline run: a few regions, the median."""
+    from bert4rec_amd.engine import Engine, make_adamw_config, make_model_config
+    V, H, NL, NH, I, L, P, B, od, ad, rate = CONFIGS[name]
+    eng = Engine(make_model_config(V, H, NL, NH, L, I, od, ad), device, seed=4321)
+    eng.init_parameters(seed=3)
+    hp = make_adamw_config()
+    batches = [synthetic_batch(B, L, P, V, rate, seed=7000 + i) for i in range(2)]
+    prepared = [eng.prepare_batch(b) for b in batches]
+    valid = float(sum(int((b["masked_lm_ids"] != 0).sum()) for b in batches)) / len(batches)
+    for i in range(warmup):
+        eng.train_step(hp, prepared[i % 2][0])
+    torch.cuda.synchronize()
+    regions = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for i in range(steps):
+            eng.train_step(hp, prepared[i % 2][0])
+        torch.cuda.synchronize()
+        regions.append(time.perf_counter() - t0)
+    regions.sort()
+    el = regions[1]
+    st = eng.read_state()
+    loss = st["loss_sum"] / max(st["valid_count"], 1.0)
+    out = {"ms_per_step": round(el / steps * 1e3, 4), "value": round(valid * steps / el, 1), "unit": "masked positions/s",
+           "steps": steps, "warmup": warmup, "regions": 3, "final_loss": round(loss, 4), "finite": bool(np.isfinite(loss)),
+           "workload": f"{name}: full train step, B={B} L={L} P={P} H={H} layers={NL} heads={NH} inner={I} V={V} dropout {od}/{ad}"}
+    del eng, prepared
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -269,6 +330,7 @@ def main():
     ap.add_argument("--config", default="ml1m", choices=list(CONFIGS))
     ap.add_argument("--cpu-steps", type=int, default=3, help="timed oracle steps for cpu_baseline (0 disables)")
     ap.add_argument("--no-eval", action="store_true", help="skip the train + evaluate leg (NDCG@10 on the synthetic log)")
+    ap.add_argument("--no-other", action="store_true", help="skip the short legs on the other BASELINE configurations (other_configs)")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the event-timed extra steps (profiling runs: tools/prof.sh)")
     ap.add_argument("--phases", action="store_true", help="also print per-phase timings to stderr")
     ap.add_argument("--ragged", action="store_true", help="diagnostic only: S-ragged rows (lengths U{5..L}); reports the padding "
@@ -281,14 +343,19 @@ def main():
                                                          "~7x less host time per step; N > 1: two graphs around the all-reduce)")
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL code path (init, broadcast, all-reduce, barriers) with "
                                                               "ONE rank: the only way to rehearse it on a one-GPU box")
+    ap.add_argument("--dry-launch", action="store_true", help="with --gpus N > 1 and no WORLD_SIZE in the environment: print the "
+                                                              "torch.distributed.run command the launcher would start (JSON) and exit")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: this process becomes the LAUNCHER.  It has made no HIP / torch.cuda call (importing torch
+        # initialises nothing), starts N fresh rank processes as children -- never an exec of a process that touched the GPU -- lets
+        # their stdout through (rank 0 prints the one JSON line) and exits with their status.
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], args.dry_launch))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs the GPU (the product has no CPU path)"
     # one rank per GPU; when the launcher isolates each rank's card (HIP_VISIBLE_DEVICES per rank) the only visible index is 0
@@ -517,6 +584,16 @@ def main():
         if world == 1 and not args.no_eval and args.config == "ml1m":
             ev = eval_leg(device)
 
+        # ---- the other BASELINE configurations, a few dozen steps each (N = 1, headline config only) -------------------------------
+        others = None
+        if world == 1 and not args.no_other and args.config == "ml1m" and not args.ragged:
+            others = {}
+            for name, k_, w_ in OTHER_LEGS:
+                try:
+                    others[name] = other_config_leg(name, k_, w_, device)
+                except Exception as e:   # a leg that fails must not take the headline line with it; it is reported as failed
+                    others[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+
         # ---- CPU baseline: the oracle's train step on the host cores (rank 0, N=1 only) ---------------------------
         cpu = None
         topk = None
@@ -582,7 +659,7 @@ def main():
                              "launch_mode": "hipGraph replay" if graphs else "eager"},
                   "per_gpu": round(value / world, 1), "final_loss": round(loss, 5),
                   "roofline": roofline, "roofline_head": roofline_head, "step_hbm": step_hbm, "roofline_materialising": roofline_mat, "eval": ev, "topk_agreement": topk,
-                  "cpu_baseline": cpu, "step_breakdown": breakdown}
+                  "cpu_baseline": cpu, "other_configs": others, "step_breakdown": breakdown}
         print(json.dumps(result), flush=True)
     if use_dist:
         dist.barrier()

@@ -171,6 +171,7 @@ PROTOTYPES = {
     "b4r_timing_begin": (C.c_int, [_P, _I32]),
     "b4r_timing_end": (C.c_int, [C.POINTER(_I32), C.POINTER(C.c_float), C.c_char_p, _I32, _I32]),
     "b4r_mask_batch": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, C.c_double, _F, _F, _I32, C.c_uint64, _P, _P, _P, _P, _P, _P, _P]),
+    "b4r_uniform_from_hash": (_F, [_U32]),
     "b4r_sample_candidates": (C.c_int, [_P, _I32, _P, _I32, _P, _I32, _I32, C.c_uint64, _P, _P]),
     "b4r_attn32_set_min_len": (_I32, [_I32]),
     "b4r_attn32_set_core_fwd": (_I32, [_I32]),

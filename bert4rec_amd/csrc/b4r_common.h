@@ -113,6 +113,13 @@ __device__ __forceinline__ uint32_t b4r_hash32(uint32_t x) {
   return x;
 }
 
+// uniform in the OPEN interval (0, 1) from the top 23 bits of a hash word: (k + 0.5) / 2^23 is exact in fp32 for every k < 2^23, so
+// the largest value is 1 - 2^-24 < 1 (24 bits would round (2^24 - 0.5) / 2^24 up to 1.0f: `u < rate` would then fail at rate = 1).
+// Restates python's random.random() in [0, 1) (dataloader_utils.py:245-253) and numpy's uniform for the Gumbel keys.
+__host__ __device__ __forceinline__ float b4r_uniform23(uint32_t h) {
+  return ((float)(h >> 9) + 0.5f) * (1.0f / 8388608.0f);
+}
+
 struct DropCtx {
   uint32_t seed, key, thr;
   float scale;

@@ -1062,7 +1062,7 @@ __global__ __launch_bounds__(64) void mask_batch_kernel(const int64_t* tokens, c
       if (finetune) out = 1;
       else {
         const uint32_t h = b4r_hash32(s_key[i] ^ 0x68E31DA4u);
-        const float rn = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float rn = b4r_uniform23(h);   // in (0, 1): with mask_rate = 1 EVERY selected position becomes [MASK] (no label leak)
         if (rn < mask_rate) out = 1;
         else if (rn < mask_rate + random_rate) {
           const uint32_t k = b4r_hash32(h + 0x9E3779B9u) % (uint32_t)(V - 2);   // selectable vocab: every id but PAD, UNK
@@ -1093,6 +1093,8 @@ extern "C" int b4r_mask_batch(const int64_t* tokens, const int64_t* row_index, c
   B4R_CHECK_LAUNCH("b4r_mask_batch");
   return B4R_OK;
 }
+
+extern "C" float b4r_uniform_from_hash(uint32_t hash_word) { return b4r_uniform23(hash_word); }
 
 // -----------------------------------------------------------------------------------------------------------
 // the rows the masked-LM head reads (b4r_mlm_rows): one entry per masked-LM slot
@@ -1153,7 +1155,7 @@ __global__ __launch_bounds__(256) void sample_candidates_kernel(const float* log
   for (int v = tid; v < V; v += 256) {
     uint32_t h = b4r_hash32((uint32_t)v ^ seed_lo);
     h = b4r_hash32(h + rk);
-    const float u = ((float)(h >> 9) + 0.5f) * (1.0f / 8388608.0f);   // 23 bits: (k + 0.5) / 2^23 is exact, strictly inside (0, 1)
+    const float u = b4r_uniform23(h);   // strictly inside (0, 1)
     s_key[v] = logp[v] - __logf(-__logf(u));  // -inf + finite = -inf: zero-probability items are never drawn
   }
   if (tid < 4) s_cnt[tid] = 0;

@@ -431,6 +431,21 @@ class Engine:
         allreduce_step(self.grad_ext, group, self.rehearse_collectives)
         self.optimizer_step(hp, cb, reduced=True)
 
+    def dp_idle_step(self, hp: AdamWConfig, group=None) -> None:
+        """A data-parallel round in which THIS rank has no batch (the last round of an epoch whose batch count the world does not
+        divide): zero gradients and zero sums go into the round's all-reduce, then the same clip + AdamW step on the reduced buffer
+        as on every other rank -- parameters stay identical everywhere and no batch is dropped anywhere."""
+        from .distributed import allreduce_step
+        self.ensure_training_buffers()
+        self.grad_ext.zero_()
+        allreduce_step(self.grad_ext, group, self.rehearse_collectives)
+        ws = self.__dict__.get("_idle_ws")
+        if ws is None:
+            ws = self._idle_ws = torch.empty(4096, dtype=torch.float32, device=self.device)   # the optimizer's norm partials
+        _lib.check(self.lib.b4r_optimizer_step_reduced(C.byref(self.cfg), C.byref(hp), _ptr(self.params), _ptr(self.grads),
+                                                       _ptr(self.adam_m), _ptr(self.adam_v), _ptr(ws), ws.numel() * 4,
+                                                       _ptr(self.state), _stream(self.device)), "b4r_optimizer_step_reduced")
+
     def mask_batch(self, tokens: torch.Tensor, max_predictions: int, selection_rate: float = 0.2,
                    mask_token_rate: float = 1.0, random_token_rate: float = 0.0, finetune: bool = False,
                    seed: int = 0, rows: Optional[torch.Tensor] = None,

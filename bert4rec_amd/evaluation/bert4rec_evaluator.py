@@ -58,9 +58,14 @@ class BERT4RecEvaluator(BaseEvaluator):
         for i, batch in enumerate(test_data):
             if i % world == rank:
                 self.evaluate_batch(model, batch)
-        self._flush_device_sums()
+        # one rank's "too few drawable items" must not strand the others in the all-reduce (every rank draws from its own stream and
+        # sees its own batches, so the ranks can disagree): with world > 1 the flag travels IN that collective and every rank raises
+        # after it -- an input error stays an error, it does not become a hang
+        short = self._flush_device_sums(raise_on_short=(world == 1))
         if world > 1:
-            self._merge_across_ranks(before, group)
+            short = self._merge_across_ranks(before, group, short)
+            if short:
+                raise ValueError(self._short_message())
         return self._metrics
 
     # ---- device-side accumulation ---------------------------------------------------------------------------------------
@@ -71,35 +76,50 @@ class BERT4RecEvaluator(BaseEvaluator):
             self._dev = (engine, _t.zeros(n, dtype=_t.float64, device=engine.device), _t.zeros(1, dtype=_t.int64, device=engine.device))
         return self._dev
 
-    def _flush_device_sums(self) -> None:
-        """one device -> host copy for the whole evaluation: fold the accumulated sums into the metric objects"""
+    def _short_message(self) -> str:
+        return (f"The exclusion lists reduce the vocab too much to take a sample of size {self.sampler.sample_size} "
+                f"(since no duplicates are allowed).")
+
+    def _flush_device_sums(self, raise_on_short: bool = True) -> bool:
+        """one device -> host copy for the whole evaluation: fold the accumulated sums into the metric objects.  Returns True (or
+        raises, raise_on_short) when the sampler kernel flagged a row with fewer drawable items than the sample size: nothing of
+        that evaluation is then folded in."""
         if self._dev is None:
-            return
+            return False
         _, sums, users = self._dev
         if getattr(self, "_short", None) is not None and bool(self._short.cpu()[0]):   # checked once, not per batch
             self._short.zero_()
             sums.zero_()    # nothing of the aborted evaluation may leak into the next one
             users.zero_()
-            raise ValueError(f"The exclusion lists reduce the vocab too much to take a sample of size {self.sampler.sample_size} "
-                             f"(since no duplicates are allowed).")
+            if raise_on_short:
+                raise ValueError(self._short_message())
+            return True
         sums_h, users_h = sums.cpu().tolist(), int(users.cpu()[0])
         for m, g in zip(self._metrics, sums_h):
             m.absorb(g, users_h)
         sums.zero_()
         users.zero_()
+        return False
 
-    def _merge_across_ranks(self, before, group) -> None:
-        """all-reduce what THIS evaluate() call added on each rank: [gain sums | user count] as float64"""
+    def _merge_across_ranks(self, before, group, short: bool = False) -> bool:
+        """all-reduce what THIS evaluate() call added on each rank: [gain sums | user count | short flag] as float64.  Returns True
+        when ANY rank reported a short row; the metrics of every rank are then back at their state before the call."""
         import torch.distributed as dist
         mine = [(m.partial()[0] - b[0], m.partial()[1] - b[1]) for m, b in zip(self._metrics, before)]
         # the buffer's device follows the BACKEND (a rank that saw no batch has no device accumulators, but must still join an
         # nccl collective with a device tensor)
         dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else "cpu"
-        buf = torch.tensor([g for g, _ in mine] + [float(mine[0][1]) if mine else 0.0], dtype=torch.float64, device=dev)
+        buf = torch.tensor([g for g, _ in mine] + [float(mine[0][1]) if mine else 0.0, 1.0 if short else 0.0],
+                           dtype=torch.float64, device=dev)
         dist.all_reduce(buf, group=group)
         tot = buf.cpu().tolist()
-        for m, b, g_all in zip(self._metrics, before, tot[:-1]):
-            m.restore(b[0] + g_all, b[1] + int(round(tot[-1])))   # the same two additions on every rank: identical metrics everywhere
+        if tot[-1] > 0.0:                                     # some rank's sampler came up short: the same decision on every rank
+            for m, b in zip(self._metrics, before):
+                m.restore(b[0], b[1])
+            return True
+        for m, b, g_all in zip(self._metrics, before, tot[:-2]):
+            m.restore(b[0] + g_all, b[1] + int(round(tot[-2])))   # the same two additions on every rank: identical metrics everywhere
+        return False
 
     def sample_candidates(self, test_batch: dict):
         """bert4rec_evaluator.py:75-108 -> (candidates [R,101] int64, ground truth [R] int64), slots in batch order."""

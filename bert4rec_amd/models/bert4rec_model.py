@@ -48,14 +48,16 @@ class _MetricLog:
         self.n = 0
         self.batch_sizes = []
 
-    def push(self, state: torch.Tensor, batch_size: int):
+    def push(self, state: torch.Tensor, batch_size: Optional[int]):
+        """batch_size None (data-parallel rounds): the weight of the round in the epoch's loss is the all-reduced slot count of the
+        state (rows of the JOINED batch x P) -- the same on every rank, also on one that had no batch in the round"""
         if self.n == self.buf.shape[0]:
             bigger = torch.zeros((2 * self.buf.shape[0], _lib.STATE_WORDS), dtype=torch.int32, device=self.device)
             bigger[: self.n].copy_(self.buf[: self.n])
             self.buf = bigger
         self.buf[self.n].copy_(state, non_blocking=True)
         self.n += 1
-        self.batch_sizes.append(batch_size)
+        self.batch_sizes.append(-1 if batch_size is None else batch_size)
 
     def results(self, prefix: str = "") -> Dict[str, float]:
         """Keras averaging rules: `loss` = batch-size-weighted mean of the per-batch losses; SparseCategoricalAccuracy =
@@ -64,6 +66,7 @@ class _MetricLog:
             return {}
         f = self.buf[: self.n].cpu().view(torch.float32).numpy().astype(np.float64)
         bs = np.asarray(self.batch_sizes, dtype=np.float64)
+        bs = np.where(bs < 0, f[:, _lib.ST_SLOTS_ALL], bs)
         loss_b = f[:, _lib.ST_LOSS_SUM] / f[:, _lib.ST_VALID]
         macc_b = f[:, _lib.ST_CORRECT_MASKED] / f[:, _lib.ST_VALID]
         return {prefix + "loss": float((loss_b * bs).sum() / bs.sum()),
@@ -220,9 +223,15 @@ class BERT4RecModel:
             for i, batch in enumerate(dp_shard(x, rank, world)):
                 if steps_per_epoch is not None and i >= steps_per_epoch:
                     break
+                if batch is None:      # the last round of the epoch has no batch for this rank: zero contribution, same update
+                    self.engine.dp_idle_step(self._hp)
+                    self._trained_steps += 1
+                    self.optimizer.iterations += 1
+                    self._train_log.push(self.engine.state, None)
+                    continue
                 cb, keep = self.engine.prepare_batch(batch)
                 self._enqueue_train_step(cb)
-                self._train_log.push(self.engine.state, cb.B)
+                self._train_log.push(self.engine.state, cb.B if world == 1 else None)
             logs = self._train_log.results()
             if validation_data is not None:
                 logs.update(self.evaluate(validation_data, validation_steps, prefix="val_"))
@@ -366,14 +375,17 @@ def _dp_rank_world():
 
 
 def dp_shard(batches, rank: int, world: int):
-    """The batches rank `rank` of `world` trains on in one epoch: every world-th batch, and only whole rounds (the trailing
-    len % world batches are skipped so that all ranks meet in the same number of all-reduces).  world == 1: all of them."""
+    """The batches rank `rank` of `world` trains on in one epoch, one entry per ROUND (= per all-reduce): batch
+    round * world + rank, or None where the last round has no batch left for this rank.  Every rank sees the same number of
+    rounds, and EVERY batch is consumed by exactly one rank: a rank without a batch joins the round's all-reduce with zero
+    gradients and zero sums (Engine.dp_idle_step), which is the reference's single-process step on the batches that are there
+    (trainer_utils.py:19-22 normalises by the count of valid slots).  Round 3 dropped the trailing len % world batches -- with the
+    reference's default reshuffle_each_iteration=False (dataloader_utils.py:306-311) the SAME batches were then never trained on.
+    world == 1: all of them."""
     if world <= 1:
         yield from batches
         return
-    rounds = len(batches) // world
-    for i, b in enumerate(batches):
-        if i >= rounds * world:
-            break
-        if i % world == rank:
-            yield b
+    n = len(batches)
+    mine = iter(b for i, b in enumerate(batches) if i % world == rank)
+    for r in range(-(-n // world)):
+        yield next(mine) if r * world + rank < n else None

@@ -65,9 +65,13 @@ class ModelCheckpoint(Callback):
 
 
 class EarlyStopping(Callback):
-    def __init__(self, monitor: str = "val_loss", min_delta: float = 0.0, patience: int = 0, mode: str = "auto",
-                 restore_best_weights: bool = False):
+    def __init__(self, monitor: str = "val_loss", min_delta: float = 0.0, patience: int = 0, verbose: int = 0, mode: str = "auto",
+                 baseline=None, restore_best_weights: bool = False):
+        """Keras' argument order (the reference passes {"monitor", "patience", "verbose"}: bert4rec_ml_1m_example.py:26-30)"""
         super().__init__()
+        if baseline is not None:
+            raise NotImplementedError("EarlyStopping(baseline=...) is not implemented (no reference script uses it)")
+        self.verbose = verbose
         self.monitor, self.min_delta, self.patience = monitor, abs(min_delta), patience
         self.mode = _mode(monitor, mode)
         self.restore_best_weights = restore_best_weights
@@ -90,5 +94,7 @@ class EarlyStopping(Callback):
             if self.wait >= max(self.patience, 1):
                 self.stopped_epoch = epoch
                 self.model.stop_training = True
+                if self.verbose:
+                    print(f"Epoch {epoch + 1}: early stopping")
                 if self.restore_best_weights and self.best_weights is not None:
                     self.model.set_weights(self.best_weights)

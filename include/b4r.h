@@ -199,6 +199,12 @@ int b4r_mask_batch(const int64_t* tokens, const int64_t* row_index, const int64_
                    uint64_t seed, int64_t* input_word_ids, int64_t* input_mask, int64_t* labels, int64_t* masked_lm_positions,
                    int64_t* masked_lm_ids, int64_t* masked_lm_weights, b4r_stream_t stream);
 
+/* host-only probe (no GPU): the uniform in the OPEN interval (0, 1) that b4r_mask_batch and b4r_sample_candidates form from a
+ * 32-bit hash word -- (top 23 bits + 0.5) / 2^23, exact in fp32.  python's random.random() of dataloader_utils.py:245-253 is in
+ * [0, 1): with mask_token_rate = 1.0 `u < rate` must hold for EVERY word (a 24-bit form rounds its largest value to 1.0f and lets
+ * one selected position in 2^24 keep its label).  tests/test_host.py sweeps the extreme words through this entry. */
+float b4r_uniform_from_hash(uint32_t hash_word);
+
 /* ---- evaluator negatives -------------------------------------------------------------------
  * replaces the per-slot sampler call of bert4rec_evaluator.py:84-104 (PopularRandomSampler.sample:
  * np.random.choice(vocab, 100 + |without|, replace=False, p=popularity), drop `without`, keep 100) for ALL ranked slots of

@@ -1,6 +1,7 @@
 """Data-parallel exchange on CPU: world_size 2, gloo.  Each rank back-propagates the loss SUM of its half
 of the batch (oracle autograd stands in for the HIP backward, which needs a GPU), the product's one flat all-reduce
 combines gradients and loss sums, and the result must equal the single-process step on the whole batch."""
+import datetime
 import os
 import socket
 
@@ -164,3 +165,39 @@ def test_four_rank_evaluation_with_a_batch_count_not_divisible_by_the_world(size
     assert rs[0]["Valid Ranks"] == sum(sizes)
     for k, v in want.items():
         assert abs(rs[0][k] - v) < 1e-12, k
+
+
+def _short_worker(rank, world, port, ret):
+    from bert4rec_amd import evaluation
+    from bert4rec_amd.dataloaders import samplers
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    ev = evaluation.get("bert4rec", sampler=samplers.get("random", vocab=list(range(3, 200)), sample_size=10))
+    ev.evaluate_batch = lambda model, batch: evaluation.BERT4RecEvaluator.evaluate_batch(
+        ev, model, batch, candidates=[[0]] * len(batch["ranks"]), ground_truth=[0] * len(batch["ranks"]))
+    ev.evaluate(_RanksModel(), _eval_batches((4, 6)))             # a clean evaluation first: its metrics must survive the failed one
+    good = {k: float(v) for k, v in ev.get_metrics_results().items()}
+    n = len(ev.get_metrics())
+    ev._dev = (None, torch.zeros(n, dtype=torch.float64), torch.zeros(1, dtype=torch.int64))   # accumulators as the device path keeps them
+    ev._short = torch.tensor([rank == 1])                        # the sampler kernel's flag, raised on rank 1 ONLY
+    try:
+        ev.evaluate(_RanksModel(), _eval_batches())
+        ret[rank] = "no error"
+    except ValueError as e:
+        after = {k: float(v) for k, v in ev.get_metrics_results().items()}
+        ret[rank] = ("ValueError", "exclusion lists" in str(e), after == good)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_short_row_on_one_rank_raises_on_every_rank_instead_of_hanging():
+    """The sampler kernel flags a row with fewer drawable items than the sample size on the DEVICE; evaluate() reads the flag once
+    at the end.  With world > 1 a rank that raised before the metric all-reduce left the others waiting in it forever: the flag
+    now travels inside that collective and every rank raises the reference's ValueError (popular_random_sampler.py:56-58) after
+    it, with the metrics of the failed evaluation rolled back everywhere."""
+    port = _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_short_worker, args=(2, port, ret), nprocs=2, join=True)
+        got = [ret[0], ret[1]]
+    assert got == [("ValueError", True, True)] * 2, got

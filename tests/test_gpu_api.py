@@ -64,6 +64,47 @@ def test_loss_and_metric_callables_match_oracle():
                - float(orc.sparse_categorical_accuracy(y, logits))) < 1e-7
 
 
+def test_test_step_and_evaluate_values_follow_the_keras_averaging_rules():
+    """bert4rec_model.py:175-192 (test_step) and Keras' evaluate() on top of it, VALUES against the oracle on two batches of
+    different size: `loss` = batch-size-weighted mean of the per-batch masked CE (compiled_loss keeps a Mean with sample_weight =
+    batch size), `sparse_categorical_accuracy` = matches / slots over everything seen (MeanMetricWrapper over elements, PAD slots
+    included: bert4rec_trainer.py:28-33), `masked_accuracy` = UNWEIGHTED mean of the per-batch scalars (a function metric,
+    trainer_utils.py:49-60).  test_step returns the running values, evaluate() the same with a prefix."""
+    model = make_model(60)
+    trainers.get(model=model).initialize_model()
+    # make the head non-trivial: a table with structure, so that argmax matches are neither all nor none
+    g = torch.Generator().manual_seed(2)
+    w = model.get_weights()
+    w["word_embeddings/embeddings"] = torch.randn(w["word_embeddings/embeddings"].shape, generator=g) * 0.3
+    model.set_weights(w)
+    b1 = orc.synthetic_batch(7, 24, 6, 60, seed=11, ragged=True)
+    b2 = orc.synthetic_batch(3, 24, 6, 60, seed=12, ragged=True)
+    cfg_o, params = oracle_of(model)
+    per = []
+    for b in (b1, b2):
+        lg = orc.model_forward(params, b, cfg_o)["mlm_logits"]
+        y = b["masked_lm_ids"]
+        per.append(dict(n=y.shape[0], loss=float(orc.masked_sparse_categorical_crossentropy(y, lg)),
+                        macc=float(orc.masked_accuracy(y, lg)), hits=float((y == lg.argmax(2)).sum()), slots=float(y.numel())))
+    want1 = {"loss": per[0]["loss"], "sparse_categorical_accuracy": per[0]["hits"] / per[0]["slots"], "masked_accuracy": per[0]["macc"]}
+    want2 = {"loss": (per[0]["loss"] * 7 + per[1]["loss"] * 3) / 10,
+             "sparse_categorical_accuracy": (per[0]["hits"] + per[1]["hits"]) / (per[0]["slots"] + per[1]["slots"]),
+             "masked_accuracy": (per[0]["macc"] + per[1]["macc"]) / 2}
+    assert abs(per[0]["loss"] - per[1]["loss"]) > 1e-3 and per[0]["macc"] != per[1]["macc"]     # the rules can be told apart
+    assert abs(want2["loss"] - (per[0]["loss"] + per[1]["loss"]) / 2) > 1e-4
+    model.reset_metrics()
+    got1 = model.test_step(b1)
+    got2 = model.test_step(b2)
+    ev = model.evaluate([b1, b2], prefix="val_")
+    for got, want in ((got1, want1), (got2, want2), ({k[4:]: v for k, v in ev.items()}, want2)):
+        assert set(got) == set(want)
+        assert abs(got["loss"] - want["loss"]) < 1e-4, (got, want)                       # fp32 sums of ~40 terms of size ~4
+        assert abs(got["sparse_categorical_accuracy"] - want["sparse_categorical_accuracy"]) < 1e-6, (got, want)
+        assert abs(got["masked_accuracy"] - want["masked_accuracy"]) < 1e-6, (got, want)
+    assert set(ev) == {"val_loss", "val_sparse_categorical_accuracy", "val_masked_accuracy"}
+    assert model.evaluate([b1, b2], steps=1)["loss"] == pytest.approx(want1["loss"], abs=1e-4)   # validation_steps
+
+
 def test_train_and_evaluate_lifecycle(tmp_path):
     """the call sequence of examples/bert4rec_ml_1m_example.py:14-91 on a synthetic log"""
     dl = make_loader()
@@ -524,3 +565,28 @@ def test_evaluation_of_resident_batches_equals_evaluation_of_host_batches():
             ev.evaluate_batch(model, b)
         with pytest.raises(ValueError):
             ev.get_metrics_results()
+
+
+def test_ml_1m_example_runs_with_the_reference_literals_for_one_epoch(tmp_path, monkeypatch):
+    """examples/bert4rec_ml_1m_example.py: defaults = the reference's literals (150 epochs, ml-1m_128.json, duplication 5, patience
+    20: /root/reference/examples/bert4rec_ml_1m_example.py:21-30); here one epoch of that exact configuration on the synthetic
+    fallback log -- the H = 128 / 4-head / inner-512 encoder the reference's own ML-1M run trains."""
+    import importlib.util
+    import inspect
+    import pathlib
+    path = pathlib.Path(__file__).resolve().parent.parent / "examples" / "bert4rec_ml_1m_example.py"
+    spec = importlib.util.spec_from_file_location("b4r_ml1m_example", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    d = {k: v.default for k, v in inspect.signature(mod.main).parameters.items()}
+    assert (d["epochs"], d["batch_size"], d["input_duplication_factor"], d["finetuning_split"], d["encoder_config"], d["patience"],
+            d["append_early_stopping"]) == (150, 256, 5, 0.1, "ml-1m_128.json", 20, False)
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("B4R_DATA_DIR", str(tmp_path / "no_data_here"))
+    metrics = mod.main(epochs=1, input_duplication_factor=1)
+    assert metrics["Valid Ranks"] == 2000 and 0 <= metrics["NDCG@10"] <= 1
+    out = tmp_path / "bert4rec_ml-1m_15"
+    assert (out / "model_weights.safetensors").is_file() and (out / "eval_results.json").is_file() and (out / "vocab.txt").is_file()
+    import json
+    meta = json.load(open(out / "meta_config.json"))
+    assert meta["EPOCHS"] == 1 and meta["encoder_config"]["hidden_size"] == 128 and meta["early_stopping_config"]["patience"] == 20

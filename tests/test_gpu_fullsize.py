@@ -55,7 +55,11 @@ def test_full_batch_forward_matches_oracle(cfg_o, shp, rate):
     for r in torch.nonzero(~same).flatten().tolist():
         gap = (tb.values[r][:-1] - tb.values[r][1:]).min()
         assert float(gap) < 2e-4, f"slot {r}: top-10 differs with a logit gap of {float(gap):.2e}"
-    assert float(same.float().mean()) > 0.99    # random-init logits are close together; measured 0.9989 (steam) .. 0.9998 (ml1m)
+    # the END-TO-END contract (README / DESIGN §6): the ranking kernel is bit-exact given the hidden state; across two float
+    # implementations of the encoder >= 99.9 % of the top-10 lists are identical at the headline configuration, and every list
+    # that differs does so between items whose oracle logits tie within 2e-4 (asserted above).  Random-init logits are close
+    # together; measured 0.9998 (ml1m, V = 3709) and 0.9989 (steam: 3.5 x the items in the same logit range)
+    assert float(same.float().mean()) >= (0.999 if cfg_o.vocab_size < 5000 else 0.998), float(same.float().mean())
 
 
 def test_full_ml1m_batch_loss_and_gradients_match_oracle():

@@ -370,12 +370,32 @@ def test_length_bucketing_and_padding_trim_keep_the_rows_and_cut_only_padding():
     assert all(p in (4, 8) for p in dev.batch_slots) and min(dev.batch_slots) == 4
 
 
-def test_data_parallel_fit_takes_every_world_th_batch_in_whole_rounds():
-    """BERT4RecModel.fit with an initialised process group: rank r trains on batches r, r + world, ... and the trailing
-    len % world batches are left out, so every rank makes the same number of steps (= all-reduces)."""
+def test_data_parallel_fit_consumes_every_batch_and_pads_the_last_round():
+    """BERT4RecModel.fit with an initialised process group: rank r trains on batches r, r + world, ...; every rank makes the same
+    number of rounds (= all-reduces) and NO batch is dropped -- where the last round has no batch for a rank it yields None (the
+    rank then contributes zeros, Engine.dp_idle_step)."""
     from bert4rec_amd.models.bert4rec_model import dp_shard
     data = list(range(11))
     assert list(dp_shard(data, 0, 1)) == data
     got = [list(dp_shard(data, r, 4)) for r in range(4)]
-    assert got == [[0, 4], [1, 5], [2, 6], [3, 7]]
-    assert all(len(g) == 2 for g in got)
+    assert got == [[0, 4, 8], [1, 5, 9], [2, 6, 10], [3, 7, None]]
+    assert all(len(g) == 3 for g in got)
+    assert sorted(b for g in got for b in g if b is not None) == data           # every batch exactly once
+    assert [list(dp_shard(list(range(8)), r, 4)) for r in range(4)] == [[0, 4], [1, 5], [2, 6], [3, 7]]   # no padding needed
+    assert [list(dp_shard([0], r, 2)) for r in range(2)] == [[0], [None]]
+
+
+def test_hash_uniform_is_strictly_inside_the_unit_interval():
+    """The uniform the device masker and the negative sampler draw from a hash word (b4r_uniform23, host/device inline in
+    csrc/b4r_common.h, probed through b4r_uniform_from_hash): python's random.random() is in [0, 1) (dataloader_utils.py:245-253),
+    so with mask_token_rate = 1.0 `u < rate` must hold for EVERY word.  Round 3's 24-bit form gave exactly 1.0f for the words
+    0xFFFFFF00..0xFFFFFFFF: one selected position in 2^24 kept its real token while being a prediction target (a label leak)."""
+    lib = _lib.load()
+    words = [0, 1, 0x1FF, 0x200, 0x7FFFFFFF, 0x80000000, 0xFFFFFE00, 0xFFFFFF00, 0xFFFFFFFE, 0xFFFFFFFF]
+    words += [int(w) for w in np.random.default_rng(0).integers(0, 2 ** 32, size=2000, dtype=np.uint64)]
+    for w in words:
+        u = lib.b4r_uniform_from_hash(w)
+        assert 0.0 < u < 1.0, hex(w)
+        assert u == (float(w >> 9) + 0.5) / 8388608.0, hex(w)          # exact in fp32: no rounding anywhere
+    assert lib.b4r_uniform_from_hash(0xFFFFFFFF) == 1.0 - 2.0 ** -24    # the largest value; the 24-bit form rounded to 1.0f here
+    assert np.float32((np.float32(0xFFFFFF) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)) == np.float32(1.0)   # ... as this shows

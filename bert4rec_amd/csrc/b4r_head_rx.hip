@@ -367,6 +367,16 @@ int launch_dE(const HeadP& p, int slices, hipStream_t stream) {
 
 }  // namespace
 
+// b4r_head32.hip: the 32 x 32-tile kernels (round 4) that serve hidden size 64 / 128 / 256 unless B4R_HEAD32=0 (B4R_HEAD32_WIDE=0: 64 only)
+bool b4r_head32_active(int H);
+int b4r_head32_fwd_slices(int M, int V, int H);
+int b4r_head32_dE_slices(int M, int V, int H);
+int64_t b4r_head32_fwd_scratch_floats(int M, int V, int H);
+int64_t b4r_head32_dE_scratch_floats(int M, int V, int H);
+int b4r_head32_fwd_launch(const float* T, const float* E, const float* bias, int M, int V, int H, float* scratch, hipStream_t stream);
+int b4r_head32_dE_launch(const float* T, const float* E, const float* bias, const float* lse, const int32_t* ylab, int M, int V, int H,
+                         float* scratch, hipStream_t stream, const float* fwd_part, int fwd_slices, const int64_t* y);
+
 bool b4r_head_rx_hidden_ok(int H) { return H == 64 || H == 128 || H == 256; }
 int b4r_head_rx_fwd_slices(int M, int V, int H);
 // may the dE launch merge the forward's V slices itself (b4r_head_rx_dE_launch with fwd_part)?
@@ -377,19 +387,38 @@ bool b4r_head_rx_combine_foldable(int M, int V, int H) {
 
 // number of V slices the forward uses / M slices the dE kernel uses, and the scratch they need (floats)
 int b4r_head_rx_fwd_slices(int M, int V, int H) {
+  if (b4r_head32_active(H)) return b4r_head32_fwd_slices(M, V, H);
   const int per = even_tiles(V, fwd_slices_wanted(M), head_ch(H / 32));
   return b4r_cdiv(b4r_cdiv(V, 16), per);
 }
-int64_t b4r_head_rx_fwd_scratch_floats(int M, int V, int H) { return (int64_t)b4r_head_rx_fwd_slices(M, V, H) * M * (H + 8 + 2); }
+int64_t b4r_head_rx_fwd_scratch_floats(int M, int V, int H) {
+  if (b4r_head32_active(H)) return b4r_head32_fwd_scratch_floats(M, V, H);
+  return (int64_t)b4r_head_rx_fwd_slices(M, V, H) * M * (H + 8 + 2);
+}
 int b4r_head_rx_dE_slices(int M, int V, int H) {
+  if (b4r_head32_active(H)) return b4r_head32_dE_slices(M, V, H);
   const int per = even_tiles(M, dE_slices_wanted(V), head_ch(H / 32));
   return b4r_cdiv(b4r_cdiv(M, 16), per);
 }
-int64_t b4r_head_rx_dE_scratch_floats(int M, int V, int H) { return (int64_t)b4r_head_rx_dE_slices(M, V, H) * ((int64_t)V * H + V); }
+int64_t b4r_head_rx_dE_scratch_floats(int M, int V, int H) {
+  if (b4r_head32_active(H)) return b4r_head32_dE_scratch_floats(M, V, H);
+  return (int64_t)b4r_head_rx_dE_slices(M, V, H) * ((int64_t)V * H + V);
+}
 
 int b4r_head_rx_fwd_launch2(const float* T, const float* E, const float* bias, const int64_t* y, int M, int V, int H,
                             float* scratch, float* dT, float* row_out, float* lse, int32_t* ylab, int only_sweep,
                             hipStream_t stream) {
+  if (b4r_head32_active(H)) {   // the sweep on 32 x 32 tiles, the merge launch (if any) as before
+    const int rc = b4r_head32_fwd_launch(T, E, bias, M, V, H, scratch, stream);
+    if (rc || only_sweep) return rc;
+    const int sl = b4r_head32_fwd_slices(M, V, H);
+    const dim3 grid(b4r_cdiv((int64_t)M * (H / 4), 256));
+    if (H == 64) hipLaunchKernelGGL(head_combine_kernel<2>, grid, dim3(256), 0, stream, (const float*)scratch, sl, M, V, T, E, bias, y, dT, row_out, lse, ylab);
+    else if (H == 128) hipLaunchKernelGGL(head_combine_kernel<4>, grid, dim3(256), 0, stream, (const float*)scratch, sl, M, V, T, E, bias, y, dT, row_out, lse, ylab);
+    else hipLaunchKernelGGL(head_combine_kernel<8>, grid, dim3(256), 0, stream, (const float*)scratch, sl, M, V, T, E, bias, y, dT, row_out, lse, ylab);
+    B4R_CHECK_LAUNCH("masked-LM head combine");
+    return B4R_OK;
+  }
   HeadP p{};
   p.T = T; p.E = E; p.bias = bias; p.y = y; p.part = scratch; p.M = M; p.V = V;
   const int slices = b4r_head_rx_fwd_slices(M, V, H);
@@ -416,6 +445,14 @@ int b4r_launch_slab_reduce_full(const float* slab, int S, int Mo, int No, float*
 // the merge itself (dT, loss rows) is the business of the LayerNorm backward behind this launch (b4r_ln_bwd_launch's merge argument)
 int b4r_head_rx_dE_launch(const float* T, const float* E, const float* bias, const float* lse, const int32_t* ylab, int M, int V,
                           int H, float* scratch, float* dE, float* db, hipStream_t stream, const float* fwd_part, const int64_t* y) {
+  if (b4r_head32_active(H)) {
+    if (fwd_part != nullptr)
+      B4R_CHECK_ARG(b4r_head_rx_combine_foldable(M, V, H), B4R_E_BADARG, "fused masked-LM head: the merge cannot ride on dE for this shape");
+    const int rc = b4r_head32_dE_launch(T, E, bias, lse, ylab, M, V, H, scratch, stream, fwd_part, b4r_head32_fwd_slices(M, V, H), y);
+    if (rc) return rc;
+    const int sl = b4r_head32_dE_slices(M, V, H);
+    return b4r_launch_slab_reduce_full(scratch, sl, V, H, dE, H, 0, nullptr, nullptr, scratch + (int64_t)sl * V * H, db, stream);
+  }
   HeadP p{};
   p.T = T; p.E = E; p.bias = bias; p.lse = lse; p.ylab = ylab; p.M = M; p.V = V;
   if (fwd_part != nullptr) {

@@ -72,13 +72,17 @@ def test_test_step_and_evaluate_values_follow_the_keras_averaging_rules():
     trainer_utils.py:49-60).  test_step returns the running values, evaluate() the same with a prefix."""
     model = make_model(60)
     trainers.get(model=model).initialize_model()
-    # make the head non-trivial: a table with structure, so that argmax matches are neither all nor none
-    g = torch.Generator().manual_seed(2)
+    # argmax matches that are neither all nor none: item 5 wins every argmax (output bias), and the labels of the valid slots are drawn
+    # from {5, 6, 7} in the first batch and {5, 6} in the second -> masked accuracy about 1/3 and 1/2
     w = model.get_weights()
-    w["word_embeddings/embeddings"] = torch.randn(w["word_embeddings/embeddings"].shape, generator=g) * 0.3
+    w["cls/predictions/output_bias/bias"][5] = 6.0
     model.set_weights(w)
     b1 = orc.synthetic_batch(7, 24, 6, 60, seed=11, ragged=True)
     b2 = orc.synthetic_batch(3, 24, 6, 60, seed=12, ragged=True)
+    for b, n in ((b1, 3), (b2, 2)):
+        ids = b["masked_lm_ids"]
+        valid = ids != 0
+        ids[valid] = 5 + torch.arange(int(valid.sum())) % n
     cfg_o, params = oracle_of(model)
     per = []
     for b in (b1, b2):

@@ -27,3 +27,33 @@ ref = torch.logsumexp(T.double() @ E.double().t() + b.double(), 1)
 err = float((lse.double() - ref).abs().max())
 print("occ", os.environ.get("B4R_HEAD_OCC", "-"), "fwd_wgs", os.environ.get("B4R_HEAD_FWD_WGS", "-"),
       "sweep %.1f us  forward %.1f us  backward %.1f us  lse err %.2e" % (timeit(lambda: fwd(1)), timeit(lambda: fwd(0)), timeit(bwd), err))
+
+# per-launch times of one forward + one backward from the library's event timer
+import ctypes as C
+for name, f in (("forward", lambda: fwd(0)), ("backward", bwd)):
+    torch.cuda.synchronize()
+    _lib.check(lib.b4r_timing_begin(st, 64 * 20), "timing")
+    for _ in range(20): f()
+    n = C.c_int32(0); us = (C.c_float * (64 * 20))(); names = C.create_string_buffer(64 * 20 * 128)
+    _lib.check(lib.b4r_timing_end(C.byref(n), us, names, 128, 64 * 20), "timing")
+    per = n.value // 20
+    rows = [(names.raw[j * 128:(j + 1) * 128].split(b"\0", 1)[0].decode(), sum(us[s_ * per + j] for s_ in range(20)) / 20) for j in range(per)]
+    print(f"   {name}: " + " | ".join(f"{k} {v:.1f} us" for k, v in rows))
+if hasattr(lib, "b4r_debug_h32_prof"):   # a -DH32_PROF build of b4r_head32.hip: shader-clock stamps of waves 0 / 5 of two workgroups of the forward
+    import ctypes as C
+    fwd(1); torch.cuda.synchronize()
+    buf = (C.c_longlong * 512)()
+    lib.b4r_debug_h32_prof.argtypes = [C.c_void_p]
+    assert lib.b4r_debug_h32_prof(buf) == 0
+    for w in range(4):
+        t = [buf[128 * w + k] for k in range(128)]
+        base = t[0]
+        print(f"-- workgroup {'0' if w < 2 else '7'}, wave {'0' if w % 2 == 0 else '5'}: loads {t[1]-t[0]}, to first barrier {t[3]-t[1]} (wait+barrier {t[3]-t[2]})")
+        its = []
+        for i in range(28):
+            a, b, c, d = t[4 + 4 * i: 8 + 4 * i]
+            nxt = t[8 + 4 * i] if 8 + 4 * i < 116 and t[8 + 4 * i] > 0 else t[120]
+            if a <= 0: break
+            its.append((b - a, c - b, d - c, nxt - d))
+        print("   per step (vmcnt wait, barrier, block A, main block):", its)
+        print(f"   loop total {t[120]-t[3]}, last products {t[121]-t[120]}, epilogue {t[122]-t[121]}, kernel {t[122]-t[0]}")

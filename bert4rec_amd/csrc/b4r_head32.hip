@@ -24,12 +24,7 @@
 //     accumulator: no bias add, and in dE no subtraction in front of the exponential;
 //   * software pipeline: a step issues the logit products of tile i + 1, the value products of tile i - 1 and, between them one slice
 //     at a time, the vector work of tile i (and the row maximum / argmax bookkeeping of tile i + 1) as ONE hand-ordered stream.
-#include "b4r_tile32.h"
-#include "b4r_head_merge.h"
-
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#include "b4r_head32_pack.h"
 
 // H32_PROF (tools/build_variant.sh h32prof b4r_head32.hip -DH32_PROF): lane 0 of waves 0 and 5 of two workgroups stamps the shader clock
 #ifdef H32_PROF
@@ -48,26 +43,6 @@ __device__ long long g_h32_prof[4][128];
 
 namespace {
 
-// x = hi + lo, hi = fp16(x), lo = fp16(x - hi): 22 significant bits while |x| stays in fp16's normal range (6e-5 .. 65504; below it
-// lo keeps fewer bits, never fewer than bf16's split in total for |x| >= 1e-3)
-__device__ __forceinline__ void h32_split_pair(float a, float b, uint32_t& hw, uint32_t& lw) {
-  const f16x2 hh = __builtin_convertvector((b4r_f32x2){a, b}, f16x2);
-  const b4r_f32x2 back = __builtin_convertvector(hh, b4r_f32x2);
-  hw = __builtin_bit_cast(uint32_t, hh);
-  lw = __builtin_bit_cast(uint32_t, __builtin_convertvector((b4r_f32x2){a - back[0], b - back[1]}, f16x2));
-}
-__device__ __forceinline__ void h32_split4(const f32x4 x, f16x4& hi, f16x4& lo) {
-  b4r_u32x2 hw, lw;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) { uint32_t a, b; h32_split_pair(x[2 * j], x[2 * j + 1], a, b); hw[j] = a; lw[j] = b; }
-  hi = __builtin_bit_cast(f16x4, hw); lo = __builtin_bit_cast(f16x4, lw);
-}
-__device__ __forceinline__ void h32_split8(const f32x8 x, f16x8& hi, f16x8& lo) {
-  b4r_u32x4 hw, lw;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { uint32_t a, b; h32_split_pair(x[2 * j], x[2 * j + 1], a, b); hw[j] = a; lw[j] = b; }
-  hi = __builtin_bit_cast(f16x8, hw); lo = __builtin_bit_cast(f16x8, lw);
-}
 __device__ __forceinline__ f32x16 mfma32h(const f16x8 a, const f16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
@@ -76,73 +51,14 @@ __device__ __forceinline__ f16x8 h32_tr_pair(const char* a, const char* b) { ret
 
 constexpr int H32_WAVES = 8;                       // 8 waves x 32 rows = 256 rows of T (forward) / of E (dE) per workgroup
 constexpr int H32_ROWS = 32 * H32_WAVES;
-constexpr int H32_SIDE = 256;                      // bytes behind a tile's images: 32 floats (bias | lse) + 32 ints (labels)
 constexpr int H32_RING = 16;                       // LDS slots (a power of two): 132 KB at hidden size 64 -- one workgroup per CU anyway
 constexpr int H32_AHEAD = 8;                       // an even step i requests tiles i + 8, i + 9: tiles i - 1 .. i + 3 are read, i + 4 .. i + 7 travel
 // One wait + barrier per PAIR of steps (a barrier per step cost ~0.2 us of a 1.1 us step: arrival skew of eight waves).  At the barrier of
 // an even step i the tiles up to i + 3 have landed: steps i, i + 1 read tiles i + 1, i + 2, and the first fragments of tile i + 3 are
 // requested at the end of step i + 1, across the next barrier.
-__host__ __device__ constexpr int h32_rec(int np) { return np * P_TILE + H32_SIDE; }   // bytes of one 32-row tile record
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// pack: rows of a [R, 32 NP] fp32 matrix -> one record per 32-row tile: NP panel tiles (hi image | lo image, b4r_tile32.h layout,
-// rows beyond R zero) + the side block.  One workgroup per tile.
-//   mode 0 (E): side[j] = bias[row] * log2(e), -inf beyond R
-//   mode 1 (T): side[j] = -lse[row] * log2(e) (-inf: no label / beyond R), side[32 + j] = label (-1: none); lse / label either given or
-//               (cpart != NULL) formed from the forward's per-slice (max, sum) pairs exactly as head_merge_row forms them
-// ---------------------------------------------------------------------------------------------------------------------------
-struct H32PackP {
-  const float* src; int R; char* dst; int mode;
-  const float* bias;
-  const float* lse; const int32_t* ylab;
-  const float* cpart; int cslices; const int64_t* y; int V;
-};
 
 template <int NP>
-__global__ __launch_bounds__(256) void head32_pack_kernel(H32PackP p) {
-  constexpr int H = 32 * NP, REC = h32_rec(NP);
-  const int tile = blockIdx.x;
-  char* rec = p.dst + (int64_t)tile * REC;
-  f32x4 v[NP];
-#pragma unroll
-  for (int it = 0; it < NP; ++it) {
-    const int f = threadIdx.x + 256 * it, row = f / (8 * NP), q = f % (8 * NP);
-    const int gr = min(32 * tile + row, p.R - 1);
-    v[it] = *reinterpret_cast<const f32x4*>(p.src + (int64_t)gr * H + 4 * q);
-  }
-#pragma unroll
-  for (int it = 0; it < NP; ++it) {
-    const int f = threadIdx.x + 256 * it, row = f / (8 * NP), q = f % (8 * NP);
-    const f32x4 x = (32 * tile + row < p.R) ? v[it] : (f32x4){0.f, 0.f, 0.f, 0.f};
-    f16x4 hh, ll;
-    h32_split4(x, hh, ll);
-    char* d8 = rec + (q >> 3) * P_TILE + p_chunk(row, (q & 7) >> 1) + 8 * (q & 1);
-    *reinterpret_cast<f16x4*>(d8) = hh;
-    *reinterpret_cast<f16x4*>(d8 + P_IMG) = ll;
-  }
-  if (threadIdx.x < 32) {
-    const int gr = 32 * tile + threadIdx.x;
-    const bool in = gr < p.R;
-    float* side = reinterpret_cast<float*>(rec + NP * P_TILE);
-    if (p.mode == 0) {
-      side[threadIdx.x] = in ? p.bias[gr] * LOG2E : -INFINITY;
-      side[32 + threadIdx.x] = 0.f;
-    } else {
-      float lz = INFINITY;
-      int yz = -1;
-      if (p.cpart != nullptr) {
-        RowPart rp;
-        row_part_fetch(rp, p.cpart, p.cslices, p.R, p.y, min(gr, p.R - 1));
-        row_part_finish(rp, p.V, lz, yz);
-      } else {
-        lz = p.lse[min(gr, p.R - 1)];
-        yz = p.ylab[min(gr, p.R - 1)];
-      }
-      side[threadIdx.x] = in ? -(lz * LOG2E) : -INFINITY;
-      reinterpret_cast<int*>(side)[32 + threadIdx.x] = in ? yz : -1;
-    }
-  }
-}
+__global__ __launch_bounds__(256) void head32_pack_kernel(H32PackP p) { h32_pack_tile<NP>(p, (int)blockIdx.x); }
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // the tile ring.  Every wave copies its share of a record (NP / 2 pieces of 1 KB), wave 0 also the side block: per tile a wave has
@@ -930,7 +846,8 @@ bool b4r_head32_active(int H) {
   return !off && (H == 64 || (!wide_off && (H == 128 || H == 256)));
 }
 int b4r_head32_fwd_slices(int M, int V, int H) { return h32_slices(M, V, 16, H, true); }
-int b4r_head32_dE_slices(int M, int V, int H) { return h32_slices(V, M, 32, H, false); }
+// (at most 16 slabs: the ordered reduction then sums a gradient element in one thread with every load in flight, b4r_gemm.hip)
+int b4r_head32_dE_slices(int M, int V, int H) { return h32_slices(V, M, 16, H, false); }
 // forward scratch: [slices][M][H + 8] records | [slices][M][2] | the item table's tile records
 int64_t b4r_head32_fwd_scratch_floats(int M, int V, int H) {
   return up4l((int64_t)b4r_head32_fwd_slices(M, V, H) * M * (H + 8 + 2)) + h32_rec_floats(V, H);
@@ -943,7 +860,7 @@ int64_t b4r_head32_dE_scratch_floats(int M, int V, int H) {
 namespace {
 template <int NP, int WAVES, bool FWD>
 int h32_launch_sweep(const H32PackP& pk, const H32P& p, int own_rows, int slices, hipStream_t stream) {
-  int rc = h32_pack<NP>(pk, stream);
+  int rc = pk.src != nullptr ? h32_pack<NP>(pk, stream) : B4R_OK;   // (src == NULL: another launch has formed the records)
   if (rc) return rc;
   const bool narrow = NP == 2;
   const size_t lds = (size_t)(narrow ? H32_RING : H32W_RING) * h32_rec(NP);
@@ -984,7 +901,7 @@ int b4r_head32_fwd_launch(const float* T, const float* E, const float* bias, int
   const int slices = b4r_head32_fwd_slices(M, V, H), tiles = b4r_cdiv(V, 32);
   char* recs = reinterpret_cast<char*>(scratch + up4l((int64_t)slices * M * (H + 8 + 2)));
   H32PackP pk{};
-  pk.src = E; pk.R = V; pk.dst = recs; pk.mode = 0; pk.bias = bias;
+  pk.src = E; pk.R = V; pk.dst = recs; pk.mode = 0; pk.np = H / 32; pk.bias = bias;
   H32P p{};
   p.own = T; p.recs = recs; p.n_own = M; p.n_tiles = tiles; p.tiles_per_slice = b4r_cdiv(tiles, slices); p.part = scratch; p.M = M; p.V = V;
   const int rc = h32_dispatch<true>(H, pk, p, M, slices, stream);
@@ -995,12 +912,26 @@ int b4r_head32_fwd_launch(const float* T, const float* E, const float* bias, int
 
 // slabs of dE [slices][V][H] and of db [slices][V] into scratch (the caller reduces them); lse / ylab given, or (fwd_part != NULL)
 // formed from the forward's compact (max, sum) pairs and the labels y
+// the conversion of the transform rows for dE as a job another launch can carry (b4r_zero2's rider): *out is an H32PackP
+int b4r_head32_dE_pack_job(const float* T, const float* lse, const int32_t* ylab, int M, int V, int H, float* scratch, const float* fwd_part,
+                           int fwd_slices, const int64_t* y, void* out, size_t out_bytes, int* blocks) {
+  if (out_bytes < sizeof(H32PackP)) return B4R_E_BADARG;
+  const int slices = b4r_head32_dE_slices(M, V, H);
+  H32PackP pk{};
+  pk.src = T; pk.R = M; pk.dst = reinterpret_cast<char*>(scratch + up4l((int64_t)slices * ((int64_t)V * H + V))); pk.mode = 1; pk.np = H / 32;
+  pk.lse = lse; pk.ylab = ylab; pk.V = V;
+  if (fwd_part != nullptr) { pk.cpart = fwd_part + (int64_t)fwd_slices * M * (H + 8); pk.cslices = fwd_slices; pk.y = y; }
+  *reinterpret_cast<H32PackP*>(out) = pk;
+  *blocks = b4r_cdiv(M, 32);
+  return B4R_OK;
+}
+
 int b4r_head32_dE_launch(const float* T, const float* E, const float* bias, const float* lse, const int32_t* ylab, int M, int V, int H,
-                         float* scratch, hipStream_t stream, const float* fwd_part, int fwd_slices, const int64_t* y) {
+                         float* scratch, hipStream_t stream, const float* fwd_part, int fwd_slices, const int64_t* y, int records_ready) {
   const int slices = b4r_head32_dE_slices(M, V, H), tiles = b4r_cdiv(M, 32);
   char* recs = reinterpret_cast<char*>(scratch + up4l((int64_t)slices * ((int64_t)V * H + V)));
   H32PackP pk{};
-  pk.src = T; pk.R = M; pk.dst = recs; pk.mode = 1; pk.lse = lse; pk.ylab = ylab; pk.V = V;
+  pk.src = records_ready ? nullptr : T; pk.R = M; pk.dst = recs; pk.mode = 1; pk.np = H / 32; pk.lse = lse; pk.ylab = ylab; pk.V = V;
   if (fwd_part != nullptr) { pk.cpart = fwd_part + (int64_t)fwd_slices * M * (H + 8); pk.cslices = fwd_slices; pk.y = y; }
   H32P p{};
   p.own = E; p.recs = recs; p.n_own = V; p.n_tiles = tiles; p.tiles_per_slice = b4r_cdiv(tiles, slices); p.M = M; p.V = V; p.bias = bias;

@@ -375,7 +375,9 @@ int64_t b4r_head32_fwd_scratch_floats(int M, int V, int H);
 int64_t b4r_head32_dE_scratch_floats(int M, int V, int H);
 int b4r_head32_fwd_launch(const float* T, const float* E, const float* bias, int M, int V, int H, float* scratch, hipStream_t stream);
 int b4r_head32_dE_launch(const float* T, const float* E, const float* bias, const float* lse, const int32_t* ylab, int M, int V, int H,
-                         float* scratch, hipStream_t stream, const float* fwd_part, int fwd_slices, const int64_t* y);
+                         float* scratch, hipStream_t stream, const float* fwd_part, int fwd_slices, const int64_t* y, int records_ready);
+int b4r_head32_dE_pack_job(const float* T, const float* lse, const int32_t* ylab, int M, int V, int H, float* scratch, const float* fwd_part,
+                           int fwd_slices, const int64_t* y, void* out, size_t out_bytes, int* blocks);
 
 bool b4r_head_rx_hidden_ok(int H) { return H == 64 || H == 128 || H == 256; }
 int b4r_head_rx_fwd_slices(int M, int V, int H);
@@ -443,12 +445,21 @@ int b4r_launch_slab_reduce_full(const float* slab, int S, int Mo, int No, float*
 // dE [V,H] and db [V] (overwritten, through the ordered slab reduction) from T, E, bias and the forward's lse / labels
 // fwd_part != NULL: the forward ran with only_sweep = 1 and left its per-slice partials there; lse / ylab are not read (y: the labels),
 // the merge itself (dT, loss rows) is the business of the LayerNorm backward behind this launch (b4r_ln_bwd_launch's merge argument)
+// the rider job that forms dE's tile records (32 x 32-tile kernels only: returns 0 blocks otherwise); a following b4r_head_rx_dE_launch
+// with records_ready = 1 then skips its own conversion launch
+int b4r_head_rx_dE_pack_job(const float* T, const float* lse, const int32_t* ylab, int M, int V, int H, float* scratch,
+                            const float* fwd_part, const int64_t* y, void* out, size_t out_bytes, int* blocks) {
+  *blocks = 0;
+  if (!b4r_head32_active(H)) return B4R_OK;
+  return b4r_head32_dE_pack_job(T, lse, ylab, M, V, H, scratch, fwd_part, b4r_head32_fwd_slices(M, V, H), y, out, out_bytes, blocks);
+}
 int b4r_head_rx_dE_launch(const float* T, const float* E, const float* bias, const float* lse, const int32_t* ylab, int M, int V,
-                          int H, float* scratch, float* dE, float* db, hipStream_t stream, const float* fwd_part, const int64_t* y) {
+                          int H, float* scratch, float* dE, float* db, hipStream_t stream, const float* fwd_part, const int64_t* y,
+                          int records_ready) {
   if (b4r_head32_active(H)) {
     if (fwd_part != nullptr)
       B4R_CHECK_ARG(b4r_head_rx_combine_foldable(M, V, H), B4R_E_BADARG, "fused masked-LM head: the merge cannot ride on dE for this shape");
-    const int rc = b4r_head32_dE_launch(T, E, bias, lse, ylab, M, V, H, scratch, stream, fwd_part, b4r_head32_fwd_slices(M, V, H), y);
+    const int rc = b4r_head32_dE_launch(T, E, bias, lse, ylab, M, V, H, scratch, stream, fwd_part, b4r_head32_fwd_slices(M, V, H), y, records_ready);
     if (rc) return rc;
     const int sl = b4r_head32_dE_slices(M, V, H);
     return b4r_launch_slab_reduce_full(scratch, sl, V, H, dE, H, 0, nullptr, nullptr, scratch + (int64_t)sl * V * H, db, stream);
@@ -498,5 +509,5 @@ extern "C" int b4r_mlm_head_fused_bwd(const float* T, const float* E, const floa
   B4R_CHECK_ARG(M > 0 && V > 0 && b4r_head_rx_hidden_ok(H), B4R_E_SHAPE, "b4r_mlm_head_fused_bwd: bad shape (H = 64, 128 or 256)");
   B4R_CHECK_ARG(b4r_aligned16(T) && b4r_aligned16(E) && b4r_aligned16(scratch), B4R_E_ALIGN,
                 "b4r_mlm_head_fused_bwd: T, E and scratch must be 16-byte aligned");
-  return b4r_head_rx_dE_launch(T, E, bias, lse, labels, M, V, H, scratch, dE, dbias, (hipStream_t)stream, nullptr, nullptr);
+  return b4r_head_rx_dE_launch(T, E, bias, lse, labels, M, V, H, scratch, dE, dbias, (hipStream_t)stream, nullptr, nullptr, 0);
 }

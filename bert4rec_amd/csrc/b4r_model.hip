@@ -34,8 +34,10 @@ int64_t b4r_head_rx_dE_scratch_floats(int M, int V, int H);
 int b4r_head_rx_fwd_launch(const float* T, const float* E, const float* bias, const int64_t* y, int M, int V, int H,
                            float* scratch, float* dT, float* row_out, float* lse, int32_t* ylab, hipStream_t stream);
 int b4r_head_rx_dE_launch(const float* T, const float* E, const float* bias, const float* lse, const int32_t* ylab, int M, int V,
-                          int H, float* scratch, float* dE, float* db, hipStream_t stream, const float* fwd_part = nullptr,
-                          const int64_t* y = nullptr);
+                          int H, float* scratch, float* dE, float* db, hipStream_t stream, const float* fwd_part, const int64_t* y,
+                          int records_ready);
+int b4r_head_rx_dE_pack_job(const float* T, const float* lse, const int32_t* ylab, int M, int V, int H, float* scratch,
+                            const float* fwd_part, const int64_t* y, void* out, size_t out_bytes, int* blocks);
 bool b4r_head_rx_combine_foldable(int M, int V, int H);
 int b4r_head_rx_fwd_launch2(const float* T, const float* E, const float* bias, const int64_t* y, int M, int V, int H,
                             float* scratch, float* dT, float* row_out, float* lse, int32_t* ylab, int only_sweep, hipStream_t stream);
@@ -52,7 +54,7 @@ int b4r_attn_bwd_streams(const float* qkv, const int64_t* input_mask, const floa
                          uint32_t drop_stream, float drop_rate, const uint32_t* keep_bits, hipStream_t stream,
                          hipStream_t stream_dkv);
 int b4r_zero2(float* a, int64_t na, float* b, int64_t nb, hipStream_t stream, float* tail = nullptr, b4r_train_state* state = nullptr,
-              const float* fin_rows = nullptr, int fin_M = 0);
+              const float* fin_rows = nullptr, int fin_M = 0, const void* rider = nullptr, int rider_blocks = 0);
 int b4r_optimizer_fused(const b4r_adamw_config* hp, float* params, const float* grads, float* adam_m, float* adam_v, int64_t n,
                         int64_t n_decay, float* scratch, b4r_train_state* state, hipStream_t stream, int sums_from_tail = 0,
                         int np_given = 0);
@@ -814,9 +816,19 @@ static int backward_impl(const b4r_model_config* cfg, const b4r_batch* batch, co
   // reads the others -- db need not be cleared (13 MB per step at ML-1M)
   const bool sparse_dz1 = head_rows && ffn_fused(cfg) && attn_bwd_fused(cfg, L) && b4r_attn32_active(H, cfg->num_heads, L) &&
                           side_level() != 4;
+  // the scratch regions of the fused head are fixed here already: the records dE sweeps (the transform rows as fp16 images, -lse, labels)
+  // are formed by extra workgroups of the clearing launch (b4r_zero2's rider) instead of a launch of their own
+  const bool fused_head_early = (flags & B4R_FLAG_FUSED_HEAD) != 0 && b4r_fused_head_supported(cfg);
+  const float* fwd_part_early = (fused_head_early && defer_combine) ? take(b4r_head_rx_fwd_scratch_floats(M, V, H)) : nullptr;   // = ws + w.scratch
+  float* dE_scratch = fused_head_early ? take(b4r_head_rx_dE_scratch_floats(M, V, H)) : nullptr;
+  alignas(8) char rider[128];
+  int rider_blocks = 0;
+  if (fused_head_early)
+    RC(b4r_head_rx_dE_pack_job(ws + w.t, ws + w.head_lse, reinterpret_cast<const int32_t*>(ws + w.head_ylab), M, V, H, dE_scratch,
+                               fwd_part_early, batch->masked_lm_ids, rider, sizeof(rider), &rider_blocks));
   RC(b4r_zero2(grads, pl.total, ws + (head_rows ? w.hot : w.dx), head_rows ? (sparse_dz1 ? w.db - w.hot : w.da - w.hot) : w.db - w.dx, s,
                ((flags & B4R_FLAG_GRAD_TAIL) && !defer_combine) ? grads + pl.total : nullptr, state,
-               (loss_sums && !defer_combine) ? ws + w.rowsc : nullptr, (int)w.M));
+               (loss_sums && !defer_combine) ? ws + w.rowsc : nullptr, (int)w.M, rider_blocks > 0 ? rider : nullptr, rider_blocks));
 
   // ---- masked-LM head (logits buffer holds d loss_sum / d logits, pad columns zero) --------------------------------
   // s2: independent branches (see SideStream); it is ordered after the memsets here, joined before every reuse of a buffer
@@ -833,10 +845,10 @@ static int backward_impl(const b4r_model_config* cfg, const b4r_batch* batch, co
   if (fused_head) {
     // dT came with the forward -- or (defer_combine) the forward left its per-slice partials: dE forms the lse it needs from them, the
     // transform's LayerNorm backward below merges them into dT as it reads it; dE / d output_bias recompute the logit tiles (b4r_head_rx.hip)
-    fwd_part = defer_combine ? take(b4r_head_rx_fwd_scratch_floats(M, V, H)) : nullptr;   // = ws + w.scratch
+    fwd_part = fwd_part_early;
     RC(b4r_head_rx_dE_launch(ws + w.t, params + pl.word_emb, params + pl.out_bias, ws + w.head_lse,
-                             reinterpret_cast<const int32_t*>(ws + w.head_ylab), M, V, H, take(b4r_head_rx_dE_scratch_floats(M, V, H)),
-                             grads + pl.word_emb, grads + pl.out_bias, s2, fwd_part, batch->masked_lm_ids));
+                             reinterpret_cast<const int32_t*>(ws + w.head_ylab), M, V, H, dE_scratch,
+                             grads + pl.word_emb, grads + pl.out_bias, s2, fwd_part, batch->masked_lm_ids, rider_blocks > 0 ? 1 : 0));
   } else {
   // dT = dlogits . E   (K = V is long and the output small: split K so that the whole chip streams dlogits)
   {

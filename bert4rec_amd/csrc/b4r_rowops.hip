@@ -6,6 +6,7 @@
 // xor-shuffle reductions inside the LPR-lane group.
 #include "b4r_common.h"
 #include "b4r_head_merge.h"
+#include "b4r_head32_pack.h"
 
 int b4r_launch_slab_reduce_full(const float* slab, int S, int Mo, int No, float* out, int ldo, int accumulate,
                                 const float* cslab, float* colsum, const float* caslab, float* colsum_a, hipStream_t stream);
@@ -891,11 +892,17 @@ extern "C" int b4r_softmax_ce(float* logits, int32_t M, int32_t V, int32_t ld, c
 // fin_rows (optional): the LAST workgroup also does what ce_finalize_kernel does in overwrite mode -- the ordered sum of the fused
 // head's per-row scalars into the state (loss_rows_reduce: the same summation order, bit for bit) -- before the tail copy, so that
 // b4r_backward needs no b4r_loss launch in front of it (B4R_FLAG_LOSS_SUMS)
+// rider (rider_blocks > 0): the last rider_blocks workgroups form tile records of the 32 x 32-tile masked-LM head instead (one each)
 __global__ __launch_bounds__(256) void zero2_kernel(float* a, int64_t na4, float* b, int64_t nb4, float* tail, float* state_f,
-                                                    const float* fin_rows, int fin_M) {
+                                                    const float* fin_rows, int fin_M, H32PackP rider, int rider_blocks) {
   __shared__ float s[4][256];
+  const int main_blocks = gridDim.x - rider_blocks;
+  if ((int)blockIdx.x >= main_blocks) {
+    h32_pack_tile_any(rider, (int)blockIdx.x - main_blocks);
+    return;
+  }
   const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-  const bool fin = fin_rows != nullptr && blockIdx.x == gridDim.x - 1;
+  const bool fin = fin_rows != nullptr && (int)blockIdx.x == main_blocks - 1;
   if (fin) {
     float r[4];
     loss_rows_reduce(fin_rows, fin_M, s, r);
@@ -907,21 +914,25 @@ __global__ __launch_bounds__(256) void zero2_kernel(float* a, int64_t na4, float
   }
   if (tail != nullptr && (fin_rows != nullptr ? fin : blockIdx.x == 0) && threadIdx.x < 8)
     tail[threadIdx.x] = threadIdx.x < 5 ? state_f[4 + threadIdx.x] : 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < na4 + nb4; i += (int64_t)gridDim.x * 256) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < na4 + nb4; i += (int64_t)main_blocks * 256) {
     if (i < na4) *reinterpret_cast<f32x4*>(a + 4 * i) = z;
     else *reinterpret_cast<f32x4*>(b + 4 * (i - na4)) = z;
   }
 }
+// rider / rider_blocks: an H32PackP job (b4r_head_rx_dE_pack_job) carried by rider_blocks extra workgroups of the launch
 int b4r_zero2(float* a, int64_t na, float* b, int64_t nb, hipStream_t stream, float* tail, b4r_train_state* state,
-              const float* fin_rows, int fin_M) {
+              const float* fin_rows, int fin_M, const void* rider, int rider_blocks) {
   B4R_CHECK_ARG(na % 4 == 0 && nb % 4 == 0 && b4r_aligned16(a) && b4r_aligned16(b), B4R_E_ALIGN, "zero2: regions must be 16-byte granular");
   B4R_CHECK_ARG(fin_rows == nullptr || (state != nullptr && fin_M > 0), B4R_E_BADARG, "zero2: the loss sums need the state");
   int64_t n4 = (na + nb) / 4;
   int grid = (int)((n4 + 255) / 256);
   if (grid > 2048) grid = 2048;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL(zero2_kernel, dim3(grid), dim3(256), 0, stream, a, na / 4, b, nb / 4, tail, reinterpret_cast<float*>(state), fin_rows,
-                     fin_M);
+  H32PackP job{};
+  if (rider != nullptr && rider_blocks > 0) job = *reinterpret_cast<const H32PackP*>(rider);
+  else rider_blocks = 0;
+  hipLaunchKernelGGL(zero2_kernel, dim3(grid + rider_blocks), dim3(256), 0, stream, a, na / 4, b, nb / 4, tail, reinterpret_cast<float*>(state),
+                     fin_rows, fin_M, job, rider_blocks);
   B4R_CHECK_LAUNCH(fin_rows ? "zero fill + loss sums" : "zero fill");
   return B4R_OK;
 }

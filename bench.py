@@ -51,14 +51,21 @@ OTHER_LEGS = (("steam", 150, 30), ("ml20m_4l", 24, 6), ("ml1m_128", 60, 15))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); 6.29 TB/s is the measured copy rate
 BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md); the split-precision kernels run on it
-DTYPE = "f32 (bf16x3 split products on the bf16 matrix cores, fp32 accumulate; softmax / LayerNorm / AdamW in fp32)"
+DTYPE = ("f32 (split products on the 16-bit matrix cores, fp32 accumulate: bf16 hi/lo x3 in the encoder, fp16 hi/lo x3 logits + x2 value "
+         "products in the masked-LM head; softmax / LayerNorm / AdamW in fp32)")
 
 
 # launch label of the library's timer -> kernel name in the rocprofv3 summaries
-KERNEL_OF_LABEL = {"b4r_attn_block_fwd": "attn_block_fwd_kernel", "b4r_attn_block_bwd": "attn32_bwd_kernel",
+KERNEL_OF_LABEL = {"b4r_attn_block_fwd": "attn32_fwd_kernel", "b4r_attn_block_bwd": "attn32_bwd_kernel",
                    "b4r_ffn_block_fwd": "ffn_fwd_kernel", "b4r_ffn_block_bwd (dx)": "ffn_bwd_dx_kernel",
-                   "b4r_ffn_block_bwd (dw)": "ffn_bwd_dw_kernel", "masked-LM head forward (fused)": "head_fwd_kernel",
-                   "masked-LM head dE (fused)": "head_dE_kernel"}
+                   "b4r_ffn_block_bwd (dw)": "ffn_bwd_dw_kernel", "masked-LM head forward (fused)": ("head", "_fwd_kernel<"),
+                   "masked-LM head dE (fused)": ("head", "_dE_kernel<")}   # (head32_fwd_kernel<2> / head32w_fwd_kernel<8, 4> / head_fwd_kernel<..>)
+# matrix instructions executed per fp32-equivalent product of the masked-LM head: the 32 x 32-tile kernels (B4R_HEAD32 != 0) form the
+# logits as a three-term fp16 hi / lo product and take the probabilities / softmax gradients as ONE fp16 operand (two terms):
+# (3 + 2) / 2 per product on average; the 16-row-tile kernels run three bf16 terms everywhere
+HEAD32 = os.environ.get("B4R_HEAD32", "1") != "0"
+def executed_factor(label):
+    return 2.5 if (HEAD32 and label.startswith("masked-LM head")) else 3.0
 
 
 def library_hash():
@@ -105,7 +112,7 @@ def profiled_traffic(kernel, config):
             i_n, i_rd, i_wr = hdr.index("n"), hdr.index("rdMB"), hdr.index("wrMB")
             tot, n = 0.0, 0.0
             for ln in lines[1:]:
-                if kernel in ln:
+                if all(k_ in ln for k_ in ((kernel,) if isinstance(kernel, str) else kernel)):
                     cols = ln.split()
                     off = len(cols) - len(hdr)          # the kernel name may contain blanks
                     k = float(cols[i_n + off])
@@ -496,8 +503,10 @@ def main():
                      "avg_launch_us": round(avg_us, 2), "launches_per_step": cnt,
                      "timer": "hipEvents on the launch stream behind every launch of 10 extra steps (b4r_timing_begin/_end)"}
                 if bound == "mfma":
-                    r["executed_mfma_flops"] = int(3 * amount)
-                    r["frac_executed"] = round(3 * ach / peak, 4)
+                    xf = executed_factor(label)
+                    r["executed_mfma_flops"] = int(xf * amount)
+                    r["frac_executed"] = round(xf * ach / peak, 4)
+                    r["executed_per_product"] = xf
                 return r
 
             for label, (tot, cnt) in sorted(per_label.items(), key=lambda kv: -kv[1][0]):
@@ -552,7 +561,8 @@ def main():
                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes": alg_bytes,
                         "avg_launch_us": round(k_us, 2), "in_timed_region": not eng.fused_head_supported()}
-        tr = profiled_traffic("rx_gemm_nk_kernel<1, false, 4>", args.config)
+        # (the train step never launches this kernel: its counters come from the API-path profile of the same build, tools/prof_api.sh)
+        tr = profiled_traffic("rx_gemm_nk_kernel<1, false, 4>", args.config + "_api") or profiled_traffic("rx_gemm_nk_kernel<1, false, 4>", args.config)
         if tr:
             roofline_mat["traffic"], roofline_mat["traffic_source"] = tr["bytes"], tr["source"]
             roofline_mat["traffic_stale"], roofline_mat["traffic_lib_sha256"] = tr["stale"], tr["source_lib_sha256"]

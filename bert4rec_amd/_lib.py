@@ -118,6 +118,7 @@ PROTOTYPES = {
                                  C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32)]),
     "b4r_pooler_floats": (_I64, [C.POINTER(ModelConfig)]),
     "b4r_workspace_bytes": (_I64, [C.POINTER(ModelConfig), _I32, _I32, _I32]),
+    "b4r_workspace_bytes_encoder": (_I64, [C.POINTER(ModelConfig), _I32, _I32, _I32]),
     "b4r_workspace_region": (C.c_int, [C.POINTER(ModelConfig), _I32, _I32, _I32, C.c_char_p, C.POINTER(_I64),
                                        C.POINTER(_I32), C.POINTER(_I32), C.POINTER(_I32)]),
     "b4r_fused_head_supported": (_I32, [C.POINTER(ModelConfig)]),

@@ -813,10 +813,16 @@ extern "C" int b4r_attn_block_bwd(const b4r_attn_block_bwd_desc* d, b4r_stream_t
 }
 
 int b4r_attn32_fwd(const b4r_attn_block_desc* d, b4r_stream_t stream);
+bool b4r_attn32_core_preferred(int L);
 extern "C" int b4r_attn_block_fwd(const b4r_attn_block_desc* d, b4r_stream_t stream) {
   B4R_CHECK_ARG(d != nullptr, B4R_E_BADARG, "b4r_attn_block_fwd: null descriptor");
   static const bool fwd32 = !(getenv("B4R_ATTN32_FWD") && atoi(getenv("B4R_ATTN32_FWD")) == 0);
-  if (fwd32 && use_attn32() && b4r_attn32_preferred(d->H, d->heads, d->L)) return b4r_attn32_fwd(d, stream);
+  // The 32-token-tile forward writes the attention-dropout decisions in the 32-key-tile layout ONLY.  Its readers are the
+  // 32-token-tile block backward and, where a step's backward is unfused (L > 208, B4R_ATTN_BWD_FUSED=0, ...), the attention core's
+  // backward -- which reads that layout only while b4r_attn32_core_preferred holds (B4R_ATTN32_CORE).  So the kernel is taken only
+  // where BOTH readers read what it writes; otherwise the 16-token-tile forward below runs, which writes both layouts.  (The minimum
+  // length of b4r_attn32_set_min_len enters both predicates: change it between steps, never between a forward and its backward.)
+  if (fwd32 && use_attn32() && b4r_attn32_preferred(d->H, d->heads, d->L) && b4r_attn32_core_preferred(d->L)) return b4r_attn32_fwd(d, stream);
   B4R_CHECK_ARG(b4r_attn_block_supported(d->H, d->heads, d->L), B4R_E_SHAPE,
                 "b4r_attn_block_fwd: needs hidden size 64, 2 heads, L <= 256 and the bf16x3 mode (H=%d heads=%d L=%d)", d->H, d->heads,
                 d->L);

@@ -46,10 +46,11 @@ struct B4rReduceJob {
   const float* slab; const float* cslab; const float* caslab;
   float* out; float* colsum; float* colsum_a;
   int S, Mo, No, ldo, accumulate;
-  // optional 64-bit fixed-point addend of the [Mo, No] matrix (units of 2^-44: the item-table scatter of b4r_embed_grads):
+  // optional 64-bit fixed-point addend of the [Mo, No] matrix (units of 2^-36: the item-table scatter of b4r_embed_grads):
   // element e receives fix[e] + sum over fix_slots of fix_hot[slot][e] (e < fix_hot_elems) on top of the slab sum
   const long long* fix = nullptr; const long long* fix_hot = nullptr;
   int fix_hot_elems = 0, fix_slots = 0;
+  const int* fix_poison = nullptr;   // != 0: a contribution was not finite or out of the fixed-point range -> every element becomes NaN
 };
 constexpr int B4R_MAX_REDUCE_JOBS = 40;
 struct B4rReduceQueue {
@@ -63,7 +64,8 @@ int b4r_reduce_queue_flush(hipStream_t stream, float* sq_partial = nullptr, int 
                            int64_t* covered = nullptr);
 bool b4r_reduce_queue_push(const B4rReduceJob& job);             // false: no queue active (caller reduces immediately)
 // give the queued job that writes `out` a fixed-point addend; false: no queue, or no queued job writes `out`
-bool b4r_reduce_queue_attach_fixed(const float* out, const long long* fix, const long long* fix_hot, int fix_hot_elems, int fix_slots);
+bool b4r_reduce_queue_attach_fixed(const float* out, const long long* fix, const long long* fix_hot, int fix_hot_elems, int fix_slots,
+                                   const int* fix_poison = nullptr);
 int b4r_launch_reduce_job(const B4rReduceJob& job, hipStream_t stream);   // queued when a queue is active, else launched
 
 // the deferred merge of the logits-free masked-LM head's forward (b4r_head_merge.h), as the hosts pass it around

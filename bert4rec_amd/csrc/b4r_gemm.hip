@@ -330,7 +330,8 @@ __device__ __forceinline__ float reduce_store(const ReduceJobView& job, int64_t 
         for (int u = 0; u < 16; ++u) q += v[u];
       }
     }
-    r += (float)q * (1.f / 17592186044416.f);
+    r += (float)q * (1.f / 68719476736.f);   // units of 2^-36 (b4r_rowops.hip: FIX_SCALE)
+    if (job.fix_poison != nullptr && *job.fix_poison != 0) r = __builtin_nanf("");   // the scatter met Inf / NaN / |x| >= 2^18
   }
   if (job.accumulate) r += *o;
   *o = r;
@@ -529,12 +530,13 @@ bool b4r_reduce_queue_push(const B4rReduceJob& job) {
   g_queue->jobs[g_queue->n++] = job;
   return true;
 }
-bool b4r_reduce_queue_attach_fixed(const float* out, const long long* fix, const long long* fix_hot, int fix_hot_elems, int fix_slots) {
+bool b4r_reduce_queue_attach_fixed(const float* out, const long long* fix, const long long* fix_hot, int fix_hot_elems, int fix_slots,
+                                   const int* fix_poison) {
   if (g_queue == nullptr) return false;
   for (int j = 0; j < g_queue->n; ++j) {
     B4rReduceJob& job = g_queue->jobs[j];
     if (job.out == out && job.ldo == job.No && job.fix == nullptr) {
-      job.fix = fix; job.fix_hot = fix_hot; job.fix_hot_elems = fix_hot_elems; job.fix_slots = fix_slots;
+      job.fix = fix; job.fix_hot = fix_hot; job.fix_hot_elems = fix_hot_elems; job.fix_slots = fix_slots; job.fix_poison = fix_poison;
       return true;
     }
   }

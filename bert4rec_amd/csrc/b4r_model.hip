@@ -563,6 +563,11 @@ extern "C" int64_t b4r_workspace_bytes(const b4r_model_config* cfg, int32_t B, i
   if (check_cfg(cfg) || B <= 0 || L <= 0 || P < 0) return -1;
   return make_ws_layout(*cfg, B, L, P).total * (int64_t)sizeof(float);
 }
+extern "C" int64_t b4r_workspace_bytes_encoder(const b4r_model_config* cfg, int32_t B, int32_t L, int32_t P) {
+  if (check_cfg(cfg) != B4R_OK || B <= 0 || L <= 0 || P < 0) return -1;
+  return make_ws_layout(*cfg, B, L, P).gath * (int64_t)sizeof(float);
+}
+
 extern "C" int b4r_workspace_region(const b4r_model_config* cfg, int32_t B, int32_t L, int32_t P, const char* name,
                                     int64_t* offset_floats, int32_t* rows, int32_t* cols, int32_t* ld) {
   RC(check_cfg(cfg));
@@ -626,8 +631,11 @@ static int forward_impl(const b4r_model_config* cfg, const b4r_batch* batch, con
   const int B = batch->B, L = batch->L, P = batch->masked_lm_positions ? batch->P : 0;
   const ParamLayout pl = make_param_layout(*cfg);
   const WsLayout w = make_ws_layout(*cfg, B, L, batch->P);
-  B4R_CHECK_ARG(workspace_bytes >= w.total * (int64_t)sizeof(float), B4R_E_NOMEM, "b4r_forward: workspace too small (%lld < %lld)",
-                (long long)workspace_bytes, (long long)(w.total * sizeof(float)));
+  // an encoder-only forward without the pooler touches nothing behind the encoder's own regions (the masked-LM head's buffers -- the
+  // [B*P, V] logits above all -- and the whole backward area): b4r_workspace_bytes_encoder is enough for it
+  const int64_t ws_need = ((flags & B4R_FLAG_ENCODER_ONLY) && !(flags & B4R_FLAG_POOLER)) ? w.gath : w.total;
+  B4R_CHECK_ARG(workspace_bytes >= ws_need * (int64_t)sizeof(float), B4R_E_NOMEM, "b4r_forward: workspace too small (%lld < %lld)",
+                (long long)workspace_bytes, (long long)(ws_need * sizeof(float)));
   const int training = (flags & B4R_FLAG_TRAINING) ? 1 : 0;
   B4R_CHECK_ARG(!training || state || (cfg->output_dropout == 0.f && cfg->attention_dropout == 0.f), B4R_E_BADARG,
                 "b4r_forward: training with dropout needs a state (rng)");

@@ -341,18 +341,25 @@ __global__ __launch_bounds__(256) void batch_colsum_kernel(const float* x, int B
   batch_colsum_body(x, B, L, H, bchunk, partial, (int)blockIdx.x, (int)blockIdx.y);
 }
 
-// Item-table scatter-add in 64-bit FIXED POINT (2^-44 units): integer sums do not depend on the order in which the adds arrive, so
-// the item-table gradient -- the one sum of a train step that float atomics left order-dependent -- comes out bit for bit the same
-// on every run.  |value| < 2^19 converts exactly down to 2^-44 (a float of magnitude >= 2^-20 is a multiple of 2^-44 already, so
-// only contributions below 1e-6 are rounded at all, to 5.7e-14); fix [table_rows * H] and hot [HOT_SLOTS][hot_rows * H] (int64,
-// zeroed by the caller) are converted and added to the float gradient by the reduce launch that follows (B4rReduceJob::fix).
+// Item-table scatter-add in 64-bit FIXED POINT: integer sums do not depend on the order in which the adds arrive, so the item-table
+// gradient -- the one sum of a train step that float atomics left order-dependent -- comes out bit for bit the same on every run.
+// fix [table_rows * H] and hot [HOT_SLOTS][hot_rows * H] (int64, zeroed by the caller, followed by the poison word) are converted and
+// added to the float gradient by the reduce launch that follows (B4rReduceJob::fix).
 // Destination rows [0, hot_rows) (PAD / MASK / UNK: [MASK] alone is ~20 % of all tokens) are summed in LDS first and leave the
 // workgroup once, into slot (workgroup % HOT_SLOTS) -- every workgroup on one row runs an order of magnitude below the atomic rate.
-constexpr float FIX_SCALE = 17592186044416.f;          // 2^44
-constexpr float FIX_UNSCALE = 1.f / 17592186044416.f;
+// Range (round 4): units of 2^-36.  A value of magnitude < 2^18 converts without overflow and a 64-bit sum holds 2^27 in total: with
+// the 2^-44 units of round 3 a row's sum wrapped silently at 2^19 = 5.2e5 -- reachable by the [MASK] row of a diverging run, whose
+// d(loss_SUM) contributions number in the tens of thousands.  Values of magnitude >= 2^-12 are multiples of the unit (fp32 carries 24
+// bits): only smaller contributions are rounded at all, to 7e-12 absolute.  A contribution that is not finite or reaches 2^18 in
+// magnitude -- float atomics would have carried an Inf / NaN into the gradient -- sets a sticky POISON word next to the sums; the
+// closing reduction then stores NaN for every element of the table gradient, so the step's gradient norm, loss checks and the
+// optimizer see the failure instead of finite garbage.
+constexpr float FIX_SCALE = 68719476736.f;             // 2^36
+constexpr float FIX_UNSCALE = 1.f / 68719476736.f;
+constexpr float FIX_LIMIT = 262144.f;                  // 2^18
 __device__ __forceinline__ void scatter_fixed_rows_body(const float* src, const int64_t* idx, int n, int H, long long* fix,
                                                         int64_t dst_rows, int hot_rows, long long* hot, const int block,
-                                                        const int nblocks) {
+                                                        const int nblocks, int* poison) {
   extern __shared__ unsigned long long s_hot64[];
   for (int k = threadIdx.x; k < hot_rows * H; k += 256) s_hot64[k] = 0ull;
   if (hot_rows > 0) __syncthreads();
@@ -361,7 +368,9 @@ __device__ __forceinline__ void scatter_fixed_rows_body(const float* src, const 
     const int i = (int)(t / H), c = (int)(t % H);
     const int64_t r = idx[i];
     if (r < 0 || r >= dst_rows) continue;
-    const unsigned long long q = (unsigned long long)__float2ll_rn(src[(int64_t)i * H + c] * FIX_SCALE);
+    const float val = src[(int64_t)i * H + c];
+    if (!(fabsf(val) < FIX_LIMIT)) { atomicOr(poison, 1); continue; }   // (also true for NaN) rare: one atomic per offending element
+    const unsigned long long q = (unsigned long long)__float2ll_rn(val * FIX_SCALE);
     if (r < hot_rows) atomicAdd(&s_hot64[(int)r * H + c], q);
     else atomicAdd(reinterpret_cast<unsigned long long*>(fix) + r * H + c, q);
   }
@@ -488,7 +497,8 @@ __global__ __launch_bounds__(256) void embed_grads_kernel(const float* x, const 
                                                           int bchunk, int gx, float* partial, int n_colsum, const float* fin_rows,
                                                           int fin_M, float* state_f, float* tail) {
   if ((int)blockIdx.x < n_scatter) {
-    scatter_fixed_rows_body(x, ids, n, H, fix, table_rows, hot_rows, hot, (int)blockIdx.x, n_scatter);
+    scatter_fixed_rows_body(x, ids, n, H, fix, table_rows, hot_rows, hot, (int)blockIdx.x, n_scatter,
+                            reinterpret_cast<int*>(hot + (int64_t)HOT_SLOTS * hot_rows * H));
   } else if ((int)blockIdx.x < n_scatter + n_colsum) {
     const int k = (int)blockIdx.x - n_scatter;
     batch_colsum_body(x, B, L, H, bchunk, partial, k % gx, k / gx);
@@ -847,7 +857,8 @@ int b4r_batch_colsum(const float* x, int B, int L, int H, float* dpos, float* sc
 // floats, ZEROED by the caller (the 64-bit fixed-point sums of scatter_fixed_rows_body); colsum_scratch >= ceil(B/16)*L*H floats.
 // Both results are completed by reduce jobs: inside the caller's queue when one is active (the item table's job is the one that
 // already sums the head's slabs into table_grad, if there is one: table_grad = slabs + fixed in ONE pass), else launched here.
-int64_t b4r_embed_fixed_floats(int64_t V, int H, int hot_rows) { return 2 * (V * H + (int64_t)HOT_SLOTS * hot_rows * H); }
+// (+ 4 floats: the sticky poison word behind the sums, zeroed with them)
+int64_t b4r_embed_fixed_floats(int64_t V, int H, int hot_rows) { return 2 * (V * H + (int64_t)HOT_SLOTS * hot_rows * H) + 4; }
 int b4r_embed_grads(const float* x, const int64_t* ids, int B, int L, int H, float* table_grad, int64_t V, int hot_rows,
                     float* fixed, float* dpos, float* colsum_scratch, hipStream_t stream, const float* fin_rows, int fin_M,
                     b4r_train_state* state, float* tail) {
@@ -862,9 +873,10 @@ int b4r_embed_grads(const float* x, const int64_t* ids, int B, int L, int H, flo
                      stream, x, ids, n, H, fix, V, hot_rows, hot, n_scatter, B, L, bchunk, gx, colsum_scratch, gx * S, fin_rows, fin_M,
                      reinterpret_cast<float*>(state), tail);
   B4R_CHECK_LAUNCH("embedding gradients (scatter-add + position sums)");
-  if (!b4r_reduce_queue_attach_fixed(table_grad, fix, hot, hot_rows * H, HOT_SLOTS)) {
+  const int* poison = reinterpret_cast<const int*>(hot + (int64_t)HOT_SLOTS * hot_rows * H);
+  if (!b4r_reduce_queue_attach_fixed(table_grad, fix, hot, hot_rows * H, HOT_SLOTS, poison)) {
     B4rReduceJob job{nullptr, nullptr, nullptr, table_grad, nullptr, nullptr, 0, (int)V, H, H, 1};
-    job.fix = fix; job.fix_hot = hot; job.fix_hot_elems = hot_rows * H; job.fix_slots = HOT_SLOTS;
+    job.fix = fix; job.fix_hot = hot; job.fix_hot_elems = hot_rows * H; job.fix_slots = HOT_SLOTS; job.fix_poison = poison;
     int rc = b4r_launch_reduce_job(job, stream);
     if (rc) return rc;
   }

@@ -239,13 +239,23 @@ class Engine:
             self.adam_v = torch.zeros_like(self.params)
 
     # ---- workspace ------------------------------------------------------------------------------------------------
-    def workspace(self, B: int, L: int, P: int) -> torch.Tensor:
+    def workspace(self, B: int, L: int, P: int, encoder_only: bool = False) -> torch.Tensor:
+        """encoder_only: a buffer that only has to hold the encoder's regions of the (B, L, P) layout (b4r_workspace_bytes_encoder: no
+        [B*P, V] logits, no backward area) -- what the evaluation path's forward needs.  A larger buffer of the same key serves it too;
+        a later full request of that key replaces an encoder-only buffer."""
         key = (B, L, P)
         ws = self._ws.get(key)
-        if ws is None:
-            nbytes = self.lib.b4r_workspace_bytes(C.byref(self.cfg), B, L, P)
+        sizes = self.__dict__.setdefault("_ws_bytes", {})
+        nbytes = sizes.get((B, L, P, encoder_only))
+        if nbytes is None:
+            query = self.lib.b4r_workspace_bytes_encoder if encoder_only else self.lib.b4r_workspace_bytes
+            nbytes = query(C.byref(self.cfg), B, L, P)
             if nbytes < 0:
                 raise B4RError("b4r_workspace_bytes: " + _lib.last_error())
+            sizes[(B, L, P, encoder_only)] = nbytes
+        if ws is not None and ws.numel() * 4 < nbytes:
+            ws = None
+        if ws is None:
             # the workspace is pure scratch (nothing in it outlives a call sequence on one batch) and the library lays its regions out
             # from (B, L, P) alone, so a shape may use any buffer that is large enough: batches trimmed to their longest sequence
             # (dataloader_utils.make_batches(trim_padding=True)) share the buffer of the longest shape instead of owning one each
@@ -269,11 +279,11 @@ class Engine:
         self.workspace(B, L, P)
         self.__dict__.setdefault("_ws_pinned", set()).add((B, L, P))
 
-    def region(self, name: str, B: int, L: int, P: int) -> torch.Tensor:
+    def region(self, name: str, B: int, L: int, P: int, encoder_only: bool = False) -> torch.Tensor:
         off, rows, cols, ld = C.c_int64(), C.c_int32(), C.c_int32(), C.c_int32()
         _lib.check(self.lib.b4r_workspace_region(C.byref(self.cfg), B, L, P, name.encode(), C.byref(off), C.byref(rows),
                                                  C.byref(cols), C.byref(ld)), "b4r_workspace_region")
-        return torch.as_strided(self.workspace(B, L, P), (rows.value, cols.value), (ld.value, 1), off.value)
+        return torch.as_strided(self.workspace(B, L, P, encoder_only), (rows.value, cols.value), (ld.value, 1), off.value)
 
     # ---- batches --------------------------------------------------------------------------------------------------
     def prepare_batch(self, batch: Dict[str, torch.Tensor]) -> Tuple[Batch, Dict[str, torch.Tensor]]:
@@ -308,11 +318,11 @@ class Engine:
         return bool(self.lib.b4r_fused_head_supported(C.byref(self.cfg)))
 
     def forward(self, cb: Batch, training: bool = False, pooler: bool = True, fused_head: bool = False,
-                head_rows_only: bool = False, encoder_only: bool = False) -> None:
+                head_rows_only: bool = False, encoder_only: bool = False) -> None:  # noqa: D401
         """fused_head: the loss / backward of the same step must be called with fused_head=True as well, and the
         "mlm_logits" region is not written.  head_rows_only (train steps: forward AND backward): the last layer's feed-forward half
         only on the rows the masked-LM head gathers; "sequence_output" is then defined on those rows only."""
-        ws = self.workspace(cb.B, cb.L, cb.P)
+        ws = self.workspace(cb.B, cb.L, cb.P, encoder_only=encoder_only and not pooler)
         flags = (_lib.FLAG_TRAINING if training else 0) | (_lib.FLAG_POOLER if pooler else 0) | \
                 (_lib.FLAG_FUSED_HEAD if fused_head else 0) | (_lib.FLAG_HEAD_ROWS_ONLY if head_rows_only else 0) | \
                 (_lib.FLAG_ENCODER_ONLY if encoder_only else 0)

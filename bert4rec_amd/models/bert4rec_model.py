@@ -276,7 +276,7 @@ class BERT4RecModel:
         if rows is None:                                                           # (the evaluator keeps them for resident batches)
             pos = keep["masked_lm_positions"].reshape(-1)[slots].clamp(0, L - 1)   # tfm MaskedLM gathers position + b*L
             rows = torch.div(slots, P, rounding_mode="floor") * L + pos
-        seq = self.engine.region("sequence_output", B, L, enc.P)
+        seq = self.engine.region("sequence_output", B, L, enc.P, encoder_only=enc.P > 0)   # (P > 0: the ranked-rows forward's own buffer)
         return self.engine.mlm_transform_rows(seq, rows), slots, counts
 
     def rank_items_tensor(self, encoder_input: Dict[str, torch.Tensor], candidates: Optional[torch.Tensor] = None,

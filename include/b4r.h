@@ -114,6 +114,11 @@ int64_t b4r_pooler_floats(const b4r_model_config* cfg); /* [H,H] kernel then [H]
  *   "sequence_output" [B*L,H], "encoder_output_<i>" [B*L,H], "mlm_logits" [B*P, ld>=V], "mlm_hidden" [B*P,H],
  *   "pooled_output" [B,H], "embeddings" [B*L,H]. */
 int64_t b4r_workspace_bytes(const b4r_model_config* cfg, int32_t B, int32_t L, int32_t P);
+/* bytes that an ENCODER-ONLY forward without the pooler needs (b4r_forward with B4R_FLAG_ENCODER_ONLY and not B4R_FLAG_POOLER:
+ * BERT4RecModel.rank_items' forward, bert4rec_model.py:215): the encoder's own regions of the (B, L, P) layout -- the same offsets as in
+ * the full workspace, so b4r_workspace_region("sequence_output" / "encoder_output_i" / "embeddings") holds -- without the masked-LM
+ * head's [B*P, V] logits and the backward area (an evaluation batch of ML-20M shape: 1.2 GB less). */
+int64_t b4r_workspace_bytes_encoder(const b4r_model_config* cfg, int32_t B, int32_t L, int32_t P);
 int b4r_workspace_region(const b4r_model_config* cfg, int32_t B, int32_t L, int32_t P, const char* name,
                          int64_t* offset_floats, int32_t* rows, int32_t* cols, int32_t* ld);
 
@@ -140,6 +145,10 @@ int b4r_workspace_region(const b4r_model_config* cfg, int32_t B, int32_t L, int3
  * all-reduces ONE flat buffer [gradients | sums] and then calls b4r_optimizer_step_reduced, which takes the
  * reduced sums from there.  No copy kernels around the collective. */
 #define B4R_FLAG_GRAD_TAIL 8
+/* Range of the item-table gradient: the embedding rows' contributions d loss_sum / d (token row) are scatter-added in 64-bit fixed
+ * point (units of 2^-36, order-free => bitwise reproducible).  A contribution that is not finite or reaches 2^18 = 262 144 in magnitude
+ * cannot be represented: the whole "word_embeddings/embeddings" gradient of that step is then NaN (and with it the step's gradient
+ * norm), as an Inf / NaN would have made it with float atomics -- never a silently wrapped finite value. */
 /* b4r_forward + b4r_backward of one TRAIN step (both or neither): the last encoder layer's feed-forward half is evaluated only on the
  * rows of the sequence output that the masked-LM head gathers (about P/L of them: 20 % at ML-1M) -- forward and backward.  Loss, metrics
  * and every gradient are unchanged (the other rows of that output reach neither the loss nor, through attention, any row that does);

@@ -225,9 +225,33 @@ def test_attn_block_forward_matches_fp64(B, L, p_rate, o_rate):
     _lib.check(lib.b4r_attn_fwd(P(out["qkv"]), P(maskd), B, L, 2, P(ctx2), P(lse2), P(st), site_p, p_rate, P(bits2), stream()))
     torch.cuda.synchronize()
     assert T.maxdiff(ctx2, out["ctx"]) < 2e-5
+    n_old = B * 2 * ((L + 15) // 16) * 128
     if p_rate > 0 and L > 224:   # the 16-token-tile block keeps round 1's layout of the decisions (first in the buffer); the
-        n_old = B * 2 * ((L + 15) // 16) * 128   # 32-token-tile block (L <= 224) one word per (query, 32-key tile) behind it
-        assert torch.equal(bits2[:n_old], bits[:n_old])
+        assert torch.equal(bits2[:n_old], bits[:n_old])   # 32-token-tile block (L <= 224) one word per (query, 32-key tile) behind it
+    if p_rate > 0 and L <= 224 and lib.b4r_attn32_set_min_len(-1) <= L:
+        # the 32-token-tile forward ran: its decision words [b, head][key tile][query tile][slot], bit j = key 32 t + j, slot = the query's
+        # place in the backward's register pairs (query 16s + 8a + 4h + b of the tile sits at 16s + 8a + 2b + h), must be
+        # (a) the oracle's keep mask of the same (seed, step, site) bit for bit, (b) identical when the forward runs again
+        NT = (L + 31) // 32
+        words = bits[n_old:n_old + B * 2 * NT * NT * 32].cpu().view(B, 2, NT, NT, 32).to(torch.int64) & 0xFFFFFFFF
+        keep = orc.dropout_keep_mask((B, 2, L, L), p_rate, seed, step, site_p, row_pitch=orc.ATTN_PITCH).bool()
+        got = torch.zeros(B, 2, NT * 32, NT * 32, dtype=torch.bool)
+        slot_of = [(r & 24) | ((r & 3) << 1) | ((r >> 2) & 1) for r in range(32)]
+        words = words[..., slot_of]                                            # [B, 2, t, qt, query in tile]
+        for j in range(32):   # got[b, h, query 32 qt + r, key 32 t + j]
+            bit = ((words >> j) & 1).bool()
+            got.view(B, 2, NT, 32, NT, 32)[:, :, :, :, :, j] = bit.permute(0, 1, 3, 4, 2)   # -> [B, 2, qt, r, t]
+        live = mask.bool()
+        for b in range(B):
+            n_b = int(live[b].sum())
+            if n_b == 0:
+                continue
+            assert torch.equal(got[b, :, :L, :L], keep[b]), f"sequence {b}: decision words differ from the oracle's keep mask"
+        bits_again = torch.zeros_like(bits)
+        d.keep_bits = P(bits_again)
+        _lib.check(lib.b4r_attn_block_fwd(C.byref(d), stream()), "b4r_attn_block_fwd")
+        torch.cuda.synchronize()
+        assert torch.equal(bits_again, bits)
 
 
 def attn_bwd_reference(t, mask, B, L, p_rate, o_rate, e_rate, seed, step, site_p, site_o, site_e, prev, eps=1e-12):

@@ -151,6 +151,23 @@ def test_train_mode_with_dropout_matches_oracle_mask_for_mask():
     assert abs(float(loss_eval) - float(loss_ref)) > 1e-4
 
 
+def test_train_mode_at_sequence_length_216_matches_oracle_mask_for_mask():
+    """L = 216 at hidden size 64: the forward runs the 32-token-tile attention block (it writes the attention-dropout decisions in the
+    32-key-tile layout only), the backward is past the resident block's limit (L > 208) and goes through the attention CORE kernels --
+    which must read those decisions in the layout the forward wrote (one predicate decides both: b4r_attn_block_fwd only takes the
+    32-token-tile kernel where the core backward reads its layout).  Wrong decision words show up as wrong gradients here."""
+    cfg_o = orc.OracleConfig(vocab_size=211, hidden_size=64, num_layers=1, num_attention_heads=2, max_sequence_length=216, inner_dim=256,
+                             output_dropout=0.1, attention_dropout=0.3)
+    eng, params = build(cfg_o)
+    batch = orc.synthetic_batch(3, 216, 12, cfg_o.vocab_size, seed=5, ragged=True)
+    batch["input_mask"][0] = 1                                      # one sequence of the full length
+    seed, step = 99, 3
+    loss_ref, grads_ref, _ = orc.loss_and_grads(params, batch, cfg_o, training=True, rng=(seed, step))
+    st, grads = run_loss_and_grads(eng, batch, training=True, seed=seed, step=step)
+    assert abs(st["loss_sum"] / st["valid_count"] - float(loss_ref)) < LOGIT_TOL
+    compare_grads(grads, grads_ref, st["valid_count"], rel=5e-3)
+
+
 def test_train_steps_follow_the_reference_optimizer():
     """k identical steps (bert4rec_model.py:151-173): same loss trajectory and same weights afterwards."""
     cfg_o, shp = CONFIGS["tiny"]
@@ -353,6 +370,36 @@ def test_item_table_gradient_with_hundreds_of_contributions_per_row():
     assert float((a - b).abs().max()) < 2e-3 * float(b.abs().max())
     counts = torch.bincount(batch["input_word_ids"].reshape(-1), minlength=cfg_o.vocab_size)
     assert int(counts.max()) > 300 and int((counts >= 10).sum()) > 30
+
+
+def test_item_table_scatter_reports_out_of_range_contributions_instead_of_wrapping():
+    """The item-table scatter adds in 64-bit fixed point (units of 2^-36: a 64-bit sum holds 2^27).  A contribution that is not finite or
+    reaches 2^18 in magnitude cannot be represented: float atomics would have carried it (or an Inf / NaN) into the gradient, round 3's
+    integer sums wrapped silently into finite garbage.  Now a sticky poison word makes the closing reduction store NaN for the whole
+    table gradient.  The backward is linear in d loss / d logits, so scaling that tensor between b4r_loss and b4r_backward scales
+    every contribution: x 1 must reproduce the oracle, x 1e9 (contributions of ~1e7: finite in fp32, out of range here) must poison
+    the table gradient and leave the gradients that do not pass through the scatter finite."""
+    cfg_o, shp = CONFIGS["tiny"]
+    batch = orc.synthetic_batch(shp["B"], shp["L"], shp["P"], cfg_o.vocab_size, seed=2, ragged=True)
+    for scale in (1.0, 1e9):
+        eng, params = build(cfg_o)
+        cb, keep = eng.prepare_batch(batch)
+        eng.begin_step()
+        eng.forward(cb, training=False, pooler=False)
+        eng.loss(cb, want_grad=True)
+        eng.region("mlm_logits", cb.B, cb.L, cb.P).mul_(scale)
+        eng.backward(cb, training=False)
+        torch.cuda.synchronize()
+        g = eng.export_named(eng.grads)
+        table, other = g["word_embeddings/embeddings"], g["transformer/layer_0/intermediate/kernel"]
+        assert bool(torch.isfinite(other).all()) and float(other.abs().max()) > 0
+        if scale == 1.0:
+            _, ref, _ = orc.loss_and_grads(params, batch, cfg_o, training=False)
+            cnt = float((batch["masked_lm_ids"] != 0).sum())
+            want = ref["word_embeddings/embeddings"] * cnt
+            assert maxdiff(table, want) < 2e-3 * float(want.abs().max())
+        else:
+            assert bool(torch.isnan(table).all()), "out-of-range contributions must poison the table gradient, not wrap"
 
 
 def test_launch_timer_lists_the_launches_of_a_train_step_in_order():

@@ -164,6 +164,10 @@ PROTOTYPES = {
     "b4r_ffn_block_bwd_scratch_floats": (_I64, [_I32]),
     "b4r_ffn_block_fwd": (C.c_int, [C.POINTER(FfnDesc), _P]),
     "b4r_ffn_block_bwd": (C.c_int, [C.POINTER(FfnDesc), _P]),
+    "b4r_ffn_wide_supported": (_I32, [_I32, _I32]),
+    "b4r_ffn_wide_scratch_floats": (_I64, [_I32, _I32]),
+    "b4r_ffn_wide_fwd": (C.c_int, [C.POINTER(FfnDesc), _P, _P, _P]),
+    "b4r_ffn_wide_bwd": (C.c_int, [C.POINTER(FfnDesc), _P, _P, _P, _I32, _P]),
     "b4r_gather_rows": (C.c_int, [_P, _I32, _P, _I64, _I32, _I32, _I32, _P, _P]),
     "b4r_scatter_add_rows": (C.c_int, [_P, _P, _I64, _I32, _I32, _I32, _P, _I32, _P, _P]),
     "b4r_mlm_head_fused_scratch_floats": (C.c_int64, [_I32, _I32, _I32]),

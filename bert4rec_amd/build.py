@@ -7,7 +7,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["b4r_gemm.hip", "b4r_gemm_rx.hip", "b4r_rowops.hip", "b4r_attn.hip", "b4r_attn_rx.hip", "b4r_head_rx.hip", "b4r_head32.hip", "b4r_ffn_rx.hip", "b4r_attn_block.hip", "b4r_attn32.hip", "b4r_rank.hip", "b4r_model.hip"]
+SOURCES = ["b4r_gemm.hip", "b4r_gemm_rx.hip", "b4r_rowops.hip", "b4r_attn.hip", "b4r_attn_rx.hip", "b4r_head_rx.hip", "b4r_head32.hip", "b4r_ffn_rx.hip", "b4r_ffn32w.hip", "b4r_attn_block.hip", "b4r_attn32.hip", "b4r_rank.hip", "b4r_model.hip"]
 OUT = os.path.join(HERE, "libb4r_hip.so")
 
 

@@ -42,6 +42,16 @@ bool b4r_head_rx_combine_foldable(int M, int V, int H);
 int b4r_head_rx_fwd_launch2(const float* T, const float* E, const float* bias, const int64_t* y, int M, int V, int H,
                             float* scratch, float* dT, float* row_out, float* lse, int32_t* ylab, int only_sweep, hipStream_t stream);
 int b4r_ffn_block_bwd_marked(const b4r_ffn_desc* d, hipStream_t stream, hipEvent_t after_dx);
+// b4r_rowops.hip: the last layer's feed-forward half on the masked-LM head's rows (compact [B*P, .] operands)
+int b4r_slot_rows_gather(const float* a, const float* b, const float* s0, const float* s1, const int64_t* pos, int L, int P, int M, int H,
+                         float* ac, float* bc, float* s0c, float* s1c, hipStream_t s);
+int b4r_slot_rows_drop(const float* src, const int64_t* pos, int L, int P, int M, int H, const DropArgs& drop, float* dst, hipStream_t s);
+int b4r_slot_rows_tail(const float* y, const float* res, const int64_t* pos, int L, int P, int M, int H, const float* gamma, const float* beta,
+                       float eps, const DropArgs& drop, float* z, float* mean, float* rstd, float* out, hipStream_t s);
+// b4r_ffn32w.hip: the feed-forward half at hidden sizes 128 / 256 as one launch (forward without a backward to follow)
+bool b4r_ffn32w_supported(int H, int I);
+int64_t b4r_ffn32w_rec_floats(int H, int I);
+int b4r_ffn32w_fwd(const b4r_ffn_desc* d, float* recs, float* f, float* fpre, hipStream_t stream);
 int b4r_embed_grads(const float* x, const int64_t* ids, int B, int L, int H, float* table_grad, int64_t V, int hot_rows,
                     float* fixed, float* dpos, float* colsum_scratch, hipStream_t stream, const float* fin_rows = nullptr,
                     int fin_M = 0, b4r_train_state* state = nullptr, float* tail = nullptr);
@@ -249,6 +259,7 @@ struct WsLayout {
   int64_t gath, upre, u, meanm, rstdm, t, logits, rowsc, pooled, head_lse, head_ylab;
   int64_t dx, hot, da, db, dctx, dqkv, df, dt, dg;   // dx | hot | db adjacent: one fill clears dx + hot, or hot + db (row-list mode)
   int64_t dz2c, maxrows;   // row-list mode of the last layer's feed-forward half: one entry per masked-LM slot
+  int64_t dzc_a, dzc_b;    // the same mode through the dense products (hidden sizes without the resident block): backward temporaries
   int64_t scratch, scratch_floats;
 };
 
@@ -274,6 +285,7 @@ WsLayout make_ws_layout(const b4r_model_config& c, int B, int L, int P) {
   w.dx = take(N * H); w.hot = take(b4r_embed_fixed_floats(c.vocab_size, (int)H, 3)); w.db = take(N * H); w.da = take(N * H); w.dctx = take(N * H);
   w.maxrows = M;
   w.dz2c = take(w.maxrows * H);
+  w.dzc_a = take(M * H); w.dzc_b = take(M * H);
   w.dqkv = take(N * 3 * H); w.df = take(N * I); w.dt = take(M * H); w.dg = take(M * H);
   // scratch: every two-stage reduction of the backward pass keeps its partials until the single deferred reduce launch,
   // so the regions are summed (not max-ed); the two immediate reductions (split-K dT, position table) have their own
@@ -291,6 +303,8 @@ WsLayout make_ws_layout(const b4r_model_config& c, int B, int L, int P) {
   }
   add(std::max(b4r_ln_bwd_scratch_floats((int)N, (int)H), b4r_gemm_ln_bwd_partial_floats((int)N)));
   if (M > 0) {
+    add(b4r_gemm_tn_scratch_floats((int)M, (int)H, (int)I));   // the last layer's weight gradients over the head's rows only
+    add(b4r_gemm_tn_scratch_floats((int)M, (int)I, (int)H));
     add(b4r_gemm_tn_scratch_floats((int)M, (int)V, (int)H));
     add(b4r_gemm_tn_scratch_floats((int)M, (int)H, (int)H));
     add(b4r_ln_bwd_scratch_floats((int)M, (int)H));
@@ -402,6 +416,22 @@ bool x1_on_load() {
 bool head_rows_ok(const b4r_model_config* c, const b4r_batch* b) {
   static const bool on = !(getenv("B4R_HEAD_ROWS") && atoi(getenv("B4R_HEAD_ROWS")) == 0);
   return on && ffn_fused(c) && b->masked_lm_positions && b->masked_lm_ids && b->P > 0;
+}
+// ... and, where that half runs as dense products (every hidden size but 64), with those products on compact [B*P, .] operands: the
+// rows are gathered first (b4r_slot_rows_*).  Worth it when the head reads a minority of the rows (P = L / 5 at the benchmark shapes).
+bool head_rows_dense_ok(const b4r_model_config* c, const b4r_batch* b) {
+  static const bool on = !(getenv("B4R_HEAD_ROWS_DENSE") && atoi(getenv("B4R_HEAD_ROWS_DENSE")) == 0);
+  return on && !ffn_fused(c) && c->num_layers > 0 && b->masked_lm_positions && b->masked_lm_ids && b->P > 0 && 2 * b->P <= b->L &&
+         c->hidden_size % 32 == 0 && c->inner_dim >= 3 * c->hidden_size + 8;
+}
+// The compact operands of that mode live inside the last layer's own dense regions (an encoder-only forward has nothing else,
+// b4r_workspace_bytes_encoder): f / fpre / z2 / mean2 / rstd2 at the start of theirs, and in the unused upper half of fpre [N, I]
+// (2 M <= N, 3 H + 8 <= I): x1 rows, z1 rows, the second product's output, mean1, rstd1.
+struct CompactRows { int64_t x1c, z1c, yc, mean1c, rstd1c; };
+CompactRows compact_rows(const WsLayout& w, int layer, int64_t M, int64_t H, int64_t I) {
+  CompactRows c;
+  c.x1c = w.fpre[layer] + up4(M * I); c.z1c = c.x1c + M * H; c.yc = c.z1c + M * H; c.mean1c = c.yc + M * H; c.rstd1c = c.mean1c + up4(M);
+  return c;
 }
 
 // pair kernels (input gradient inside the weight-gradient kernel, b4r_gemm_tn_desc.dgrad_*): B4R_PAIR bit 0 = the 64 x 64 layers
@@ -653,6 +683,7 @@ static int forward_impl(const b4r_model_config* cfg, const b4r_batch* batch, con
     RC(b4r_embed_ln_fwd(batch->input_word_ids, B, L, params + pl.word_emb, V, params + pl.pos_emb, params + pl.emb_ln_g,
                         params + pl.emb_ln_b, H, cfg->ln_eps, ws + w.x0, ws + w.mean0, ws + w.rstd0, rng, od, stream));
   const bool head_rows = (flags & B4R_FLAG_HEAD_ROWS_ONLY) && head_rows_ok(cfg, batch);
+  const bool head_rows_dense = (flags & B4R_FLAG_HEAD_ROWS_ONLY) && head_rows_dense_ok(cfg, batch);
   const float* x = ws + w.x0;
   for (int i = 0; i < cfg->num_layers; ++i) {
     const bool layer_fused = attn_fused(cfg, L) && ffn_fused(cfg);
@@ -698,6 +729,28 @@ static int forward_impl(const b4r_model_config* cfg, const b4r_batch* batch, con
       }
       if (layer_fused) RC(b4r_encoder_layer_fwd(&ad, &fd, stream));
       else RC(b4r_ffn_block_fwd(&fd, stream));
+    } else if (head_rows_dense && i == cfg->num_layers - 1) {
+      // only the rows the head reads: gather x1 (and, for the backward, z1 and its statistics), the two products on [M, .] operands,
+      // then dropout + residual + LayerNorm per compact row with the result scattered to its row of x2.  The compact f / fpre / z2 /
+      // mean2 / rstd2 lie at the start of the layer's dense regions (the backward of this mode reads them there).
+      const CompactRows cr = compact_rows(w, i, M, H, I);
+      RC(b4r_slot_rows_gather(ws + w.x1[i], ws + w.z1[i], ws + w.mean1[i], ws + w.rstd1[i], batch->masked_lm_positions, L, P, M, H,
+                              ws + cr.x1c, ws + cr.z1c, ws + cr.mean1c, ws + cr.rstd1c, s));
+      RC(gemm(ws + cr.x1c, H, params + pl.w1[i], I, ws + w.f[i], I, M, I, H, 0, B4R_EPI_BIAS_GELU, params + pl.b1[i], ws + w.fpre[i], I,
+              nullptr, 0, 1.f, 0, nullptr, 0, 0.f, 0, s));
+      RC(gemm(ws + w.f[i], I, params + pl.w2[i], H, ws + cr.yc, H, M, H, I, 0, B4R_EPI_BIAS, params + pl.b2[i], nullptr, 0, nullptr, 0,
+              1.f, 0, nullptr, 0, 0.f, 0, s));
+      RC(b4r_slot_rows_tail(ws + cr.yc, ws + cr.x1c, batch->masked_lm_positions, L, P, M, H, params + pl.ln2_g[i], params + pl.ln2_b[i],
+                            cfg->ln_eps, b4r_make_drop(rng, B4R_STREAM_FFN_OUT(i), od, 1), ws + w.z2[i], ws + w.mean2[i], ws + w.rstd2[i],
+                            ws + w.x2[i], s));
+    } else if ((flags & B4R_FLAG_ENCODER_ONLY) && b4r_ffn32w_supported(H, I) && (int64_t)N * I >= b4r_ffn32w_rec_floats(H, I)) {
+      // no backward follows an encoder-only forward: the one-launch form that keeps [N, inner] on the chip (b4r_ffn32w.hip)
+      fd.N = N; fd.H = H; fd.I = I; fd.x1 = ws + w.x1[i];
+      fd.W1 = params + pl.w1[i]; fd.b1 = params + pl.b1[i]; fd.W2 = params + pl.w2[i]; fd.b2 = params + pl.b2[i];
+      fd.ln_gamma = params + pl.ln2_g[i]; fd.ln_beta = params + pl.ln2_b[i]; fd.ln_eps = cfg->ln_eps;
+      fd.rng = od > 0.f ? rng : nullptr; fd.drop_stream = B4R_STREAM_FFN_OUT(i); fd.drop_rate = od;
+      fd.z2 = ws + w.z2[i]; fd.x2 = ws + w.x2[i]; fd.mean2 = ws + w.mean2[i]; fd.rstd2 = ws + w.rstd2[i];
+      RC(b4r_ffn32w_fwd(&fd, ws + w.fpre[i], nullptr, nullptr, s));   // (the weight records: the layer's [N, inner] region is free here)
     } else {
     RC(gemm(ws + w.x1[i], H, params + pl.w1[i], I, ws + w.f[i], I, N, I, H, 0, B4R_EPI_BIAS_GELU, params + pl.b1[i],
             ws + w.fpre[i], I, nullptr, 0, 1.f, 0, nullptr, 0, 0.f, 0, s));
@@ -815,7 +868,8 @@ static int backward_impl(const b4r_model_config* cfg, const b4r_batch* batch, co
   // the gradient buffer; dx and the scatter's hot-row slots (row-list mode: the hot-row slots and db, whose rows outside the list
   // carry no gradient); with B4R_FLAG_GRAD_TAIL also the step's sums behind the gradients
   B4R_CHECK_ARG(!(flags & B4R_FLAG_GRAD_TAIL) || state, B4R_E_BADARG, "b4r_backward: B4R_FLAG_GRAD_TAIL needs the state");
-  const bool head_rows = (flags & B4R_FLAG_HEAD_ROWS_ONLY) && head_rows_ok(cfg, batch);
+  const bool head_rows_dense = (flags & B4R_FLAG_HEAD_ROWS_ONLY) && head_rows_dense_ok(cfg, batch);
+  const bool head_rows = ((flags & B4R_FLAG_HEAD_ROWS_ONLY) && head_rows_ok(cfg, batch)) || head_rows_dense;
   const bool loss_sums = (flags & B4R_FLAG_LOSS_SUMS) != 0;
   const bool defer_combine = (flags & B4R_FLAG_DEFER_COMBINE_INTERNAL) && loss_sums;
   B4R_CHECK_ARG(!loss_sums || ((flags & B4R_FLAG_FUSED_HEAD) && state && batch->masked_lm_ids), B4R_E_BADARG,
@@ -940,6 +994,28 @@ static int backward_impl(const b4r_model_config* cfg, const b4r_batch* batch, co
       } else {
         RC(b4r_ffn_block_bwd(&fd, stream));
       }
+    } else if (rows_here) {
+      // the compact form of the chain below: every operand is [M, .], one row per masked-LM slot (slots without a label carry an exactly
+      // zero gradient; two labelled slots never share a row).  dz1 (db) was cleared by the opening launch; the compact result is
+      // scatter-added into it.
+      const CompactRows cr = compact_rows(w, i, M, H, I);
+      float* dz2c = ws + w.dzc_a;                 // LayerNorm2 backward of the slot gradients
+      float* dz2d = od > 0.f ? ws + w.dzc_b : dz2c;   // ... through the output dropout
+      RC(b4r_ln_bwd_launch(ws + w.dg, ws + w.z2[i], ws + w.mean2[i], ws + w.rstd2[i], params + pl.ln2_g[i], M, H, dz2c,
+                           grads + pl.ln2_g[i], grads + pl.ln2_b[i], take(ln_scratch), nullptr, nullptr, nullptr, 1, 1, nodrop, s));
+      if (od > 0.f)
+        RC(b4r_slot_rows_drop(dz2c, batch->masked_lm_positions, L, P, M, H, b4r_make_drop(rng, B4R_STREAM_FFN_OUT(i), od, 1), dz2d, s));
+      RC(gemm(dz2d, H, params + pl.w2[i], H, ws + w.df, I, M, I, H, 1, B4R_EPI_GELU_BWD, nullptr, nullptr, 0, ws + w.fpre[i], I, 1.f, 0,
+              nullptr, 0, 0.f, 0, s));
+      RC(order_after(s, s_tn));
+      RC(gemm_tn(ws + w.f[i], I, dz2d, H, grads + pl.w2[i], H, M, I, H, grads + pl.b2[i], nullptr, nullptr, 0, 0.f, 0,
+                 take(b4r_gemm_tn_scratch_floats(M, I, H)), s_tn));
+      RC(dgrad_ln_bwd(ws + w.df, I, params + pl.w1[i], I, dz2c, ws + w.dz2c, M, H, ws + cr.z1c, ws + cr.mean1c, ws + cr.rstd1c,
+                      params + pl.ln1_g[i], grads + pl.ln1_g[i], grads + pl.ln1_b[i], take(ln_scratch), s));
+      RC(order_after(s, s_tn));
+      RC(gemm_tn(ws + cr.x1c, H, ws + w.df, I, grads + pl.w1[i], I, M, H, I, grads + pl.b1[i], nullptr, nullptr, 0, 0.f, 0,
+                 take(b4r_gemm_tn_scratch_floats(M, H, I)), s_tn));
+      RC(b4r_scatter_add_rows_impl(ws + w.dz2c, batch->masked_lm_positions, L, P, M, H, ws + w.db, H, batch->masked_lm_ids, N, 0, nullptr, s));
     } else {
     // FFN: dFpre = (dropmask(dz2) . W2^T) * gelu'(fpre) and dW2 = f^T . dropmask(dz2) (+ bias gradient): one pass over dz2
     // where the pair kernel applies (B4R_PAIR bit 1), else two products

@@ -1301,3 +1301,121 @@ extern "C" int b4r_sample_candidates_flagged(const float* logp, int32_t V, const
   return B4R_OK;
 }
 
+
+// -----------------------------------------------------------------------------------------------------------
+// The last encoder layer's feed-forward half on the rows the masked-LM head gathers only, for every hidden size the resident block
+// (b4r_ffn_rx.hip) does not cover: B4R_FLAG_HEAD_ROWS_ONLY with the dense products on COMPACT [B*P, .] operands (b4r_model.hip).
+// Compact row m = masked-LM slot m reads / writes sequence row (m / P) * L + clamp(position[m]) (padded slots gather position 0, as
+// tfm MaskedLM does, bert4rec_model.py:143: their compact rows repeat a row with the same values).  Dropout decisions are indexed by
+// the SEQUENCE row, so the compact path draws the masks the dense path would.
+// -----------------------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ int64_t slot_row(const int64_t* pos, int m, int L, int P) {
+  int64_t q = pos[m];
+  q = q < 0 ? 0 : (q >= L ? L - 1 : q);
+  return (int64_t)(m / P) * L + q;
+}
+// ac[m] = a[row(m)], bc[m] = b[row(m)] ([., H] rows; b may be NULL), s0c / s1c [m] = s0 / s1 [row(m)] (may be NULL)
+__global__ __launch_bounds__(256) void slot_rows_gather_kernel(const float* a, const float* b, const float* s0, const float* s1,
+                                                               const int64_t* pos, int L, int P, int M, int H, float* ac, float* bc,
+                                                               float* s0c, float* s1c) {
+  const int q4 = H >> 2;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)M * q4) return;
+  const int m = (int)(idx / q4), c = 4 * (int)(idx % q4);
+  const int64_t row = slot_row(pos, m, L, P);
+  *reinterpret_cast<f32x4*>(ac + (int64_t)m * H + c) = *reinterpret_cast<const f32x4*>(a + row * H + c);
+  if (b != nullptr) *reinterpret_cast<f32x4*>(bc + (int64_t)m * H + c) = *reinterpret_cast<const f32x4*>(b + row * H + c);
+  if (c == 0 && s0 != nullptr) { s0c[m] = s0[row]; s1c[m] = s1[row]; }
+}
+// dst[m] = dropout(src[m]) with the decisions of sequence row row(m)
+__global__ __launch_bounds__(256) void slot_rows_drop_kernel(const float* src, const int64_t* pos, int L, int P, int M, int H,
+                                                             DropArgs drop, float* dst) {
+  const int q4 = H >> 2;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)M * q4) return;
+  const int m = (int)(idx / q4), c = 4 * (int)(idx % q4);
+  const DropCtx dctx = b4r_drop_ctx(drop);
+  const int64_t row = slot_row(pos, m, L, P);
+  *reinterpret_cast<f32x4*>(dst + (int64_t)m * H + c) =
+      b4r_drop4(dctx, *reinterpret_cast<const f32x4*>(src + (int64_t)m * H + c), (uint64_t)row * (uint64_t)H + (uint64_t)c);
+}
+// z[m] = res[m] + dropout(y[m]); mean / rstd [m]; out[row(m)] = LayerNorm(z[m])   (the thread layout of ln_fwd_kernel)
+struct SlotTailP {
+  const float* y; const float* res; const int64_t* pos; int L, P;
+  const float* gamma; const float* beta; float eps; DropArgs drop;
+  float* z; float* mean; float* rstd; float* out;
+  int rows, H;
+};
+template <int LPR, int NV>
+__global__ __launch_bounds__(256) void slot_rows_tail_kernel(SlotTailP p) {
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int sub = lane % LPR, slot = lane / LPR;
+  const int64_t m = ((int64_t)blockIdx.x * 4 + wave) * RPW + slot;
+  if (m >= p.rows) return;
+  const DropCtx dctx = b4r_drop_ctx(p.drop);
+  const int64_t row = slot_row(p.pos, (int)m, p.L, p.P);
+  f32x4 x[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int c = (v * LPR + sub) * 4;
+    const f32x4 y = b4r_drop4(dctx, *reinterpret_cast<const f32x4*>(p.y + m * p.H + c), (uint64_t)row * (uint64_t)p.H + (uint64_t)c);
+    x[v] = *reinterpret_cast<const f32x4*>(p.res + m * p.H + c) + y;
+    s += (x[v][0] + x[v][1]) + (x[v][2] + x[v][3]);
+  }
+  const float mean = group_sum<LPR>(s) / (float)p.H;
+  float q = 0.f;
+#pragma unroll
+  for (int v = 0; v < NV; ++v)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float d = x[v][e] - mean; q += d * d; }
+  const float rstd = rsqrtf(group_sum<LPR>(q) / (float)p.H + p.eps);
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int c = (v * LPR + sub) * 4;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + c), b = *reinterpret_cast<const f32x4*>(p.beta + c);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float inv = rstd * g[e];
+      o[e] = x[v][e] * inv + (b[e] - mean * inv);
+    }
+    *reinterpret_cast<f32x4*>(p.z + m * p.H + c) = x[v];
+    *reinterpret_cast<f32x4*>(p.out + row * p.H + c) = o;
+  }
+  if (sub == 0) { p.mean[m] = mean; p.rstd[m] = rstd; }
+}
+}  // namespace
+
+int b4r_slot_rows_gather(const float* a, const float* b, const float* s0, const float* s1, const int64_t* pos, int L, int P, int M, int H,
+                         float* ac, float* bc, float* s0c, float* s1c, hipStream_t s) {
+  hipLaunchKernelGGL(slot_rows_gather_kernel, dim3(b4r_cdiv((int64_t)M * (H / 4), 256)), dim3(256), 0, s, a, b, s0, s1, pos, L, P, M, H, ac,
+                     bc, s0c, s1c);
+  B4R_CHECK_LAUNCH("last layer on the head's rows: gather");
+  return B4R_OK;
+}
+int b4r_slot_rows_drop(const float* src, const int64_t* pos, int L, int P, int M, int H, const DropArgs& drop, float* dst, hipStream_t s) {
+  hipLaunchKernelGGL(slot_rows_drop_kernel, dim3(b4r_cdiv((int64_t)M * (H / 4), 256)), dim3(256), 0, s, src, pos, L, P, M, H, drop, dst);
+  B4R_CHECK_LAUNCH("last layer on the head's rows: dropout of the gradient");
+  return B4R_OK;
+}
+int b4r_slot_rows_tail(const float* y, const float* res, const int64_t* pos, int L, int P, int M, int H, const float* gamma, const float* beta,
+                       float eps, const DropArgs& drop, float* z, float* mean, float* rstd, float* out, hipStream_t s) {
+  SlotTailP p{y, res, pos, L, P, gamma, beta, eps, drop, z, mean, rstd, out, M, H};
+#define SLOT_TAIL_CASE(LPR_, NV_) \
+  hipLaunchKernelGGL((slot_rows_tail_kernel<LPR_, NV_>), dim3(b4r_cdiv(M, 4 * (64 / LPR_))), dim3(256), 0, s, p)
+  switch (H) {
+    case 32: SLOT_TAIL_CASE(8, 1); break;
+    case 64: SLOT_TAIL_CASE(16, 1); break;
+    case 128: SLOT_TAIL_CASE(32, 1); break;
+    case 256: SLOT_TAIL_CASE(64, 1); break;
+    case 512: SLOT_TAIL_CASE(64, 2); break;
+    case 1024: SLOT_TAIL_CASE(64, 4); break;
+    default: b4r_set_error("last layer on the head's rows: hidden size %d not supported", H); return B4R_E_SHAPE;
+  }
+#undef SLOT_TAIL_CASE
+  B4R_CHECK_LAUNCH("last layer on the head's rows: dropout + residual + LayerNorm");
+  return B4R_OK;
+}

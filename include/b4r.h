@@ -519,6 +519,18 @@ int32_t b4r_ffn_block_supported(int32_t hidden_size, int32_t inner_dim);
 int64_t b4r_ffn_block_bwd_scratch_floats(int32_t N);
 int b4r_ffn_block_fwd(const b4r_ffn_desc* d, b4r_stream_t stream);
 int b4r_ffn_block_bwd(const b4r_ffn_desc* d, b4r_stream_t stream);
+/* The same half at hidden sizes 128 / 256 (the reference's *_128.json / *_256.json configurations; bert4rec_encoder.py:136-147,
+ * :220-222), b4r_ffn32w.hip: the weights stream past 32-token row blocks held in registers, [N, inner] stays on the chip.
+ *   b4r_ffn_wide_fwd: x1 -> z2 (may be NULL), x2, mean2 / rstd2 (may be NULL).  d->x1 given, no row list, d->scratch =
+ *     b4r_ffn_wide_scratch_floats(H, I) floats (the packed weight records, valid until W1 / b1 / W2 change).  f / fpre: both NULL
+ *     (inference) or both [N, I]: gelu(x1.W1 + b1) and its argument, the inputs of the backward.
+ *   b4r_ffn_wide_bwd: dz2 -> dx1 [N,H] = dL/dx1 INCLUDING the residual path (the caller continues with LayerNorm1's backward),
+ *     df [N, I] = dL/d(x1.W1 + b1) (the caller forms dW1 = x1^T.df, dW2 = f^T.dropmask(dz2) with b4r_gemm_tn_f32).  d->scratch as
+ *     left by the forward of the same weights (records_ready != 0) or to be packed again (0). */
+int32_t b4r_ffn_wide_supported(int32_t hidden_size, int32_t inner_dim);
+int64_t b4r_ffn_wide_scratch_floats(int32_t hidden_size, int32_t inner_dim);
+int b4r_ffn_wide_fwd(const b4r_ffn_desc* d, float* f, float* fpre, b4r_stream_t stream);
+int b4r_ffn_wide_bwd(const b4r_ffn_desc* d, const float* fpre, float* df, float* dx1, int32_t records_ready, b4r_stream_t stream);
 
 /* ---- one whole encoder layer ---------------------------------------------------------------------------------------------
  * One call of the Keras TransformerEncoderBlock (bert4rec_encoder.py:136-147 builds it post-LN, :220-222 calls it once per

@@ -545,3 +545,86 @@ def test_attention_block_can_form_its_input_from_the_embedding_tables(B, L, rate
     for k, tol in (("x0", 2e-6), ("m0", 1e-6), ("ctx", 2e-5), ("z1", 2e-5), ("x1", 2e-5), ("lse", 2e-5)):
         assert T.maxdiff(a[k], b[k].cpu()) < tol * max(1.0, float(b[k].abs().max())), k
     assert T.maxdiff(a["r0"] / b["r0"], torch.ones(N)) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# feed-forward half at hidden sizes 128 / 256 (b4r_ffn_wide_*: the reference's *_128.json / *_256.json configurations)
+# ---------------------------------------------------------------------------------------------------------------------------
+def wide_ffn_inputs(N, H, I, seed):
+    return dict(x1=rnd(N, H, seed=seed + 1), W1=rnd(H, I, seed=seed + 4, scale=0.1), b1=0.1 * rnd(I, seed=seed + 5),
+                W2=rnd(I, H, seed=seed + 6, scale=0.08), b2=0.1 * rnd(H, seed=seed + 7), g2=1.0 + 0.2 * rnd(H, seed=seed + 8),
+                be2=0.1 * rnd(H, seed=seed + 9), dx2=rnd(N, H, seed=seed + 10))
+
+
+def wide_ffn_reference(t, N, H, rate, seed, step, site, eps=1e-12):
+    """fp64: fpre = x1 W1 + b1; f = gelu(fpre); x2 = LN2(x1 + drop(f W2 + b2)); loss = sum(x2 * dx2); autograd gradients."""
+    d = {k: v.double().requires_grad_(k != "dx2") for k, v in t.items()}
+    fpre = d["x1"] @ d["W1"] + d["b1"]
+    fpre.retain_grad()
+    f = gelu64(fpre)
+    y = f @ d["W2"] + d["b2"]
+    if rate > 0:
+        y = y * orc.dropout_keep_mask((N, H), rate, seed, step, site).double() / (1.0 - rate)
+    z2 = d["x1"] + y
+    z2.retain_grad()
+    x2, mean2, rstd2 = ln64(z2, d["g2"], d["be2"], eps)
+    (x2 * d["dx2"]).sum().backward()
+    return dict(fpre=fpre.detach(), f=f.detach(), z2=z2.detach(), x2=x2.detach(), mean2=mean2.detach(), rstd2=rstd2.detach(),
+                dz2=z2.grad, df=fpre.grad, dx1=d["x1"].grad)
+
+
+@pytest.mark.parametrize("H,I,N,rate", [(128, 512, 256, 0.0), (128, 512, 1000, 0.2), (128, 64, 31, 0.5), (256, 1024, 128, 0.0),
+                                        (256, 1024, 777, 0.2), (256, 96, 200, 0.1), (128, 512, 51200 // 8 + 7, 0.2)])
+def test_wide_ffn_block_matches_fp64_autograd(H, I, N, rate):
+    lib = _lib.load()
+    _lib.check(lib.b4r_set_gemm_mode(_lib.GEMM_BF16X3))
+    assert lib.b4r_ffn_wide_supported(H, I) == 1
+    seed, step, site = 977, 5, 9
+    t = wide_ffn_inputs(N, H, I, seed=N + H)
+    ref = wide_ffn_reference(t, N, H, rate, seed, step, site)
+    g = {k: v.to(DEV) for k, v in t.items()}
+    st = T.new_state(seed, step) if rate > 0 else None
+    nan = float("nan")
+    out = {k: torch.full(s, nan, dtype=torch.float32, device=DEV) for k, s in
+           dict(z2=(N, H), x2=(N, H), mean2=(N,), rstd2=(N,), f=(N, I), fpre=(N, I), df=(N, I), dx1=(N, H)).items()}
+    scratch = torch.empty(lib.b4r_ffn_wide_scratch_floats(H, I), dtype=torch.float32, device=DEV)
+    d = _lib.FfnDesc()
+    d.N, d.H, d.I = N, H, I
+    d.x1, d.W1, d.b1, d.W2, d.b2 = P(g["x1"]), P(g["W1"]), P(g["b1"]), P(g["W2"]), P(g["b2"])
+    d.ln_gamma, d.ln_beta, d.ln_eps = P(g["g2"]), P(g["be2"]), 1e-12
+    d.rng, d.drop_stream, d.drop_rate = P(st), site, rate
+    d.z2, d.x2, d.mean2, d.rstd2 = P(out["z2"]), P(out["x2"]), P(out["mean2"]), P(out["rstd2"])
+    d.scratch = P(scratch)
+    _lib.check(lib.b4r_ffn_wide_fwd(C.byref(d), P(out["f"]), P(out["fpre"]), stream()), "b4r_ffn_wide_fwd")
+    torch.cuda.synchronize()
+    for k in ("fpre", "f", "z2", "x2", "mean2"):   # 2e-5 of the largest entry (|z2| reaches 8 at inner size 1024), as the sums of the H = 64 test
+        assert T.maxdiff(out[k], ref[k]) < max(1e-4, 2e-5 * float(ref[k].abs().max())), k
+    assert T.maxdiff(out["rstd2"] / ref["rstd2"].float().to(DEV), torch.ones(N)) < 1e-4
+    # the inference form (nothing of size [N, I] written) gives the same bits
+    x2_keep = out["x2"].clone()
+    out["x2"].fill_(nan)
+    _lib.check(lib.b4r_ffn_wide_fwd(C.byref(d), None, None, stream()), "b4r_ffn_wide_fwd")
+    torch.cuda.synchronize()
+    assert torch.equal(out["x2"], x2_keep)
+
+    dz2 = ref["dz2"].float().to(DEV)
+    d.dz2 = P(dz2)
+    for ready in (1, 0):
+        out["df"].fill_(nan); out["dx1"].fill_(nan)
+        _lib.check(lib.b4r_ffn_wide_bwd(C.byref(d), P(out["fpre"]), P(out["df"]), P(out["dx1"]), ready, stream()), "b4r_ffn_wide_bwd")
+        torch.cuda.synchronize()
+        scale = max(1.0, float(ref["dx1"].abs().max()))
+        assert T.maxdiff(out["df"], ref["df"]) < 1e-4 * max(1.0, float(ref["df"].abs().max())), "df"
+        assert T.maxdiff(out["dx1"], ref["dx1"]) < 1e-4 * scale, "dx1"
+
+
+def test_wide_ffn_block_refuses_other_shapes():
+    lib = _lib.load()
+    _lib.check(lib.b4r_set_gemm_mode(_lib.GEMM_BF16X3))
+    assert lib.b4r_ffn_wide_supported(64, 256) == 0 and lib.b4r_ffn_wide_supported(128, 500) == 0
+    d = _lib.FfnDesc()
+    d.N, d.H, d.I = 16, 64, 256
+    assert lib.b4r_ffn_wide_fwd(C.byref(d), None, None, stream()) == -2   # B4R_E_SHAPE
+    _lib.check(lib.b4r_set_gemm_mode(_lib.GEMM_F32))
+    assert lib.b4r_ffn_wide_supported(128, 512) == 0
+    _lib.check(lib.b4r_set_gemm_mode(_lib.GEMM_BF16X3))

@@ -111,9 +111,10 @@ __device__ __forceinline__ void f32w_barrier() {
 // ---------------------------------------------------------------------------------------------------------------------------
 struct GeluPair { float x[2], v[2], d[2], t[2], e[2], q[2], g[2], keep[2]; };
 constexpr double F32W_S = 1.2011224087864498;   // sqrt(log2 e)
-// frow != NULL: the pair's gelu values also go to frow[8 (q >> 1) + 2 (q & 1) + e] (a 16-byte store behind every second pair)
+// gv: the gelu values in the accumulator's register order (KEEP: they leave as f through the staged store) -- or, qdst != NULL (a
+// compile-time fact after inlining), every second pair stores its 16 bytes to qdst[8 (q >> 1) ..] at once
 __device__ __forceinline__ void f32w_gelu_stage(int st, int q, const f32x16& S, GeluPair& a, uint32_t (&hw)[8], uint32_t (&lw)[8],
-                                                float* frow) {
+                                                f32x16& gv, float* qdst) {
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     switch (st) {
@@ -155,10 +156,9 @@ __device__ __forceinline__ void f32w_gelu_stage(int st, int q, const f32x16& S, 
   if (st == 7) {
     b4r_split_pair(a.g[0], a.g[1], hw[q], lw[q]);
     asm volatile("" : "+v"(hw[q]), "+v"(lw[q]));
-    if (frow != nullptr) {
-      if ((q & 1) == 0) { a.keep[0] = a.g[0]; a.keep[1] = a.g[1]; }
-      else *reinterpret_cast<f32x4*>(frow + 8 * (q >> 1)) = (f32x4){a.keep[0], a.keep[1], a.g[0], a.g[1]};
-    }
+    if (qdst == nullptr) { gv[2 * q] = a.g[0]; gv[2 * q + 1] = a.g[1]; }
+    else if ((q & 1) == 0) { a.keep[0] = a.g[0]; a.keep[1] = a.g[1]; }
+    else *reinterpret_cast<f32x4*>(qdst + 8 * (q >> 1)) = (f32x4){a.keep[0], a.keep[1], a.g[0], a.g[1]};
   }
 }
 __device__ __forceinline__ bf16x8 f32w_frag(const uint32_t (&w)[8], int s) {
@@ -169,7 +169,7 @@ __device__ __forceinline__ bf16x8 f32w_frag(const uint32_t (&w)[8], int s) {
 // chunk c + 1 on entry and S^T(c + 1) on exit.
 template <int NP>
 __device__ __forceinline__ void f32w_step(const char* a_nxt, const char* b_cur, const Lane32& lk, const bf16x8 (&xh)[NP][2],
-                                          const bf16x8 (&xl)[NP][2], f32x16& Sn, f32x16 (&acc)[NP], const f32x16& S, float* frow) {
+                                          const bf16x8 (&xl)[NP][2], f32x16& Sn, f32x16 (&acc)[NP], const f32x16& S, f32x16& gv, float* qdst) {
   constexpr int NT = 2 * NP, PER = 8 / NP;
   static_assert(PER >= 1 && 32 <= PER * 6 * NP && 64 <= PER * 9 * NP, "GELU sub-slices must meet the second product's operands");
   GeluPair gp;
@@ -179,7 +179,7 @@ __device__ __forceinline__ void f32w_step(const char* a_nxt, const char* b_cur, 
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int ss = PER * m + u;
-      if (!(F32W_EXP & 1) && ss < 64) f32w_gelu_stage(ss & 7, ss >> 3, S, gp, ghw, glw, frow);
+      if (!(F32W_EXP & 1) && ss < 64) f32w_gelu_stage(ss & 7, ss >> 3, S, gp, ghw, glw, gv, qdst);
     }
     ++m;
     __builtin_amdgcn_sched_barrier(0);
@@ -227,6 +227,36 @@ __device__ __forceinline__ void f32w_step(const char* a_nxt, const char* b_cur, 
   }
 }
 
+// accumulator registers 4 g4 .. 4 g4 + 3 of lane half h = inner units (or features) 8 g4 + 4 h .. + 3 of the 32-row block
+__device__ __forceinline__ f32x4 f32w_quad(const f32x16& v, int g4) { return (f32x4){v[4 * g4], v[4 * g4 + 1], v[4 * g4 + 2], v[4 * g4 + 3]}; }
+// A wave's [32 inner units x 32 tokens] accumulator tile -> 32 x 128 bytes of a [N, I] tensor as whole 128-byte row segments: through
+// 4.5 KB of the wave's own LDS ([token][36 floats]); a wave-instruction then stores 8 rows x 128 contiguous bytes.  (Straight from the
+// accumulator layout a lane holds 4 x 16 bytes of ITS token's row: 32 rows x 32 bytes per instruction -- 420 MB of f and fpre cost the
+// hidden-256 forward 135 us that way.)
+// MEASURED (N = 51 200, us): hidden 256 forward keeping f / fpre 394 -> 323, backward 414 -> 403; hidden 128 (row pitch 2 KB, a step of
+// half the length) 102 -> 110 and 103 -> 115: there the lanes store their own 16-byte pieces (STAGED = false).
+constexpr int F32W_STG_LD = 36, F32W_STG_BYTES = 32 * F32W_STG_LD * 4;
+template <bool STAGED>
+__device__ __forceinline__ void f32w_store_tile(float* stg, const f32x16& v, float* dst, int ld, int rows_left, int lane, int r, int h) {
+  if (!STAGED) {
+    if (r < rows_left) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) *reinterpret_cast<f32x4*>(dst + (int64_t)r * ld + 8 * g4 + 4 * h) = f32w_quad(v, g4);
+    }
+    return;
+  }
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) *reinterpret_cast<f32x4*>(stg + r * F32W_STG_LD + 8 * g4 + 4 * h) = f32w_quad(v, g4);
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int row = (lane >> 3) + 8 * k;
+    const f32x4 q = *reinterpret_cast<const f32x4*>(stg + row * F32W_STG_LD + 4 * (lane & 7));
+    if (row < rows_left) *reinterpret_cast<f32x4*>(dst + (int64_t)row * ld + 4 * (lane & 7)) = q;
+  }
+  asm volatile("" ::: "memory");
+}
+
 struct F32wP {
   const float* x1; int N;
   const char* recs; int n_chunks;
@@ -236,8 +266,6 @@ struct F32wP {
   float* f; float* fpre; int I;            // optional [N, I]: gelu output and pre-activation for a backward
 };
 
-// accumulator registers 4 g4 .. 4 g4 + 3 of lane half h = inner units (or features) 8 g4 + 4 h .. + 3 of the 32-row block
-__device__ __forceinline__ f32x4 f32w_quad(const f32x16& v, int g4) { return (f32x4){v[4 * g4], v[4 * g4 + 1], v[4 * g4 + 2], v[4 * g4 + 3]}; }
 
 // KEEP: the launch also writes f = gelu(.) and the pre-activation [N, I] (the backward's inputs)
 template <int NP, int WAVES, bool KEEP>
@@ -247,8 +275,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void ffn32w_fwd_kernel(F32wP
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const Lane32 lk = lane32(lane);
   const int r = lk.r, h = lk.h;
-  const int m = blockIdx.x * ROWS + 32 * wave + r;
+  const int m0 = blockIdx.x * ROWS + 32 * wave, m = m0 + r;   // (a wave whose rows all lie beyond N still runs: barriers)
   const int64_t mc = min(m, p.N - 1);
+  float* stg = reinterpret_cast<float*>(smem_f32w + 2 * REC + wave * F32W_STG_BYTES);   // KEEP: the wave's store staging
   bf16x8 xh[NP][2], xl[NP][2];
 #pragma unroll
   for (int pp = 0; pp < NP; ++pp)
@@ -282,15 +311,12 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void ffn32w_fwd_kernel(F32wP
     if (!(F32W_EXP & 16)) f32w_barrier();                     // ... every wave's; and every wave is done with A(i), B(i - 1)
     if (!(F32W_EXP & 8)) { issue_a(i + 2); issue_b(i + 1); }
     __builtin_amdgcn_sched_barrier(0);
-    float* frow = nullptr;
-    if (KEEP) {   // (rows beyond N are clamped copies of row N - 1: they rewrite its values)
-      float* dst = p.fpre + mc * p.I + 32 * i + 4 * h;
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) *reinterpret_cast<f32x4*>(dst + 8 * g4) = f32w_quad(S, g4);
-      frow = p.f + mc * p.I + 32 * i + 4 * h;
-    }
+    if (KEEP) f32w_store_tile<(NP > 4)>(stg, S, p.fpre + (int64_t)m0 * p.I + 32 * i, p.I, p.N - m0, lane, r, h);
     Sn = rows_of(reinterpret_cast<const float*>(slot_a(i + 1) + NP * P_TILE), h);
-    f32w_step<NP>(slot_a(i + 1), slot_b(i), lk, xh, xl, Sn, acc, S, frow);
+    f32x16 gv;
+    constexpr bool STAGED = NP > 4;
+    f32w_step<NP>(slot_a(i + 1), slot_b(i), lk, xh, xl, Sn, acc, S, gv, (KEEP && !STAGED) ? p.f + mc * p.I + 32 * i + 4 * h : nullptr);
+    if (KEEP && STAGED) f32w_store_tile<true>(stg, gv, p.f + (int64_t)m0 * p.I + 32 * i, p.I, p.N - m0, lane, r, h);
   };
   for (int i = 0; i < n; i += 2) {
     step(i, S0, S1);
@@ -349,7 +375,7 @@ template <int NP, int WAVES, bool KEEP>
 int f32w_launch_fwd(const F32wPackP& pk, const F32wP& p, hipStream_t stream) {
   hipLaunchKernelGGL(ffn32w_pack_kernel<NP>, dim3(p.n_chunks), dim3(256), 0, stream, pk);
   B4R_CHECK_LAUNCH("wide feed-forward block: weight records");
-  const size_t lds = 2 * (size_t)f32w_rec(NP);
+  const size_t lds = 2 * (size_t)f32w_rec(NP) + ((KEEP && NP > 4) ? (size_t)WAVES * F32W_STG_BYTES : 0);
   int rc = b4r_raise_lds((const void*)ffn32w_fwd_kernel<NP, WAVES, KEEP>, lds, "wide feed-forward block");
   if (rc) return rc;
   hipLaunchKernelGGL((ffn32w_fwd_kernel<NP, WAVES, KEEP>), dim3(b4r_cdiv(p.N, 32 * WAVES)), dim3(64 * WAVES), lds, stream, p);
@@ -368,7 +394,7 @@ int f32w_launch_fwd(const F32wPackP& pk, const F32wP& p, hipStream_t stream) {
 // ===========================================================================================================================
 struct GeluGradPair { float x[2], v[2], d[2], t[2], e[2], q[2], g[2], keep[2]; };
 __device__ __forceinline__ void f32w_dgelu_stage(int st, int q, const f32x16& X, const f32x16& G, GeluGradPair& a, uint32_t (&hw)[8],
-                                                 uint32_t (&lw)[8], float* dfrow) {
+                                                 uint32_t (&lw)[8], f32x16& dv, float* qdst) {
 #pragma unroll
   for (int e = 0; e < 2; ++e) {
     switch (st) {
@@ -412,8 +438,9 @@ __device__ __forceinline__ void f32w_dgelu_stage(int st, int q, const f32x16& X,
   if (st == 8) {
     b4r_split_pair(a.g[0], a.g[1], hw[q], lw[q]);
     asm volatile("" : "+v"(hw[q]), "+v"(lw[q]));
-    if ((q & 1) == 0) { a.keep[0] = a.g[0]; a.keep[1] = a.g[1]; }
-    else *reinterpret_cast<f32x4*>(dfrow + 8 * (q >> 1)) = (f32x4){a.keep[0], a.keep[1], a.g[0], a.g[1]};
+    if (qdst == nullptr) { dv[2 * q] = a.g[0]; dv[2 * q + 1] = a.g[1]; }
+    else if ((q & 1) == 0) { a.keep[0] = a.g[0]; a.keep[1] = a.g[1]; }
+    else *reinterpret_cast<f32x4*>(qdst + 8 * (q >> 1)) = (f32x4){a.keep[0], a.keep[1], a.g[0], a.g[1]};
   }
 }
 
@@ -421,7 +448,7 @@ __device__ __forceinline__ void f32w_dgelu_stage(int st, int q, const f32x16& X,
 template <int NP>
 __device__ __forceinline__ void f32w_bstep(const char* b_nxt, const char* a_cur, const Lane32& lk, const bf16x8 (&dh)[NP][2],
                                            const bf16x8 (&dl)[NP][2], f32x16& Gn, f32x16 (&acc)[NP], const f32x16& G, const f32x16& X,
-                                           float* dfrow) {
+                                           f32x16& dv, float* qdst) {
   constexpr int NT = 2 * NP, PER = 8 / NP;
   static_assert(PER >= 1 && 36 <= PER * 6 * NP && 72 <= PER * 9 * NP, "GELU' sub-slices must meet the second product's operands");
   GeluGradPair gp;
@@ -431,7 +458,7 @@ __device__ __forceinline__ void f32w_bstep(const char* b_nxt, const char* a_cur,
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
       const int ss = PER * m + u;
-      if (ss < 72) f32w_dgelu_stage(ss % 9, ss / 9, X, G, gp, ghw, glw, dfrow);
+      if (ss < 72) f32w_dgelu_stage(ss % 9, ss / 9, X, G, gp, ghw, glw, dv, qdst);
     }
     ++m;
     __builtin_amdgcn_sched_barrier(0);
@@ -502,8 +529,9 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void ffn32w_bwd_kernel(F32wB
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const Lane32 lk = lane32(lane);
   const int r = lk.r, h = lk.h;
-  const int m = blockIdx.x * ROWS + 32 * wave + r;
+  const int m0 = blockIdx.x * ROWS + 32 * wave, m = m0 + r;
   const int64_t mc = min(m, p.N - 1);
+  float* stg = reinterpret_cast<float*>(smem_f32w + 2 * REC + wave * F32W_STG_BYTES);
   const DropCtx dctx = b4r_drop_ctx(p.drop);
   bf16x8 dh[NP][2], dl[NP][2];
 #pragma unroll
@@ -547,7 +575,10 @@ __global__ __launch_bounds__(64 * WAVES, WAVES / 4) void ffn32w_bwd_kernel(F32wB
     Xn = f32w_tile_rows(xrow + 32 * min(i + 1, n - 1), h);
     __builtin_amdgcn_sched_barrier(0);
     Gn = zero16();
-    f32w_bstep<NP>(slot_b(i + 1), slot_a(i), lk, dh, dl, Gn, acc, G, X, p.df + mc * p.I + 32 * i + 4 * h);
+    f32x16 dv;
+    constexpr bool STAGED = NP > 4;
+    f32w_bstep<NP>(slot_b(i + 1), slot_a(i), lk, dh, dl, Gn, acc, G, X, dv, STAGED ? nullptr : p.df + mc * p.I + 32 * i + 4 * h);
+    if (STAGED) f32w_store_tile<true>(stg, dv, p.df + (int64_t)m0 * p.I + 32 * i, p.I, p.N - m0, lane, r, h);
   };
   for (int i = 0; i < n; i += 2) {
     step(i, G0, G1, X0, X1);
@@ -572,7 +603,7 @@ int f32w_launch_bwd(const F32wPackP* pk, const F32wBwdP& p, hipStream_t stream) 
     hipLaunchKernelGGL(ffn32w_pack_kernel<NP>, dim3(p.n_chunks), dim3(256), 0, stream, *pk);
     B4R_CHECK_LAUNCH("wide feed-forward block: weight records");
   }
-  const size_t lds = 2 * (size_t)f32w_rec(NP);
+  const size_t lds = 2 * (size_t)f32w_rec(NP) + (NP > 4 ? (size_t)WAVES * F32W_STG_BYTES : 0);
   int rc = b4r_raise_lds((const void*)ffn32w_bwd_kernel<NP, WAVES>, lds, "wide feed-forward block");
   if (rc) return rc;
   hipLaunchKernelGGL((ffn32w_bwd_kernel<NP, WAVES>), dim3(b4r_cdiv(p.N, 32 * WAVES)), dim3(64 * WAVES), lds, stream, p);

@@ -52,6 +52,7 @@ int b4r_slot_rows_tail(const float* y, const float* res, const int64_t* pos, int
 bool b4r_ffn32w_supported(int H, int I);
 int64_t b4r_ffn32w_rec_floats(int H, int I);
 int b4r_ffn32w_fwd(const b4r_ffn_desc* d, float* recs, float* f, float* fpre, hipStream_t stream);
+int b4r_ffn32w_bwd(const b4r_ffn_desc* d, float* recs, const float* fpre, float* df, float* dx1, bool records_ready, hipStream_t stream);
 int b4r_embed_grads(const float* x, const int64_t* ids, int B, int L, int H, float* table_grad, int64_t V, int hot_rows,
                     float* fixed, float* dpos, float* colsum_scratch, hipStream_t stream, const float* fin_rows = nullptr,
                     int fin_M = 0, b4r_train_state* state = nullptr, float* tail = nullptr);
@@ -255,7 +256,7 @@ struct WsLayout {
   int64_t x0, mean0, rstd0;
   int64_t qkv[B4R_MAX_LAYERS], lse[B4R_MAX_LAYERS], keep[B4R_MAX_LAYERS], ctx[B4R_MAX_LAYERS], z1[B4R_MAX_LAYERS], mean1[B4R_MAX_LAYERS],
       rstd1[B4R_MAX_LAYERS], x1[B4R_MAX_LAYERS], fpre[B4R_MAX_LAYERS], f[B4R_MAX_LAYERS], z2[B4R_MAX_LAYERS],
-      mean2[B4R_MAX_LAYERS], rstd2[B4R_MAX_LAYERS], x2[B4R_MAX_LAYERS];
+      mean2[B4R_MAX_LAYERS], rstd2[B4R_MAX_LAYERS], x2[B4R_MAX_LAYERS], ffnrec[B4R_MAX_LAYERS];
   int64_t gath, upre, u, meanm, rstdm, t, logits, rowsc, pooled, head_lse, head_ylab;
   int64_t dx, hot, da, db, dctx, dqkv, df, dt, dg;   // dx | hot | db adjacent: one fill clears dx + hot, or hot + db (row-list mode)
   int64_t dz2c, maxrows;   // row-list mode of the last layer's feed-forward half: one entry per masked-LM slot
@@ -278,6 +279,7 @@ WsLayout make_ws_layout(const b4r_model_config& c, int B, int L, int P) {
     w.z1[i] = take(N * H); w.mean1[i] = take(N); w.rstd1[i] = take(N); w.x1[i] = take(N * H);
     w.fpre[i] = take(N * I); w.f[i] = take(N * I);
     w.z2[i] = take(N * H); w.mean2[i] = take(N); w.rstd2[i] = take(N); w.x2[i] = take(N * H);
+    w.ffnrec[i] = take(b4r_ffn32w_supported((int)H, (int)I) ? b4r_ffn32w_rec_floats((int)H, (int)I) : 0);   // packed W1 / b1 / W2 records
   }
   w.gath = take(M * H); w.upre = take(M * H); w.u = take(M * H); w.meanm = take(M); w.rstdm = take(M);
   w.t = take(M * H); w.logits = take(M * w.Vp); w.rowsc = take(4 * M); w.pooled = take((int64_t)B * H);
@@ -427,6 +429,13 @@ bool head_rows_dense_ok(const b4r_model_config* c, const b4r_batch* b) {
 // The compact operands of that mode live inside the last layer's own dense regions (an encoder-only forward has nothing else,
 // b4r_workspace_bytes_encoder): f / fpre / z2 / mean2 / rstd2 at the start of theirs, and in the unused upper half of fpre [N, I]
 // (2 M <= N, 3 H + 8 <= I): x1 rows, z1 rows, the second product's output, mean1, rstd1.
+// The one-launch feed-forward pair of b4r_ffn32w.hip inside a TRAIN step (it then also writes f and the pre-activation): measured per
+// dense layer at N = 51 200 -- hidden 128: forward 102 us against 121 (two tile products + LayerNorm), backward 103 against 124; hidden
+// 256: 323 against 320 and 403 against 313.  So: hidden 128 only.  B4R_FFN32W_TRAIN = 0 never, 2 both sizes.
+bool ffn32w_train_ok(const b4r_model_config* c) {
+  static const int lv = getenv("B4R_FFN32W_TRAIN") ? atoi(getenv("B4R_FFN32W_TRAIN")) : 1;
+  return lv > 0 && b4r_ffn32w_supported(c->hidden_size, c->inner_dim) && (c->hidden_size == 128 || lv > 1);
+}
 struct CompactRows { int64_t x1c, z1c, yc, mean1c, rstd1c; };
 CompactRows compact_rows(const WsLayout& w, int layer, int64_t M, int64_t H, int64_t I) {
   CompactRows c;
@@ -743,14 +752,16 @@ static int forward_impl(const b4r_model_config* cfg, const b4r_batch* batch, con
       RC(b4r_slot_rows_tail(ws + cr.yc, ws + cr.x1c, batch->masked_lm_positions, L, P, M, H, params + pl.ln2_g[i], params + pl.ln2_b[i],
                             cfg->ln_eps, b4r_make_drop(rng, B4R_STREAM_FFN_OUT(i), od, 1), ws + w.z2[i], ws + w.mean2[i], ws + w.rstd2[i],
                             ws + w.x2[i], s));
-    } else if ((flags & B4R_FLAG_ENCODER_ONLY) && b4r_ffn32w_supported(H, I) && (int64_t)N * I >= b4r_ffn32w_rec_floats(H, I)) {
-      // no backward follows an encoder-only forward: the one-launch form that keeps [N, inner] on the chip (b4r_ffn32w.hip)
+    } else if (((flags & B4R_FLAG_ENCODER_ONLY) && b4r_ffn32w_supported(H, I)) || ffn32w_train_ok(cfg)) {
+      // the one-launch form (b4r_ffn32w.hip).  No backward follows an encoder-only forward: [N, inner] stays on the chip; otherwise the
+      // launch also writes f and the pre-activation, where the backward of this step expects them
+      const bool keep = !(flags & B4R_FLAG_ENCODER_ONLY);
       fd.N = N; fd.H = H; fd.I = I; fd.x1 = ws + w.x1[i];
       fd.W1 = params + pl.w1[i]; fd.b1 = params + pl.b1[i]; fd.W2 = params + pl.w2[i]; fd.b2 = params + pl.b2[i];
       fd.ln_gamma = params + pl.ln2_g[i]; fd.ln_beta = params + pl.ln2_b[i]; fd.ln_eps = cfg->ln_eps;
       fd.rng = od > 0.f ? rng : nullptr; fd.drop_stream = B4R_STREAM_FFN_OUT(i); fd.drop_rate = od;
       fd.z2 = ws + w.z2[i]; fd.x2 = ws + w.x2[i]; fd.mean2 = ws + w.mean2[i]; fd.rstd2 = ws + w.rstd2[i];
-      RC(b4r_ffn32w_fwd(&fd, ws + w.fpre[i], nullptr, nullptr, s));   // (the weight records: the layer's [N, inner] region is free here)
+      RC(b4r_ffn32w_fwd(&fd, ws + w.ffnrec[i], keep ? ws + w.f[i] : nullptr, keep ? ws + w.fpre[i] : nullptr, s));
     } else {
     RC(gemm(ws + w.x1[i], H, params + pl.w1[i], I, ws + w.f[i], I, N, I, H, 0, B4R_EPI_BIAS_GELU, params + pl.b1[i],
             ws + w.fpre[i], I, nullptr, 0, 1.f, 0, nullptr, 0, 0.f, 0, s));
@@ -1016,6 +1027,22 @@ static int backward_impl(const b4r_model_config* cfg, const b4r_batch* batch, co
       RC(gemm_tn(ws + cr.x1c, H, ws + w.df, I, grads + pl.w1[i], I, M, H, I, grads + pl.b1[i], nullptr, nullptr, 0, 0.f, 0,
                  take(b4r_gemm_tn_scratch_floats(M, H, I)), s_tn));
       RC(b4r_scatter_add_rows_impl(ws + w.dz2c, batch->masked_lm_positions, L, P, M, H, ws + w.db, H, batch->masked_lm_ids, N, 0, nullptr, s));
+    } else if (ffn32w_train_ok(cfg)) {
+      // dF and dX1 (residual included) in one launch from the records the forward packed; LayerNorm1's backward in place; the two
+      // weight gradients as before
+      b4r_ffn_desc fd{};
+      fd.N = N; fd.H = H; fd.I = I;
+      fd.W1 = params + pl.w1[i]; fd.b1 = params + pl.b1[i]; fd.W2 = params + pl.w2[i]; fd.b2 = params + pl.b2[i];
+      fd.rng = od > 0.f ? rng : nullptr; fd.drop_stream = B4R_STREAM_FFN_OUT(i); fd.drop_rate = od;
+      fd.dz2 = ws + w.da;
+      RC(b4r_ffn32w_bwd(&fd, ws + w.ffnrec[i], ws + w.fpre[i], ws + w.df, ws + w.db, true, s));
+      RC(order_after(s, s_tn));
+      RC(gemm_tn(ws + w.f[i], I, ws + w.da, H, grads + pl.w2[i], H, N, I, H, grads + pl.b2[i], nullptr, rng, B4R_STREAM_FFN_OUT(i), od, 1,
+                 take(b4r_gemm_tn_scratch_floats(N, I, H)), s_tn));
+      RC(b4r_ln_bwd_launch(ws + w.db, ws + w.z1[i], ws + w.mean1[i], ws + w.rstd1[i], params + pl.ln1_g[i], N, H, ws + w.db,
+                           grads + pl.ln1_g[i], grads + pl.ln1_b[i], take(ln_scratch), nullptr, nullptr, nullptr, 1, 1, nodrop, s));
+      RC(gemm_tn(ws + w.x1[i], H, ws + w.df, I, grads + pl.w1[i], I, N, H, I, grads + pl.b1[i], nullptr, nullptr, 0, 0.f, 0,
+                 take(b4r_gemm_tn_scratch_floats(N, H, I)), s_tn));
     } else {
     // FFN: dFpre = (dropmask(dz2) . W2^T) * gelu'(fpre) and dW2 = f^T . dropmask(dz2) (+ bias gradient): one pass over dz2
     // where the pair kernel applies (B4R_PAIR bit 1), else two products

@@ -1363,6 +1363,347 @@ Lo = tr_pair(scr + P_IMG + lk.trn[ks][0], scr + P_IMG + lk.trn[ks][1])
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The attention core with the QUERIES restricted to the masked-LM slots (the last encoder layer of a train step or of an evaluation
+// forward: only the rows the head gathers are read downstream, B4R_FLAG_HEAD_ROWS_ONLY).  Keys and values are all L tokens of the
+// sequence, queries the P <= 64 slot positions: one or two COMPACT query tiles (query j of a sequence = its slot j, token
+// clamp(position[b, j])), outputs in compact [B * P, .] tensors.  Forks of the two kernels above:
+//   forward  -- every wave still writes the K / V images of its 32 tokens; waves 0 .. NQ - 1 then each sweep one compact query tile;
+//   backward -- key owners as above, but a wave walks the NQ compact query tiles itself (no rotation, no step barrier) and keeps its dQ
+//               partials in registers; they are summed over the key owners in wave order afterwards (ordered: bitwise reproducible).
+// Dropout decisions are those of the (token query, key) pairs (the same counter hash index); the decision words live in a compact
+// buffer of their own, [B][head][key tile][compact query tile][32].  Padded slots repeat position 0 with zero gradient; their dq rows
+// are not written (a labelled slot may share that token).
+// ---------------------------------------------------------------------------------------------------------------------------
+struct A32SlotFwdP {
+  const float* qkv; const int64_t* mask; const int64_t* pos;
+  float* ctx_c; float* lse_c; uint32_t* bits_c;
+  int B, L, NT, heads, P, NQ;
+  DropArgs drop_p;
+};
+
+template <int NTT, bool DROP>
+__global__ __launch_bounds__(512, 2) void attn32_slotq_fwd_kernel(A32SlotFwdP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem32[];
+  const int NT = p.NT, L = p.L;
+  char* const kimg = smem32;
+  char* const vimg = smem32 + NT * P_TILE;
+  float* const sAdd = reinterpret_cast<float*>(smem32 + 2 * NT * P_TILE);
+  const int b = blockIdx.x / p.heads, head = blockIdx.x % p.heads;
+  const int Hh = 32 * p.heads;
+  const int64_t row0 = (int64_t)b * L;
+  const int64_t bh = (int64_t)b * p.heads + head;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  A32_LANE_CONSTS();
+  const int64_t mval = (int)threadIdx.x < L ? p.mask[row0 + threadIdx.x] : 0;
+  const int any_key = mval != 0 ? 1 : 0;
+  const float* const src = p.qkv + (row0 + tokc) * (3 * Hh) + 32 * head;
+  f32x16 kacc = load_acc_layout(src + Hh, h), vacc = load_acc_layout(src + 2 * Hh, h);
+  // the wave's compact queries (waves 0 .. NQ - 1)
+  const bool qwave = wave < p.NQ;
+  const int j = 32 * wave + r, jc = min(j, p.P - 1);
+  const bool livej = qwave && j < p.P;
+  int posq = 0;
+  f32x16 qa = zero16();
+  if (qwave) {
+    const int64_t pq = p.pos[(int64_t)b * p.P + jc];
+    posq = (int)(pq < 0 ? 0 : (pq >= L ? L - 1 : pq));
+    qa = load_acc_layout(p.qkv + (row0 + posq) * (3 * Hh) + 32 * head, h);
+  }
+  const float amax = __syncthreads_or(any_key) ? 0.0f : -1e9f;
+  if ((int)threadIdx.x < NT * 32)
+    sAdd[threadIdx.x] = (int)threadIdx.x < L ? (((1.0f - (float)mval) * -1e9f) - amax) * LOG2E : -INFINITY;
+  qa = qa * (amax != 0.0f ? 0.0f : LOG2E);
+  bf16x8 qBh[2], qBl[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) acc_frag(qa, s, qBh[s], qBl[s]);
+  if (!live) { kacc = zero16(); vacc = zero16(); }
+  acc_to_rows(kimg + wave * P_TILE, lk, kacc);
+  acc_to_rows(vimg + wave * P_TILE, lk, vacc);
+  lds_barrier();
+  if (!qwave) return;
+
+  const DropCtx dcp = b4r_drop_ctx(p.drop_p);
+  f32x16 O;
+  const int qt = wave;
+  const int slot = (r & 24) | ((r & 3) << 1) | ((r >> 2) & 1);
+  {
+  f32x16 S[NTT];
+  float m = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NTT; ++t) {
+    if (t < NT) {
+      S[t] = rows_of(sAdd + 32 * t, h);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const char* ka = kimg + t * P_TILE + lk.rowc[ks];
+        S[t] = mfma32x3(row_at(ka), row_at(ka + P_IMG), qBh[ks], qBl[ks], S[t]);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) S[t][e] = -INFINITY;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NTT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) m = fmaxf(m, S[t][e]);
+  m = fmaxf(m, other_half(m, h));
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < NTT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { S[t][e] = __builtin_amdgcn_exp2f(S[t][e] - m); sum += S[t][e]; }
+  sum += other_half(sum, h);
+  const float inv = 1.0f / sum;
+  if (h == 0 && livej) p.lse_c[bh * p.P + j] = m * LN2 + __logf(sum);
+
+  O = zero16();
+  const uint64_t dbase = ((uint64_t)bh * L + (uint64_t)posq) * (uint64_t)B4R_ATTN_PITCH;
+#pragma unroll
+  for (int t = 0; t < NTT; ++t) {
+    if (t >= NT) continue;
+    if (DROP) {
+      uint32_t word = 0;
+      const float sc = inv * dcp.scale;
+#pragma unroll
+      for (int gp = 0; gp < 4; ++gp) {
+        const B4rKeep4 k4 = b4r_keep4p(dcp, dbase + (uint64_t)(32 * t + 8 * gp + 4 * h));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) S[t][4 * gp + e] = k4.k[e] ? S[t][4 * gp + e] * sc : 0.f;
+        word |= k4.bits() << (8 * gp + 4 * h);
+      }
+      word |= other_half_u(word, h);
+      if (h == 0) p.bits_c[((bh * NT + t) * p.NQ + qt) * 32 + slot] = word;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) S[t][e] *= inv;
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 ph, pl;
+      acc_frag(S[t], s2, ph, pl);
+      const char* va = vimg + t * P_TILE;
+      O = mfma32x3(tr_pair(va + lk.trp[s2][0], va + lk.trp[s2][1]), tr_pair(va + P_IMG + lk.trp[s2][0], va + P_IMG + lk.trp[s2][1]),
+                       ph, pl, O);
+    }
+  }
+  }
+  if (livej) {
+    float* dst = p.ctx_c + ((int64_t)b * p.P + j) * Hh + 32 * head + 8 * h;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      *reinterpret_cast<f32x4*>(dst + 16 * s) = (f32x4){O[8 * s], O[8 * s + 1], O[8 * s + 2], O[8 * s + 3]};
+      *reinterpret_cast<f32x4*>(dst + 16 * s + 4) = (f32x4){O[8 * s + 4], O[8 * s + 5], O[8 * s + 6], O[8 * s + 7]};
+    }
+  }
+}
+
+struct A32SlotBwdP {
+  const float* qkv; const float* dctx_c; const float* ctx_c; const float* lse_c; const uint32_t* bits_c; const int64_t* mask;
+  const int64_t* pos; const int64_t* ids;
+  float* dqkv;
+  int B, L, NT, heads, P, NQ;
+  float qscale;
+  DropArgs drop_p;
+};
+// LDS (bytes): [Q~ images NQ x 4 KB | dO images NQ x 4 KB | per-wave scratch NT x 4 KB | mask adders NT x 32, -lse and D NQ x 32 each]
+__host__ __device__ constexpr int slotq_bwd_lds(int NT, int NQ) { return (2 * NQ + NT) * P_TILE + (NT * 32 + 2 * NQ * 32) * 4; }
+
+template <int NQT, bool DROP>
+__global__ __launch_bounds__(512, 2) void attn32_slotq_bwd_kernel(A32SlotBwdP p) {
+  extern __shared__ __attribute__((aligned(16))) char smem32[];
+  const int NT = p.NT, L = p.L, NQ = p.NQ;
+  char* const QIMG = smem32;
+  char* const DOIMG = QIMG + NQ * P_TILE;
+  char* const SCRALL = DOIMG + NQ * P_TILE;
+  float* const sAdd = reinterpret_cast<float*>(SCRALL + NT * P_TILE);
+  float* const sCS = sAdd + NT * 32;
+  float* const sD = sCS + NQ * 32;
+  const int b = blockIdx.x / p.heads, head = blockIdx.x % p.heads;
+  const int Hh = 32 * p.heads;
+  const int64_t row0 = (int64_t)b * L;
+  const int64_t bh = (int64_t)b * p.heads + head;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char* const scr = SCRALL + wave * P_TILE;
+  A32_LANE_CONSTS();
+  const int64_t mval = (int)threadIdx.x < L ? p.mask[row0 + threadIdx.x] : 0;
+  const int any_key = mval != 0 ? 1 : 0;
+  // key side: k, v of the wave's tokens; the q part of their dqkv rows is zero unless a labelled slot writes it below
+  const float* const src = p.qkv + (row0 + tokc) * (3 * Hh) + 32 * head;
+  f32x16 kT = load_acc_layout(src + Hh, h), vT = load_acc_layout(src + 2 * Hh, h);
+  if (live) {
+    float* dz = p.dqkv + (row0 + tok) * (3 * Hh) + 32 * head + 8 * h;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      *reinterpret_cast<f32x4*>(dz + 16 * s) = (f32x4){0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(dz + 16 * s + 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  // query side (waves 0 .. NQ - 1): the compact rows
+  const bool qwave = wave < NQ;
+  const int j = 32 * wave + r, jc = min(j, p.P - 1);
+  const bool livej = qwave && j < p.P;
+  int posq = 0;
+  if (qwave) {
+    const int64_t m = (int64_t)b * p.P + jc;
+    const int64_t pq = p.pos[m];
+    posq = (int)(pq < 0 ? 0 : (pq >= L ? L - 1 : pq));
+    f32x16 qT = load_acc_layout(p.qkv + (row0 + posq) * (3 * Hh) + 32 * head, h);
+    const f32x16 dcT = load_acc_layout(p.dctx_c + m * Hh + 32 * head, h);
+    const f32x16 cxT = load_acc_layout(p.ctx_c + m * Hh + 32 * head, h);
+    const float lse_q = livej ? p.lse_c[bh * p.P + j] : INFINITY;
+    qT = qT * LOG2E;
+    float d = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) d = fmaf(dcT[e], cxT[e], d);
+    d += other_half(d, h);
+    if (h == 0) { sD[j] = d; sCS[j] = -lse_q * LOG2E; }
+    acc_to_rows(QIMG + wave * P_TILE, lk, qT);
+    acc_to_rows(DOIMG + wave * P_TILE, lk, dcT);
+  }
+  const float amax = __syncthreads_or(any_key) ? 0.0f : -1e9f;
+  const bool dead = amax != 0.0f;
+  if ((int)threadIdx.x < NT * 32)
+    sAdd[threadIdx.x] = (int)threadIdx.x < L ? (((1.0f - (float)mval) * -1e9f) - amax) * LOG2E : -INFINITY;
+  const DropCtx dcp = b4r_drop_ctx(p.drop_p);
+  const float pscale = DROP ? dcp.scale : 1.0f;
+  if (!live) { kT = zero16(); vT = zero16(); }
+  bf16x8 kBh[2], kBl[2], vBh[2], vBl[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) { acc_frag(kT, s, kBh[s], kBl[s]); acc_frag(vT, s, vBh[s], vBl[s]); }
+  acc_to_rows(scr, lk, kT);
+  lds_barrier();
+  bf16x8 kTh[2], kTl[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    kTh[s] = tr_pair(scr + lk.trn[s][0], scr + lk.trn[s][1]);
+    kTl[s] = tr_pair(scr + P_IMG + lk.trn[s][0], scr + P_IMG + lk.trn[s][1]);
+  }
+  lds_barrier();   // query images, D, -lse and the mask adders in place; the K^T reads have landed
+  const float adk = sAdd[tok];
+  if (dead) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { kBh[ks][e] = (__bf16)0.f; kBl[ks][e] = (__bf16)0.f; }
+  }
+  typedef const __attribute__((address_space(4))) uint64_t* kmask_ptr;
+  f32x16 dK = zero16(), dV = zero16(), dQp[NQT];
+#pragma unroll
+  for (int t = 0; t < NQT; ++t) {
+    dQp[t] = zero16();
+    if (t >= NQ) continue;   // (wave-uniform)
+    const char* qimg = QIMG + t * P_TILE;
+    const char* dimg = DOIMG + t * P_TILE;
+    f32x16 S = rows_of(sCS + 32 * t, h), dA = zero16();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) S[e] += adk;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 ah, al;
+      A32_LD_ROW(qimg, ks, ah, al);
+      S = mfma32x3(ah, al, kBh[ks], kBl[ks], S);
+      A32_LD_ROW(dimg, ks, ah, al);
+      dA = mfma32x3(ah, al, vBh[ks], vBl[ks], dA);
+    }
+    const f32x16 Dq = rows_of(sD + 32 * t, h);
+    uint64_t km[16];
+    if (DROP) {
+      kmask_ptr mp = (kmask_ptr)(reinterpret_cast<const uint64_t*>(p.bits_c) + ((bh * NT + wave) * NQ + t) * 16);
+#pragma unroll
+      for (int tt = 0; tt < 16; ++tt) km[tt] = mp[tt];
+    }
+    bf16x8 pdh[2], pdl[2], dsh[2], dsl[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      f32x8 pd, ds;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const int tt = 8 * s2 + jj;
+        const float pr = __builtin_amdgcn_exp2f(S[tt]);
+        if (DROP) {
+          const float kf = __builtin_amdgcn_inverse_ballot_w64(km[tt]) ? pscale : 0.f;
+          pd[jj] = pr * kf;
+          ds[jj] = pr * fmaf(dA[tt], kf, -Dq[tt]);
+        } else {
+          pd[jj] = pr;
+          ds[jj] = pr * (dA[tt] - Dq[tt]);
+        }
+      }
+      split8(pd, pdh[s2], pdl[s2]);
+      split8(ds, dsh[s2], dsl[s2]);
+      const s16x8 hv = __builtin_bit_cast(s16x8, dsh[s2]), lv = __builtin_bit_cast(s16x8, dsl[s2]);
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        char* w8 = scr + p_chunk(r, 2 * s2 + a) + 8 * h;
+        *reinterpret_cast<s16x4*>(w8) = a ? __builtin_shufflevector(hv, hv, 4, 5, 6, 7) : __builtin_shufflevector(hv, hv, 0, 1, 2, 3);
+        *reinterpret_cast<s16x4*>(w8 + P_IMG) = a ? __builtin_shufflevector(lv, lv, 4, 5, 6, 7) : __builtin_shufflevector(lv, lv, 0, 1, 2, 3);
+      }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      bf16x8 fh, fl;
+      A32_LD_TR(dimg, s2, fh, fl);
+      dV = mfma32x3(fh, fl, pdh[s2], pdl[s2], dV);   // dV^T[feature][key] += dO^T[feature][query] . Pd[query][key]
+      A32_LD_TR(qimg, s2, fh, fl);
+      dK = mfma32x3(fh, fl, dsh[s2], dsl[s2], dK);   // dK^T += Q~^T . dS
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fh, fl;
+      A32_LD_SCR(ks, fh, fl);
+      dQp[t] = mfma32x3(kTh[ks], kTl[ks], fh, fl, dQp[t]);   // dQ^T[feature position][query] = K^T . dS^T
+    }
+  }
+  // results of the wave's tokens as keys: registers 8s .. 8s+7 = features 16s + 8h + (0..7)
+  if (live) {
+    const f32x16 gk = dK * LN2;   // Q~ carries log2(e)
+    float* dst = p.dqkv + (row0 + tok) * (3 * Hh) + 32 * head + 8 * h;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int o = 8 * s + 4 * hf;
+        *reinterpret_cast<f32x4*>(dst + Hh + 16 * s + 4 * hf) = (f32x4){gk[o], gk[o + 1], gk[o + 2], gk[o + 3]};
+        *reinterpret_cast<f32x4*>(dst + 2 * Hh + 16 * s + 4 * hf) = (f32x4){dV[o], dV[o + 1], dV[o + 2], dV[o + 3]};
+      }
+  }
+  // dQ of compact tile t = the key owners' partials in wave order (through the scratch tiles, one compact tile at a time); the zero
+  // fill of the q parts above is complete before the first labelled row is written (vmcnt(0) in front of the barrier)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int t = 0; t < NQT; ++t) {
+    if (t >= NQ) continue;
+    lds_barrier();   // (t == 0: the sweep's last scratch reads; t > 0: the previous tile's sums have been read)
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+      *reinterpret_cast<f32x4*>(scr + jj * 1024 + lane * 16) = (f32x4){dQp[t][4 * jj], dQp[t][4 * jj + 1], dQp[t][4 * jj + 2], dQp[t][4 * jj + 3]};
+    lds_barrier();
+    if (wave == t) {
+      f32x16 gq = zero16();
+      for (int w = 0; w < NT; ++w)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const f32x4 a4 = *reinterpret_cast<const f32x4*>(SCRALL + w * P_TILE + jj * 1024 + lane * 16);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) gq[4 * jj + e] += a4[e];
+        }
+      if (livej && p.ids[(int64_t)b * p.P + j] != 0) {
+        float* dst = p.dqkv + (row0 + posq) * (3 * Hh) + 32 * head + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            const int o = 8 * s + 4 * hf;
+            *reinterpret_cast<f32x4*>(dst + 16 * s + 4 * hf) =
+                (f32x4){gq[o] * p.qscale, gq[o + 1] * p.qscale, gq[o + 2] * p.qscale, gq[o + 3] * p.qscale};
+          }
+      }
+    }
+  }
+}
+
 bool al16(const void* q) { return q == nullptr || b4r_aligned16(q); }
 
 }  // namespace
@@ -1451,6 +1792,62 @@ int b4r_attn32_core_bwd_launch(const float* qkv, const int64_t* mask, const floa
 int64_t b4r_attn32_keep_words(int32_t B, int32_t L, int32_t heads) {
   const int64_t NT = b4r_cdiv(L, 32);
   return (int64_t)B * heads * NT * NT * 32;
+}
+
+// ---- the attention core on the masked-LM slots' queries only (b4r_model.hip: the last layer under B4R_FLAG_HEAD_ROWS_ONLY) -------------
+bool b4r_attn32_slotq_supported(int L, int P) {
+  static const bool on = !(getenv("B4R_ATTN_SLOTQ") && atoi(getenv("B4R_ATTN_SLOTQ")) == 0);
+  return on && L > 64 && L <= 224 && P > 0 && P <= 64 && 2 * P <= L && b4r_get_gemm_mode() == B4R_GEMM_BF16X3;
+}
+int64_t b4r_attn32_slotq_keep_words(int B, int L, int heads, int P) {
+  return (int64_t)B * heads * b4r_cdiv(L, 32) * b4r_cdiv(P, 32) * 32;
+}
+int b4r_attn32_slotq_fwd_launch(const float* qkv, const int64_t* mask, const int64_t* pos, int B, int L, int heads, int P, float* ctx_c,
+                                float* lse_c, const DropArgs& drop, uint32_t* bits_c, hipStream_t stream) {
+  A32SlotFwdP p{};
+  p.qkv = qkv; p.mask = mask; p.pos = pos; p.ctx_c = ctx_c; p.lse_c = lse_c; p.bits_c = bits_c;
+  p.B = B; p.L = L; p.NT = b4r_cdiv(L, 32); p.heads = heads; p.P = P; p.NQ = b4r_cdiv(P, 32);
+  p.drop_p = drop;
+  const bool dropping = drop.rng != nullptr && drop.thr != 0;
+  B4R_CHECK_ARG(!dropping || bits_c, B4R_E_BADARG, "attention on the slots' queries: dropout needs the decision buffer");
+  const size_t sh = (size_t)core_fwd_lds(p.NT);
+  const dim3 grid((unsigned)(B * heads)), block((unsigned)(64 * p.NT));
+  int rc;
+#define A32_SLOT_FWD_CASE(N_, D_)                                                                        \
+  {                                                                                                      \
+    rc = b4r_raise_lds((const void*)attn32_slotq_fwd_kernel<N_, D_>, sh, "attention on the slots' queries"); \
+    if (rc) return rc;                                                                                   \
+    hipLaunchKernelGGL((attn32_slotq_fwd_kernel<N_, D_>), grid, block, sh, stream, p);                   \
+  }
+  if (p.NT <= 4) { if (dropping) A32_SLOT_FWD_CASE(4, true) else A32_SLOT_FWD_CASE(4, false) }
+  else { if (dropping) A32_SLOT_FWD_CASE(7, true) else A32_SLOT_FWD_CASE(7, false) }
+#undef A32_SLOT_FWD_CASE
+  B4R_CHECK_LAUNCH("attention core forward, queries = the head's slots");
+  return B4R_OK;
+}
+int b4r_attn32_slotq_bwd_launch(const float* qkv, const int64_t* mask, const int64_t* pos, const int64_t* ids, const float* ctx_c,
+                                const float* lse_c, const float* dctx_c, int B, int L, int heads, int P, float qscale, float* dqkv,
+                                const DropArgs& drop, const uint32_t* bits_c, hipStream_t stream) {
+  A32SlotBwdP p{};
+  p.qkv = qkv; p.mask = mask; p.pos = pos; p.ids = ids; p.ctx_c = ctx_c; p.lse_c = lse_c; p.dctx_c = dctx_c; p.dqkv = dqkv; p.bits_c = bits_c;
+  p.B = B; p.L = L; p.NT = b4r_cdiv(L, 32); p.heads = heads; p.P = P; p.NQ = b4r_cdiv(P, 32); p.qscale = qscale;
+  p.drop_p = drop;
+  const bool dropping = drop.rng != nullptr && drop.thr != 0;
+  B4R_CHECK_ARG(!dropping || bits_c, B4R_E_BADARG, "attention on the slots' queries: dropout needs the forward's decisions");
+  const size_t sh = (size_t)slotq_bwd_lds(p.NT, p.NQ);
+  const dim3 grid((unsigned)(B * heads)), block((unsigned)(64 * p.NT));
+  int rc;
+#define A32_SLOT_BWD_CASE(Q_, D_)                                                                        \
+  {                                                                                                      \
+    rc = b4r_raise_lds((const void*)attn32_slotq_bwd_kernel<Q_, D_>, sh, "attention on the slots' queries"); \
+    if (rc) return rc;                                                                                   \
+    hipLaunchKernelGGL((attn32_slotq_bwd_kernel<Q_, D_>), grid, block, sh, stream, p);                   \
+  }
+  if (p.NQ <= 1) { if (dropping) A32_SLOT_BWD_CASE(1, true) else A32_SLOT_BWD_CASE(1, false) }
+  else { if (dropping) A32_SLOT_BWD_CASE(2, true) else A32_SLOT_BWD_CASE(2, false) }
+#undef A32_SLOT_BWD_CASE
+  B4R_CHECK_LAUNCH("attention core backward, queries = the head's slots");
+  return B4R_OK;
 }
 
 #ifdef A32_PROF

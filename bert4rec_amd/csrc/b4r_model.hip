@@ -47,7 +47,15 @@ int b4r_slot_rows_gather(const float* a, const float* b, const float* s0, const 
                          float* ac, float* bc, float* s0c, float* s1c, hipStream_t s);
 int b4r_slot_rows_drop(const float* src, const int64_t* pos, int L, int P, int M, int H, const DropArgs& drop, float* dst, hipStream_t s);
 int b4r_slot_rows_tail(const float* y, const float* res, const int64_t* pos, int L, int P, int M, int H, const float* gamma, const float* beta,
-                       float eps, const DropArgs& drop, float* z, float* mean, float* rstd, float* out, hipStream_t s);
+                       float eps, const DropArgs& drop, float* z, float* mean, float* rstd, float* out, float* outc, hipStream_t s);
+// b4r_attn32.hip: the attention core with the queries restricted to the masked-LM slots (compact [B*P, .] outputs)
+bool b4r_attn32_slotq_supported(int L, int P);
+int64_t b4r_attn32_slotq_keep_words(int B, int L, int heads, int P);
+int b4r_attn32_slotq_fwd_launch(const float* qkv, const int64_t* mask, const int64_t* pos, int B, int L, int heads, int P, float* ctx_c,
+                                float* lse_c, const DropArgs& drop, uint32_t* bits_c, hipStream_t stream);
+int b4r_attn32_slotq_bwd_launch(const float* qkv, const int64_t* mask, const int64_t* pos, const int64_t* ids, const float* ctx_c,
+                                const float* lse_c, const float* dctx_c, int B, int L, int heads, int P, float qscale, float* dqkv,
+                                const DropArgs& drop, const uint32_t* bits_c, hipStream_t stream);
 // b4r_ffn32w.hip: the feed-forward half at hidden sizes 128 / 256 as one launch (forward without a backward to follow)
 bool b4r_ffn32w_supported(int H, int I);
 int64_t b4r_ffn32w_rec_floats(int H, int I);
@@ -436,6 +444,12 @@ bool ffn32w_train_ok(const b4r_model_config* c) {
   static const int lv = getenv("B4R_FFN32W_TRAIN") ? atoi(getenv("B4R_FFN32W_TRAIN")) : 1;
   return lv > 0 && b4r_ffn32w_supported(c->hidden_size, c->inner_dim) && (c->hidden_size == 128 || lv > 1);
 }
+// ... and the attention half of that layer with the slots as its only queries (hidden sizes on the tile products; P <= 64)
+bool slotq_layer(const b4r_model_config* c, const b4r_batch* b, uint32_t flags, int layer) {
+  return (flags & B4R_FLAG_HEAD_ROWS_ONLY) && layer == c->num_layers - 1 && head_rows_dense_ok(c, b) && !attn_fused(c, b->L) &&
+         b4r_attn32_slotq_supported(b->L, b->P) &&
+         b4r_attn32_slotq_keep_words(b->B, b->L, c->num_heads, b->P) <= b4r_attn_keep_words(b->B, b->L, c->num_heads);
+}
 struct CompactRows { int64_t x1c, z1c, yc, mean1c, rstd1c; };
 CompactRows compact_rows(const WsLayout& w, int layer, int64_t M, int64_t H, int64_t I) {
   CompactRows c;
@@ -718,11 +732,29 @@ static int forward_impl(const b4r_model_config* cfg, const b4r_batch* batch, con
     } else {
     RC(gemm(x, H, params + pl.wqkv[i], 3 * H, ws + w.qkv[i], 3 * H, N, 3 * H, H, 0, B4R_EPI_BIAS_QSCALE, params + pl.bqkv[i],
             nullptr, 0, nullptr, 0, qscale, H, nullptr, 0, 0.f, 0, s));
+    if (slotq_layer(cfg, batch, flags, i)) {
+      // only the rows the head reads leave this layer: the attention core with the slots as its queries (keys: all tokens), then the
+      // output projection, dropout, residual and LayerNorm on the compact [M, H] rows.  ctx / lse / decision words: compact, at the
+      // start of the layer's dense regions; x1 / z1 / statistics: where the compact feed-forward half below expects them
+      const CompactRows cr = compact_rows(w, i, M, H, I);
+      float* xc = ws + w.x1[i];              // the layer input's rows (the residual)
+      float* yc = ws + w.x1[i] + up4((int64_t)M * H);
+      RC(b4r_attn32_slotq_fwd_launch(ws + w.qkv[i], batch->input_mask, batch->masked_lm_positions, B, L, cfg->num_heads, P, ws + w.ctx[i],
+                                     ws + w.lse[i], b4r_make_drop(rng, B4R_STREAM_ATTN_PROBS(i), adp, 1),
+                                     reinterpret_cast<uint32_t*>(ws + w.keep[i]), s));
+      RC(b4r_slot_rows_gather(x, nullptr, nullptr, nullptr, batch->masked_lm_positions, L, P, M, H, xc, nullptr, nullptr, nullptr, s));
+      RC(gemm(ws + w.ctx[i], H, params + pl.wo[i], H, yc, H, M, H, H, 0, B4R_EPI_BIAS, params + pl.bo[i], nullptr, 0, nullptr, 0, 1.f, 0,
+              nullptr, 0, 0.f, 0, s));
+      RC(b4r_slot_rows_tail(yc, xc, batch->masked_lm_positions, L, P, M, H, params + pl.ln1_g[i], params + pl.ln1_b[i], cfg->ln_eps,
+                            b4r_make_drop(rng, B4R_STREAM_ATTN_OUT(i), od, 1), ws + cr.z1c, ws + cr.mean1c, ws + cr.rstd1c, nullptr,
+                            ws + cr.x1c, s));
+    } else {
     RC(b4r_attn_fwd(ws + w.qkv[i], batch->input_mask, B, L, cfg->num_heads, ws + w.ctx[i], ws + w.lse[i], rng,
                     B4R_STREAM_ATTN_PROBS(i), adp, reinterpret_cast<uint32_t*>(ws + w.keep[i]), stream));
     RC(dense_res_ln(ws + w.ctx[i], H, params + pl.wo[i], ws + w.z1[i], ws + w.x1[i], ws + w.mean1[i], ws + w.rstd1[i], N, H, H,
                     params + pl.bo[i], x, params + pl.ln1_g[i], params + pl.ln1_b[i], cfg->ln_eps, rng, B4R_STREAM_ATTN_OUT(i),
                     od, s));
+    }
     }
     if (ffn_fused(cfg)) {
       fd.N = N; fd.H = H; fd.I = I; fd.x1 = (layer_fused && x1_on_load()) ? nullptr : ws + w.x1[i];
@@ -743,15 +775,16 @@ static int forward_impl(const b4r_model_config* cfg, const b4r_batch* batch, con
       // then dropout + residual + LayerNorm per compact row with the result scattered to its row of x2.  The compact f / fpre / z2 /
       // mean2 / rstd2 lie at the start of the layer's dense regions (the backward of this mode reads them there).
       const CompactRows cr = compact_rows(w, i, M, H, I);
-      RC(b4r_slot_rows_gather(ws + w.x1[i], ws + w.z1[i], ws + w.mean1[i], ws + w.rstd1[i], batch->masked_lm_positions, L, P, M, H,
-                              ws + cr.x1c, ws + cr.z1c, ws + cr.mean1c, ws + cr.rstd1c, s));
+      if (!slotq_layer(cfg, batch, flags, i))   // (else the attention half above left the compact rows itself)
+        RC(b4r_slot_rows_gather(ws + w.x1[i], ws + w.z1[i], ws + w.mean1[i], ws + w.rstd1[i], batch->masked_lm_positions, L, P, M, H,
+                                ws + cr.x1c, ws + cr.z1c, ws + cr.mean1c, ws + cr.rstd1c, s));
       RC(gemm(ws + cr.x1c, H, params + pl.w1[i], I, ws + w.f[i], I, M, I, H, 0, B4R_EPI_BIAS_GELU, params + pl.b1[i], ws + w.fpre[i], I,
               nullptr, 0, 1.f, 0, nullptr, 0, 0.f, 0, s));
       RC(gemm(ws + w.f[i], I, params + pl.w2[i], H, ws + cr.yc, H, M, H, I, 0, B4R_EPI_BIAS, params + pl.b2[i], nullptr, 0, nullptr, 0,
               1.f, 0, nullptr, 0, 0.f, 0, s));
       RC(b4r_slot_rows_tail(ws + cr.yc, ws + cr.x1c, batch->masked_lm_positions, L, P, M, H, params + pl.ln2_g[i], params + pl.ln2_b[i],
                             cfg->ln_eps, b4r_make_drop(rng, B4R_STREAM_FFN_OUT(i), od, 1), ws + w.z2[i], ws + w.mean2[i], ws + w.rstd2[i],
-                            ws + w.x2[i], s));
+                            ws + w.x2[i], nullptr, s));
     } else if (((flags & B4R_FLAG_ENCODER_ONLY) && b4r_ffn32w_supported(H, I)) || ffn32w_train_ok(cfg)) {
       // the one-launch form (b4r_ffn32w.hip).  No backward follows an encoder-only forward: [N, inner] stays on the chip; otherwise the
       // launch also writes f and the pre-activation, where the backward of this step expects them
@@ -1109,6 +1142,24 @@ static int backward_impl(const b4r_model_config* cfg, const b4r_batch* batch, co
       }
       RC(b4r_attn_block_bwd(&bd, stream));
     } else {
+    if (slotq_layer(cfg, batch, flags, i)) {
+      // compact: dz1 of the slots (left in dz2c by the feed-forward half above) -> dropout of the output projection -> dWo / dbo and
+      // dctx on [M, H] rows -> the attention core's backward with the slots as its queries (dq rows of the labelled slots, dk / dv of
+      // every token)
+      float* dz1d = od > 0.f ? ws + w.dctx + up4((int64_t)M * H) : ws + w.dz2c;   // (the dense dctx region is free in this mode)
+      float* dctx_c = ws + w.dctx;
+      if (od > 0.f)
+        RC(b4r_slot_rows_drop(ws + w.dz2c, batch->masked_lm_positions, L, P, M, H, b4r_make_drop(rng, B4R_STREAM_ATTN_OUT(i), od, 1), dz1d, s));
+      RC(order_after(s, s_tn));
+      RC(gemm_tn(ws + w.ctx[i], H, dz1d, H, grads + pl.wo[i], H, M, H, H, grads + pl.bo[i], nullptr, nullptr, 0, 0.f, 0,
+                 take(b4r_gemm_tn_scratch_floats(N, H, H)), s_tn));
+      RC(gemm(dz1d, H, params + pl.wo[i], H, dctx_c, H, M, H, H, 1, B4R_EPI_NONE, nullptr, nullptr, 0, nullptr, 0, 1.f, 0, nullptr, 0,
+              0.f, 0, s));
+      RC(b4r_attn32_slotq_bwd_launch(ws + w.qkv[i], batch->input_mask, batch->masked_lm_positions, batch->masked_lm_ids, ws + w.ctx[i],
+                                     ws + w.lse[i], dctx_c, B, L, cfg->num_heads, P, qscale, ws + w.dqkv,
+                                     b4r_make_drop(rng, B4R_STREAM_ATTN_PROBS(i), adp, 1),
+                                     reinterpret_cast<const uint32_t*>(ws + w.keep[i]), s));
+    } else {
     // attention output projection: dctx = dropmask(dz1) . Wo^T and dWo = ctx^T . dropmask(dz1) (+ bias gradient) read dz1
     // once where the pair kernel applies (hidden size 64), else as two products
     {
@@ -1132,6 +1183,7 @@ static int backward_impl(const b4r_model_config* cfg, const b4r_batch* batch, co
                             qscale, ws + w.dqkv, rng, B4R_STREAM_ATTN_PROBS(i), adp,
                             reinterpret_cast<const uint32_t*>(ws + w.keep[i]), s, s_kv));
     RC(order_after(s_kv, s));
+    }
     // QKV projection: dX_in = dqkv . Wqkv^T + dz1, and for i > 0 straight on to layer i-1's output LayerNorm backward (-> da)
     if (i > 0) RC(order_after(s_tn, s));   // this layer's side branches still read da, which the fused product rewrites
     if (i > 0)

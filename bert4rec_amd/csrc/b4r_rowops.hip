@@ -1344,7 +1344,7 @@ __global__ __launch_bounds__(256) void slot_rows_drop_kernel(const float* src, c
 struct SlotTailP {
   const float* y; const float* res; const int64_t* pos; int L, P;
   const float* gamma; const float* beta; float eps; DropArgs drop;
-  float* z; float* mean; float* rstd; float* out;
+  float* z; float* mean; float* rstd; float* out; float* outc;   // out [N, H] by sequence row, outc [M, H] compact (either may be NULL)
   int rows, H;
 };
 template <int LPR, int NV>
@@ -1383,7 +1383,8 @@ __global__ __launch_bounds__(256) void slot_rows_tail_kernel(SlotTailP p) {
       o[e] = x[v][e] * inv + (b[e] - mean * inv);
     }
     *reinterpret_cast<f32x4*>(p.z + m * p.H + c) = x[v];
-    *reinterpret_cast<f32x4*>(p.out + row * p.H + c) = o;
+    if (p.out != nullptr) *reinterpret_cast<f32x4*>(p.out + row * p.H + c) = o;
+    if (p.outc != nullptr) *reinterpret_cast<f32x4*>(p.outc + m * p.H + c) = o;
   }
   if (sub == 0) { p.mean[m] = mean; p.rstd[m] = rstd; }
 }
@@ -1402,8 +1403,8 @@ int b4r_slot_rows_drop(const float* src, const int64_t* pos, int L, int P, int M
   return B4R_OK;
 }
 int b4r_slot_rows_tail(const float* y, const float* res, const int64_t* pos, int L, int P, int M, int H, const float* gamma, const float* beta,
-                       float eps, const DropArgs& drop, float* z, float* mean, float* rstd, float* out, hipStream_t s) {
-  SlotTailP p{y, res, pos, L, P, gamma, beta, eps, drop, z, mean, rstd, out, M, H};
+                       float eps, const DropArgs& drop, float* z, float* mean, float* rstd, float* out, float* outc, hipStream_t s) {
+  SlotTailP p{y, res, pos, L, P, gamma, beta, eps, drop, z, mean, rstd, out, outc, M, H};
 #define SLOT_TAIL_CASE(LPR_, NV_) \
   hipLaunchKernelGGL((slot_rows_tail_kernel<LPR_, NV_>), dim3(b4r_cdiv(M, 4 * (64 / LPR_))), dim3(256), 0, s, p)
   switch (H) {

@@ -53,6 +53,12 @@ CONFIGS = {
                               inner_dim=512), dict(B=8, L=48, P=20)),
     "h256": (orc.OracleConfig(vocab_size=1000, hidden_size=256, num_layers=2, num_attention_heads=8, max_sequence_length=64,
                               inner_dim=1024), dict(B=4, L=40, P=8)),
+    # sequences of more than two 32-token tiles with at most 64 slots: under B4R_FLAG_HEAD_ROWS_ONLY the last layer's attention core runs
+    # with the slots as its only queries (one / two compact query tiles: P = 24 / 40)
+    "h128_long": (orc.OracleConfig(vocab_size=700, hidden_size=128, num_layers=2, num_attention_heads=4, max_sequence_length=100,
+                                   inner_dim=512), dict(B=6, L=96, P=24)),
+    "h256_long": (orc.OracleConfig(vocab_size=900, hidden_size=256, num_layers=1, num_attention_heads=8, max_sequence_length=200,
+                                   inner_dim=1024), dict(B=3, L=200, P=40)),
     # token / slot counts that are NOT multiples of 32: the dense layers fall back to the exact-fp32 LDS-tiled kernels
     "odd_rows": (orc.OracleConfig(vocab_size=301, hidden_size=64, num_layers=1, num_attention_heads=2, max_sequence_length=50,
                                   inner_dim=256), dict(B=5, L=50, P=7)),
@@ -328,7 +334,7 @@ def test_train_step_takes_the_gradient_norm_from_the_closing_reduce_launch():
     assert "global norm" not in labels and labels.count("multi_slab_reduce") == 1, labels
 
 
-@pytest.mark.parametrize("name", ["ml1m_slice", "h128", "h256"])
+@pytest.mark.parametrize("name", ["ml1m_slice", "h128", "h256", "h128_long", "h256_long"])
 def test_encoder_only_forward_on_the_ranked_rows_equals_the_full_forward_there(name):
     """B4R_FLAG_ENCODER_ONLY | B4R_FLAG_HEAD_ROWS_ONLY (what an evaluation runs): no masked-LM head although the batch carries
     masked_lm_positions / masked_lm_ids, the last layer's feed-forward half only on the rows of the valid slots.  Those rows of the
@@ -363,7 +369,7 @@ def test_encoder_only_forward_on_the_ranked_rows_equals_the_full_forward_there(n
         assert skipped > 0.7, skipped
 
 
-@pytest.mark.parametrize("name", ["h128", "h256"])
+@pytest.mark.parametrize("name", ["h128", "h256", "h128_long", "h256_long"])
 def test_wide_train_mode_on_the_heads_rows_matches_oracle_mask_for_mask(name):
     """Hidden sizes 128 / 256 in train mode with both dropouts on, as b4r_train_step runs them: the logits-free head and the last
     layer's feed-forward half on the gathered rows only (compact [B*P, .] operands; the dropout decisions are those of the sequence

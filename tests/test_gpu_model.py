@@ -393,6 +393,28 @@ def test_wide_train_mode_on_the_heads_rows_matches_oracle_mask_for_mask(name):
         assert float((grads[k] - g).abs().max()) < 2e-4 * max(float(g.abs().max()), floor), k
 
 
+def test_slot_query_attention_with_a_fully_masked_sequence_equals_the_dense_path():
+    """The last layer's attention with the slots as its only queries (hidden 128, L = 96, P = 24) on a batch whose first sequence has
+    EVERY key masked (Keras' -1e9 adder then gives a uniform softmax over all L keys) and whose second has a single real token: loss
+    and gradients equal the dense path's (flag off), which the block tests pin against fp64 autograd for these cases."""
+    cfg_o, shp = CONFIGS["h128_long"]
+    cfg_o = orc.OracleConfig(**{**cfg_o.__dict__, "output_dropout": 0.1, "attention_dropout": 0.3})
+    eng, params = build(cfg_o)
+    if not eng.fused_head_supported():
+        pytest.skip("the compact last layer runs in the bf16x3 mode")
+    batch = orc.synthetic_batch(shp["B"], shp["L"], shp["P"], cfg_o.vocab_size, seed=8, ragged=True)
+    batch["input_mask"][0, :] = 0
+    batch["input_mask"][1, 1:] = 0
+    st, grads = run_loss_and_grads(eng, batch, training=True, seed=31, step=2, fused_head=True, head_rows_only=True)
+    grads = {k: v.clone() for k, v in grads.items()}
+    st2, dense = run_loss_and_grads(eng, batch, training=True, seed=31, step=2, fused_head=True, head_rows_only=False)
+    assert st["valid_count"] == st2["valid_count"] and abs(st2["loss_sum"] - st["loss_sum"]) < 1e-5 * abs(st["loss_sum"])
+    floor = 1e-4 * max(float(g.abs().max()) for g in dense.values())
+    for k, g in dense.items():
+        assert bool(torch.isfinite(grads[k]).all()), k
+        assert float((grads[k] - g).abs().max()) < 2e-4 * max(float(g.abs().max()), floor), k
+
+
 def test_item_table_gradient_with_hundreds_of_contributions_per_row():
     """The fixed-point item-table sum against autograd on a batch where every item row receives ten or more contributions
     (64 sequences over 37 items; the PAD and [MASK] rows hundreds): same tolerance as the other gradients, and the gradient of an

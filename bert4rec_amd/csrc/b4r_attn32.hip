@@ -1382,13 +1382,22 @@ struct A32SlotFwdP {
   DropArgs drop_p;
 };
 
-template <int NTT, bool DROP>
+// forward: every wave owns the 32 KEYS of its tokens for both compact query tiles (S^T = K_w . Q~^T, a local softmax over its 32 keys,
+// O^T partial = V_w^T . Pd^T); waves 0 .. NQ - 1 then merge the NT partials of their query tile (running maximum, rescaled sums) --
+// the seven key tiles of a query are swept in parallel instead of one after the other by the query's wave.
+// LDS (bytes): [K images NT x 4 KB | V images NT x 4 KB | Q~ images NQ x 4 KB | mask adders NT x 32 | (max, sum) NT x NQ x 32 x 2];
+// a wave's O^T partials of query tile 0 / 1 go over its own (then dead) K / V image.
+__host__ __device__ constexpr int slotq_fwd_lds(int NT, int NQ) { return (2 * NT + NQ) * P_TILE + (NT * 32 + NT * NQ * 64) * 4; }
+
+template <int NQT, bool DROP>
 __global__ __launch_bounds__(512, 2) void attn32_slotq_fwd_kernel(A32SlotFwdP p) {
   extern __shared__ __attribute__((aligned(16))) char smem32[];
-  const int NT = p.NT, L = p.L;
+  const int NT = p.NT, L = p.L, NQ = p.NQ;
   char* const kimg = smem32;
   char* const vimg = smem32 + NT * P_TILE;
-  float* const sAdd = reinterpret_cast<float*>(smem32 + 2 * NT * P_TILE);
+  char* const QIMG = vimg + NT * P_TILE;
+  float* const sAdd = reinterpret_cast<float*>(QIMG + NQ * P_TILE);
+  float* const sMS = sAdd + NT * 32;                   // [key tile][query tile][32 queries][max, sum]
   const int b = blockIdx.x / p.heads, head = blockIdx.x % p.heads;
   const int Hh = 32 * p.heads;
   const int64_t row0 = (int64_t)b * L;
@@ -1400,101 +1409,116 @@ __global__ __launch_bounds__(512, 2) void attn32_slotq_fwd_kernel(A32SlotFwdP p)
   const float* const src = p.qkv + (row0 + tokc) * (3 * Hh) + 32 * head;
   f32x16 kacc = load_acc_layout(src + Hh, h), vacc = load_acc_layout(src + 2 * Hh, h);
   // the wave's compact queries (waves 0 .. NQ - 1)
-  const bool qwave = wave < p.NQ;
+  const bool qwave = wave < NQ;
   const int j = 32 * wave + r, jc = min(j, p.P - 1);
   const bool livej = qwave && j < p.P;
-  int posq = 0;
   f32x16 qa = zero16();
   if (qwave) {
     const int64_t pq = p.pos[(int64_t)b * p.P + jc];
-    posq = (int)(pq < 0 ? 0 : (pq >= L ? L - 1 : pq));
+    const int posq = (int)(pq < 0 ? 0 : (pq >= L ? L - 1 : pq));
     qa = load_acc_layout(p.qkv + (row0 + posq) * (3 * Hh) + 32 * head, h);
   }
   const float amax = __syncthreads_or(any_key) ? 0.0f : -1e9f;
   if ((int)threadIdx.x < NT * 32)
     sAdd[threadIdx.x] = (int)threadIdx.x < L ? (((1.0f - (float)mval) * -1e9f) - amax) * LOG2E : -INFINITY;
-  qa = qa * (amax != 0.0f ? 0.0f : LOG2E);
-  bf16x8 qBh[2], qBl[2];
-#pragma unroll
-  for (int s = 0; s < 2; ++s) acc_frag(qa, s, qBh[s], qBl[s]);
+  qa = qa * (amax != 0.0f ? 0.0f : LOG2E);   // every key masked: Keras' -1e9 absorbs the scores -> a uniform softmax over the L keys
+  if (qwave) acc_to_rows(QIMG + wave * P_TILE, lk, qa);
   if (!live) { kacc = zero16(); vacc = zero16(); }
-  acc_to_rows(kimg + wave * P_TILE, lk, kacc);
-  acc_to_rows(vimg + wave * P_TILE, lk, vacc);
+  char* const kown = kimg + wave * P_TILE;
+  char* const vown = vimg + wave * P_TILE;
+  acc_to_rows(kown, lk, kacc);
+  acc_to_rows(vown, lk, vacc);
   lds_barrier();
-  if (!qwave) return;
 
   const DropCtx dcp = b4r_drop_ctx(p.drop_p);
-  f32x16 O;
-  const int qt = wave;
   const int slot = (r & 24) | ((r & 3) << 1) | ((r >> 2) & 1);
-  {
-  f32x16 S[NTT];
-  float m = -INFINITY;
+  bf16x8 kAh[2], kAl[2];
 #pragma unroll
-  for (int t = 0; t < NTT; ++t) {
-    if (t < NT) {
-      S[t] = rows_of(sAdd + 32 * t, h);
+  for (int ks = 0; ks < 2; ++ks) { kAh[ks] = row_at(kown + lk.rowc[ks]); kAl[ks] = row_at(kown + P_IMG + lk.rowc[ks]); }
+  const f32x16 add = rows_of(sAdd + 32 * wave, h);
+  f32x16 O[NQT];
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const char* ka = kimg + t * P_TILE + lk.rowc[ks];
-        S[t] = mfma32x3(row_at(ka), row_at(ka + P_IMG), qBh[ks], qBl[ks], S[t]);
-      }
-    } else {
+  for (int t = 0; t < NQT; ++t) {
+    O[t] = zero16();
+    if (t >= NQ) continue;   // (wave-uniform)
+    // the token of this lane's query in tile t (for the decisions' hash index)
+    const int jt = min(32 * t + r, p.P - 1);
+    const int64_t pq = p.pos[(int64_t)b * p.P + jt];
+    const int post = (int)(pq < 0 ? 0 : (pq >= L ? L - 1 : pq));
+    f32x16 S = add;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) S[t][e] = -INFINITY;
+    for (int ks = 0; ks < 2; ++ks) {
+      const char* qi = QIMG + t * P_TILE + lk.rowc[ks];
+      S = mfma32x3(kAh[ks], kAl[ks], row_at(qi), row_at(qi + P_IMG), S);   // S^T[key][query] = K_w . Q~_t^T
     }
-  }
+    float m = S[0];
 #pragma unroll
-  for (int t = 0; t < NTT; ++t)
+    for (int e = 1; e < 16; ++e) m = fmaxf(m, S[e]);
+    m = fmaxf(m, other_half(m, h));
+    const float mref = m == -INFINITY ? 0.0f : m;    // a tile of pad keys only: every term is 0
+    float sum = 0.f;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) m = fmaxf(m, S[t][e]);
-  m = fmaxf(m, other_half(m, h));
-  float sum = 0.f;
-#pragma unroll
-  for (int t = 0; t < NTT; ++t)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { S[t][e] = __builtin_amdgcn_exp2f(S[t][e] - m); sum += S[t][e]; }
-  sum += other_half(sum, h);
-  const float inv = 1.0f / sum;
-  if (h == 0 && livej) p.lse_c[bh * p.P + j] = m * LN2 + __logf(sum);
-
-  O = zero16();
-  const uint64_t dbase = ((uint64_t)bh * L + (uint64_t)posq) * (uint64_t)B4R_ATTN_PITCH;
-#pragma unroll
-  for (int t = 0; t < NTT; ++t) {
-    if (t >= NT) continue;
+    for (int e = 0; e < 16; ++e) { S[e] = __builtin_amdgcn_exp2f(S[e] - mref); sum += S[e]; }
+    sum += other_half(sum, h);
+    if (h == 0) { float* ms = sMS + ((wave * NQ + t) * 32 + r) * 2; ms[0] = m; ms[1] = sum; }
     if (DROP) {
       uint32_t word = 0;
-      const float sc = inv * dcp.scale;
+      const uint64_t dbase = ((uint64_t)bh * L + (uint64_t)post) * (uint64_t)B4R_ATTN_PITCH;
 #pragma unroll
       for (int gp = 0; gp < 4; ++gp) {
-        const B4rKeep4 k4 = b4r_keep4p(dcp, dbase + (uint64_t)(32 * t + 8 * gp + 4 * h));
+        const B4rKeep4 k4 = b4r_keep4p(dcp, dbase + (uint64_t)(32 * wave + 8 * gp + 4 * h));
 #pragma unroll
-        for (int e = 0; e < 4; ++e) S[t][4 * gp + e] = k4.k[e] ? S[t][4 * gp + e] * sc : 0.f;
+        for (int e = 0; e < 4; ++e) S[4 * gp + e] = k4.k[e] ? S[4 * gp + e] : 0.f;
         word |= k4.bits() << (8 * gp + 4 * h);
       }
       word |= other_half_u(word, h);
-      if (h == 0) p.bits_c[((bh * NT + t) * p.NQ + qt) * 32 + slot] = word;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) S[t][e] *= inv;
+      if (h == 0) p.bits_c[((bh * NT + wave) * NQ + t) * 32 + slot] = word;
     }
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
       bf16x8 ph, pl;
-      acc_frag(S[t], s2, ph, pl);
-      const char* va = vimg + t * P_TILE;
-      O = mfma32x3(tr_pair(va + lk.trp[s2][0], va + lk.trp[s2][1]), tr_pair(va + P_IMG + lk.trp[s2][0], va + P_IMG + lk.trp[s2][1]),
-                       ph, pl, O);
+      acc_frag(S, s2, ph, pl);
+      O[t] = mfma32x3(tr_pair(vown + lk.trp[s2][0], vown + lk.trp[s2][1]), tr_pair(vown + P_IMG + lk.trp[s2][0], vown + P_IMG + lk.trp[s2][1]),
+                      ph, pl, O[t]);
     }
   }
+  // the partials over the wave's own images (every read of them above was the wave's own and has been consumed by a product)
+#pragma unroll
+  for (int t = 0; t < NQT; ++t) {
+    if (t >= NQ) continue;
+    char* dst = (t == 0 ? kown : vown) + lane * 16;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+      *reinterpret_cast<f32x4*>(dst + jj * 1024) = (f32x4){O[t][4 * jj], O[t][4 * jj + 1], O[t][4 * jj + 2], O[t][4 * jj + 3]};
   }
+  lds_barrier();
+  if (!qwave) return;
+  // merge of query tile t = wave: M = max_w m_w, sum = sum_w 2^(m_w - M) sum_w, O = sum_w 2^(m_w - M) O_w
+  float M = -INFINITY;
+  for (int w = 0; w < NT; ++w) M = fmaxf(M, sMS[((w * NQ + wave) * 32 + r) * 2]);
+  float tot = 0.f;
+  f32x16 Om = zero16();
+  for (int w = 0; w < NT; ++w) {
+    const float* ms = sMS + ((w * NQ + wave) * 32 + r) * 2;
+    const float a = ms[0] == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(ms[0] - M);
+    tot = fmaf(a, ms[1], tot);
+    const char* srcp = (wave == 0 ? kimg : vimg) + w * P_TILE + lane * 16;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const f32x4 o4 = *reinterpret_cast<const f32x4*>(srcp + jj * 1024);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) Om[4 * jj + e] = fmaf(a, o4[e], Om[4 * jj + e]);
+    }
+  }
+  const float inv = (DROP ? dcp.scale : 1.0f) / tot;
+  if (h == 0 && livej) p.lse_c[bh * p.P + j] = M * LN2 + __logf(tot);
+  // O's registers 8s .. 8s+7 are context columns 16s + 8h + (0..7) of the head (V image in swapped column order, transposed reads)
   if (livej) {
     float* dst = p.ctx_c + ((int64_t)b * p.P + j) * Hh + 32 * head + 8 * h;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      *reinterpret_cast<f32x4*>(dst + 16 * s) = (f32x4){O[8 * s], O[8 * s + 1], O[8 * s + 2], O[8 * s + 3]};
-      *reinterpret_cast<f32x4*>(dst + 16 * s + 4) = (f32x4){O[8 * s + 4], O[8 * s + 5], O[8 * s + 6], O[8 * s + 7]};
+      *reinterpret_cast<f32x4*>(dst + 16 * s) = (f32x4){Om[8 * s] * inv, Om[8 * s + 1] * inv, Om[8 * s + 2] * inv, Om[8 * s + 3] * inv};
+      *reinterpret_cast<f32x4*>(dst + 16 * s + 4) = (f32x4){Om[8 * s + 4] * inv, Om[8 * s + 5] * inv, Om[8 * s + 6] * inv, Om[8 * s + 7] * inv};
     }
   }
 }
@@ -1810,17 +1834,17 @@ int b4r_attn32_slotq_fwd_launch(const float* qkv, const int64_t* mask, const int
   p.drop_p = drop;
   const bool dropping = drop.rng != nullptr && drop.thr != 0;
   B4R_CHECK_ARG(!dropping || bits_c, B4R_E_BADARG, "attention on the slots' queries: dropout needs the decision buffer");
-  const size_t sh = (size_t)core_fwd_lds(p.NT);
+  const size_t sh = (size_t)slotq_fwd_lds(p.NT, p.NQ);
   const dim3 grid((unsigned)(B * heads)), block((unsigned)(64 * p.NT));
   int rc;
-#define A32_SLOT_FWD_CASE(N_, D_)                                                                        \
+#define A32_SLOT_FWD_CASE(Q_, D_)                                                                        \
   {                                                                                                      \
-    rc = b4r_raise_lds((const void*)attn32_slotq_fwd_kernel<N_, D_>, sh, "attention on the slots' queries"); \
+    rc = b4r_raise_lds((const void*)attn32_slotq_fwd_kernel<Q_, D_>, sh, "attention on the slots' queries"); \
     if (rc) return rc;                                                                                   \
-    hipLaunchKernelGGL((attn32_slotq_fwd_kernel<N_, D_>), grid, block, sh, stream, p);                   \
+    hipLaunchKernelGGL((attn32_slotq_fwd_kernel<Q_, D_>), grid, block, sh, stream, p);                   \
   }
-  if (p.NT <= 4) { if (dropping) A32_SLOT_FWD_CASE(4, true) else A32_SLOT_FWD_CASE(4, false) }
-  else { if (dropping) A32_SLOT_FWD_CASE(7, true) else A32_SLOT_FWD_CASE(7, false) }
+  if (p.NQ <= 1) { if (dropping) A32_SLOT_FWD_CASE(1, true) else A32_SLOT_FWD_CASE(1, false) }
+  else { if (dropping) A32_SLOT_FWD_CASE(2, true) else A32_SLOT_FWD_CASE(2, false) }
 #undef A32_SLOT_FWD_CASE
   B4R_CHECK_LAUNCH("attention core forward, queries = the head's slots");
   return B4R_OK;

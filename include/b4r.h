@@ -153,7 +153,11 @@ int b4r_workspace_region(const b4r_model_config* cfg, int32_t B, int32_t L, int3
  * rows of the sequence output that the masked-LM head gathers (about P/L of them: 20 % at ML-1M) -- forward and backward.  Loss, metrics
  * and every gradient are unchanged (the other rows of that output reach neither the loss nor, through attention, any row that does);
  * "sequence_output" / "encoder_output_<last>" are then only defined on those rows, which is why the forward / evaluation API never sets
- * the flag.  b4r_train_step uses it; ignored where the fused feed-forward block does not apply.
+ * the flag.  b4r_train_step uses it.  Hidden size 64: the resident feed-forward block in its slot mode.  Every other hidden size (the
+ * tile-product path), when P <= L / 2 and inner_dim >= 3 hidden + 8: the same half as dense products on compact [B*P, .] rows, and
+ * for 64 < L <= 224, P <= 64 also the layer's attention half -- the core with the slots as its ONLY queries (keys / values: all
+ * tokens), output projection, dropout, residual and LayerNorm on the compact rows; "encoder_output_<last>" is written at the
+ * slots' rows only, the layer's ctx / z1 / x1 regions hold compact data.  Ignored otherwise.
  * PRECONDITION: the valid masked-LM slots (masked_lm_ids != 0) of one sequence name distinct positions -- what the reference's
  * preprocessor and b4r_mask_batch produce (dataloader_utils.py:221-226 samples positions without replacement).  Two valid slots on
  * one position would each write that row's gradient (last writer wins) where the scatter-add path sums them. */

@@ -123,6 +123,19 @@ __device__ __forceinline__ void acc_to_rl(const RowLay& k, char* halfA, char* ha
 // ---------------------------------------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------------------------------------
+// accumulator (rows = the image's columns) -> row `row` of a tile for lane half h (acc_to_rows with the row chosen per lane)
+__device__ __forceinline__ void acc_rows_at(char* tile, int row, int h, const f32x16& v) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    bf16x8 hi, lo;
+    split8(regs8(v, s), hi, lo);
+    char* d = tile + p_chunk(row, 2 * s + h);
+    *reinterpret_cast<bf16x8*>(d) = hi;
+    *reinterpret_cast<bf16x8*>(d + P_IMG) = lo;
+  }
+}
+__device__ __forceinline__ int a32_slot_perm(int r) { return (r & 24) | ((r & 3) << 1) | ((r >> 2) & 1); }   // query r of a tile -> its decision word
+
 struct A32BwdP {
   const float* x; const float* dz1; const float* ctx; const float* lse; const uint32_t* bits; const int64_t* mask;
   const float* Wqkv; const float* bqkv; const float* Wo;
@@ -143,8 +156,16 @@ struct A32BwdP {
 // staging, then dS) | weight slices of one head 32 KB | key mask adders, -lse, D, biases, LayerNorm partials]
 __host__ __device__ constexpr int bwd32_small_floats(int NT) { return 3 * NT * 32 + 192 + NT * 128 + 8 + NT * 96 + NT * 32; }
 __host__ __device__ constexpr int bwd32_lds(int NT) { return 4 * NT * P_TILE + 8 * P_TILE + bwd32_small_floats(NT) * 4; }
+// CQ (compact queries, below): + token -> slot [NT x 32], slot -> token [64], the sweep's decision words [NT key tiles][2][32]
+__host__ __device__ constexpr int bwd32_lds_cq(int NT) { return bwd32_lds(NT) + (NT * 32 + 64 + NT * 64) * 4; }
 
-template <bool EMBED, bool DROP>
+// CQ (the last layer of a train step, p.slot_pos != NULL, at most 64 slots): only the labelled slots' rows of dz1 carry a gradient,
+// so only those QUERIES have a non-zero dO -- every other query's softmax backward is exactly zero.  The sweep then walks one or two
+// COMPACT query tiles (query j = slot j; rows of padded slots are empty: -lse = -inf) instead of the NT token tiles: every wave still
+// projects q~ / dO of its own tokens, the labelled ones scatter their rows into the compact Q~ / dO images, a key owner walks the compact
+// tiles itself (no rotating ownership), keeps its dQ partials in registers, the partials are summed over the key owners in wave order
+// and each token picks up its slot's dq row (zero without a slot).  The forward's decision words are regathered into the compact order.
+template <bool EMBED, bool DROP, bool CQ = false>
 __global__ __launch_bounds__(512, 2) void attn32_bwd_kernel(A32BwdP p) {
   extern __shared__ __attribute__((aligned(16))) char smem32[];
   const int NT = p.NT, L = p.L;
@@ -161,6 +182,10 @@ __global__ __launch_bounds__(512, 2) void attn32_bwd_kernel(A32BwdP p) {
   int* const sflag = reinterpret_cast<int*>(sred + NT * 128);   // [NT] steps of the sweep each wave has finished
   float* const sdb = reinterpret_cast<float*>(sflag + 8);      // [NT][96] column sums of dq | dk | dv over a wave's tokens
   float* const sHas = sdb + NT * 96;                            // [NT * 32] 1 where the token's dz1 row carries a gradient
+  int* const sSlot = reinterpret_cast<int*>(sHas + NT * 32);   // CQ: [NT * 32] the token's slot, -1: none
+  int* const sTok = sSlot + NT * 32;                            // CQ: [64] the slot's token, -1: padded slot
+  uint32_t* const sCW = reinterpret_cast<uint32_t*>(sTok + 64); // CQ: [NT][2][32] decision words of (key tile, compact query tile)
+  const int NQ = CQ ? (p.slots + 31) >> 5 : 0;
 
   const int nthreads = blockDim.x;
   const int b = blockIdx.x;
@@ -197,13 +222,16 @@ __global__ __launch_bounds__(512, 2) void attn32_bwd_kernel(A32BwdP p) {
   if ((int)threadIdx.x < NT * 32) {
     sAdd[threadIdx.x] = (int)threadIdx.x < L ? (((1.0f - (float)mval) * -1e9f) - amax) * LOG2E : -INFINITY;
     sHas[threadIdx.x] = p.slot_pos != nullptr ? 0.f : 1.f;
+    if (CQ) { sSlot[threadIdx.x] = -1; if (threadIdx.x < 64) sTok[threadIdx.x] = -1; }
   }
   if (p.slot_pos != nullptr) {   // (block-uniform)
     lds_barrier();
     for (int j = threadIdx.x; j < p.slots; j += nthreads)
       if (p.slot_ids[(int64_t)b * p.slots + j] != 0) {
         const int64_t q = p.slot_pos[(int64_t)b * p.slots + j];
-        sHas[q < 0 ? 0 : (q >= L ? L - 1 : (int)q)] = 1.f;
+        const int qc = q < 0 ? 0 : (q >= L ? L - 1 : (int)q);
+        sHas[qc] = 1.f;
+        if (CQ) { sSlot[qc] = j; sTok[j] = qc; }
       }
   }
   lds_barrier();
@@ -312,6 +340,7 @@ __global__ __launch_bounds__(512, 2) void attn32_bwd_kernel(A32BwdP p) {
     }
     A32_MARK(1 + 10 * hd);
     lds_barrier();   // every wave is done with the previous head's weight slices (the wave's own tiles were free before)
+    if (CQ && threadIdx.x < 64) { sCS[threadIdx.x] = -INFINITY; sD[threadIdx.x] = 0.f; }   // (padded slots: empty query rows)
     A32_MARK(2 + 10 * hd);
     // tiles 0..5: W_j[hidden 32 rt ..][features 32 hd ..] (j = q, k, v; tile 2j + rt); 6, 7: Wo[32 hd ..][hidden 32 (gt - 6) ..]
     stage_tiles<5>(WIMG, 8, nthreads, [&](int gt, int& ld) __attribute__((always_inline)) -> const float* {
@@ -363,14 +392,31 @@ __global__ __launch_bounds__(512, 2) void attn32_bwd_kernel(A32BwdP p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) d = fmaf(dcT[4 * gp + e], cx[gp][e], d);
       d += other_half(d, h);
-      if (h == 0) { sD[tok] = d; sCS[tok] = -lse_q * LOG2E; }
+      if (!CQ) { if (h == 0) { sD[tok] = d; sCS[tok] = -lse_q * LOG2E; } }
+      else { const int js_ = live ? sSlot[tok] : -1; if (h == 0 && js_ >= 0) { sD[js_] = d; sCS[js_] = -lse_q * LOG2E; } }
     }
     // operand forms and images of the wave's tile (the x / dz1 images are dead: every read of them is in front of these writes)
     bf16x8 kBh[2], kBl[2], vBh[2], vBl[2];     // K^T, V^T [feature][key] as B operands of S = Q~.K^T and dA = dO.V^T
 #pragma unroll
     for (int s = 0; s < 2; ++s) { acc_frag(kT, s, kBh[s], kBl[s]); acc_frag(vT, s, vBh[s], vBl[s]); }
-    acc_to_rows(ownA, lk, qT);
-    acc_to_rows(ownB, lk, dcT);
+    const int js = (CQ && live) ? sSlot[tok] : -1;
+    if (!CQ) {
+      acc_to_rows(ownA, lk, qT);
+      acc_to_rows(ownB, lk, dcT);
+    } else {
+      lds_barrier();   // the compact rows go into OTHER waves' tiles: every wave has finished the projections' reads of its x / dz1 images
+      if (js >= 0) {
+        acc_rows_at(QIMG + (js >> 5) * P_TILE, js & 31, h, qT);
+        acc_rows_at(DOIMG + (js >> 5) * P_TILE, js & 31, h, dcT);
+      }
+      // the decision words of (key tile w, compact tile): slot j's word is its token's, in the slot's place
+      for (int i = threadIdx.x; i < NT * 64; i += nthreads) {
+        const int w_ = i >> 6, jj = i & 63, tq = sTok[jj];
+        uint32_t word = 0;
+        if (DROP && tq >= 0) word = p.bits[((bh * NT + w_) * NT + (tq >> 5)) * 32 + a32_slot_perm(tq & 31)];
+        sCW[(w_ * 2 + (jj >> 5)) * 32 + a32_slot_perm(jj & 31)] = word;
+      }
+    }
     acc_to_rows(scr, lk, kT);
     bf16x8 kTh[2], kTl[2];                     // K^T[feature position][key] as the A operand of dQ^T = K^T.dS^T
 #pragma unroll
@@ -378,8 +424,10 @@ __global__ __launch_bounds__(512, 2) void attn32_bwd_kernel(A32BwdP p) {
       kTh[s] = tr_pair(scr + lk.trn[s][0], scr + lk.trn[s][1]);
       kTl[s] = tr_pair(scr + P_IMG + lk.trn[s][0], scr + P_IMG + lk.trn[s][1]);
     }
+    if (!CQ) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(ownC + j * 1024 + lane * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(ownC + j * 1024 + lane * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     A32_MARK(6 + 10 * hd);
     if (lane == 0) sflag[wave] = 0;
     lds_barrier();   // images, D, -lse of every tile in place; accumulators zero; (the K^T reads above have landed: lgkmcnt(0))
@@ -412,6 +460,102 @@ __global__ __launch_bounds__(512, 2) void attn32_bwd_kernel(A32BwdP p) {
 #define A32_SB() __builtin_amdgcn_sched_barrier(0)
     auto tile_of = [&](int s) __attribute__((always_inline)) { const int t = wave + s; return t >= NT ? t - NT : t; };
     typedef const __attribute__((address_space(4))) uint64_t* kmask_ptr;   // constant address space: scalar loads
+    if (CQ) {
+      f32x16 dQp[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        dQp[t] = zero16();
+        if (t >= NQ) continue;   // (block-uniform)
+        const char* qimg = QIMG + t * P_TILE;
+        const char* dimg = DOIMG + t * P_TILE;
+        S = rows_of(sCS + 32 * t, h);
+        dA = zero16();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) S[e] += adk;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          bf16x8 ah, al;
+          A32_LD_ROW(qimg, ks, ah, al);
+          S = mfma32x3(ah, al, kBh[ks], kBl[ks], S);
+          A32_LD_ROW(dimg, ks, ah, al);
+          dA = mfma32x3(ah, al, vBh[ks], vBl[ks], dA);
+        }
+        const f32x16 Dq = rows_of(sD + 32 * t, h);
+        uint64_t km[16];
+        if (DROP) {
+          const uint32_t* cw = sCW + (wave * 2 + t) * 32;
+#pragma unroll
+          for (int tt = 0; tt < 16; ++tt) {
+            const uint32_t lo_ = __builtin_amdgcn_readfirstlane(cw[2 * tt]), hi_ = __builtin_amdgcn_readfirstlane(cw[2 * tt + 1]);
+            km[tt] = ((uint64_t)hi_ << 32) | lo_;
+          }
+        }
+        bf16x8 pdh[2], pdl[2], dsh[2], dsl[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          f32x8 pd, ds;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int tt = 8 * s2 + j;
+            const float pr = __builtin_amdgcn_exp2f(S[tt]);
+            if (DROP) {
+              const float kf = __builtin_amdgcn_inverse_ballot_w64(km[tt]) ? pscale : 0.f;
+              pd[j] = pr * kf;
+              ds[j] = pr * fmaf(dA[tt], kf, -Dq[tt]);
+            } else {
+              pd[j] = pr;
+              ds[j] = pr * (dA[tt] - Dq[tt]);
+            }
+          }
+          split8(pd, pdh[s2], pdl[s2]);
+          split8(ds, dsh[s2], dsl[s2]);
+          const s16x8 hv = __builtin_bit_cast(s16x8, dsh[s2]), lv = __builtin_bit_cast(s16x8, dsl[s2]);
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
+            char* w8 = scr + p_chunk(r, 2 * s2 + a) + 8 * h;
+            *reinterpret_cast<s16x4*>(w8) = a ? __builtin_shufflevector(hv, hv, 4, 5, 6, 7) : __builtin_shufflevector(hv, hv, 0, 1, 2, 3);
+            *reinterpret_cast<s16x4*>(w8 + P_IMG) = a ? __builtin_shufflevector(lv, lv, 4, 5, 6, 7) : __builtin_shufflevector(lv, lv, 0, 1, 2, 3);
+          }
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          bf16x8 fh, fl;
+          A32_LD_TR(dimg, s2, fh, fl);
+          dV = mfma32x3(fh, fl, pdh[s2], pdl[s2], dV);
+          A32_LD_TR(qimg, s2, fh, fl);
+          dK = mfma32x3(fh, fl, dsh[s2], dsl[s2], dK);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          bf16x8 fh, fl;
+          A32_LD_SCR(ks, fh, fl);
+          dQp[t] = mfma32x3(kTh[ks], kTl[ks], fh, fl, dQp[t]);
+        }
+      }
+      // dQ of compact tile t = the key owners' partials in wave order, left in accumulator tile t (register layout)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (t >= NQ) continue;
+        lds_barrier();   // (t == 0: every sweep is over; t > 0: the previous tile's partials have been read)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<f32x4*>(scr + j * 1024 + lane * 16) = (f32x4){dQp[t][4 * j], dQp[t][4 * j + 1], dQp[t][4 * j + 2], dQp[t][4 * j + 3]};
+        lds_barrier();
+        if (wave == t) {
+          f32x16 gsum = zero16();
+          for (int w_ = 0; w_ < NT; ++w_)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const f32x4 a4 = *reinterpret_cast<const f32x4*>(SCRALL + w_ * P_TILE + j * 1024 + lane * 16);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) gsum[4 * j + e] += a4[e];
+            }
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<f32x4*>(DQACC + t * P_TILE + j * 1024 + lane * 16) = (f32x4){gsum[4 * j], gsum[4 * j + 1], gsum[4 * j + 2], gsum[4 * j + 3]};
+        }
+      }
+    } else {
     {   // S, dA of the first tile
       const char* qimg = QIMG + wave * P_TILE;
       const char* dimg = DOIMG + wave * P_TILE;
@@ -526,16 +670,27 @@ __global__ __launch_bounds__(512, 2) void attn32_bwd_kernel(A32BwdP p) {
       *reinterpret_cast<volatile int*>(sflag + wave) = s + 1;   // LDS operations of a wave complete in order: the sums are in place
       A32_SWEEP(5 + 4 * s);
     }
+    }
     lds_barrier();   // every accumulator is complete
 
     // ---- results of this head for the wave's tokens: registers 8s .. 8s+7 = features 16s + 8h + (0..7) ----------------------------
     A32_MARK(8 + 10 * hd);
     f32x16 gq;
+    if (!CQ) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const f32x4 a4 = *reinterpret_cast<const f32x4*>(ownC + j * 1024 + lane * 16);
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(ownC + j * 1024 + lane * 16);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) gq[4 * j + e] = a4[e] * p.qscale;
+        for (int e = 0; e < 4; ++e) gq[4 * j + e] = a4[e] * p.qscale;
+      }
+    } else {   // the token's slot row of the compact dQ (lane (slot & 31, h) of tile slot >> 5), zero without a slot
+      const char* src = DQACC + (max(js, 0) >> 5) * P_TILE + (32 * h + (max(js, 0) & 31)) * 16;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 a4 = *reinterpret_cast<const f32x4*>(src + j * 1024);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gq[4 * j + e] = js >= 0 ? a4[e] * p.qscale : 0.f;
+      }
     }
     const f32x16 gk = dK * LN2;   // Q~ carries log2(e)
     const bool fold = p.dw_slab != nullptr;   // dWqkv / dbqkv formed here instead of writing dqkv for a weight-gradient launch
@@ -1926,19 +2081,27 @@ int b4r_attn32_bwd(const b4r_attn_block_bwd_desc* d, b4r_stream_t stream) {
   p.drop_o = b4r_make_drop(d->rng, d->out_stream, d->out_rate, d->rng != nullptr);
   p.drop_e = b4r_make_drop(d->rng, d->emb_stream, d->emb_rate, d->rng != nullptr && embed);
   B4R_CHECK_ARG(!p.drop_p.rng || d->keep_bits, B4R_E_BADARG, "b4r_attn_block_bwd: attention dropout needs the forward's keep_bits");
-  const size_t sh = (size_t)bwd32_lds(p.NT);
+  // the slots as the sweep's only queries (the kernel's CQ form): a row list of at most 64 slots on at least three token tiles
+  static const bool cq_on = !(getenv("B4R_ATTN32_CQ") && atoi(getenv("B4R_ATTN32_CQ")) == 0);
+  const bool cq = cq_on && p.slot_pos != nullptr && p.slots <= 64 && p.NT >= 3;
+  const size_t sh = cq ? (size_t)bwd32_lds_cq(p.NT) : (size_t)bwd32_lds(p.NT);
   const dim3 grid((unsigned)d->B), block((unsigned)(64 * p.NT));
   hipStream_t s = (hipStream_t)stream;
   int rc;
   const bool drop = p.drop_p.rng != nullptr && p.drop_p.thr != 0;
-#define A32_BWD_CASE(E_, D_)                                                                          \
+#define A32_BWD_CASE(E_, D_, C_)                                                                      \
   {                                                                                                   \
-    rc = b4r_raise_lds((const void*)attn32_bwd_kernel<E_, D_>, sh, "b4r_attn_block_bwd");             \
+    rc = b4r_raise_lds((const void*)attn32_bwd_kernel<E_, D_, C_>, sh, "b4r_attn_block_bwd");         \
     if (rc) return rc;                                                                                \
-    hipLaunchKernelGGL((attn32_bwd_kernel<E_, D_>), grid, block, sh, s, p);                           \
+    hipLaunchKernelGGL((attn32_bwd_kernel<E_, D_, C_>), grid, block, sh, s, p);                       \
   }
-  if (embed) { if (drop) A32_BWD_CASE(true, true) else A32_BWD_CASE(true, false) }
-  else { if (drop) A32_BWD_CASE(false, true) else A32_BWD_CASE(false, false) }
+  if (cq) {
+    if (embed) { if (drop) A32_BWD_CASE(true, true, true) else A32_BWD_CASE(true, false, true) }
+    else { if (drop) A32_BWD_CASE(false, true, true) else A32_BWD_CASE(false, false, true) }
+  } else {
+    if (embed) { if (drop) A32_BWD_CASE(true, true, false) else A32_BWD_CASE(true, false, false) }
+    else { if (drop) A32_BWD_CASE(false, true, false) else A32_BWD_CASE(false, false, false) }
+  }
 #undef A32_BWD_CASE
   B4R_CHECK_LAUNCH("b4r_attn_block_bwd");
   // gamma / beta gradients of the previous LayerNorm: ordered sum over the sequences (queued with the caller's reductions)

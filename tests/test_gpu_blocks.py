@@ -387,7 +387,9 @@ def test_attn_block_backward_matches_fp64_autograd(B, L, p_rate, o_rate, embed, 
     assert all(torch.equal(a, b_) for a, b_ in zip(keep, (dw, dbq, dwo, dbo)))
 
     # sparse dz1 (the last layer of a train step): only the rows named by (slot positions, slot ids != 0) exist; the launch must give
-    # bit for bit what it gives for the dense tensor with zeros elsewhere, without ever reading the other rows (NaN there)
+    # what it gives for the dense tensor with zeros elsewhere, without ever reading the other rows (NaN there).  With at most 64 slots
+    # on three or more token tiles the sweep walks the slots as its only queries (compact query tiles, another summation order):
+    # equal within the split products' rounding there, bit for bit otherwise -- and bit for bit between two runs of itself
     Ps = 5
     gen = torch.Generator().manual_seed(B + L)
     slot_pos = torch.stack([torch.randperm(L, generator=gen)[:Ps] if L >= Ps else torch.arange(Ps) % L for _ in range(B)]).to(torch.int64)
@@ -409,8 +411,18 @@ def test_attn_block_backward_matches_fp64_autograd(B, L, p_rate, o_rate, embed, 
         torch.cuda.synchronize()
         res.append([v.clone() for v in (dw, dbq, dwo, dbo, out["da"], out["dln"])])
     assert all(bool(torch.isfinite(v).all()) for v in res[1])
+    compact_queries = L > 64   # (three or more 32-token tiles: the 32-token-tile kernel under either tile choice)
     for name, a, b_ in zip(("dWqkv", "dbqkv", "dWo", "dbo", "dx_prev", "dprev_gamma"), *res):
-        assert torch.equal(a, b_), (name, float((a - b_).abs().max()))
+        if compact_queries:
+            assert float((a - b_).abs().max()) < 1e-4 * max(1.0, float(a.abs().max())), (name, float((a - b_).abs().max()))
+        else:
+            assert torch.equal(a, b_), (name, float((a - b_).abs().max()))
+    for v in (dw, dbq, dwo, dbo, out["da"], out["dln"]):
+        v.fill_(nan)
+    _lib.check(lib.b4r_attn_block_bwd(C.byref(bd), stream()), "b4r_attn_block_bwd (sparse dz1, again)")
+    torch.cuda.synchronize()
+    for name, a, b_ in zip(("dWqkv", "dbqkv", "dWo", "dbo", "dx_prev", "dprev_gamma"), res[1], (dw, dbq, dwo, dbo, out["da"], out["dln"])):
+        assert torch.equal(a, b_), name
 
 
 # ---------------------------------------------------------------------------------------------------------------------------

@@ -64,7 +64,8 @@ class AttnBlockDesc(C.Structure):
                 ("x1", C.c_void_p), ("mean1", C.c_void_p), ("rstd1", C.c_void_p),
                 ("emb_ids", C.c_void_p), ("emb_table", C.c_void_p), ("emb_pos", C.c_void_p), ("emb_gamma", C.c_void_p),
                 ("emb_beta", C.c_void_p), ("emb_vocab", C.c_int32), ("emb_eps", C.c_float), ("emb_stream", C.c_uint32),
-                ("emb_rate", C.c_float), ("emb_x", C.c_void_p), ("emb_mean", C.c_void_p), ("emb_rstd", C.c_void_p)]
+                ("emb_rate", C.c_float), ("emb_x", C.c_void_p), ("emb_mean", C.c_void_p), ("emb_rstd", C.c_void_p),
+                ("out_slot_positions", C.c_void_p), ("out_slots", C.c_int32)]
 
 
 class AttnBlockBwdDesc(C.Structure):

@@ -262,7 +262,8 @@ __global__ __launch_bounds__(512, 2) void attn32_bwd_kernel(A32BwdP p) {
     for (int i = 0; i < 8; ++i) {
       const bool lv = 32 * wave + 4 * i + rl_row < L;
       f32x4 dy = dz_row(i);
-      const f32x4 cr = ld4(ctxb, rl_off(rl, i));
+      f32x4 cr = ld4(ctxb, rl_off(rl, i));
+      if (CQ && sHas[min(32 * wave + 4 * i + rl_row, L - 1)] == 0.f) cr = (f32x4){0.f, 0.f, 0.f, 0.f};   // (the forward wrote the slots' rows only)
       if (dco.on) dy = b4r_drop4(dco, dy, (uint64_t)(row0 + 32 * wave + 4 * i + rl_row) * HID + (uint64_t)(4 * rl_c4));
       if (!lv) dy = (f32x4){0.f, 0.f, 0.f, 0.f};   // pad tokens: no contribution
       dbo += dy;
@@ -870,12 +871,24 @@ struct A32FwdP {
   float* x_out; float* mean0; float* rstd0;
   int V; float eps0;
   DropArgs drop_e;
+  // CQ: the only rows anything downstream reads -- token clamp(slot_pos[b][j]), j < slots <= 64 (every slot, labelled or padded)
+  const int64_t* slot_pos; int slots;
 };
 
 __host__ __device__ constexpr int fwd32_region_a(int NT) { return 4 * NT * P_TILE > 12 * P_TILE + 2 * NT * P_TILE ? 4 * NT * P_TILE : 12 * P_TILE + 2 * NT * P_TILE; }
 __host__ __device__ constexpr int fwd32_lds(int NT) { return 4 * P_TILE + fwd32_region_a(NT) + (NT * 32 + 192) * 4; }
+// CQ: + compact Q~ images [head][2 tiles], per-head (max, sum) of the key owners' partial softmax [2][NT][2][32][2], token -> slot [NT x 32],
+// slot -> token [64]
+__host__ __device__ constexpr int fwd32_lds_cq(int NT) { return fwd32_lds(NT) + 4 * P_TILE + (2 * NT * 2 * 64 + NT * 32 + 64) * 4; }
 
-template <int NTT, bool DROP>
+// CQ (the last layer under B4R_FLAG_HEAD_ROWS_ONLY, at most 64 slots on three or more token tiles): only the slots' rows of this block's
+// outputs are read downstream (the feed-forward half in its slot mode, the backward's CQ form), so only those QUERIES are swept.  Every
+// wave still projects q~ / k / v of its own tokens and writes its K / V images; the slot tokens scatter their q~ rows into compact Q~
+// images; then every wave owns the 32 KEYS of its tokens for the one or two compact query tiles (S^T = K_w . Q~^T, a local softmax over
+// its keys, an O^T partial over its own -- then dead -- K / V tile) and waves 0 .. NQ - 1 merge the NT partials of their tile (running
+// maximum, rescaled sums), project, and run the row epilogue on the slots' rows: ctx, z1 (x1), statistics, lse and the decision words
+// leave for the slots' TOKENS only.  Padded slots repeat position 0: one slot per token computes the row, the others are empty.
+template <int NTT, bool DROP, bool CQ = false>
 __global__ __launch_bounds__(512, 2) void attn32_fwd_kernel(A32FwdP p) {
   extern __shared__ __attribute__((aligned(16))) char smem32[];
   const int NT = p.NT, L = p.L;
@@ -886,6 +899,11 @@ __global__ __launch_bounds__(512, 2) void attn32_fwd_kernel(A32FwdP p) {
   char* const KV = RA;                              // phase 2: [head][K | V][token tile]
   float* const sAdd = reinterpret_cast<float*>(RA + fwd32_region_a(NT));   // (mask adder - amax) * log2e per key, -inf beyond L
   float* const sbq = sAdd + NT * 32;
+  char* const QC = reinterpret_cast<char*>(sbq + 192);                      // CQ: compact Q~ images, tile 2 hd + t
+  float* const sMS = reinterpret_cast<float*>(QC + 4 * P_TILE);             // CQ: [head][key tile][compact tile][32 queries][max, sum]
+  int* const sSlot = reinterpret_cast<int*>(sMS + 2 * NT * 2 * 64);        // CQ: [NT * 32] a slot of the token, -1: none
+  int* const sTok = sSlot + NT * 32;                                        // CQ: [64] the slot's token, -1: empty (padded duplicate)
+  const int NQ = CQ ? (p.slots + 31) >> 5 : 0;
 
   const int nthreads = blockDim.x;
   const int b = blockIdx.x;
@@ -893,6 +911,24 @@ __global__ __launch_bounds__(512, 2) void attn32_fwd_kernel(A32FwdP p) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   A32_LANE_CONSTS();
   char* const own = RA + wave * 4 * P_TILE;         // phase 3: 16 KB of transposition space per wave
+  if (CQ) {   // token <-> slot (a token named by several slots -- position 0 of padded slots -- keeps one of them)
+    if ((int)threadIdx.x < NT * 32) sSlot[threadIdx.x] = -1;
+    lds_barrier();
+    if ((int)threadIdx.x < p.slots) {
+      const int64_t q = p.slot_pos[(int64_t)b * p.slots + threadIdx.x];
+      sSlot[q < 0 ? 0 : (q >= L ? L - 1 : (int)q)] = threadIdx.x;
+    }
+    lds_barrier();
+    if (threadIdx.x < 64) {
+      int tq = -1;
+      if ((int)threadIdx.x < p.slots) {
+        const int64_t q = p.slot_pos[(int64_t)b * p.slots + threadIdx.x];
+        const int qc = q < 0 ? 0 : (q >= L ? L - 1 : (int)q);
+        tq = sSlot[qc] == (int)threadIdx.x ? qc : -1;
+      }
+      sTok[threadIdx.x] = tq;
+    }
+  }
   // (s_setprio(1) for waves 4.., the younger wave of every SIMD, was measured: forward 42.7 / 42.9 us with, 43.0 / 42.2 without)
 
   const int64_t mval = (int)threadIdx.x < L ? p.mask[row0 + threadIdx.x] : 0;
@@ -985,8 +1021,13 @@ __global__ __launch_bounds__(512, 2) void attn32_fwd_kernel(A32FwdP p) {
             *reinterpret_cast<f32x4*>(dst + HID * j + 8 * gp) = (f32x4){acc[j][4 * gp], acc[j][4 * gp + 1], acc[j][4 * gp + 2], acc[j][4 * gp + 3]};
       }
       acc[0] = acc[0] * LOG2E;
+      if (CQ) {   // (every key masked: zero, as the dense form's operand)
+        const int js_ = live ? sSlot[tok] : -1;
+        if (js_ >= 0) acc_rows_at(QC + (2 * hd + (js_ >> 5)) * P_TILE, js_ & 31, h, acc[0] * (amax != 0.0f ? 0.0f : 1.0f));
+      } else {
 #pragma unroll
-      for (int s = 0; s < 2; ++s) acc_frag(acc[0], s, qBh[hd][s], qBl[hd][s]);
+        for (int s = 0; s < 2; ++s) acc_frag(acc[0], s, qBh[hd][s], qBl[hd][s]);
+      }
       kT[hd] = acc[1]; vT[hd] = acc[2];
     }
   }
@@ -1017,6 +1058,95 @@ __global__ __launch_bounds__(512, 2) void attn32_fwd_kernel(A32FwdP p) {
   f32x16 O[2];
   const int qt = wave;
   const int slot = (r & 24) | ((r & 3) << 1) | ((r >> 2) & 1);   // query 16s + 8a + 4h' + b -> 16s + 8a + 2b + h' (the backward's register pairs)
+  if (CQ) {
+    const f32x16 add = rows_of(sAdd + 32 * wave, h);
+    const bool qwave = wave < NQ;
+#pragma unroll
+    for (int hd = 0; hd < 2; ++hd) {
+      char* const kown = KV + ((2 * hd) * NT + wave) * P_TILE;
+      char* const vown = KV + ((2 * hd + 1) * NT + wave) * P_TILE;
+      const int64_t bh = (int64_t)b * 2 + hd;
+      float* const ms_h = sMS + hd * (NT * 2 * 64);
+      bf16x8 kAh[2], kAl[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) { kAh[ks] = row_at(kown + lk.rowc[ks]); kAl[ks] = row_at(kown + P_IMG + lk.rowc[ks]); }
+      f32x16 Op[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        Op[t] = zero16();
+        if (t >= NQ) continue;   // (block-uniform)
+        const int tq = sTok[32 * t + r];   // this lane's query: the token of slot 32 t + r, -1: empty
+        f32x16 S = add;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const char* qi = QC + (2 * hd + t) * P_TILE + lk.rowc[ks];
+          S = mfma32x3(kAh[ks], kAl[ks], row_at(qi), row_at(qi + P_IMG), S);   // S^T[key][query] = K_w . Q~_t^T
+        }
+        float m = S[0];
+#pragma unroll
+        for (int e = 1; e < 16; ++e) m = fmaxf(m, S[e]);
+        m = fmaxf(m, other_half(m, h));
+        const float mref = m == -INFINITY ? 0.0f : m;   // a tile of pad keys only: every term is 0
+        float sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { S[e] = __builtin_amdgcn_exp2f(S[e] - mref); sum += S[e]; }
+        sum += other_half(sum, h);
+        if (h == 0) { float* ms = ms_h + ((wave * 2 + t) * 32 + r) * 2; ms[0] = m; ms[1] = sum; }
+        if (DROP) {
+          uint32_t word = 0;
+          const uint64_t dbase = ((uint64_t)bh * L + (uint64_t)max(tq, 0)) * (uint64_t)B4R_ATTN_PITCH;
+#pragma unroll
+          for (int gp = 0; gp < 4; ++gp) {
+            const B4rKeep4 k4 = b4r_keep4p(dcp, dbase + (uint64_t)(32 * wave + 8 * gp + 4 * h));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) S[4 * gp + e] = k4.k[e] ? S[4 * gp + e] : 0.f;
+            word |= k4.bits() << (8 * gp + 4 * h);
+          }
+          word |= other_half_u(word, h);
+          if (h == 0 && tq >= 0) p.bits[((bh * NT + wave) * NT + (tq >> 5)) * 32 + a32_slot_perm(tq & 31)] = word;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          bf16x8 ph, pl;
+          acc_frag(S, s2, ph, pl);
+          Op[t] = mfma32x3(tr_pair(vown + lk.trp[s2][0], vown + lk.trp[s2][1]), tr_pair(vown + P_IMG + lk.trp[s2][0], vown + P_IMG + lk.trp[s2][1]),
+                           ph, pl, Op[t]);
+        }
+      }
+      // the partials go over the wave's own K / V tile of this head (its reads of them above are the wave's own, consumed by products)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (t >= NQ) continue;
+        char* dst = (t == 0 ? kown : vown) + lane * 16;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          *reinterpret_cast<f32x4*>(dst + jj * 1024) = (f32x4){Op[t][4 * jj], Op[t][4 * jj + 1], Op[t][4 * jj + 2], Op[t][4 * jj + 3]};
+      }
+      lds_barrier();
+      O[hd] = zero16();
+      if (qwave) {   // merge of compact tile t = wave
+        const int tq = sTok[32 * wave + r];
+        float M = -INFINITY;
+        for (int w_ = 0; w_ < NT; ++w_) M = fmaxf(M, ms_h[((w_ * 2 + wave) * 32 + r) * 2]);
+        float tot = 0.f;
+        for (int w_ = 0; w_ < NT; ++w_) {
+          const float* ms = ms_h + ((w_ * 2 + wave) * 32 + r) * 2;
+          const float a = ms[0] == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(ms[0] - M);
+          tot = fmaf(a, ms[1], tot);
+          const char* srcp = KV + ((2 * hd + (wave == 0 ? 0 : 1)) * NT + w_) * P_TILE + lane * 16;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const f32x4 o4 = *reinterpret_cast<const f32x4*>(srcp + jj * 1024);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) O[hd][4 * jj + e] = fmaf(a, o4[e], O[hd][4 * jj + e]);
+          }
+        }
+        const float inv = (DROP ? dcp.scale : 1.0f) / tot;
+        O[hd] = O[hd] * inv;
+        if (h == 0 && tq >= 0 && p.lse) p.lse[bh * L + tq] = M * LN2 + __logf(tot);
+      }
+    }
+  } else {
 #pragma unroll
   for (int hd = 0; hd < 2; ++hd) {
     const char* kimg = KV + (2 * hd) * NT * P_TILE;
@@ -1086,6 +1216,7 @@ __global__ __launch_bounds__(512, 2) void attn32_fwd_kernel(A32FwdP p) {
     }
   }
 
+  }
   A32F_MARK(16);
   // ---- y^T[hidden][token] = Wo^T . ctx^T: registers 8s .. 8s+7 of O are context columns 16s + 8h + .. of the head: natural k order
   f32x16 y[2] = {zero16(), zero16()};
@@ -1105,6 +1236,43 @@ __global__ __launch_bounds__(512, 2) void attn32_fwd_kernel(A32FwdP p) {
   lds_barrier();   // every wave is done with the K / V images: the waves' transposition space overlays them
   A32F_MARK(18);
 
+  if (CQ) {   // the rows of the wave's compact tile: slot 32 wave + 4 i + rl_row -> its token's row (empty slots: nothing)
+    if (wave >= NQ) return;
+    f32x4 cr[8], yr[8];
+    acc_to_rl<true>(rl, own, own + P_TILE, r, h, O, cr);
+    acc_to_rl(rl, own + 2 * P_TILE, own + 3 * P_TILE, r, h, y, yr);
+    const DropCtx dco = b4r_drop_ctx(p.drop_o);
+    const f32x4 bo4 = *reinterpret_cast<const f32x4*>(p.bo + 4 * rl_c4);
+    const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.g1 + 4 * rl_c4), be4 = *reinterpret_cast<const f32x4*>(p.be1 + 4 * rl_c4);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int tj = sTok[32 * wave + 4 * i + rl_row];
+      const uint32_t off = (uint32_t)(max(tj, 0) * HID + 4 * rl_c4);
+      const f32x4 res = ld4(xb, off);
+      const f32x4 z = res + b4r_drop4(dco, yr[i] + bo4, (uint64_t)(row0 + max(tj, 0)) * HID + (uint64_t)(4 * rl_c4));
+      const float mean = row_allsum16(sum4(z)) * (1.0f / HID);
+      const f32x4 d = z - mean;
+      const float rstd = rsqrtf(row_allsum16(sum4(d * d)) * (1.0f / HID) + p.eps);
+      if (tj >= 0) {
+        if (p.ctx) st4(p.ctx + row0 * HID, off, cr[i]);
+        if (p.z1) st4(p.z1 + row0 * HID, off, z);
+        if (p.x1) {
+          f32x4 o;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float inv = rstd * g4[c];
+            o[c] = fmaf(z[c], inv, fmaf(-mean, inv, be4[c]));
+          }
+          st4(p.x1 + row0 * HID, off, o);
+        }
+        if (rl_c4 == 0) {
+          if (p.mean1) p.mean1[row0 + tj] = mean;
+          if (p.rstd1) p.rstd1[row0 + tj] = rstd;
+        }
+      }
+    }
+    return;
+  }
   // ---- row layout: ctx out; z1 = x + dropout(y + bo), LayerNorm ------------------------------------------------------------------
   {
     f32x4 cr[8];
@@ -2143,19 +2311,27 @@ int b4r_attn32_fwd(const b4r_attn_block_desc* d, b4r_stream_t stream) {
     p.drop_e = b4r_make_drop(d->rng, d->emb_stream, d->emb_rate, d->rng != nullptr);
   }
   const bool drop = p.drop_p.rng != nullptr && p.drop_p.thr != 0;
-  const size_t sh = (size_t)fwd32_lds(p.NT);
+  // the slots as the only queries (the kernel's CQ form): a list of at most 64 rows on at least three token tiles, not the first layer
+  // (B4R_ATTN32_CQ=0 switches the backward's form off: it then reads every token's ctx / lse, so the forward must write them all)
+  static const bool cq_on = !(getenv("B4R_ATTN32_CQ_FWD") && atoi(getenv("B4R_ATTN32_CQ_FWD")) == 0) &&
+                            !(getenv("B4R_ATTN32_CQ") && atoi(getenv("B4R_ATTN32_CQ")) == 0);
+  B4R_CHECK_ARG(d->out_slot_positions == nullptr || d->out_slots > 0, B4R_E_BADARG, "b4r_attn_block_fwd: out_slot_positions needs out_slots");
+  const bool cq = cq_on && d->out_slot_positions != nullptr && d->out_slots <= 64 && p.NT >= 3 && !embed && d->qkv == nullptr;
+  if (cq) { p.slot_pos = d->out_slot_positions; p.slots = d->out_slots; }
+  const size_t sh = cq ? (size_t)fwd32_lds_cq(p.NT) : (size_t)fwd32_lds(p.NT);
   const dim3 grid((unsigned)d->B), block((unsigned)(64 * p.NT));
   hipStream_t s = (hipStream_t)stream;
   int rc;
-#define A32_FWD_CASE(N_, D_)                                                                          \
+#define A32_FWD_CASE(N_, D_, C_)                                                                      \
   {                                                                                                   \
-    rc = b4r_raise_lds((const void*)attn32_fwd_kernel<N_, D_>, sh, "b4r_attn_block_fwd");             \
+    rc = b4r_raise_lds((const void*)attn32_fwd_kernel<N_, D_, C_>, sh, "b4r_attn_block_fwd");         \
     if (rc) return rc;                                                                                \
-    hipLaunchKernelGGL((attn32_fwd_kernel<N_, D_>), grid, block, sh, s, p);                           \
+    hipLaunchKernelGGL((attn32_fwd_kernel<N_, D_, C_>), grid, block, sh, s, p);                       \
   }
-  if (p.NT <= 2) { if (drop) A32_FWD_CASE(2, true) else A32_FWD_CASE(2, false) }
-  else if (p.NT <= 4) { if (drop) A32_FWD_CASE(4, true) else A32_FWD_CASE(4, false) }
-  else { if (drop) A32_FWD_CASE(7, true) else A32_FWD_CASE(7, false) }
+  if (cq) { if (drop) A32_FWD_CASE(7, true, true) else A32_FWD_CASE(7, false, true) }
+  else if (p.NT <= 2) { if (drop) A32_FWD_CASE(2, true, false) else A32_FWD_CASE(2, false, false) }
+  else if (p.NT <= 4) { if (drop) A32_FWD_CASE(4, true, false) else A32_FWD_CASE(4, false, false) }
+  else { if (drop) A32_FWD_CASE(7, true, false) else A32_FWD_CASE(7, false, false) }
 #undef A32_FWD_CASE
   B4R_CHECK_LAUNCH("b4r_attn_block_fwd");
   return B4R_OK;

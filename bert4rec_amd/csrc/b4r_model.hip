@@ -722,6 +722,9 @@ static int forward_impl(const b4r_model_config* cfg, const b4r_batch* batch, con
       ad.ctx = ws + w.ctx[i]; ad.lse = ws + w.lse[i]; ad.keep_bits = reinterpret_cast<uint32_t*>(ws + w.keep[i]);
       ad.z1 = ws + w.z1[i]; ad.mean1 = ws + w.mean1[i]; ad.rstd1 = ws + w.rstd1[i];
       ad.x1 = (layer_fused && x1_on_load()) ? nullptr : ws + w.x1[i];   // the fused feed-forward half forms x1 from z1 itself
+      if (head_rows && i == cfg->num_layers - 1) {   // nothing but the head's rows leaves the last layer: only those queries are swept
+        ad.out_slot_positions = batch->masked_lm_positions; ad.out_slots = batch->P;
+      }
       if (i == 0 && emb_fused) {
         ad.emb_ids = batch->input_word_ids; ad.emb_table = params + pl.word_emb; ad.emb_pos = params + pl.pos_emb; ad.emb_vocab = V;
         ad.emb_gamma = params + pl.emb_ln_g; ad.emb_beta = params + pl.emb_ln_b; ad.emb_eps = cfg->ln_eps;

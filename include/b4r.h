@@ -432,6 +432,11 @@ typedef struct b4r_attn_block_desc {
   const int64_t* emb_ids; const float* emb_table; const float* emb_pos; const float* emb_gamma; const float* emb_beta;
   int32_t emb_vocab; float emb_eps; uint32_t emb_stream; float emb_rate;
   float* emb_x; float* emb_mean; float* emb_rstd;
+  /* optional (hidden 64, 64 < L <= 224, out_slots <= 64, no emb_ids): only the rows clamp(out_slot_positions[b][j]), j < out_slots, of
+   * this block's outputs are wanted (the last layer under B4R_FLAG_HEAD_ROWS_ONLY: every masked-LM slot of the batch, labelled or
+   * padded).  ctx / z1 / x1 / mean1 / rstd1 / lse / keep_bits are then written for those tokens ONLY and only those queries are swept
+   * (keys and values: every token).  A backward of such a forward must name a subset of these rows in dz1_slot_positions. */
+  const int64_t* out_slot_positions; int32_t out_slots;
 } b4r_attn_block_desc;
 int32_t b4r_attn_block_supported(int32_t hidden_size, int32_t num_heads, int32_t L);
 int b4r_attn_block_fwd(const b4r_attn_block_desc* d, b4r_stream_t stream);

@@ -254,6 +254,65 @@ def test_attn_block_forward_matches_fp64(B, L, p_rate, o_rate):
         assert torch.equal(bits_again, bits)
 
 
+@pytest.mark.parametrize("B,L,Ps,p_rate,o_rate", [(4, 200, 40, 0.2, 0.2), (3, 160, 20, 0.0, 0.3), (2, 96, 33, 0.5, 0.0)])
+def test_attn_block_forward_on_the_slots_rows_only(B, L, Ps, p_rate, o_rate):
+    """out_slot_positions: only the named rows of the block's outputs are written, and only those queries are swept (compact query
+    tiles, the softmax of a query merged from per-key-tile partials).  Against the dense launch on the same inputs: the slots' rows of
+    ctx / z1 / x1 / mean1 / rstd1 / lse within the products' rounding, their decision words bit for bit, every other row untouched (NaN);
+    padded slots repeat position 0; one sequence is fully masked."""
+    lib = _lib.load()
+    _lib.check(lib.b4r_set_gemm_mode(_lib.GEMM_BF16X3))
+    seed, step, site_p, site_o = 771, 9, 5, 6
+    t, mask = attn_inputs(B, L, seed=B * 77 + L)
+    mask[0, :] = 0
+    g = {k: v.to(DEV) for k, v in t.items()}
+    st = T.new_state(seed, step) if (p_rate > 0 or o_rate > 0) else None
+    N, nan = B * L, float("nan")
+    gen = torch.Generator().manual_seed(L + Ps)
+    slot_pos = torch.stack([torch.randperm(L, generator=gen)[:Ps] for _ in range(B)]).to(torch.int64)
+    slot_pos[:, Ps - 3:] = 0                                             # padded slots gather position 0 (tfm MaskedLM)
+    slot_pos[1, 0] = 0                                                   # ... which a real slot may name too
+    maskd, sposd = mask.to(DEV), slot_pos.to(DEV)
+    res = []
+    for slots in (False, True):
+        out = {k: torch.full(sh, nan, dtype=torch.float32, device=DEV) for k, sh in
+               dict(ctx=(N, 64), lse=(B, 2, L), z1=(N, 64), x1=(N, 64), mean1=(N,), rstd1=(N,)).items()}
+        bits = torch.zeros(lib.b4r_attn_keep_words(B, L, 2), dtype=torch.int32, device=DEV)
+        d = _lib.AttnBlockDesc()
+        d.B, d.L, d.H, d.heads = B, L, 64, 2
+        d.x, d.input_mask = P(g["x"]), P(maskd)
+        d.Wqkv, d.bqkv, d.Wo, d.bo = P(g["Wqkv"]), P(g["bqkv"]), P(g["Wo"]), P(g["bo"])
+        d.ln_gamma, d.ln_beta, d.ln_eps = P(g["g1"]), P(g["be1"]), 1e-12
+        d.rng, d.probs_stream, d.probs_rate, d.out_stream, d.out_rate = P(st), site_p, p_rate, site_o, o_rate
+        d.ctx, d.lse, d.keep_bits = P(out["ctx"]), P(out["lse"]), P(bits)
+        d.z1, d.x1, d.mean1, d.rstd1 = P(out["z1"]), P(out["x1"]), P(out["mean1"]), P(out["rstd1"])
+        if slots:
+            d.out_slot_positions, d.out_slots = P(sposd), Ps
+        _lib.check(lib.b4r_attn_block_fwd(C.byref(d), stream()), "b4r_attn_block_fwd")
+        torch.cuda.synchronize()
+        res.append((out, bits))
+    (dense, bits_d), (comp, bits_c) = res
+    rows = torch.unique((torch.arange(B)[:, None] * L + slot_pos).reshape(-1)).to(DEV)
+    others = torch.ones(N, dtype=torch.bool, device=DEV)
+    others[rows] = False
+    for k in ("ctx", "z1", "x1"):
+        assert T.maxdiff(comp[k][rows], dense[k][rows]) < 2e-5, k
+        assert bool(torch.isnan(comp[k][others]).all()), k              # nothing else was written
+    assert T.maxdiff(comp["mean1"][rows], dense["mean1"][rows]) < 2e-5
+    assert T.maxdiff(comp["rstd1"][rows] / dense["rstd1"][rows], torch.ones(rows.numel())) < 2e-5
+    lse_c, lse_d = comp["lse"].permute(0, 2, 1).reshape(N, 2), dense["lse"].permute(0, 2, 1).reshape(N, 2)
+    assert T.maxdiff(lse_c[rows], lse_d[rows]) < 2e-5
+    if p_rate > 0:   # the slots' decision words [b, head][key tile][query tile][slot of the query]: the dense launch's, bit for bit
+        NT = (L + 31) // 32
+        n_old = B * 2 * ((L + 15) // 16) * 128
+        wd = bits_d[n_old:n_old + B * 2 * NT * NT * 32].view(B, 2, NT, NT, 32).cpu()
+        wc = bits_c[n_old:n_old + B * 2 * NT * NT * 32].view(B, 2, NT, NT, 32).cpu()
+        slot_of = [(r & 24) | ((r & 3) << 1) | ((r >> 2) & 1) for r in range(32)]
+        for b in range(B):
+            for q in set(int(v) for v in slot_pos[b]):
+                assert torch.equal(wc[b, :, :, q // 32, slot_of[q % 32]], wd[b, :, :, q // 32, slot_of[q % 32]]), (b, q)
+
+
 def attn_bwd_reference(t, mask, B, L, p_rate, o_rate, e_rate, seed, step, site_p, site_o, site_e, prev, eps=1e-12):
     """fp64 autograd through [previous LayerNorm (+ embedding dropout)] -> attention block; loss = sum(z1 * dz1)."""
     H, heads, dh = 64, 2, 32

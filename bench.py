@@ -182,14 +182,28 @@ def algorithmic_work(label, V, H, NL, NH, I, L, P, B):
     # the attention blocks: 9.5 GFLOP (fp32-equivalent, 3x that executed as bf16 MFMA) over ~110 MB = below the machine balance of
     # 312 FLOP/byte even counting the split products -> the HBM roof is the binding one
     small = B * NH * L * 4 + 2 * N * 4 + (B * NH * ((L + 15) // 16) * 2 * 64) * 4    # lse, mean / rstd, keep bits
+    # the LAST layer's launches of a train step touch the masked-LM slots' rows only where the library sweeps the slots as the only
+    # queries (hidden 64, 64 < L <= 224, P <= 64: b4r_attn32.hip's CQ instances): the label's figure is the MEAN over the NL launches
+    slots_only = H == 64 and 64 < L <= 224 and P <= 64 and NL >= 1
+    slot_rows = M * H * 4
     if label.startswith("b4r_attn_block_fwd"):
-        return "hbm", 3 * act + small, "x in; ctx, z1 out (x1 is formed on load by the feed-forward kernels); lse, statistics, dropout bits"
+        dense = 3 * act + small
+        if not slots_only:
+            return "hbm", dense, "x in; ctx, z1 out (x1 is formed on load by the feed-forward kernels); lse, statistics, dropout bits"
+        last = act + 2 * slot_rows + small * P // L
+        return "hbm", ((NL - 1) * dense + last) // NL, ("mean of the layers' launches: x in; ctx, z1 out; lse, statistics, dropout bits -- the last "
+                                                       "layer's launch writes the masked-LM slots' rows only")
     if label.startswith("b4r_attn_block_bwd"):
         nt = (L + 31) // 32
         small_b = B * NH * L * 4 + 2 * N * 4 + B * NH * nt * nt * 32 * 4                  # lse, mean / rstd, keep words
         slabs = B * (H * 3 * H + 3 * H + H * H + H) * 4                                   # dWqkv, dbqkv, dWo, dbo partials per sequence
-        return "hbm", 4 * act + act + slabs + small_b, ("x, dz1, ctx, previous z in; dx_prev out; per-sequence partials of dWqkv / dbqkv / "
-                                                        "dWo / dbo out (no [N,3H] round trip); lse, statistics, dropout words")
+        dense = 4 * act + act + slabs + small_b
+        what = ("x, dz1, ctx, previous z in; dx_prev out; per-sequence partials of dWqkv / dbqkv / dWo / dbo out (no [N,3H] round trip); "
+                "lse, statistics, dropout words")
+        if not slots_only:
+            return "hbm", dense, what
+        last = 2 * act + 2 * slot_rows + act + slabs + (B * NH * L * 4 + B * NH * nt * nt * 32 * 4) * P // L + 2 * N * 4
+        return "hbm", ((NL - 1) * dense + last) // NL, "mean of the layers' launches: " + what + " -- the last layer's launch reads dz1 / ctx at the masked-LM slots' rows only"
     if label.startswith("b4r_attn_fwd"):
         return "mfma", N * 4 * L * H, "QK^T + PV"
     if label.startswith("b4r_attn_bwd dq"):

@@ -21,7 +21,10 @@ struct HeadMergeP {
 // max and sum of a row over the forward's V slices (at most CMAX: the host does not fold the merge into dE beyond that), requested
 // early and finished a chunk later -> log-sum-exp in natural units (+inf for a slot without a label: zero gradient rows in
 // head_dE_kernel) and the label (-1: none).  The same arithmetic as head_merge_row: slices past the end add +0.
-constexpr int CMAX = 8;
+#ifndef B4R_CMAX
+#define B4R_CMAX 16   // (the 32 x 32-tile forward uses up to 16 slices: Steam 12; 8 until round 4)
+#endif
+constexpr int CMAX = B4R_CMAX;
 struct RowPart { float mx[CMAX], sm[CMAX]; long long y; };
 // ms: the forward's compact copy [slices][M][2] of (max, sum), behind its records
 __device__ __forceinline__ void row_part_fetch(RowPart& rp, const float* ms, int slices, int M, const int64_t* y, int m) {

@@ -262,8 +262,8 @@ __global__ __launch_bounds__(512, 2) void attn32_bwd_kernel(A32BwdP p) {
     for (int i = 0; i < 8; ++i) {
       const bool lv = 32 * wave + 4 * i + rl_row < L;
       f32x4 dy = dz_row(i);
-      f32x4 cr = ld4(ctxb, rl_off(rl, i));
-      if (CQ && sHas[min(32 * wave + 4 * i + rl_row, L - 1)] == 0.f) cr = (f32x4){0.f, 0.f, 0.f, 0.f};   // (the forward wrote the slots' rows only)
+      // (CQ: the forward wrote the slots' rows of ctx only -- the others are neither defined nor needed: their dy is zero)
+      const f32x4 cr = (CQ && sHas[min(32 * wave + 4 * i + rl_row, L - 1)] == 0.f) ? (f32x4){0.f, 0.f, 0.f, 0.f} : ld4(ctxb, rl_off(rl, i));
       if (dco.on) dy = b4r_drop4(dco, dy, (uint64_t)(row0 + 32 * wave + 4 * i + rl_row) * HID + (uint64_t)(4 * rl_c4));
       if (!lv) dy = (f32x4){0.f, 0.f, 0.f, 0.f};   // pad tokens: no contribution
       dbo += dy;
@@ -311,7 +311,8 @@ __global__ __launch_bounds__(512, 2) void attn32_bwd_kernel(A32BwdP p) {
   do {                                                                                                                  \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) { nxr[i] = ld4(xb, rl_off(rl, i)); nyr[i] = (SKIP_DY_) ? nxr[i] : dz_row(i); } \
     nlse = live ? (p.lse + ((int64_t)b * 2 + (HD_)) * L)[(uint32_t)tok] : INFINITY;                                    \
-    _Pragma("unroll") for (int gp = 0; gp < 4; ++gp) ncx[gp] = ld4(ctxb, (uint32_t)(tokc * HID + 32 * (HD_) + 4 * h + 8 * gp)); \
+    _Pragma("unroll") for (int gp = 0; gp < 4; ++gp)                                                                    \
+      ncx[gp] = (CQ && sHas[tokc] == 0.f) ? (f32x4){0.f, 0.f, 0.f, 0.f} : ld4(ctxb, (uint32_t)(tokc * HID + 32 * (HD_) + 4 * h + 8 * gp)); \
   } while (0)
   {
     A32_LANE_CONSTS();

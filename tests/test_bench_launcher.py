@@ -36,3 +36,23 @@ def test_a_rank_under_a_launcher_does_not_launch_again():
     import torch
     if not torch.cuda.is_available():
         assert out.returncode != 0 and "needs the GPU" in out.stderr
+
+
+def test_attention_roofline_bytes_are_the_mean_over_the_layers_launches():
+    """bench.py prices the attention block launches of a step with ONE figure per label: where the library sweeps the last layer's
+    slots only (hidden 64, 64 < L <= 224, P <= 64) that figure is the mean of a dense launch and the smaller last-layer one."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    dense_like = bench.algorithmic_work("b4r_attn_block_bwd", 13047, 64, 2, 2, 256, 50, 20, 256)[1]      # Steam: L = 50, every launch dense
+    assert dense_like == 5 * 256 * 50 * 64 * 4 + 256 * (64 * 192 + 192 + 64 * 64 + 64) * 4 + 256 * 2 * 50 * 4 + 2 * 256 * 50 * 4 + 256 * 2 * 2 * 2 * 32 * 4
+    two = bench.algorithmic_work("b4r_attn_block_bwd", 3709, 64, 2, 2, 256, 200, 40, 256)[1]
+    one = bench.algorithmic_work("b4r_attn_block_bwd", 3709, 64, 1, 2, 256, 200, 40, 256)[1]            # a single layer: the small figure
+    four = bench.algorithmic_work("b4r_attn_block_bwd", 3709, 64, 4, 2, 256, 200, 40, 256)[1]
+    dense = 2 * two - one
+    assert one < two < four < dense and abs(four - (3 * dense + one) // 4) <= 1
+    fwd_two = bench.algorithmic_work("b4r_attn_block_fwd", 3709, 64, 2, 2, 256, 200, 40, 256)[1]
+    fwd_wide = bench.algorithmic_work("b4r_attn_block_fwd", 3709, 64, 2, 2, 256, 200, 80, 256)[1]        # more than 64 slots: dense
+    assert fwd_two < fwd_wide
